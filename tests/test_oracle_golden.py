@@ -1,0 +1,100 @@
+"""CPU suite: the oracle restatement vs golden outputs of the unmodified reference
+(fixtures made by tests/golden/make_golden.py)."""
+import pytest
+import torch
+
+from oracle import codec as ocodec
+from oracle import lm as olm
+from oracle import patterns as opat
+from conftest import load_golden
+
+CODEC_KEYS = ['channels', 'dimension', 'n_filters', 'n_residual_layers', 'ratios', 'kernel_size',
+              'last_kernel_size', 'residual_kernel_size', 'dilation_base', 'causal', 'pad_mode', 'true_skip',
+              'compress', 'lstm', 'norm', 'elu_alpha', 'trim_right_ratio', 'n_q', 'bins', 'sample_rate',
+              'frame_rate', 'renormalize']
+LM_KEYS = ['dim', 'num_heads', 'num_layers', 'hidden_scale', 'n_q', 'card', 'cross_attention', 'delays', 'cfg_coef']
+
+
+def codec_cfg(cfg):
+    return ocodec.CodecConfig(**{k: cfg[k] for k in CODEC_KEYS})
+
+
+def lm_cfg(cfg):
+    return olm.LMConfig(**{k: cfg[k] for k in LM_KEYS})
+
+
+@pytest.mark.parametrize('name', ['codec_noncausal', 'codec_causal', 'codec_renorm'])
+@pytest.mark.parametrize('fast_lstm', [False, True])
+def test_codec_oracle_matches_reference(name, fast_lstm):
+    cfg, sd, a = load_golden(name)
+    c = codec_cfg(cfg)
+    wav = a['wav']
+    x = wav
+    if c.renormalize:
+        mono = wav.mean(dim=1, keepdim=True)
+        x = wav / (1e-8 + mono.pow(2).mean(dim=2, keepdim=True).sqrt())
+    lat = ocodec.seanet_encoder(sd, c, x, fast_lstm)
+    assert lat.shape == a['latents'].shape
+    assert torch.allclose(lat, a['latents'], atol=2e-5, rtol=1e-4)
+    # RVQ on the reference's own latents: bit exact
+    codes = ocodec.rvq_encode(a['latents'], ocodec.codebooks_from_state(sd, c.n_q))
+    assert torch.equal(codes, a['codes'])
+    codes2, scale = ocodec.encodec_encode(sd, c, wav, fast_lstm)
+    assert (codes2 == a['codes']).float().mean() > 0.98
+    assert torch.allclose(ocodec.rvq_decode(a['codes'], ocodec.codebooks_from_state(sd, c.n_q)),
+                          a['quantized_latents'], atol=1e-6)
+    dec = ocodec.encodec_decode(sd, c, a['codes'], a.get('scale'), fast_lstm)
+    assert dec.shape == a['decoded'].shape
+    assert torch.allclose(dec, a['decoded'], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(dec[..., :wav.shape[-1]], a['forward'], atol=2e-5, rtol=1e-4)
+
+
+def test_lm_text_oracle_matches_reference():
+    cfg, sd, a = load_golden('lm_text')
+    c = lm_cfg(cfg)
+    assert torch.allclose(olm.create_sin_embedding(torch.arange(7).view(1, -1, 1) + 3, c.dim), a['sin_emb'],
+                          atol=1e-6)
+    # teacher-forced, non streaming
+    logits = olm.lm_forward(sd, c, a['tf_sequence'], a['cross_src'])
+    assert torch.allclose(logits, a['tf_logits'], atol=2e-5, rtol=1e-4)
+    # streaming == batch (tests/modules/test_transformer.py:16-49 invariant)
+    st = olm.LMState(c.num_layers)
+    steps = [olm.lm_forward(sd, c, a['tf_sequence'][..., i:i + 1], a['cross_src'], None, st)
+             for i in range(a['tf_sequence'].shape[-1])]
+    assert torch.allclose(torch.cat(steps, dim=2), a['tf_logits'], atol=3e-5, rtol=1e-4)
+    # greedy generate, no prompt
+    toks, lg = olm.generate(sd, c, None, 3, a['cross_src'], max_gen_len=12, use_sampling=False, return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    ref = olm.cfg_mix(a['greedy_step_logits'], c.cfg_coef)
+    assert torch.allclose(lg, ref, atol=1e-4, rtol=1e-4)
+    # continuation
+    toks = olm.generate(sd, c, a['prompt'], 3, a['cross_src'], max_gen_len=10, use_sampling=False)
+    assert torch.equal(toks, a['cont_tokens'])
+    toks = olm.generate(sd, c, a['prompt'], 3, a['cross_src'], max_gen_len=10, use_sampling=False,
+                        remove_prompts=True)
+    assert torch.equal(toks, a['cont_tokens_removed'])
+    assert torch.allclose(olm.top_k_filter(a['probs'], 5), a['probs_top5'], atol=1e-7)
+
+
+def test_lm_melody_oracle_matches_reference():
+    cfg, sd, a = load_golden('lm_melody')
+    c = lm_cfg(cfg)
+    toks, lg = olm.generate(sd, c, None, 2, None, a['prepend_src'], max_gen_len=9, use_sampling=False,
+                            return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    assert torch.allclose(lg, olm.cfg_mix(a['greedy_step_logits'], c.cfg_coef), atol=1e-4, rtol=1e-4)
+
+
+def test_pattern_roundtrip_and_layout():
+    # tests/modules/test_codebooks_patterns.py:22-102 layout properties for the delay pattern
+    z = torch.arange(2 * 4 * 7).view(2, 4, 7)
+    seq, mask = opat.build_pattern_sequence(z, 99)
+    assert seq.shape == (2, 4, 7 + 3 + 1)
+    assert (seq[:, :, 0] == 99).all()
+    for q in range(4):
+        assert torch.equal(seq[:, q, 1 + q:1 + q + 7], z[:, q])
+        assert mask[q].sum() == 7
+    back, bmask = opat.revert_pattern_sequence(seq, -1, 7)
+    assert torch.equal(back, z) and bmask.all()
+    assert opat.first_step_with_timestep(4, 7, 0) == 1
+    assert opat.first_step_with_timestep(4, 7, 3) == 4
