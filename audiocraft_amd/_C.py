@@ -1,0 +1,186 @@
+"""ctypes binding of libacmi.so (include/acmi.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing this module raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `python -m audiocraft_amd.build`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libacmi.so')
+
+F32, BF16 = 0, 1
+PAD_ZERO, PAD_REFLECT = 0, 1
+STEP_PREFILL, STEP_DECODE = 0, 1
+
+
+class AcmiError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the MI355X kernel library has not been built. "
+        "Run `python -m audiocraft_amd.build` (needs hipcc). There is no CPU fallback.")
+lib = C.CDLL(LIB_PATH)
+
+vp, i32, f32, u64, i64p = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('B', i32), ('Cin', i32), ('Tin', i32), ('Cout', i32), ('Tout', i32), ('ksize', i32),
+                ('stride', i32), ('dilation', i32), ('pad_left', i32), ('pad_mode', i32), ('reflect_len', i32),
+                ('elu_in', i32), ('elu_alpha', f32), ('shuffle', i32), ('trim_left', i32)]
+
+
+class LMLayer(C.Structure):
+    _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_ff1', vp), ('w_ff2', vp),
+                ('ln1_g', vp), ('ln1_b', vp), ('lnc_g', vp), ('lnc_b', vp), ('ln2_g', vp), ('ln2_b', vp),
+                ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp)]
+
+
+class LMModelDesc(C.Structure):
+    _fields_ = [('dim', i32), ('num_heads', i32), ('num_layers', i32), ('ffn_dim', i32), ('n_q', i32),
+                ('card', i32), ('wdtype', i32), ('kvdtype', i32), ('cross_attention', i32), ('eps', f32),
+                ('positional_scale', f32), ('layers', C.POINTER(LMLayer)), ('emb', C.POINTER(vp)),
+                ('pos_freq', vp), ('out_norm_g', vp), ('out_norm_b', vp), ('w_head', vp)]
+
+
+class LMState(C.Structure):
+    _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
+                ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
+                ('x', vp), ('q', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
+                ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
+                ('seed', u64)]
+
+
+def _sig(name, argtypes, restype=i32):
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+_version = _sig('acmi_version', [])
+_last_error = _sig('acmi_last_error', [], C.c_char_p)
+_rvq_norms = _sig('acmi_rvq_codebook_norms', [vp, vp, i32, i32, i32, vp])
+_rvq_encode = _sig('acmi_rvq_encode', [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
+_rvq_decode = _sig('acmi_rvq_decode', [vp, vp, vp, i32, i32, i32, i32, i32, vp])
+_conv1d = _sig('acmi_conv1d', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp])
+_lstm_layer = _sig('acmi_lstm_layer', [vp, vp, vp, vp, vp, i32, i32, i32, vp])
+_lstm_work = _sig('acmi_lstm_work_floats', [i32, i32], C.c_size_t)
+_lm_step = _sig('acmi_lm_step', [C.POINTER(LMModelDesc), C.POINTER(LMState), i32, vp])
+_linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp])
+_attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp])
+_kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
+_sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, i32, f32, u64, u64, vp])
+
+EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
+           'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample']
+
+
+def version() -> int:
+    return _version()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise AcmiError(f"{what} failed ({rc}): {_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "libacmi takes device pointers only (no CPU fallback)"
+    assert t.is_contiguous(), "libacmi takes dense row-major tensors"
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported dtype {dt}")
+
+
+# ---------------------------------------------------------------------------------- thin wrappers
+
+def rvq_codebook_norms(codebooks: torch.Tensor) -> torch.Tensor:
+    K, bins, D = codebooks.shape
+    norms = torch.empty(K, bins, device=codebooks.device, dtype=torch.float32)
+    check(_rvq_norms(ptr(codebooks), ptr(norms), K, bins, D, stream()), 'acmi_rvq_codebook_norms')
+    return norms
+
+
+def rvq_encode(latents: torch.Tensor, codebooks: torch.Tensor, norms: torch.Tensor, n_q: int) -> torch.Tensor:
+    B, D, T = latents.shape
+    codes = torch.empty(B, n_q, T, device=latents.device, dtype=torch.int64)
+    check(_rvq_encode(ptr(latents), ptr(codebooks), ptr(norms), ptr(codes), B, D, T, n_q, codebooks.shape[1],
+                      stream()), 'acmi_rvq_encode')
+    return codes
+
+
+def rvq_decode(codes: torch.Tensor, codebooks: torch.Tensor) -> torch.Tensor:
+    B, K, T = codes.shape
+    D = codebooks.shape[2]
+    out = torch.empty(B, D, T, device=codes.device, dtype=torch.float32)
+    check(_rvq_decode(ptr(codes), ptr(codebooks), ptr(out), B, D, T, K, codebooks.shape[1], stream()),
+          'acmi_rvq_decode')
+    return out
+
+
+def conv1d(desc: ConvDesc, x, w, bias, residual, y):
+    check(_conv1d(C.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), stream()), 'acmi_conv1d')
+
+
+def lstm_layer(gates_in, w_hh, skip, y, work, B, H, T):
+    check(_lstm_layer(ptr(gates_in), ptr(w_hh), ptr(skip), ptr(y), ptr(work), B, H, T, stream()), 'acmi_lstm_layer')
+
+
+def lstm_work_floats(B, H) -> int:
+    return int(_lstm_work(B, H))
+
+
+def linear(a, w, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, residual=None, act=0):
+    """out[M, N] = LN?(a)[M, K] @ w[N, K]^T (+ residual), see acmi_linear."""
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and tuple(out.shape) == (M, N)
+    check(_linear(ptr(a), dtype_code(a.dtype), ptr(ln_g), ptr(ln_b), eps, ptr(w), dtype_code(w.dtype),
+                  ptr(bias), ptr(residual), ptr(out), dtype_code(out.dtype), act, M, N, K, stream()), 'acmi_linear')
+    return out
+
+
+def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0):
+    Beff, H, Tcap, hd = k_cache.shape
+    check(_attn(ptr(q), ptr(k_cache), ptr(v_cache), dtype_code(k_cache.dtype), ptr(out), Beff, H, hd, Tcap, length,
+                ptr(len_dev), len_bias, stream()), 'acmi_attn_decode')
+    return out
+
+
+def kv_store(src, cache, t0):
+    """src [Beff, L, H*hd] f32 -> cache[:, :, t0:t0+L, :]."""
+    Beff, H, Tcap, hd = cache.shape
+    L = src.shape[1]
+    check(_kv_store(ptr(src), ptr(cache), dtype_code(cache.dtype), Beff, H, hd, Tcap, t0, L, stream()), 'acmi_kv_store')
+
+
+def sample(logits, B, K, card, use_cfg, cfg_coef, use_sampling, temp, top_k, top_p, seed, step, want_mixed=False):
+    tokens = torch.empty(B, K, device=logits.device, dtype=torch.int64)
+    mixed = torch.empty(B, K, card, device=logits.device, dtype=torch.float32) if want_mixed else None
+    check(_sample(ptr(logits), ptr(tokens), ptr(mixed), B, K, card, int(use_cfg), cfg_coef, int(use_sampling), temp,
+                  top_k, top_p, seed, step, stream()), 'acmi_sample')
+    return tokens, mixed
+
+
+def lm_step(model_desc: LMModelDesc, state: LMState, mode: int):
+    check(_lm_step(C.byref(model_desc), C.byref(state), mode, stream()), 'acmi_lm_step')

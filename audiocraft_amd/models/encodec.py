@@ -1,0 +1,175 @@
+"""EnCodec compression model on MI355X.
+
+API mirror of `audiocraft.models.encodec.CompressionModel` / `EncodecModel`
+(reference audiocraft/models/encodec.py:28-259): encode / decode / decode_latent / forward and the
+channels / frame_rate / sample_rate / cardinality / num_codebooks / total_codebooks properties.
+The HF / DAC / stereo-interleave wrappers of the reference are outside this path.
+"""
+import typing as tp
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from ..modules.seanet import invalidate_prepared
+from ..quantization.vq import BaseQuantizer
+
+
+@dataclass
+class QuantizedResult:
+    x: torch.Tensor
+    codes: torch.Tensor
+    bandwidth: torch.Tensor
+    penalty: tp.Optional[torch.Tensor] = None
+
+
+class CompressionModel(ABC, nn.Module):
+    """Base API for all compression models that aim at being used as audio tokenizers (encodec.py:28-85)."""
+
+    @abstractmethod
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        ...
+
+    @abstractmethod
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        ...
+
+    @abstractmethod
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        ...
+
+    @abstractmethod
+    def decode_latent(self, codes: torch.Tensor):
+        ...
+
+    @property
+    @abstractmethod
+    def channels(self) -> int:
+        ...
+
+    @property
+    @abstractmethod
+    def frame_rate(self) -> float:
+        ...
+
+    @property
+    @abstractmethod
+    def sample_rate(self) -> int:
+        ...
+
+    @property
+    @abstractmethod
+    def cardinality(self) -> int:
+        ...
+
+    @property
+    @abstractmethod
+    def num_codebooks(self) -> int:
+        ...
+
+    @property
+    @abstractmethod
+    def total_codebooks(self) -> int:
+        ...
+
+    @abstractmethod
+    def set_num_codebooks(self, n: int):
+        ...
+
+
+class EncodecModel(CompressionModel):
+    """SEANet encoder + RVQ + SEANet decoder (encodec.py:125-259)."""
+    frame_rate: float = 0
+    sample_rate: int = 0
+    channels: int = 0
+
+    def __init__(self, encoder: nn.Module, decoder: nn.Module, quantizer: BaseQuantizer, frame_rate: int,
+                 sample_rate: int, channels: int, causal: bool = False, renormalize: bool = False):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.quantizer = quantizer
+        self.frame_rate = frame_rate
+        self.sample_rate = sample_rate
+        self.channels = channels
+        self.renormalize = renormalize
+        self.causal = causal
+        if self.causal:
+            assert not self.renormalize, 'Causal model does not support renormalize'
+        self.eval()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        invalidate_prepared(self)
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        invalidate_prepared(self)
+        return out
+
+    @property
+    def total_codebooks(self):
+        return self.quantizer.total_codebooks
+
+    @property
+    def num_codebooks(self):
+        return self.quantizer.num_codebooks
+
+    def set_num_codebooks(self, n: int):
+        self.quantizer.set_num_codebooks(n)
+
+    @property
+    def cardinality(self):
+        return self.quantizer.bins
+
+    def preprocess(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        scale: tp.Optional[torch.Tensor]
+        if self.renormalize:  # encodec.py:186-196 (not used by the MusicGen codecs)
+            mono = x.mean(dim=1, keepdim=True)
+            volume = mono.pow(2).mean(dim=2, keepdim=True).sqrt()
+            scale = 1e-8 + volume
+            x = x / scale
+            scale = scale.view(-1, 1)
+        else:
+            scale = None
+        return x, scale
+
+    def postprocess(self, x: torch.Tensor, scale: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        if scale is not None:
+            assert self.renormalize
+            x = x * scale.view(-1, 1, 1)
+        return x
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        assert x.dim() == 3
+        length = x.shape[-1]
+        x, scale = self.preprocess(x)
+        emb = self.encoder(x)
+        codes = self.quantizer.encode(emb)
+        out = self.decoder(self.quantizer.decode(codes))
+        assert out.shape[-1] >= length, (out.shape[-1], length)
+        out = self.postprocess(out[..., :length], scale)
+        import math
+        bw = torch.tensor(codes.shape[1] * math.log2(self.cardinality) * self.frame_rate / 1000).to(out)
+        return QuantizedResult(out, codes, bw)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        assert x.dim() == 3
+        x, scale = self.preprocess(x)
+        emb = self.encoder(x)
+        codes = self.quantizer.encode(emb)
+        return codes, scale
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        emb = self.decode_latent(codes)
+        out = self.decoder(emb)
+        return self.postprocess(out, scale)
+
+    @torch.no_grad()
+    def decode_latent(self, codes: torch.Tensor):
+        return self.quantizer.decode(codes)

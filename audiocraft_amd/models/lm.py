@@ -1,0 +1,498 @@
+"""MusicGen language model on MI355X -- host side.
+
+API mirror of `audiocraft.models.lm.LMModel` (reference audiocraft/models/lm.py:120-587): same
+constructor arguments for the options MusicGen uses, same parameter names (so reference
+checkpoints load with `load_state_dict`), same `generate(...)` signature and return value.
+
+What differs is the execution model.  The reference walks ~25 ATen ops per layer per step from a
+Python loop and re-concatenates the KV cache every step.  Here one decode position is a single
+C-ABI call (`acmi_lm_step`, include/acmi.h) that enqueues ~9 fused HIP kernels per layer; the call
+is captured once into a hipGraph and replayed for every step: the position counter, the token
+sequence, the KV cache (written in place) and the sampler all live on the device, so the host does
+nothing between steps except replay (and the optional progress callback).
+
+ * weights: packed once (`_pack`) into bf16 (default on GPU, `BASELINE.json` config) or f32 (parity
+   mode) [out, in] matrices; the 4 output heads are stacked into one [K*card, d] matrix;
+ * cross-attention keys/values are projected ONCE per generate() instead of every step
+   (reference transformer.py:344-361 recomputes them);
+ * prompt / prepended-condition prefill is run position by position through the same step
+   (streaming == batch, reference tests/modules/test_transformer.py:16-49).
+"""
+import ctypes as C
+import math
+import typing as tp
+
+import torch
+from torch import nn
+
+from .. import _C
+from ..modules.codebooks_patterns import CodebooksPatternProvider
+from ..modules.conditioners import (ClassifierFreeGuidanceDropout, ConditionFuser, ConditioningAttributes,
+                                    ConditioningProvider, ConditionType)
+
+ConditionTensors = tp.Dict[str, ConditionType]
+
+
+def _trunc_normal_(t: torch.Tensor, std: float):
+    # reference get_init_fn('gaussian') (lm.py:35-59): N(0, std) truncated at 3 std
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-3 * std, b=3 * std)
+
+
+class _Attn(nn.Module):
+    """Parameter container named like StreamingMultiheadAttention (custom / memory-efficient layout)."""
+    def __init__(self, dim: int, bias: bool, device=None):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim, device=device))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim, device=device)) if bias else None
+        self.out_proj = nn.Linear(dim, dim, bias=bias, device=device)
+
+
+class _Layer(nn.Module):
+    """Parameter container named like StreamingTransformerLayer (transformer.py:454-574)."""
+    def __init__(self, dim: int, ffn: int, cross_attention: bool, bias_ff: bool, bias_attn: bool, device=None):
+        super().__init__()
+        self.self_attn = _Attn(dim, bias_attn, device)
+        self.linear1 = nn.Linear(dim, ffn, bias=bias_ff, device=device)
+        self.linear2 = nn.Linear(ffn, dim, bias=bias_ff, device=device)
+        self.norm1 = nn.LayerNorm(dim, eps=1e-5, device=device)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-5, device=device)
+        self.cross_attention: tp.Optional[_Attn] = None
+        if cross_attention:
+            self.cross_attention = _Attn(dim, bias_attn, device)
+            self.norm_cross = nn.LayerNorm(dim, eps=1e-5, device=device)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, dim, ffn, num_layers, cross_attention, bias_ff, bias_attn, device=None):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(dim, ffn, cross_attention, bias_ff, bias_attn, device)
+                                     for _ in range(num_layers)])
+
+
+class LMModel(nn.Module):
+    """Transformer LM over K parallel codebook streams, MI355X execution.
+
+    Args mirror `audiocraft.models.lm.LMModel.__init__` (lm.py:145-177) plus:
+        weight_dtype: torch.bfloat16 (bench / serving) or torch.float32 (parity mode) for the packed matrices.
+        kv_dtype: dtype of the KV caches (defaults to weight_dtype).
+    Unsupported reference options raise: norm_first=False, rope, layer_scale, kv_repeat>1, qk_layer_norm,
+    past_context (none is used by a MusicGen config).
+    """
+
+    def __init__(self, pattern_provider: CodebooksPatternProvider, condition_provider: ConditioningProvider,
+                 fuser: ConditionFuser, n_q: int = 8, card: int = 1024, dim: int = 128, num_heads: int = 8,
+                 hidden_scale: int = 4, norm: str = 'layer_norm', norm_first: bool = False,
+                 emb_lr: tp.Optional[float] = None, bias_proj: bool = True,
+                 weight_init: tp.Optional[str] = None, depthwise_init: tp.Optional[str] = None,
+                 zero_bias_init: bool = False, cfg_dropout: float = 0, cfg_coef: float = 1.0,
+                 attribute_dropout: tp.Dict[str, tp.Dict[str, float]] = {}, two_step_cfg: bool = False,
+                 num_layers: int = 2, cross_attention: bool = False, bias_ff: bool = True, bias_attn: bool = True,
+                 positional_embedding: str = 'sin', max_period: float = 10000., positional_scale: float = 1.0,
+                 causal: bool = True, activation: str = 'gelu', dropout: float = 0.0,
+                 weight_dtype: torch.dtype = torch.bfloat16, kv_dtype: tp.Optional[torch.dtype] = None,
+                 device=None, **kwargs):
+        super().__init__()
+        if not norm_first or norm != 'layer_norm':
+            raise NotImplementedError("only pre-norm LayerNorm transformers (the MusicGen configuration)")
+        if positional_embedding != 'sin':
+            raise NotImplementedError("only sinusoidal positions (config/model/lm/default.yaml:32)")
+        if activation != 'gelu' or not causal:
+            raise NotImplementedError("only causal, GELU transformers")
+        for k in ('layer_scale', 'past_context', 'rope'):
+            if kwargs.get(k) is not None:
+                raise NotImplementedError(f"{k} is not used by MusicGen and not implemented")
+        if kwargs.get('kv_repeat', 1) != 1 or kwargs.get('qk_layer_norm', False):
+            raise NotImplementedError("kv_repeat / qk_layer_norm are not used by MusicGen")
+        if two_step_cfg:
+            raise NotImplementedError("two_step_cfg (lm.py:378-387) is a 'next' row; MusicGen configs use one-step CFG")
+        assert dim % num_heads == 0 and dim % 8 == 0
+        self.cfg_coef = cfg_coef
+        self.cfg_dropout = ClassifierFreeGuidanceDropout(p=cfg_dropout)
+        self.condition_provider = condition_provider
+        self.fuser = fuser
+        self.card = card
+        self.n_q = n_q
+        self.dim = dim
+        self.num_heads = num_heads
+        self.num_layers = num_layers
+        self.ffn_dim = int(hidden_scale * dim)
+        self.pattern_provider = pattern_provider
+        self.two_step_cfg = two_step_cfg
+        self.max_period = max_period
+        self.positional_scale = positional_scale
+        self.has_cross_attention = cross_attention
+        self.weight_dtype = weight_dtype
+        self.kv_dtype = kv_dtype or weight_dtype
+        self.emb = nn.ModuleList([nn.Embedding(card + 1, dim, device=device) for _ in range(n_q)])
+        self.transformer = _Transformer(dim, self.ffn_dim, num_layers, cross_attention, bias_ff, bias_attn, device)
+        self.out_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
+        self.linears = nn.ModuleList([nn.Linear(dim, card, bias=bias_proj, device=device) for _ in range(n_q)])
+        self._init_weights(weight_init, depthwise_init, zero_bias_init)
+        self._packed: tp.Optional[dict] = None
+        self._run: tp.Optional[dict] = None
+        self.eval()
+
+    # ------------------------------------------------------------------------------------- init
+    def _init_weights(self, weight_init, depthwise_init, zero_bias_init):
+        """Same distributions as the reference (lm.py:179-211); never used for parity (tests copy weights)."""
+        with torch.no_grad():
+            for li, layer in enumerate(self.transformer.layers):
+                nn.init.kaiming_uniform_(layer.self_attn.in_proj_weight, a=math.sqrt(5))
+                if layer.cross_attention is not None:
+                    nn.init.kaiming_uniform_(layer.cross_attention.in_proj_weight, a=math.sqrt(5))
+            if weight_init is None:
+                return
+            assert weight_init == 'gaussian', "only 'gaussian' init is implemented"
+            for e in self.emb:
+                _trunc_normal_(e.weight, 1 / math.sqrt(self.dim))
+            for li, layer in enumerate(self.transformer.layers):
+                depth = {'current': li + 1, 'global': self.num_layers, None: None}[depthwise_init]
+                for m in layer.modules():
+                    if isinstance(m, nn.Linear):
+                        std = 1 / math.sqrt(m.in_features)
+                        if depth is not None:
+                            std /= math.sqrt(2 * depth)
+                        _trunc_normal_(m.weight, std)
+                        if zero_bias_init and m.bias is not None:
+                            nn.init.zeros_(m.bias)
+            for lin in self.linears:
+                _trunc_normal_(lin.weight, 1 / math.sqrt(self.dim))
+
+    @property
+    def special_token_id(self) -> int:
+        return self.card
+
+    @property
+    def num_codebooks(self) -> int:
+        return self.n_q
+
+    @property
+    def device(self):
+        return next(iter(self.parameters())).device
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._packed = None
+        self._run = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    # ------------------------------------------------------------------------------------- packing
+    def _pack(self):
+        """Kernel-side weight layout + ctypes descriptors (rebuilt after load_state_dict / .to())."""
+        dev = self.device
+        if dev.type != 'cuda':
+            raise RuntimeError("audiocraft_amd.LMModel runs on an MI355X only (no CPU fallback); move it to 'cuda'")
+        wd = self.weight_dtype
+        keep: tp.List[torch.Tensor] = []
+
+        def W(t):
+            t = t.detach().to(device=dev, dtype=wd).contiguous()
+            keep.append(t)
+            return t
+
+        def Fp(t):
+            if t is None:
+                return None
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        d = self.dim
+        layers = (_C.LMLayer * self.num_layers)()
+        pk: dict = {'keep': keep, 'layers': layers, 'per_layer': []}
+        for li, layer in enumerate(self.transformer.layers):
+            for b in (layer.self_attn.in_proj_bias, layer.self_attn.out_proj.bias, layer.linear1.bias,
+                      layer.linear2.bias):
+                if b is not None and bool((b != 0).any()):
+                    raise NotImplementedError("transformer biases (bias_attn / bias_ff) are not wired into "
+                                              "acmi_lm_step; MusicGen checkpoints have none")
+            ent = {
+                'w_qkv': W(layer.self_attn.in_proj_weight), 'w_out': W(layer.self_attn.out_proj.weight),
+                'w_ff1': W(layer.linear1.weight), 'w_ff2': W(layer.linear2.weight),
+                'ln1_g': Fp(layer.norm1.weight), 'ln1_b': Fp(layer.norm1.bias),
+                'ln2_g': Fp(layer.norm2.weight), 'ln2_b': Fp(layer.norm2.bias),
+            }
+            if layer.cross_attention is not None:
+                ipw = layer.cross_attention.in_proj_weight
+                ent.update({'w_cq': W(ipw[:d]), 'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]),
+                            'w_cout': W(layer.cross_attention.out_proj.weight),
+                            'lnc_g': Fp(layer.norm_cross.weight), 'lnc_b': Fp(layer.norm_cross.bias)})
+            L = layers[li]
+            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_ff1', 'w_ff2', 'ln1_g', 'ln1_b', 'lnc_g', 'lnc_b',
+                      'ln2_g', 'ln2_b'):
+                setattr(L, k, ent[k].data_ptr() if k in ent else None)
+            pk['per_layer'].append(ent)
+        embs = [W(e.weight) for e in self.emb]
+        emb_arr = (_C.vp * self.n_q)(*[e.data_ptr() for e in embs])
+        for lin in self.linears:
+            if lin.bias is not None and bool((lin.bias != 0).any()):
+                raise NotImplementedError("bias_proj heads are not wired into acmi_lm_step")
+        w_head = W(torch.cat([lin.weight for lin in self.linears], dim=0))
+        half = d // 2
+        # divisor table of create_sin_embedding, computed exactly like the reference does
+        # (transformer.py:83-88: f32 tensor ops on the host)
+        adim = torch.arange(half, dtype=torch.float32)
+        pos_freq = Fp(torch.full([], self.max_period, dtype=torch.float32) ** (adim / (half - 1)))
+        og, ob = Fp(self.out_norm.weight), Fp(self.out_norm.bias)
+        desc = _C.LMModelDesc()
+        desc.dim, desc.num_heads, desc.num_layers, desc.ffn_dim = d, self.num_heads, self.num_layers, self.ffn_dim
+        desc.n_q, desc.card = self.n_q, self.card
+        desc.wdtype, desc.kvdtype = _C.dtype_code(wd), _C.dtype_code(self.kv_dtype)
+        desc.cross_attention = int(self.has_cross_attention)
+        desc.eps, desc.positional_scale = 1e-5, self.positional_scale
+        desc.layers = C.cast(layers, C.POINTER(_C.LMLayer))
+        desc.emb = C.cast(emb_arr, C.POINTER(_C.vp))
+        desc.pos_freq, desc.out_norm_g, desc.out_norm_b = pos_freq.data_ptr(), og.data_ptr(), ob.data_ptr()
+        desc.w_head = w_head.data_ptr()
+        pk.update({'desc': desc, 'emb_arr': emb_arr})
+        self._packed = pk
+        self._run = None
+        return pk
+
+    # ------------------------------------------------------------------------------------- run state
+    def _prepare_run(self, B: int, use_cfg: bool, Tmax: int, Lc: int, S: int):
+        """(Re)allocate KV caches / activations for this batch geometry; reused across generate() calls."""
+        pk = self._packed or self._pack()
+        key = (B, use_cfg, Tmax, Lc, S)
+        if self._run is not None and self._run['key'] == key:
+            return self._run
+        dev = self.device
+        Beff = 2 * B if use_cfg else B
+        H, hd, d = self.num_heads, self.dim // self.num_heads, self.dim
+        f32 = dict(device=dev, dtype=torch.float32)
+        run: dict = {'key': key, 'Beff': Beff, 'graphs': {}}
+        run['k'] = torch.zeros(self.num_layers, Beff, H, Tmax, hd, device=dev, dtype=self.kv_dtype)
+        run['v'] = torch.zeros(self.num_layers, Beff, H, Tmax, hd, device=dev, dtype=self.kv_dtype)
+        if self.has_cross_attention:
+            run['ck'] = torch.zeros(self.num_layers, Beff, H, max(Lc, 1), hd, device=dev, dtype=self.kv_dtype)
+            run['cv'] = torch.zeros(self.num_layers, Beff, H, max(Lc, 1), hd, device=dev, dtype=self.kv_dtype)
+        for li in range(self.num_layers):
+            L = pk['layers'][li]
+            L.k_cache, L.v_cache = run['k'][li].data_ptr(), run['v'][li].data_ptr()
+            if self.has_cross_attention:
+                L.ck_cache, L.cv_cache = run['ck'][li].data_ptr(), run['cv'][li].data_ptr()
+        run['x'] = torch.zeros(Beff, d, **f32)
+        run['q'] = torch.zeros(Beff, d, **f32)
+        run['att'] = torch.zeros(Beff, d, **f32)
+        hdt = torch.bfloat16 if self.weight_dtype == torch.bfloat16 else torch.float32
+        run['hidden'] = torch.zeros(Beff, self.ffn_dim, device=dev, dtype=hdt)
+        run['logits'] = torch.zeros(Beff, self.n_q * self.card, **f32)
+        run['step_logits'] = torch.zeros(B, self.n_q, self.card, **f32)
+        run['pos'] = torch.zeros(4, device=dev, dtype=torch.int32)
+        run['gen_sequence'] = torch.zeros(B, self.n_q, S, device=dev, dtype=torch.int64)
+        run['seq_mask'] = torch.zeros(self.n_q, S, device=dev, dtype=torch.uint8)
+        self._run = run
+        return run
+
+    def _make_state(self, run, B, use_cfg, Tmax, Lc, S, prepend, record_logits, use_sampling, temp, top_k, top_p,
+                    cfg_coef, seed) -> _C.LMState:
+        st = _C.LMState()
+        st.Beff, st.B, st.use_cfg, st.Tmax, st.Lc = run['Beff'], B, int(use_cfg), Tmax, Lc
+        st.n_prepend = 0 if prepend is None else prepend.shape[1]
+        st.S = S
+        st.gen_sequence, st.seq_mask = run['gen_sequence'].data_ptr(), run['seq_mask'].data_ptr()
+        st.prepend = None if prepend is None else prepend.data_ptr()
+        st.pos = run['pos'].data_ptr()
+        st.x, st.q, st.att = run['x'].data_ptr(), run['q'].data_ptr(), run['att'].data_ptr()
+        st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
+        st.step_logits = run['step_logits'].data_ptr() if record_logits else None
+        st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)
+        st.cfg_coef, st.seed = float(cfg_coef), int(seed) & ((1 << 64) - 1)
+        return st
+
+    def _project_cross_kv(self, run, cross_src: torch.Tensor):
+        """K/V projection of the cross-attention source, once per generate (vs. every step in the
+        reference, transformer.py:344-361).  cross_src [Beff, Lc, d] f32."""
+        pk = self._packed
+        Beff, Lc, d = cross_src.shape
+        flat = cross_src.reshape(Beff * Lc, d).contiguous()
+        tmp = torch.empty(Beff * Lc, d, device=flat.device, dtype=torch.float32)
+        for li in range(self.num_layers):
+            ent = pk['per_layer'][li]
+            _C.linear(flat, ent['w_ck'], tmp)
+            _C.kv_store(tmp.view(Beff, Lc, d), run['ck'][li], 0)
+            _C.linear(flat, ent['w_cv'], tmp)
+            _C.kv_store(tmp.view(Beff, Lc, d), run['cv'][li], 0)
+
+    # ------------------------------------------------------------------------------------- conditions
+    def _cfg_condition_tensors(self, conditions: tp.List[ConditioningAttributes]) -> ConditionTensors:
+        """conditions + null conditions, batched as [cond; uncond] (lm.py:497-509)."""
+        null_conditions = ClassifierFreeGuidanceDropout(p=1.0)(conditions)
+        conditions = conditions + null_conditions
+        tokenized = self.condition_provider.tokenize(conditions)
+        return self.condition_provider(tokenized)
+
+    # ------------------------------------------------------------------------------------- generate
+    @torch.no_grad()
+    def generate(self,
+                 prompt: tp.Optional[torch.Tensor] = None,
+                 conditions: tp.List[ConditioningAttributes] = [],
+                 num_samples: tp.Optional[int] = None,
+                 max_gen_len: int = 256,
+                 use_sampling: bool = True,
+                 temp: float = 1.0,
+                 top_k: int = 250,
+                 top_p: float = 0.0,
+                 cfg_coef: tp.Optional[float] = None,
+                 cfg_coef_beta: tp.Optional[float] = None,
+                 two_step_cfg: tp.Optional[bool] = None,
+                 remove_prompts: bool = False,
+                 check: bool = False,
+                 callback: tp.Optional[tp.Callable[[int, int], None]] = None,
+                 condition_tensors: tp.Optional[ConditionTensors] = None,
+                 seed: tp.Optional[int] = None,
+                 return_logits: bool = False,
+                 use_graph: bool = True,
+                 ) -> torch.Tensor:
+        """Same contract as the reference `LMModel.generate` (lm.py:420-587) -> LongTensor [B, K, T].
+
+        Extra keyword-only conveniences (not in the reference): `condition_tensors` (already batched
+        `[cond; uncond]` output of the condition provider -- the multi-GPU path broadcasts these),
+        `seed` (device Philox stream; default drawn from torch's global generator), `return_logits`
+        (also return the CFG-mixed logits of every step, [B, K, steps, card]) and `use_graph`.
+        """
+        assert not self.training, "generation shouldn't be used in training mode."
+        if cfg_coef_beta is not None:
+            raise NotImplementedError("double CFG (cfg_coef_beta, MusicGen-Style) is a 'next' row")
+        if two_step_cfg or (two_step_cfg is None and self.two_step_cfg):
+            raise NotImplementedError("two_step_cfg is a 'next' row")
+        dev = self.device
+        if num_samples is None:
+            if prompt is not None:
+                num_samples = prompt.shape[0]
+            elif conditions:
+                num_samples = len(conditions)
+            elif condition_tensors:
+                num_samples = next(iter(condition_tensors.values()))[0].shape[0] // 2
+            else:
+                num_samples = 1
+        cfg_conditions: ConditionTensors = {}
+        if condition_tensors is not None:
+            assert not conditions, "Shouldn't pass both conditions and condition_tensors."
+            cfg_conditions = condition_tensors
+        elif conditions:
+            cfg_conditions = self._cfg_condition_tensors(conditions)
+        use_cfg = bool(cfg_conditions)
+        coef = self.cfg_coef if cfg_coef is None else cfg_coef
+
+        if prompt is None:
+            assert num_samples > 0
+            prompt = torch.zeros((num_samples, self.num_codebooks, 0), dtype=torch.long, device=dev)
+        prompt = prompt.to(dev)
+        B, K, T0 = prompt.shape
+        assert K == self.n_q
+        start_offset = T0
+        assert start_offset < max_gen_len
+
+        pattern = self.pattern_provider.get_pattern(max_gen_len)
+        unknown_token = -1
+        gen_codes = torch.full((B, K, max_gen_len), unknown_token, dtype=torch.long, device=dev)
+        gen_codes[..., :start_offset] = prompt
+        gen_sequence, _, mask = pattern.build_pattern_sequence(gen_codes, self.special_token_id)
+        start_offset_sequence = pattern.get_first_step_with_timesteps(start_offset)
+        assert start_offset_sequence is not None
+        S = gen_sequence.shape[-1]
+
+        # fuse conditions: what is prepended to the token stream, what is cross-attended to
+        prepend, cross_src = self.fuser.fuse(cfg_conditions)
+        if self.has_cross_attention:
+            assert cross_src is not None, "this model cross-attends to a condition but none was given"
+        else:
+            assert cross_src is None, "this model has no cross-attention layers"
+        P = 0 if prepend is None else prepend.shape[1]
+        Lc = 0 if cross_src is None else cross_src.shape[1]
+        Tmax = P + S  # positions g = 0 .. P + S - 2 are ever run
+
+        run = self._prepare_run(B, use_cfg, Tmax, Lc, S)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if prepend is not None:
+            prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
+        state = self._make_state(run, B, use_cfg, Tmax, Lc, S, prepend, return_logits, use_sampling, temp, top_k,
+                                 top_p, coef, seed)
+        desc = self._packed['desc']
+        run['gen_sequence'].copy_(gen_sequence)
+        run['seq_mask'].copy_(mask.to(torch.uint8))
+        run['pos'].zero_()
+        if cross_src is not None:
+            self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
+
+        # ---- prefill: prepended condition rows and prompt steps, position by position, no sampling
+        n_prefill = P + start_offset_sequence - 1
+        for _ in range(n_prefill):
+            _C.lm_step(desc, state, _C.STEP_PREFILL)
+
+        # ---- decode: one hipGraph replay per position
+        n_steps = S - start_offset_sequence
+        all_logits = []
+        graph = None
+        if use_graph and n_steps > 2:
+            graph = self._capture(desc, state)
+        for i in range(n_steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                _C.lm_step(desc, state, _C.STEP_DECODE)
+            if return_logits:
+                all_logits.append(run['step_logits'].clone())
+            if callback is not None:
+                callback(1 + i, n_steps)
+        gen_sequence = run['gen_sequence'].clone()
+
+        if check:
+            assert not (gen_sequence == unknown_token).any()
+            assert (gen_sequence == torch.where(mask[None, ...].expand(B, -1, -1), gen_sequence,
+                                                self.special_token_id)).all()
+        out_codes, _, out_mask = pattern.revert_pattern_sequence(gen_sequence, special_token=unknown_token)
+        out_start_offset = start_offset if remove_prompts else 0
+        out_codes = out_codes[..., out_start_offset:max_gen_len]
+        if check:
+            assert (out_mask[..., :max_gen_len] == 1).all()
+            assert (out_codes >= 0).all() and (out_codes <= self.card).all()
+        if return_logits:
+            return out_codes, torch.stack(all_logits, dim=2)
+        return out_codes
+
+    def _capture(self, desc, state):
+        """Capture one decode position into a hipGraph (torch.cuda.CUDAGraph is only the capture/replay
+        plumbing; every node is an acmi kernel).  Device-side position counter => replayable."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            g.capture_begin()
+            _C.lm_step(desc, state, _C.STEP_DECODE)
+            g.capture_end()
+        torch.cuda.current_stream().wait_stream(s)
+        self._graph_keepalive = (g, desc, state)
+        return g
+
+    # ------------------------------------------------------------------------------------- teacher forcing
+    @torch.no_grad()
+    def forward_steps(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
+        """Teacher-forced streaming forward for parity tests: runs the pattern `sequence` [B, K, S]
+        through the decode step one position at a time (no CFG mixing: rows are taken as given) and
+        returns logits [B, K, S, card] like `LMModel.forward` (lm.py:221-268)."""
+        dev = self.device
+        B, K, S = sequence.shape
+        prepend, cross_src = self.fuser.fuse(condition_tensors)
+        P = 0 if prepend is None else prepend.shape[1]
+        Lc = 0 if cross_src is None else cross_src.shape[1]
+        run = self._prepare_run(B, False, P + S + 1, Lc, S + 1)
+        if prepend is not None:
+            prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
+        state = self._make_state(run, B, False, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
+        desc = self._packed['desc']
+        seq = torch.full((B, K, S + 1), -1, dtype=torch.long, device=dev)
+        seq[..., :S] = sequence.to(dev)
+        run['gen_sequence'].copy_(seq)
+        run['seq_mask'].fill_(1)
+        run['pos'].zero_()
+        if cross_src is not None:
+            self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
+        for _ in range(P):
+            _C.lm_step(desc, state, _C.STEP_PREFILL)
+        outs = []
+        for i in range(S):
+            _C.lm_step(desc, state, _C.STEP_DECODE)
+            outs.append(run['step_logits'].clone())  # the sampler only writes slots still at -1
+        return torch.stack(outs, dim=2)

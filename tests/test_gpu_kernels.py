@@ -1,0 +1,255 @@
+"""-m gpu: every HIP kernel, called through the C ABI (ctypes), against the CPU oracle on seeded inputs.
+
+Tolerances (stated per test): integer outputs bit-exact; f32 kernels within f32 round-off of a
+differently ordered summation; bf16 weight/KV paths within bf16 quantisation of the operands.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import codec as ocodec  # noqa: E402
+from oracle import lm as olm  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def C():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from audiocraft_amd import _C
+    return _C
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------ RVQ
+
+@pytest.mark.parametrize('B,D,T,K,bins', [(2, 128, 333, 4, 2048), (1, 128, 50, 32, 1024), (3, 16, 7, 4, 32),
+                                           (1, 128, 1, 4, 2048), (8, 128, 1500, 4, 2048)])
+def test_rvq_encode_bit_exact(C, B, D, T, K, bins):
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    cb = (torch.rand(K, bins, D, generator=g) * 2 - 1) * math.sqrt(3.0 / D)  # kaiming-uniform like core_vq.py:36-39
+    x = torch.randn(B, D, T, generator=g)
+    ref = ocodec.rvq_encode(x, cb)
+    cbd = cb.cuda()
+    got = C.rvq_encode(x.cuda(), cbd, C.rvq_codebook_norms(cbd), K).cpu()
+    assert got.dtype == torch.int64 and got.shape == ref.shape
+    mism = (got != ref).sum().item()
+    assert mism == 0, f"{mism}/{ref.numel()} codes differ"
+
+
+def test_rvq_encode_empty(C):
+    cb = torch.randn(4, 32, 16).cuda()
+    got = C.rvq_encode(torch.zeros(2, 16, 0).cuda(), cb, C.rvq_codebook_norms(cb), 4)
+    assert got.shape == (2, 4, 0)
+
+
+@pytest.mark.parametrize('B,D,T,K,bins', [(2, 128, 333, 4, 2048), (1, 16, 5, 8, 16)])
+def test_rvq_decode_exact(C, B, D, T, K, bins):
+    g = torch.Generator().manual_seed(7)
+    cb = torch.randn(K, bins, D, generator=g)
+    codes = torch.randint(0, bins, (B, K, T), generator=g)
+    ref = ocodec.rvq_decode(codes, cb)
+    got = C.rvq_decode(codes.cuda(), cb.cuda()).cpu()
+    assert torch.equal(got, ref)  # same summation order => bit exact
+
+
+def test_rvq_encode_decode_roundtrip_reduces_error(C):
+    """size-independent property at the BASELINE.json size: each extra level reduces the residual."""
+    g = torch.Generator().manual_seed(3)
+    cb = (torch.rand(4, 2048, 128, generator=g) * 2 - 1).cuda()
+    x = torch.randn(8, 128, 1500, generator=g).cuda()
+    norms = C.rvq_codebook_norms(cb)
+    codes = C.rvq_encode(x, cb, norms, 4)
+    errs = []
+    for k in range(1, 5):
+        errs.append((x - C.rvq_decode(codes[:, :k].contiguous(), cb[:k].contiguous())).norm().item())
+    assert errs[0] > errs[1] > errs[2] > errs[3]
+
+
+# ------------------------------------------------------------------------------------------ conv
+
+def _run_conv(C, x, w, b, stride, dilation, causal, pad_mode, elu, residual=None):
+    from audiocraft_amd.modules.seanet import StreamableConv1d
+    m = StreamableConv1d(w.shape[1], w.shape[0], w.shape[2], stride=stride, dilation=dilation, causal=causal,
+                         norm='none', pad_mode=pad_mode, device='cuda')
+    with torch.no_grad():
+        m.conv.conv.weight.copy_(w)
+        m.conv.conv.bias.copy_(b)
+    return m.run(x.cuda().contiguous(), elu_alpha=1.0 if elu else None,
+                 residual=None if residual is None else residual.cuda()).cpu()
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, dil, causal, pad, T
+    (1, 64, 7, 1, 1, False, 'constant', 1000),
+    (64, 32, 3, 1, 1, False, 'constant', 517),
+    (32, 64, 1, 1, 1, False, 'constant', 517),
+    (64, 128, 8, 4, 1, False, 'constant', 1003),
+    (128, 256, 10, 5, 1, False, 'constant', 400),
+    (256, 512, 16, 8, 1, False, 'constant', 203),
+    (32, 64, 4, 2, 1, True, 'constant', 101),
+    (16, 16, 3, 1, 2, False, 'reflect', 300),
+    (16, 16, 3, 1, 4, True, 'reflect', 77),
+    (8, 8, 7, 1, 1, False, 'reflect', 3),      # shorter than the padding: pad1d's zero-extension rule
+    (64, 1, 7, 1, 1, False, 'constant', 640),
+    (1024, 128, 7, 1, 1, False, 'constant', 50),
+    (128, 1024, 7, 1, 1, True, 'constant', 75),
+]
+
+
+@pytest.mark.parametrize('Cin,Cout,k,stride,dil,causal,pad,T', CONV_CASES)
+@pytest.mark.parametrize('elu', [False, True])
+def test_conv1d_vs_oracle(C, Cin, Cout, k, stride, dil, causal, pad, T, elu):
+    g = torch.Generator().manual_seed(Cin * 31 + T)
+    B = 2
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g) * 0.1
+    xin = F.elu(x) if elu else x
+    ref = ocodec.streamable_conv1d(xin, w, b, stride, dil, causal, pad)
+    res = torch.randn(ref.shape, generator=g)
+    got = _run_conv(C, x, w, b, stride, dil, causal, pad, elu, residual=res)
+    assert got.shape == ref.shape
+    err = (got - (ref + res)).abs().max().item()
+    assert err < 2e-5, f"max abs err {err}"  # f32 accumulate, different summation order than oneDNN
+
+
+@pytest.mark.parametrize('Cin,Cout,k,stride,causal,trr,T', [
+    (1024, 512, 16, 8, False, 1.0, 50), (512, 256, 10, 5, False, 1.0, 123), (256, 128, 8, 4, False, 1.0, 77),
+    (128, 64, 8, 4, True, 1.0, 201), (32, 16, 4, 2, True, 0.5, 33), (16, 8, 7, 3, False, 1.0, 20), (8, 4, 4, 2, True, 0.0, 1)])
+def test_convtr1d_vs_oracle(C, Cin, Cout, k, stride, causal, trr, T):
+    from audiocraft_amd.modules.seanet import StreamableConvTranspose1d
+    g = torch.Generator().manual_seed(Cin + T)
+    x = torch.randn(2, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, k, generator=g) / math.sqrt(Cin * k / stride)
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = ocodec.streamable_convtr1d(F.elu(x), w, b, stride, causal, trr)
+    m = StreamableConvTranspose1d(Cin, Cout, k, stride, causal=causal, norm='none', trim_right_ratio=trr, device='cuda')
+    with torch.no_grad():
+        m.convtr.convtr.weight.copy_(w)
+        m.convtr.convtr.bias.copy_(b)
+    got = m.run(x.cuda(), elu_alpha=1.0).cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5, f"max abs err {err}"
+
+
+@pytest.mark.parametrize('B,H,T,layers', [(2, 32, 17, 2), (8, 1024, 20, 2), (3, 64, 5, 1), (11, 128, 9, 2)])
+def test_lstm_vs_oracle(C, B, H, T, layers):
+    from audiocraft_amd.modules.seanet import StreamableLSTM
+    g = torch.Generator().manual_seed(H + T)
+    m = StreamableLSTM(H, layers, device='cuda')
+    sd = {}
+    for k_, p in m.lstm.named_parameters():
+        with torch.no_grad():
+            p.copy_(torch.empty_like(p).cpu().uniform_(-1 / math.sqrt(H), 1 / math.sqrt(H), generator=g))
+        sd['l.lstm.' + k_] = p.detach().cpu()
+    x = torch.randn(B, H, T, generator=g)
+    ref = ocodec.lstm_stack(x, sd, 'l.lstm', layers)
+    got = m.run(x.cuda()).cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5, f"max abs err {err}"
+
+
+# ------------------------------------------------------------------------------------------ LM operators
+
+@pytest.mark.parametrize('M,N,K', [(16, 4608, 1536), (2, 3072, 1024), (16, 1536, 6144), (32, 1536, 1536),
+                                    (5, 96, 32), (16, 8192, 1536), (7, 40, 24), (40, 2048, 2048)])
+@pytest.mark.parametrize('wdt', ['f32', 'bf16'])
+@pytest.mark.parametrize('ln', [False, True])
+def test_linear_vs_torch(C, M, N, K, wdt, ln):
+    if ln and K > 2048:
+        pytest.skip("LayerNorm-fused inputs are model-dim sized")
+    g = torch.Generator().manual_seed(M * N + K)
+    a = torch.randn(M, K, generator=g) * 1.5 + 0.3
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    gam = 1 + 0.1 * torch.randn(K, generator=g)
+    bet = 0.1 * torch.randn(K, generator=g)
+    bias = 0.1 * torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    wq = w.bfloat16() if wdt == 'bf16' else w
+    xin = F.layer_norm(a, (K,), gam, bet, 1e-5) if ln else a
+    ref = F.gelu(xin.double() @ wq.double().t() + bias.double()).float() + res
+    out = torch.empty(M, N, device='cuda')
+    C.linear(a.cuda(), wq.cuda(), out, ln_g=gam.cuda() if ln else None, ln_b=bet.cuda() if ln else None,
+             bias=bias.cuda(), residual=res.cuda(), act=1)
+    r = rel(out.cpu(), ref)
+    # f32: exact-f32 MFMA chain; bf16: activations rounded to bf16 (2^-9 relative per element)
+    tol = 2e-6 if wdt == 'f32' else 4e-3
+    assert r < tol, f"rel-L2 {r}"
+
+
+@pytest.mark.parametrize('Beff,H,hd,Tcap,length', [(16, 24, 64, 1504, 1503), (2, 16, 64, 600, 1), (4, 4, 8, 40, 13),
+                                                    (3, 2, 16, 100, 100), (2, 2, 32, 70, 65), (2, 3, 128, 300, 257)])
+@pytest.mark.parametrize('kvdt', [torch.float32, torch.bfloat16])
+def test_attn_decode_vs_oracle(C, Beff, H, hd, Tcap, length, kvdt):
+    g = torch.Generator().manual_seed(Tcap + length)
+    q = torch.randn(Beff, H * hd, generator=g)
+    k = torch.randn(Beff, H, Tcap, hd, generator=g).to(kvdt)
+    v = torch.randn(Beff, H, Tcap, hd, generator=g).to(kvdt)
+    ref = olm._attention(q.view(Beff, H, 1, hd), k[:, :, :length].float(), v[:, :, :length].float(), False)
+    ref = ref.transpose(1, 2).reshape(Beff, H * hd)
+    out = torch.empty(Beff, H * hd, device='cuda')
+    C.attn_decode(q.cuda(), k.cuda(), v.cuda(), out, length)
+    assert rel(out.cpu(), ref) < 2e-6
+    # device-side length
+    ld = torch.tensor([length - 1, 0, 0, 0], dtype=torch.int32, device='cuda')
+    out2 = torch.empty_like(out)
+    C.attn_decode(q.cuda(), k.cuda(), v.cuda(), out2, 0, len_dev=ld, len_bias=1)
+    assert torch.equal(out, out2)
+
+
+def test_sample_greedy_and_cfg(C):
+    g = torch.Generator().manual_seed(0)
+    B, K, card = 3, 4, 2048
+    logits = torch.randn(2 * B, K * card, generator=g)
+    toks, mixed = C.sample(logits.cuda(), B, K, card, True, 3.0, False, 1.0, 0, 0.0, 0, 0, want_mixed=True)
+    ref_mixed = olm.cfg_mix(logits.view(2 * B, K, card), 3.0)
+    assert torch.equal(mixed.cpu(), ref_mixed)
+    assert torch.equal(toks.cpu(), ref_mixed.argmax(-1))
+
+
+def test_sample_topk_support_and_distribution(C):
+    """Sampled tokens always lie in the reference's top-k support (ties kept, utils.py:117-120) and
+    their empirical distribution matches the renormalised top-k probabilities (chi-square)."""
+    g = torch.Generator().manual_seed(1)
+    B, K, card, k = 1, 1, 64, 5
+    logits = torch.randn(1, card, generator=g) * 2
+    logits[0, 7] = logits[0].topk(k)[0][-1]  # force a tie at the k-th value
+    probs = olm.top_k_filter(torch.softmax(logits.view(1, 1, card), -1), k)[0, 0]
+    support = probs > 0
+    assert support.sum() == k + 1
+    n = 4000
+    counts = torch.zeros(card)
+    lg = logits.cuda()
+    for step in range(n):
+        t, _ = C.sample(lg, B, K, card, False, 1.0, True, 1.0, k, 0.0, 1234, step)
+        counts[t.item()] += 1
+    assert counts[~support].sum() == 0
+    exp = probs[support] * n
+    chi2 = ((counts[support] - exp) ** 2 / exp).sum().item()
+    assert chi2 < 30, f"chi2={chi2} (df={int(support.sum()) - 1})"
+    # same (seed, step) => same draw
+    a, _ = C.sample(lg, B, K, card, False, 1.0, True, 1.0, k, 0.0, 99, 5)
+    b, _ = C.sample(lg, B, K, card, False, 1.0, True, 1.0, k, 0.0, 99, 5)
+    assert torch.equal(a, b)
+
+
+def test_sample_top_p_support(C):
+    g = torch.Generator().manual_seed(2)
+    card = 128
+    logits = torch.randn(1, card, generator=g) * 3
+    probs = torch.softmax(logits.view(1, 1, card), -1)
+    ps, pi = olm.top_p_filter(probs, 0.7)
+    support = torch.zeros(card, dtype=torch.bool)
+    support[pi[0, 0][ps[0, 0] > 0]] = True
+    lg = logits.cuda()
+    for step in range(300):
+        t, _ = C.sample(lg, 1, 1, card, False, 1.0, True, 1.0, 0, 0.7, 5, step)
+        assert support[t.item()]

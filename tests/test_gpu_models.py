@@ -1,0 +1,212 @@
+"""-m gpu: the product classes (EncodecModel / LMModel on HIP kernels) against
+(a) the committed golden vectors of the unmodified reference and (b) the CPU oracle at larger seeded sizes."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from oracle import codec as ocodec  # noqa: E402
+from oracle import lm as olm  # noqa: E402
+from test_oracle_golden import codec_cfg, lm_cfg  # noqa: E402
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def build_codec(cfg, sd):
+    from audiocraft_amd.models import builders
+    sk = dict(channels=cfg['channels'], dimension=cfg['dimension'], n_filters=cfg['n_filters'],
+              n_residual_layers=cfg['n_residual_layers'], ratios=cfg['ratios'], activation='ELU',
+              activation_params={'alpha': cfg['elu_alpha']}, norm=cfg['norm'], norm_params={},
+              kernel_size=cfg['kernel_size'], residual_kernel_size=cfg['residual_kernel_size'],
+              last_kernel_size=cfg['last_kernel_size'], dilation_base=cfg['dilation_base'], causal=cfg['causal'],
+              pad_mode=cfg['pad_mode'], true_skip=cfg['true_skip'], compress=cfg['compress'], lstm=cfg['lstm'],
+              disable_norm_outer_blocks=0)
+    m = builders.get_compression_model(dict(seanet=sk, rvq=dict(n_q=cfg['n_q'], bins=cfg['bins']),
+                                            sample_rate=cfg['sample_rate'], frame_rate=cfg['frame_rate'],
+                                            channels=cfg['channels'], causal=cfg['causal'],
+                                            renormalize=cfg['renormalize'],
+                                            trim_right_ratio=cfg['trim_right_ratio']), 'cuda')
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    return m
+
+
+@pytest.mark.parametrize('name', ['codec_noncausal', 'codec_causal', 'codec_renorm'])
+def test_encodec_vs_reference_golden(name):
+    cfg, sd, a = load_golden(name)
+    m = build_codec(cfg, sd)
+    wav = a['wav'].cuda()
+    x, _ = m.preprocess(wav)
+    lat = m.encoder(x).cpu()
+    assert lat.shape == a['latents'].shape
+    assert torch.allclose(lat, a['latents'], atol=3e-5, rtol=1e-4), (lat - a['latents']).abs().max()
+    # hard gate: RVQ on the reference's own latents is bit exact
+    codes = m.quantizer.encode(a['latents'].cuda()).cpu()
+    assert torch.equal(codes, a['codes'])
+    # end to end encode: report agreement (a flip needs a near-tie in the oracle)
+    codes2, scale = m.encode(wav)
+    agree = (codes2.cpu() == a['codes']).float().mean().item()
+    assert agree > 0.97, f"end-to-end code agreement {agree}"
+    assert torch.equal(m.decode_latent(a['codes'].cuda()).cpu(), a['quantized_latents'])
+    dec = m.decode(a['codes'].cuda(), None if 'scale' not in a else a['scale'].cuda()).cpu()
+    assert dec.shape == a['decoded'].shape
+    err = (dec - a['decoded']).abs().max().item()
+    assert err < 1e-4, f"waveform max abs err {err}"   # BASELINE.md section 4 gate
+    out = m(wav)
+    assert out.x.shape == wav.shape and out.codes.shape == a['codes'].shape
+
+
+def test_encodec_32khz_geometry_vs_oracle():
+    """facebook/encodec_32khz architecture, seeded random weights, 1.3 s of audio, vs the CPU oracle."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(0)
+    m = builders.get_compression_model(builders.ENCODEC_32KHZ, 'cuda')
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    c = ocodec.CodecConfig(channels=1, dimension=128, n_filters=64, n_residual_layers=1, ratios=[8, 5, 4, 4],
+                           causal=False, pad_mode='constant', lstm=2, norm='weight_norm', n_q=4, bins=2048,
+                           sample_rate=32000, frame_rate=50)
+    wav = 0.3 * torch.randn(2, 1, 41611, generator=torch.Generator().manual_seed(1))
+    lat_ref = ocodec.seanet_encoder(sd, c, wav, fast_lstm=True)
+    lat = m.encoder(wav.cuda()).cpu()
+    assert lat.shape == lat_ref.shape == (2, 128, math.ceil(41611 / 640))
+    assert rel(lat, lat_ref) < 2e-5
+    codes_ref = ocodec.rvq_encode(lat_ref, ocodec.codebooks_from_state(sd, 4))
+    assert torch.equal(m.quantizer.encode(lat_ref.cuda()).cpu(), codes_ref)   # identical latents: bit exact
+    codes, _ = m.encode(wav.cuda())
+    assert (codes.cpu() == codes_ref).float().mean() > 0.97
+    dec_ref = ocodec.encodec_decode(sd, c, codes_ref, fast_lstm=True)
+    dec = m.decode(codes_ref.cuda()).cpu()
+    assert dec.shape == dec_ref.shape
+    assert (dec - dec_ref).abs().max().item() < 1e-4
+
+
+def test_encodec_random_lengths_roundtrip_shapes():
+    """reference tests/models/test_encodec_model.py:37-46"""
+    from audiocraft_amd.models import builders
+    m = builders.get_debug_compression_model('cuda')
+    g = torch.Generator().manual_seed(0)
+    for _ in range(6):
+        length = int(torch.randint(1, 10000, (1,), generator=g))
+        x = torch.randn(2, 1, length).cuda()
+        res = m(x)
+        assert res.x.shape == x.shape
+        codes, scale = m.encode(x)
+        assert codes.shape[:2] == (2, 4) and scale is None
+        assert m.decode(codes).shape[-1] >= length
+
+
+# ------------------------------------------------------------------------------------------ LM
+
+def build_lm(cfg, sd, weight_dtype=torch.float32):
+    from audiocraft_amd.models import builders
+    conds = {'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': cfg['cond_dim'], 'length': cfg['Lc']}}
+    fuser = {'cross': ['description']} if cfg['cross_attention'] else {'prepend': ['self_wav', 'description']}
+    if not cfg['cross_attention']:
+        conds['self_wav'] = {'kind': 'chroma', 'embedder': 'synthetic', 'n_frames': cfg['P']}
+    lm = builders.get_lm_model(dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'],
+                                    n_q=cfg['n_q'], card=cfg['card'], hidden_scale=cfg['hidden_scale'],
+                                    cfg_coef=cfg['cfg_coef'], conditioners=conds, fuser=fuser,
+                                    codebooks_pattern={'modeling': 'delay', 'delay': {'delays': cfg['delays']}}),
+                               'cuda', weight_dtype)
+    missing = lm.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    assert all('self_wav' in k for k in missing.missing_keys), missing.missing_keys
+    return lm
+
+
+def test_lm_text_vs_reference_golden():
+    cfg, sd, a = load_golden('lm_text')
+    lm = build_lm(cfg, sd)
+    ones = torch.ones(a['cross_src'].shape[:2], dtype=torch.int64)
+    ct = {'description': (a['cross_src'].cuda(), ones.cuda())}
+    # teacher forced streaming logits == reference batch forward (streaming == batch invariant)
+    logits = lm.forward_steps(a['tf_sequence'].cuda(), ct).cpu()
+    assert logits.shape == a['tf_logits'].shape
+    r = rel(logits, a['tf_logits'])
+    assert r < 1e-4, f"logits rel-L2 {r}"     # BASELINE.md section 4 gate (fp32 mode)
+    # greedy generation: identical tokens, per-step CFG logits within tolerance
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
+    # continuation from a 3 step prompt
+    toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=10, use_sampling=False, condition_tensors=ct, check=True)
+    assert torch.equal(toks.cpu(), a['cont_tokens'])
+    toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=10, use_sampling=False, condition_tensors=ct,
+                       remove_prompts=True)
+    assert torch.equal(toks.cpu(), a['cont_tokens_removed'])
+    # graph replay and eager launches agree bit for bit
+    t1 = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct, use_graph=False)
+    assert torch.equal(t1.cpu(), a['greedy_tokens'])
+
+
+def test_lm_melody_vs_reference_golden():
+    cfg, sd, a = load_golden('lm_melody')
+    lm = build_lm(cfg, sd)
+    P, Lc = cfg['P'], cfg['Lc']
+    pre = a['prepend_src'].cuda()
+    ct = {'description': (pre[:, P:], torch.ones(pre.shape[0], Lc, dtype=torch.int64).cuda()),
+          'self_wav': (pre[:, :P], torch.ones(pre.shape[0], P, dtype=torch.int64).cuda())}
+    toks, lg = lm.generate(None, [], num_samples=2, max_gen_len=9, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
+
+
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_lm_midsize_vs_oracle(wdt, tol):
+    """d=256, 4 layers, card 2048, cross attention: teacher-forced logits + greedy tokens vs the oracle."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(0)
+    cfg = dict(dim=256, num_heads=4, num_layers=4, n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0,
+               conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 64, 'length': 6}},
+               fuser={'cross': ['description']})
+    lm = builders.get_lm_model(cfg, 'cuda', wdt)
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            if 'norm' in k:
+                p.add_(0.1 * torch.randn_like(p))
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    if wdt == torch.bfloat16:   # the oracle sees the same bf16-rounded matrices; activations stay f32 there
+        sd = {k: (v.bfloat16().float() if v.dim() == 2 and 'output_proj' not in k else v) for k, v in sd.items()}
+    oc = olm.LMConfig(dim=256, num_heads=4, num_layers=4, n_q=4, card=2048, cross_attention=True)
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    cross = torch.randn(2 * B, 6, 256, generator=g)
+    cross[B:] = 0
+    ct = {'description': (cross.cuda(), torch.ones(2 * B, 6, dtype=torch.int64).cuda())}
+    seq = torch.randint(0, 2049, (2 * B, 4, 20), generator=g)
+    ref = olm.lm_forward(sd, oc, seq, cross)
+    got = lm.forward_steps(seq.cuda(), ct).cpu()
+    r = rel(got, ref)
+    assert r < tol, f"teacher-forced logits rel-L2 {r} (tol {tol})"
+    if wdt == torch.float32:
+        toks = lm.generate(None, [], num_samples=B, max_gen_len=16, use_sampling=False, condition_tensors=ct)
+        ref_t = olm.generate(sd, oc, None, B, cross, max_gen_len=16, use_sampling=False)
+        assert torch.equal(toks.cpu(), ref_t)
+
+
+def test_lm_sampling_generate_is_well_formed():
+    from audiocraft_amd.models import builders
+    lm = builders.get_debug_lm_model('cuda')
+    from audiocraft_amd.modules.conditioners import ConditioningAttributes
+    conds = [ConditioningAttributes(text={'description': 'a b c'}), ConditioningAttributes(text={'description': None})]
+    calls = []
+    toks = lm.generate(None, conds, max_gen_len=30, use_sampling=True, top_k=50, seed=1, check=True,
+                       callback=lambda i, n: calls.append((i, n)))
+    assert toks.shape == (2, 4, 30) and toks.min() >= 0 and toks.max() < 400
+    assert calls[0] == (1, 33) and calls[-1] == (33, 33)
+    toks2 = lm.generate(None, conds, max_gen_len=30, use_sampling=True, top_k=50, seed=1)
+    assert torch.equal(toks, toks2)
+    toks3 = lm.generate(None, conds, max_gen_len=30, use_sampling=True, top_k=50, seed=2)
+    assert not torch.equal(toks, toks3)
