@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
 
 class LMLayer(C.Structure):
     _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_ff1', vp), ('w_ff2', vp),
-                ('ln1_g', vp), ('ln1_b', vp), ('lnc_g', vp), ('lnc_b', vp), ('ln2_g', vp), ('ln2_b', vp),
+                ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp)]
 
 
@@ -45,13 +45,13 @@ class LMModelDesc(C.Structure):
     _fields_ = [('dim', i32), ('num_heads', i32), ('num_layers', i32), ('ffn_dim', i32), ('n_q', i32),
                 ('card', i32), ('wdtype', i32), ('kvdtype', i32), ('cross_attention', i32), ('eps', f32),
                 ('positional_scale', f32), ('layers', C.POINTER(LMLayer)), ('emb', C.POINTER(vp)),
-                ('pos_freq', vp), ('out_norm_g', vp), ('out_norm_b', vp), ('w_head', vp)]
+                ('pos_table', vp), ('w_head', vp), ('b_head', vp)]
 
 
 class LMState(C.Structure):
     _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
                 ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
-                ('x', vp), ('q', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
+                ('x', vp), ('q', vp), ('xn', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64)]
 
@@ -73,13 +73,15 @@ _lstm_layer = _sig('acmi_lstm_layer', [vp, vp, vp, vp, vp, i32, i32, i32, vp])
 _lstm_work = _sig('acmi_lstm_work_floats', [i32, i32], C.c_size_t)
 _lm_step = _sig('acmi_lm_step', [C.POINTER(LMModelDesc), C.POINTER(LMState), i32, vp])
 _linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp])
-_attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp])
+_attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
+_pos_table = _sig('acmi_pos_table', [vp, vp, i32, i32, vp])
+_ln_tile = _sig('acmi_ln_tile', [vp, vp, i32, i32, i32, f32, vp])
 _kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, i32, f32, u64, u64, vp])
 
 EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
-           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample']
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile']
 
 
 def version() -> int:
@@ -150,21 +152,90 @@ def lstm_work_floats(B, H) -> int:
     return int(_lstm_work(B, H))
 
 
-def linear(a, w, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, residual=None, act=0):
-    """out[M, N] = LN?(a)[M, K] @ w[N, K]^T (+ residual), see acmi_linear."""
-    M, K = a.shape
-    N = w.shape[0]
-    assert w.shape[1] == K and tuple(out.shape) == (M, N)
-    check(_linear(ptr(a), dtype_code(a.dtype), ptr(ln_g), ptr(ln_b), eps, ptr(w), dtype_code(w.dtype),
-                  ptr(bias), ptr(residual), ptr(out), dtype_code(out.dtype), act, M, N, K, stream()), 'acmi_linear')
+A_ROWMAJOR_F32, A_TILED, A_ROWMAJOR_F32_NORM = 0, 1, 2
+OUT_F32, OUT_BF16, OUT_TILED = 0, 1, 2
+
+
+def _tile_params(dtype: torch.dtype):
+    epl = 8 if dtype == torch.bfloat16 else 4
+    return epl, 4 * epl
+
+
+def tile_matrix(m: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[R, K] -> MFMA fragment order of include/acmi.h ("tiled weight" / "tiled activation"):
+    T[rt][kc][lane = kg*16 + r][j] = m[rt*16 + r][kc*KT + kg*e + j], zero padded to 16 rows / KT columns."""
+    epl, kt = _tile_params(dtype)
+    R, K = m.shape
+    Rp, Kp = -(-R // 16) * 16, -(-K // kt) * kt
+    p = torch.zeros(Rp, Kp, device=m.device, dtype=dtype)
+    p[:R, :K] = m.to(dtype)
+    return p.view(Rp // 16, 16, Kp // kt, 4, epl).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def untile_matrix(t: torch.Tensor, R: int, K: int) -> torch.Tensor:
+    """Inverse of tile_matrix -> [R, K] (same dtype)."""
+    rt, nkc, kg, r16, epl = t.shape
+    return t.permute(0, 3, 1, 2, 4).reshape(rt * 16, nkc * 4 * epl)[:R, :K]
+
+
+class TiledWeight:
+    """nn.Linear weight [N, K] in tiled (B-fragment) order + its logical shape."""
+
+    def __init__(self, w: torch.Tensor, dtype: torch.dtype):
+        self.N, self.K = w.shape
+        self.dtype = dtype
+        self.data = tile_matrix(w.detach(), dtype)
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def nbytes(self):
+        return self.data.numel() * self.data.element_size()
+
+
+def tiled_activation_buffer(M: int, K: int, dtype: torch.dtype, device) -> torch.Tensor:
+    epl, kt = _tile_params(dtype)
+    return torch.zeros(-(-M // 16), -(-K // kt), 4, 16, epl, device=device, dtype=dtype)
+
+
+def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, residual=None, act=0,
+           a_tiled=False, out_mode=None, M=None, standardize=False):
+    """out[M, N] = act(LN?(a)[M, K] @ W[N, K]^T + bias) + residual, see acmi_linear.
+    a: row-major f32 [M, K] (a_tiled=False) or a tiled activation buffer (a_tiled=True, pass M)."""
+    if a_tiled:
+        assert M is not None and a.dtype == w.dtype
+    else:
+        M = a.shape[0]
+        assert a.dtype == torch.float32 and a.shape[1] == w.K
+    if out_mode is None:
+        out_mode = OUT_BF16 if out.dtype == torch.bfloat16 else OUT_F32
+    a_mode = A_TILED if a_tiled else (A_ROWMAJOR_F32_NORM if standardize else A_ROWMAJOR_F32)
+    check(_linear(ptr(a), a_mode, ptr(ln_g), ptr(ln_b), eps, ptr(w.data),
+                  dtype_code(w.dtype), ptr(bias), ptr(residual), ptr(out), out_mode, act, M, w.N, w.K, stream()),
+          'acmi_linear')
     return out
 
 
-def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0):
+def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False):
+    """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True)."""
     Beff, H, Tcap, hd = k_cache.shape
-    check(_attn(ptr(q), ptr(k_cache), ptr(v_cache), dtype_code(k_cache.dtype), ptr(out), Beff, H, hd, Tcap, length,
+    check(_attn(ptr(q), ptr(k_cache), ptr(v_cache), dtype_code(k_cache.dtype), ptr(out),
+                OUT_TILED if out_tiled else OUT_F32, dtype_code(out.dtype), Beff, H, hd, Tcap, length,
                 ptr(len_dev), len_bias, stream()), 'acmi_attn_decode')
     return out
+
+
+def ln_tile(x: torch.Tensor, out: torch.Tensor, eps: float = 1e-5):
+    """x [M, K] f32 -> standardised rows in the tiled activation buffer `out`."""
+    M, K = x.shape
+    check(_ln_tile(ptr(x), ptr(out), dtype_code(out.dtype), M, K, eps, stream()), 'acmi_ln_tile')
+    return out
+
+
+def pos_table(freq: torch.Tensor, T: int, d: int) -> torch.Tensor:
+    table = torch.empty(T, d, device=freq.device, dtype=torch.float32)
+    check(_pos_table(ptr(freq), ptr(table), T, d, stream()), 'acmi_pos_table')
+    return table
 
 
 def kv_store(src, cache, t0):

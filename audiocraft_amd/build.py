@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
     cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-pass-failed', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-o', OUT + '.tmp']
+           '-Wno-pass-failed', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-o', OUT + '.tmp']
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)

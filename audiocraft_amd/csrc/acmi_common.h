@@ -59,6 +59,16 @@ __device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
+// N (= 4 or 8) consecutive elements -> floats
+template <int N, typename T> __device__ __forceinline__ void ldn(const T* p, float (&o)[N]) {
+    if constexpr (N == 8) {
+        ld8(p, o);
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = ld_f32<T>(p + e);
+    }
+}
+
 // ---------------------------------------------------------------- wave / block reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

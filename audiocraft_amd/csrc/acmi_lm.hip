@@ -13,182 +13,225 @@
 #include "acmi_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 // =====================================================================================================
-// skinny GEMM
+// skinny GEMM   out[M,N] = act(LN?(a)[M,K] @ W[N,K]^T + bias) + residual
+//
+// One 16-feature n-tile per workgroup, K split across its (up to 16) waves.  Weights are stored as
+// 1 KB MFMA B-fragments (include/acmi.h "tiled weight"), so each fragment is ONE fully coalesced
+// non-temporal 64 x 16 B load; all of a wave's fragments are in flight before anything else happens.
+// Row-major f32 activations (the residual stream) are staged through LDS once per workgroup -- one
+// wave per row, which is also where LayerNorm runs (two-pass statistics with wave shuffles only) --
+// and read back as A-fragments with ds_read_b128.  Activations produced on the path (attention
+// output, FFN hidden) arrive already in A-fragment order and are loaded like the weights.
+// Cross-wave reduction through LDS in a fixed order (deterministic), then the fused epilogue.
 // =====================================================================================================
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct LinArgs {
-    const void* a; int a_bf16;
-    const float* ln_g; const float* ln_b; float eps;
+    const void* a; int a_tiled;
+    int ln_mode; const float* ln_g; const float* ln_b; float eps;
     const void* w;
     const float* bias;
     const float* residual;
-    void* out; int out_bf16; int act;
+    void* out; int out_mode; int act;
     int M, N, K;
-    int mode;  // 0 plain, 1 QKV scatter
+    int NKC;      // K tiles
+    int NKC_out;  // K tiles of a tiled output (its K is this GEMM's N)
+    int RS;       // LDS row pitch (bytes) of the staged activation
+    int dbg;      // experiment switch (ACMI_DBG env), 0 in production
+    int qkv;      // QKV scatter epilogue
     float* q_out; void* k_cache; void* v_cache; int kv_bf16; int H, hd, Tcap, d; const int* pos;
 };
 
-template <typename WT> struct WTr;
-template <> struct WTr<float> { static constexpr int EPL = 16; };    // elements per lane per super-step (64 B)
-template <> struct WTr<bf16_t> { static constexpr int EPL = 32; };
+template <typename WT> struct WTr { static constexpr int EPL = 16 / (int)sizeof(WT); static constexpr int KT = 4 * EPL; };
 
-template <typename WT>
-__device__ __forceinline__ void load_w(const WT* wrow, int k, int K, bool valid, uint4 (&wv)[4]) {
-    constexpr int EPV = 16 / (int)sizeof(WT);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kk = k + j * EPV;
-        if (valid && kk < K) wv[j] = *reinterpret_cast<const uint4*>(wrow + kk);
-        else wv[j] = make_uint4(0u, 0u, 0u, 0u);
-    }
-}
+__device__ __forceinline__ u32x4 ld_frag_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
-template <int EPL>
-__device__ __forceinline__ void load_a(const void* a, int a_bf16, size_t row_off, int k, int K, bool valid,
-                                       float (&xa)[EPL]) {
-#pragma unroll
-    for (int g = 0; g < EPL / 8; ++g) {
-        const int kk = k + 8 * g;
-        float t[8];
-        if (valid && kk < K) {
-            if (a_bf16) ld8(reinterpret_cast<const bf16_t*>(a) + row_off + kk, t);
-            else ld8(reinterpret_cast<const float*>(a) + row_off + kk, t);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xa[8 * g + e] = t[e];
-    }
+__device__ __forceinline__ void mma_frag(const u32x4& a, const u32x4& b, f32x4& acc, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
-
-// one super-step of MFMAs: acc[16x16] += A[16 x KSS] * W[16 x KSS]^T with the k-permutation
-// "lane (row, kg) owns k0 + kg*EPL + [0, EPL)" applied identically to A and W.
-__device__ __forceinline__ void mma_ss(const float (&xa)[32], const uint4 (&wv)[4], f32x4& acc, bf16_t) {
+__device__ __forceinline__ void mma_frag(const u32x4& a, const u32x4& b, f32x4& acc, float) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        union { uint4 u; bf16x8 v; } A, B;
-        A.u = make_uint4(pack_bf16x2(xa[8 * j + 0], xa[8 * j + 1]), pack_bf16x2(xa[8 * j + 2], xa[8 * j + 3]),
-                         pack_bf16x2(xa[8 * j + 4], xa[8 * j + 5]), pack_bf16x2(xa[8 * j + 6], xa[8 * j + 7]));
-        B.u = wv[j];
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, B.v, acc, 0, 0, 0);
-    }
-}
-__device__ __forceinline__ void mma_ss(const float (&xa)[16], const uint4 (&wv)[4], f32x4& acc, float) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float wf[4] = {__uint_as_float(wv[j].x), __uint_as_float(wv[j].y), __uint_as_float(wv[j].z),
-                             __uint_as_float(wv[j].w)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * j + e], wf[e], acc, 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <typename WT, bool HAS_LN>
-__global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
-    constexpr int EPL = WTr<WT>::EPL;
-    constexpr int KSS = 4 * EPL;
-    constexpr int SSMAX = sizeof(WT) == 2 ? 1 : 2;  // LN path: the wave's slice of the row lives in registers
-    __shared__ float smem[16 * 256 + 16 * 16];
-    float* red = smem;
-    float* stat = smem + 16 * 256;
+// element index of (row, col) inside a tiled activation with `nkc` K tiles
+template <typename WT>
+__device__ __forceinline__ size_t tiled_index(int row, int col, int nkc) {
+    constexpr int EPL = WTr<WT>::EPL, KT = WTr<WT>::KT;
+    const int kc = col / KT, r = col - kc * KT;
+    return ((((size_t)(row >> 4) * nkc + kc) * 64 + (r / EPL) * 16 + (row & 15)) * EPL) + (r % EPL);
+}
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int nl = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int n = n0 + nl;
-    const bool nvalid = n < p.N;
-    const int K = p.K;
-    const int nss = (K + KSS - 1) / KSS;
-    const WT* wrow = reinterpret_cast<const WT*>(p.w) + (size_t)(nvalid ? n : 0) * K;
-    const int tpos = (p.mode == 1) ? *p.pos : 0;
+// Staging of one activation row by one wave: row load (issued by the caller BEFORE the weight fragments:
+// vmcnt retires in order, so the row must not queue behind HBM-latency weight loads), then LayerNorm
+// (ln_mode 1: standardise only -- the affine part is folded into the weights on the host; 2: affine here)
+// and the store to LDS in the weight's element type.
+#define ACMI_STAGE_JMAX 8  // Kpad <= 2048
 
-    for (int m0 = 0; m0 < p.M; m0 += 16) {
-        const int m = m0 + nl;
-        const bool mvalid = m < p.M;
-        const size_t arow = (size_t)(mvalid ? m : 0) * K;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-
-        if (HAS_LN) {
-            uint4 wv[SSMAX][4];
-            float xr[SSMAX][EPL];
+__device__ __forceinline__ void load_row(const float* __restrict__ xrow, int K, int lane, float4 (&v)[ACMI_STAGE_JMAX]) {
 #pragma unroll
-            for (int i = 0; i < SSMAX; ++i) {
-                const int ss = wave + i * nw;
-                const int k = ss * KSS + kg * EPL;
-                load_w<WT>(wrow, k, K, nvalid && ss < nss, wv[i]);
-                load_a<EPL>(p.a, p.a_bf16, arow, k, K, mvalid && ss < nss, xr[i]);
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+        const int k = (lane + 64 * j) * 4;
+        v[j] = (xrow != nullptr && k < K) ? *reinterpret_cast<const float4*>(xrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <typename WT>
+__device__ __forceinline__ void norm_store_row(float4 (&v)[ACMI_STAGE_JMAX], int K, int Kpad, int ln_mode,
+                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                               unsigned char* dst, int lane) {
+    constexpr int JMAX = ACMI_STAGE_JMAX;
+    if (ln_mode != 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        const float mean = wave_sum(s) / (float)K;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            if ((lane + 64 * j) * 4 < K) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
             }
-            // ---- LayerNorm statistics of row m (two pass: mean, then centred second moment)
-            float s = 0.f;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)K + eps);
 #pragma unroll
-            for (int i = 0; i < SSMAX; ++i)
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) s += xr[i][e];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (kg == 0) stat[wave * 16 + nl] = s;
-            __syncthreads();
-            float tot = 0.f;
-            for (int w = 0; w < nw; ++w) tot += stat[w * 16 + nl];
-            const float mean = tot / (float)K;
-            __syncthreads();
-            float s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < SSMAX; ++i) {
-                const int k = (wave + i * nw) * KSS + kg * EPL;
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const float dlt = xr[i][e] - mean;
-                    s2 += (k + e < K && wave + i * nw < nss) ? dlt * dlt : 0.f;
+        for (int j = 0; j < JMAX; ++j) {
+            const int k = (lane + 64 * j) * 4;
+            if (k < K) {
+                v[j].x = (v[j].x - mean) * rstd; v[j].y = (v[j].y - mean) * rstd;
+                v[j].z = (v[j].z - mean) * rstd; v[j].w = (v[j].w - mean) * rstd;
+                if (ln_mode == 2) {
+                    const float4 gg = *reinterpret_cast<const float4*>(g + k);
+                    const float4 bb = *reinterpret_cast<const float4*>(b + k);
+                    v[j].x = v[j].x * gg.x + bb.x; v[j].y = v[j].y * gg.y + bb.y;
+                    v[j].z = v[j].z * gg.z + bb.z; v[j].w = v[j].w * gg.w + bb.w;
                 }
             }
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (kg == 0) stat[wave * 16 + nl] = s2;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = (lane + 64 * j) * 4;
+        if (k < Kpad) {
+            if (sizeof(WT) == 2)
+                *reinterpret_cast<uint2*>(dst + (size_t)k * 2) = make_uint2(pack_bf16x2(v[j].x, v[j].y), pack_bf16x2(v[j].z, v[j].w));
+            else
+                *reinterpret_cast<float4*>(dst + (size_t)k * 4) = v[j];
+        }
+    }
+}
+
+// Row standardisation as its own tiny kernel (one wave per row): x [M, K] f32 row-major ->
+// ((x - mean) * rstd) in A-fragment order, element type WT.  The affine part of the LayerNorm lives in
+// the consuming matrix (see acmi_lm_layer).  Doing this once per LayerNorm instead of once per GEMM
+// workgroup takes ~5 us of redundant VALU + LDS staging off the critical path of every GEMM workgroup.
+template <typename WT>
+__global__ __launch_bounds__(64) void ln_tile_kernel(const float* __restrict__ x, WT* __restrict__ out, int M, int K,
+                                                     int nkc, float eps) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if (m >= M) return;
+    float4 v[ACMI_STAGE_JMAX];
+    load_row(x + (size_t)m * K, K, lane, v);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum(s) / (float)K;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+        if ((lane + 64 * j) * 4 < K) {
+            const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+            s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)K + eps);
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+        const int k = (lane + 64 * j) * 4;
+        if (k < K) {
+            const float y0 = (v[j].x - mean) * rstd, y1 = (v[j].y - mean) * rstd;
+            const float y2 = (v[j].z - mean) * rstd, y3 = (v[j].w - mean) * rstd;
+            WT* dst = out + tiled_index<WT>(m, k, nkc);  // 4 consecutive k stay inside one lane fragment
+            if (sizeof(WT) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+            else *reinterpret_cast<float4*>(dst) = make_float4(y0, y1, y2, y3);
+        }
+    }
+}
+
+extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream) {
+    ACMI_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && K <= 2048, "acmi_ln_tile: needs K %% 4 == 0 and K <= 2048 (K=%d)", K);
+    hipStream_t st = (hipStream_t)stream;
+    if (wdtype == ACMI_BF16)
+        hipLaunchKernelGGL(ln_tile_kernel<bf16_t>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<bf16_t*>(out), M, K,
+                           (K + 31) / 32, eps);
+    else
+        hipLaunchKernelGGL(ln_tile_kernel<float>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<float*>(out), M, K,
+                           (K + 15) / 16, eps);
+    return acmi_check_launch("ln_tile_kernel");
+}
+
+template <typename WT, bool A_TILED>
+__global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
+    constexpr int EPL = WTr<WT>::EPL, KT = WTr<WT>::KT;
+    constexpr int TMAX = sizeof(WT) == 2 ? 4 : 8;  // staged path: fragments per wave held in registers (K <= 2048)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float* red = reinterpret_cast<float*>(smem);       // [nw][256]
+    unsigned char* As = smem + (size_t)nw * 1024;      // [16][RS] staged activation
+    const int nl = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int NKC = p.NKC;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)blockIdx.x * NKC * 64 + lane;
+    const int tpos = p.qkv ? *p.pos : 0;
+
+    u32x4 wv[TMAX];
+    float4 xv[ACMI_STAGE_JMAX];
+    if (!A_TILED) {
+        load_row(wave < p.M && wave < 16 ? reinterpret_cast<const float*>(p.a) + (size_t)wave * p.K : nullptr, p.K, lane, xv);
+#pragma unroll
+        for (int i = 0; i < TMAX; ++i) {
+            const int kc = wave + i * nw;
+            if (kc < NKC && p.dbg != 3) wv[i] = ld_frag_nt(wt + (size_t)kc * 64);
+            else wv[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    for (int m0 = 0; m0 < p.M; m0 += 16) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!A_TILED) {
+            const int Kpad = NKC * KT;
+            for (int r = wave; r < 16; r += nw) {
+                const int m = m0 + r;
+                if (p.dbg == 2) continue;
+                if (m0 != 0 || r != wave)  // the first row of the first tile was requested before the weights
+                    load_row(m < p.M ? reinterpret_cast<const float*>(p.a) + (size_t)m * p.K : nullptr, p.K, lane, xv);
+                norm_store_row<WT>(xv, p.K, Kpad, p.dbg == 1 ? 0 : p.ln_mode, p.ln_g, p.ln_b, p.eps, As + (size_t)r * p.RS, lane);
+            }
             __syncthreads();
-            float tot2 = 0.f;
-            for (int w = 0; w < nw; ++w) tot2 += stat[w * 16 + nl];
-            const float rstd = 1.0f / sqrtf(tot2 / (float)K + p.eps);
-            __syncthreads();
+            const unsigned char* arow = As + (size_t)nl * p.RS + (size_t)kg * 16;
 #pragma unroll
-            for (int i = 0; i < SSMAX; ++i) {
-                const int ss = wave + i * nw;
-                const int k = ss * KSS + kg * EPL;
-                if (ss < nss) {
-#pragma unroll
-                    for (int e = 0; e < EPL; e += 4) {
-                        if (k + e < K) {
-                            const float4 g = *reinterpret_cast<const float4*>(p.ln_g + k + e);
-                            const float4 bb = *reinterpret_cast<const float4*>(p.ln_b + k + e);
-                            xr[i][e + 0] = (xr[i][e + 0] - mean) * rstd * g.x + bb.x;
-                            xr[i][e + 1] = (xr[i][e + 1] - mean) * rstd * g.y + bb.y;
-                            xr[i][e + 2] = (xr[i][e + 2] - mean) * rstd * g.z + bb.z;
-                            xr[i][e + 3] = (xr[i][e + 3] - mean) * rstd * g.w + bb.w;
-                        } else {
-                            xr[i][e + 0] = xr[i][e + 1] = xr[i][e + 2] = xr[i][e + 3] = 0.f;
-                        }
-                    }
-                    if (!mvalid) {
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) xr[i][e] = 0.f;
-                    }
-                    mma_ss(xr[i], wv[i], acc, WT());
+            for (int i = 0; i < TMAX; ++i) {
+                const int kc = wave + i * nw;
+                if (kc < NKC) {
+                    const u32x4 av = *reinterpret_cast<const u32x4*>(arow + (size_t)kc * 64);
+                    mma_frag(av, wv[i], acc, WT());
                 }
             }
         } else {
-#pragma unroll 2
-            for (int ss = wave; ss < nss; ss += nw) {
-                const int k = ss * KSS + kg * EPL;
-                uint4 wv[4];
-                float xa[EPL];
-                load_w<WT>(wrow, k, K, nvalid, wv);
-                load_a<EPL>(p.a, p.a_bf16, arow, k, K, mvalid, xa);
-                mma_ss(xa, wv, acc, WT());
+            const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)(m0 >> 4) * NKC * 64 + lane;
+#pragma unroll 4
+            for (int kc = wave; kc < NKC; kc += nw) {
+                const u32x4 bv = ld_frag_nt(wt + (size_t)kc * 64);
+                const u32x4 av = at[(size_t)kc * 64];
+                mma_frag(av, bv, acc, WT());
             }
         }
 
@@ -204,7 +247,7 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
             const int gm = m0 + mm, gn = n0 + nn;
             if (gm < p.M && gn < p.N) {
                 if (p.bias) v += p.bias[gn];
-                if (p.mode == 1) {
+                if (p.qkv) {
                     const int part = gn / p.d, f = gn - part * p.d;
                     if (part == 0) {
                         p.q_out[(size_t)gm * p.d + f] = v;
@@ -219,7 +262,8 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
                     if (p.act == 1) v = gelu_exact(v);
                     const size_t oi = (size_t)gm * p.N + gn;
                     if (p.residual) v += p.residual[oi];
-                    if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
+                    if (p.out_mode == ACMI_OUT_TILED) st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
+                    else if (p.out_mode == ACMI_OUT_BF16) reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
                     else reinterpret_cast<float*>(p.out)[oi] = v;
                 }
             }
@@ -228,40 +272,55 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
     }
 }
 
-static int launch_lin(const LinArgs& a, int wdtype, hipStream_t st) {
-    ACMI_REQUIRE(a.K % 8 == 0, "acmi_linear: K=%d must be a multiple of 8", a.K);
-    ACMI_REQUIRE(a.M > 0 && a.N > 0, "acmi_linear: empty problem M=%d N=%d", a.M, a.N);
-    const bool ln = a.ln_g != nullptr;
-    const int kss = (wdtype == ACMI_BF16) ? 128 : 64;
-    const int nss = (a.K + kss - 1) / kss;
-    int nw;
-    if (ln) {
-        const int ssmax = (wdtype == ACMI_BF16) ? 1 : 2;
-        ACMI_REQUIRE(nss <= 16 * ssmax, "acmi_linear: LayerNorm-fused K=%d too large (max %d)", a.K, 16 * ssmax * kss);
-        nw = nss <= 16 ? nss : (nss + 1) / 2;
+template <typename WT, bool A_TILED>
+static int launch_lin_t(LinArgs& a, hipStream_t st) {
+    constexpr int KT = WTr<WT>::KT;
+    a.NKC = (a.K + KT - 1) / KT;
+    a.NKC_out = (a.N + KT - 1) / KT;
+    int nw = a.NKC < 16 ? a.NKC : 16;
+    size_t lds;
+    if (A_TILED) {
+        if (nw < 1) nw = 1;
+        a.RS = 0;
+        lds = (size_t)nw * 1024;
     } else {
-        nw = nss < 16 ? nss : 16;
+        if (nw < 4) nw = 4;
+        ACMI_REQUIRE(a.K % 4 == 0 && a.NKC * KT <= 2048, "acmi_linear: row-major activation needs K %% 4 == 0 and K <= 2048 (K=%d)", a.K);
+        a.RS = a.NKC * KT * (int)sizeof(WT) + 16;
+        lds = (size_t)nw * 1024 + (size_t)16 * a.RS;
     }
-    if (nw < 1) nw = 1;
-    dim3 grid((a.N + 15) / 16), block(nw * 64);
-    if (wdtype == ACMI_BF16) {
-        if (ln) hipLaunchKernelGGL((lin_kernel<bf16_t, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<bf16_t, false>), grid, block, 0, st, a);
-    } else {
-        if (ln) hipLaunchKernelGGL((lin_kernel<float, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((lin_kernel<float, false>), grid, block, 0, st, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WT, A_TILED>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
+            return ACMI_ELAUNCH;
+        }
+        attr_set = true;
     }
+    hipLaunchKernelGGL((lin_kernel<WT, A_TILED>), dim3((a.N + 15) / 16), dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_kernel");
 }
 
-extern "C" int acmi_linear(const void* a, int a_dtype, const float* ln_g, const float* ln_b, float eps, const void* w,
-                           int wdtype, const float* bias, const float* residual, void* out, int out_dtype, int act, int M,
+static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
+    { const char* e = getenv("ACMI_DBG"); a.dbg = e ? atoi(e) : 0; }
+    ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
+    if (wdtype == ACMI_BF16) return a.a_tiled ? launch_lin_t<bf16_t, true>(a, st) : launch_lin_t<bf16_t, false>(a, st);
+    return a.a_tiled ? launch_lin_t<float, true>(a, st) : launch_lin_t<float, false>(a, st);
+}
+
+extern "C" int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps, const void* w,
+                           int wdtype, const float* bias, const float* residual, void* out, int out_mode, int act, int M,
                            int N, int K, void* stream) {
     LinArgs p = {};
-    p.a = a; p.a_bf16 = a_dtype == ACMI_BF16;
+    p.a = a; p.a_tiled = a_mode == ACMI_A_TILED;
+    ACMI_REQUIRE(a_mode >= 0 && a_mode <= 2, "acmi_linear: bad a_mode %d", a_mode);
+    ACMI_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "acmi_linear: ln_g and ln_b go together");
+    p.ln_mode = ln_g ? 2 : (a_mode == ACMI_A_ROWMAJOR_F32_NORM ? 1 : 0);
     p.ln_g = ln_g; p.ln_b = ln_b; p.eps = eps;
-    p.w = w; p.bias = bias; p.residual = residual; p.out = out; p.out_bf16 = out_dtype == ACMI_BF16; p.act = act;
-    p.M = M; p.N = N; p.K = K; p.mode = 0;
+    p.w = w; p.bias = bias; p.residual = residual; p.out = out; p.out_mode = out_mode; p.act = act;
+    p.M = M; p.N = N; p.K = K;
     return launch_lin(p, wdtype, (hipStream_t)stream);
 }
 
@@ -269,42 +328,56 @@ extern "C" int acmi_linear(const void* a, int a_dtype, const float* ln_g, const 
 // single-query attention over a KV cache
 // =====================================================================================================
 
+__device__ __forceinline__ float raw_to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float raw_to_f32(float v) { return v; }
+
 template <typename KT, int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const KT* __restrict__ kc,
-                                                          const KT* __restrict__ vc, float* __restrict__ out, int H,
-                                                          int Tcap, int len_arg, const int* len_dev, int len_bias,
-                                                          float scale) {
-    constexpr int LPP = HD / 8;    // lanes per position (8 dims each)
-    constexpr int PPI = 64 / LPP;  // positions covered by one load instruction of a wave
-    constexpr int NI = 8;          // load instructions in flight per chunk
+                                                          const KT* __restrict__ vc, void* __restrict__ out,
+                                                          int out_tiled, int out_bf16, int H, int Tcap, int len_arg,
+                                                          const int* len_dev, int len_bias, float scale) {
+    constexpr int DPL = HD >= 8 ? 8 : HD;  // dims per lane
+    constexpr int LPP = HD / DPL;          // lanes per position
+    constexpr int PPI = 64 / LPP;          // positions covered by one load instruction of a wave
+    constexpr int NI = sizeof(KT) == 2 ? 8 : 4;  // positions per lane per chunk (K and V loads in flight: 2 * NI)
+    typedef KT rawv __attribute__((ext_vector_type(DPL)));
     constexpr int CH = NI * PPI;
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
     const int len = len_dev ? (*len_dev + len_bias) : len_arg;
 
-    float qv[8];
+    float qv[DPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * 8 + e];
-    const KT* kb = kc + ((size_t)b * H + h) * Tcap * HD + c * 8;
-    const KT* vb = vc + ((size_t)b * H + h) * Tcap * HD + c * 8;
+    for (int e = 0; e < DPL; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * DPL + e];
+    const KT* kb = kc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
+    const KT* vb = vc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
 
-    float m = -INFINITY, l = 0.f, o[8];
+    float m = -INFINITY, l = 0.f, o[DPL];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int e = 0; e < DPL; ++e) o[e] = 0.f;
 
     for (int t0 = wave * CH; t0 < len; t0 += 4 * CH) {
+        // K and V of the whole chunk are requested together (2 * NI wide loads in flight per lane)
+        rawv kr[NI], vr[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + i * PPI + pp;
+            if (t < len) {
+                kr[i] = *reinterpret_cast<const rawv*>(kb + (size_t)t * HD);
+                vr[i] = *reinterpret_cast<const rawv*>(vb + (size_t)t * HD);
+            } else {
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) { kr[i][e] = 0; vr[i][e] = 0; }
+            }
+        }
         float s[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = t0 + i * PPI + pp;
             float part = 0.f;
-            if (t < len) {
-                float kf[8];
-                ld8(kb + (size_t)t * HD, kf);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) part = fmaf(qv[e], kf[e], part);
-            }
+            for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kr[i][e]), part);
 #pragma unroll
             for (int off = 1; off < LPP; off <<= 1) part += __shfl_xor(part, off, 64);
             s[i] = (t < len) ? part * scale : -INFINITY;
@@ -318,18 +391,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         const float alpha = expf(m - m_new);
         l *= alpha;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] *= alpha;
+        for (int e = 0; e < DPL; ++e) o[e] *= alpha;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = t0 + i * PPI + pp;
-            if (t < len) {
-                const float pr = expf(s[i] - m_new);
-                l += pr;
-                float vf[8];
-                ld8(vb + (size_t)t * HD, vf);
+            const float pr = (t < len) ? expf(s[i] - m_new) : 0.f;
+            l += pr;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, vf[e], o[e]);
-            }
+            for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vr[i][e]), o[e]);
         }
         m = m_new;
     }
@@ -337,13 +406,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     for (int off = LPP; off < 64; off <<= 1) {
         l += __shfl_xor(l, off, 64);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += __shfl_xor(o[e], off, 64);
+        for (int e = 0; e < DPL; ++e) o[e] += __shfl_xor(o[e], off, 64);
     }
     __shared__ float sm_o[4][HD];
     __shared__ float sm_m[4], sm_l[4];
     if (lane < LPP) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sm_o[wave][c * 8 + e] = o[e];
+        for (int e = 0; e < DPL; ++e) sm_o[wave][c * DPL + e] = o[e];
     }
     if (lane == 0) { sm_m[wave] = m; sm_l[wave] = l; }
     __syncthreads();
@@ -356,45 +425,56 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
             num += f * sm_o[w][threadIdx.x];
             den += f * sm_l[w];
         }
-        out[((size_t)b * H + h) * HD + threadIdx.x] = num / den;
+        const float r = num / den;
+        const int f = h * HD + threadIdx.x;
+        if (!out_tiled) {
+            reinterpret_cast<float*>(out)[(size_t)b * H * HD + f] = r;
+        } else if (out_bf16) {  // A-fragment order for the out-projection GEMM (include/acmi.h)
+            reinterpret_cast<bf16_t*>(out)[tiled_index<bf16_t>(b, f, (H * HD + 31) / 32)] = f32_to_bf16(r);
+        } else {
+            reinterpret_cast<float*>(out)[tiled_index<float>(b, f, (H * HD + 15) / 16)] = r;
+        }
     }
 }
 
 template <typename KT>
-static int launch_attn_t(const float* q, const void* kc, const void* vc, float* out, int Beff, int H, int hd, int Tcap,
-                         int len, const int* len_dev, int len_bias, hipStream_t st) {
+static int launch_attn_t(const float* q, const void* kc, const void* vc, void* out, int out_tiled, int out_bf16, int Beff,
+                         int H, int hd, int Tcap, int len, const int* len_dev, int len_bias, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)hd);
     dim3 grid(H, Beff), block(256);
     const KT* k = reinterpret_cast<const KT*>(kc);
     const KT* v = reinterpret_cast<const KT*>(vc);
 #define ACMI_ATTN_CASE(HD)                                                                                      \
     case HD:                                                                                                    \
-        hipLaunchKernelGGL((attn_decode_kernel<KT, HD>), grid, block, 0, st, q, k, v, out, H, Tcap, len, len_dev, \
-                           len_bias, scale);                                                                    \
+        hipLaunchKernelGGL((attn_decode_kernel<KT, HD>), grid, block, 0, st, q, k, v, out, out_tiled, out_bf16, H, Tcap, \
+                           len, len_dev, len_bias, scale);                                                      \
         break;
     switch (hd) {
+        ACMI_ATTN_CASE(4)
         ACMI_ATTN_CASE(8)
         ACMI_ATTN_CASE(16)
         ACMI_ATTN_CASE(32)
         ACMI_ATTN_CASE(64)
         ACMI_ATTN_CASE(128)
         default:
-            acmi_set_error("acmi_attn_decode: head dim %d unsupported (8,16,32,64,128)", hd);
+            acmi_set_error("acmi_attn_decode: head dim %d unsupported (4,8,16,32,64,128)", hd);
             return ACMI_EINVAL;
     }
 #undef ACMI_ATTN_CASE
     return acmi_check_launch("attn_decode_kernel");
 }
 
-extern "C" int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, float* out,
-                                int Beff, int H, int hd, int Tcap, int len, const int* len_dev, int len_bias,
-                                void* stream) {
+extern "C" int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, void* out,
+                                int out_mode, int out_dtype, int Beff, int H, int hd, int Tcap, int len,
+                                const int* len_dev, int len_bias, void* stream) {
+    const int out_tiled = out_mode == ACMI_OUT_TILED, out_bf16 = out_dtype == ACMI_BF16;
+    ACMI_REQUIRE(out_mode == ACMI_OUT_TILED || out_mode == ACMI_OUT_F32, "acmi_attn_decode: bad out_mode %d", out_mode);
     ACMI_REQUIRE(Beff > 0 && H > 0 && Tcap > 0, "acmi_attn_decode: bad shape");
     ACMI_REQUIRE(len_dev != nullptr || (len > 0 && len <= Tcap), "acmi_attn_decode: len=%d out of (0, %d]", len, Tcap);
     if (kvdtype == ACMI_BF16)
-        return launch_attn_t<bf16_t>(q, k_cache, v_cache, out, Beff, H, hd, Tcap, len, len_dev, len_bias,
-                                     (hipStream_t)stream);
-    return launch_attn_t<float>(q, k_cache, v_cache, out, Beff, H, hd, Tcap, len, len_dev, len_bias,
+        return launch_attn_t<bf16_t>(q, k_cache, v_cache, out, out_tiled, out_bf16, Beff, H, hd, Tcap, len, len_dev,
+                                     len_bias, (hipStream_t)stream);
+    return launch_attn_t<float>(q, k_cache, v_cache, out, out_tiled, out_bf16, Beff, H, hd, Tcap, len, len_dev, len_bias,
                                 (hipStream_t)stream);
 }
 
@@ -434,7 +514,7 @@ struct EmbedArgs {
     const void* emb[16]; int w_bf16;
     const int64_t* gen_sequence; int B, K, S, card;
     const float* prepend; int P;
-    const float* pos_freq; float pos_scale;
+    const float* pos_table; float pos_scale;
     const int* pos;
     float* x; int d;
 };
@@ -442,7 +522,6 @@ struct EmbedArgs {
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     const int m = blockIdx.x;
     const int g = *p.pos;
-    const int half = p.d / 2;
     const int b = m % p.B;
     for (int cch = threadIdx.x; cch < p.d; cch += blockDim.x) {
         float v;
@@ -459,11 +538,24 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
                               : reinterpret_cast<const float*>(p.emb[k])[ei];
             }
         }
-        const int i = cch < half ? cch : cch - half;
-        const float phase = (float)g / p.pos_freq[i];
-        const float pe = cch < half ? cosf(phase) : sinf(phase);
-        p.x[(size_t)m * p.d + cch] = v + p.pos_scale * pe;
+        p.x[(size_t)m * p.d + cch] = v + p.pos_scale * p.pos_table[(size_t)g * p.d + cch];
     }
+}
+
+// create_sin_embedding (transformer.py:70-89): one block per position, computed once per run geometry
+__global__ __launch_bounds__(256) void pos_table_kernel(const float* __restrict__ freq, float* __restrict__ table, int d) {
+    const int t = blockIdx.x, half = d / 2;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const int i = c < half ? c : c - half;
+        const float phase = (float)t / freq[i];
+        table[(size_t)t * d + c] = c < half ? cosf(phase) : sinf(phase);
+    }
+}
+
+extern "C" int acmi_pos_table(const float* freq, float* table, int T, int d, void* stream) {
+    ACMI_REQUIRE(T > 0 && d > 0 && d % 2 == 0, "acmi_pos_table: bad shape T=%d d=%d", T, d);
+    hipLaunchKernelGGL(pos_table_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, freq, table, d);
+    return acmi_check_launch("pos_table_kernel");
 }
 
 // =====================================================================================================
@@ -477,7 +569,8 @@ struct SampleArgs {
     int B, K, card, use_cfg;
     float cfg_coef;
     int use_sampling; float temp; int top_k; float top_p;
-    uint64_t seed; uint64_t step; const int* pos;  // step counter = step + *pos when pos != NULL
+    uint64_t seed; uint64_t step; int* pos;  // step counter = step + pos[0] when pos != NULL
+    int advance;          // last block to finish does pos[0] += 1 (pos[1] is the ticket counter)
     int64_t* tokens_out;  // [B, K] or NULL
     float* mixed_out;     // [B, K, card] or NULL
     // write-back (NULL gen_sequence: skipped)
@@ -543,13 +636,18 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
     __shared__ int sidx[4];
     __shared__ unsigned hist[256];
     __shared__ unsigned sel[2];
+    __shared__ unsigned wtot[4];
     const int k = blockIdx.x, b = blockIdx.y;
     const int card = p.card;
     const float* cond = p.logits + ((size_t)b * p.K + k) * card;
     const float* uncond = p.logits + ((size_t)(p.B + b) * p.K + k) * card;
+    const int gpos = p.pos ? p.pos[0] : 0;
     for (int i = threadIdx.x; i < card; i += blockDim.x) {
         float v = cond[i];
-        if (p.use_cfg) { const float u = uncond[i]; v = u + (v - u) * p.cfg_coef; }
+        if (p.use_cfg) {  // uncond + (cond - uncond) * coef, rounded after every op like the reference (no fma)
+            const float u = uncond[i];
+            v = __fadd_rn(u, __fmul_rn(__fsub_rn(v, u), p.cfg_coef));
+        }
         vals[i] = v;
         if (p.mixed_out) p.mixed_out[((size_t)b * p.K + k) * card + i] = v;
     }
@@ -599,13 +697,20 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
                     if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> (8 * pass)) & 255u], 1u);
                 }
                 __syncthreads();
-                if (threadIdx.x == 0) {
-                    unsigned acc = 0u; int dsel = 0;
-                    for (int dgt = 255; dgt >= 0; --dgt) {
-                        if (acc + hist[dgt] >= remaining) { dsel = dgt; break; }
-                        acc += hist[dgt];
+                {   // suffix sums S[t] = sum_{j >= t} hist[j] with 256 threads; digit d is selected when
+                    // S[d] >= remaining > S[d+1]
+                    const unsigned hcnt = hist[threadIdx.x];
+                    unsigned sfx = hcnt;
+                    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned o = __shfl_down(sfx, off, 64);
+                        if (ln + off < 64) sfx += o;
                     }
-                    sel[0] = (unsigned)dsel; sel[1] = remaining - acc;
+                    if (ln == 0) wtot[wv] = sfx;
+                    __syncthreads();
+                    for (int w2 = wv + 1; w2 < 4; ++w2) sfx += wtot[w2];
+                    if (sfx >= remaining && sfx - hcnt < remaining) { sel[0] = threadIdx.x; sel[1] = remaining - (sfx - hcnt); }
                 }
                 __syncthreads();
                 prefix |= sel[0] << (8 * pass);
@@ -616,7 +721,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
             thr = __uint_as_float(prefix);
         }
         // multinomial(num_samples=1) as an exponential race: argmax_i p_i / q_i, q_i ~ Exp(1)
-        const uint64_t stepc = p.step + (p.pos ? (uint64_t)*p.pos : 0ull);
+        const uint64_t stepc = p.step + (uint64_t)gpos;
         float bv = -1.f; int bi = 0x7fffffff;
         for (int i = threadIdx.x; i < card; i += blockDim.x) {
             const float pi = vals[i];
@@ -633,11 +738,19 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
     if (threadIdx.x == 0) {
         if (p.tokens_out) p.tokens_out[(size_t)b * p.K + k] = token;
         if (p.gen_sequence) {
-            const int offset = (*p.pos - p.P) + 1;  // sequence step being filled (lm.py:540-562)
+            const int offset = (gpos - p.P) + 1;  // sequence step being filled (lm.py:540-562)
             if (offset >= 0 && offset < p.S) {
                 const int64_t tok = p.seq_mask[(size_t)k * p.S + offset] ? (int64_t)token : (int64_t)p.card;
                 int64_t* dst = p.gen_sequence + ((size_t)b * p.K + k) * p.S + offset;
                 if (*dst == -1) *dst = tok;
+            }
+        }
+        if (p.advance) {  // every block has read pos[0] before taking its ticket
+            __threadfence();
+            const int ticket = atomicAdd(&p.pos[1], 1);
+            if (ticket == (int)(gridDim.x * gridDim.y) - 1) {
+                p.pos[1] = 0;
+                p.pos[0] = gpos + 1;
             }
         }
     }
@@ -670,7 +783,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     hipStream_t st = (hipStream_t)stream;
     ACMI_REQUIRE(m && s, "acmi_lm_step: null argument");
     const int d = m->dim, H = m->num_heads, hd = d / H, M = s->Beff;
-    ACMI_REQUIRE(d % H == 0 && d % 8 == 0 && m->ffn_dim % 8 == 0, "acmi_lm_step: bad dims d=%d H=%d", d, H);
+    ACMI_REQUIRE(d % H == 0 && d % 4 == 0 && d <= 2048 && m->ffn_dim % 4 == 0, "acmi_lm_step: bad dims d=%d H=%d", d, H);
     ACMI_REQUIRE(m->n_q <= 16, "acmi_lm_step: n_q=%d > 16", m->n_q);
     ACMI_REQUIRE(s->Beff == (s->use_cfg ? 2 * s->B : s->B), "acmi_lm_step: Beff/B mismatch");
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
@@ -679,7 +792,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.K = m->n_q; e.S = s->S; e.card = m->card;
-    e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_freq = m->pos_freq;
+    e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d;
     hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, st, e);
     if ((rc = acmi_check_launch("embed_kernel"))) return rc;
@@ -687,48 +800,52 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     for (int li = 0; li < m->num_layers; ++li) {
         const acmi_lm_layer& L = m->layers[li];
         // x -> LN1 -> QKV ; K,V appended in place at position g, q to scratch
+        if ((rc = acmi_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, stream))) return rc;
         LinArgs a = {};
-        a.a = s->x; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.eps = m->eps; a.w = L.w_qkv;
-        a.M = M; a.N = 3 * d; a.K = d; a.mode = 1;
+        a.a = s->xn; a.a_tiled = 1; a.w = L.w_qkv; a.bias = L.b_qkv;  // LN1 affine folded into w/b
+        a.M = M; a.N = 3 * d; a.K = d; a.qkv = 1;
         a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
         a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos;
         if ((rc = launch_lin(a, m->wdtype, st))) return rc;
-        if ((rc = acmi_attn_decode(s->q, L.k_cache, L.v_cache, m->kvdtype, s->att, M, H, hd, s->Tmax, 0, s->pos, 1,
-                                   stream)))
+        // self attention over positions [0, g]; output already in A-fragment order for the out projection
+        if ((rc = acmi_attn_decode(s->q, L.k_cache, L.v_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H, hd,
+                                   s->Tmax, 0, s->pos, 1, stream)))
             return rc;
-        if ((rc = acmi_linear(s->att, ACMI_F32, nullptr, nullptr, 0.f, L.w_out, m->wdtype, nullptr, s->x, s->x, ACMI_F32, 0, M,
-                              d, d, stream)))
+        if ((rc = acmi_linear(s->att, ACMI_A_TILED, nullptr, nullptr, 0.f, L.w_out, m->wdtype, nullptr, s->x, s->x,
+                              ACMI_OUT_F32, 0, M, d, d, stream)))
             return rc;
         if (m->cross_attention) {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache, "acmi_lm_step: cross-attention caches missing");
-            if ((rc = acmi_linear(s->x, ACMI_F32, L.lnc_g, L.lnc_b, m->eps, L.w_cq, m->wdtype, nullptr, nullptr, s->q, ACMI_F32,
-                                  0, M, d, d, stream)))
+            if ((rc = acmi_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, stream))) return rc;
+            if ((rc = acmi_linear(s->xn, ACMI_A_TILED, nullptr, nullptr, 0.f, L.w_cq, m->wdtype, L.b_cq, nullptr, s->q,
+                                  ACMI_OUT_F32, 0, M, d, d, stream)))
                 return rc;
-            if ((rc = acmi_attn_decode(s->q, L.ck_cache, L.cv_cache, m->kvdtype, s->att, M, H, hd, s->Lc, s->Lc,
-                                       nullptr, 0, stream)))
+            if ((rc = acmi_attn_decode(s->q, L.ck_cache, L.cv_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H,
+                                       hd, s->Lc, s->Lc, nullptr, 0, stream)))
                 return rc;
-            if ((rc = acmi_linear(s->att, ACMI_F32, nullptr, nullptr, 0.f, L.w_cout, m->wdtype, nullptr, s->x, s->x, ACMI_F32, 0,
-                                  M, d, d, stream)))
+            if ((rc = acmi_linear(s->att, ACMI_A_TILED, nullptr, nullptr, 0.f, L.w_cout, m->wdtype, nullptr, s->x, s->x,
+                                  ACMI_OUT_F32, 0, M, d, d, stream)))
                 return rc;
         }
-        const int hdt = wbf ? ACMI_BF16 : ACMI_F32;
-        if ((rc = acmi_linear(s->x, ACMI_F32, L.ln2_g, L.ln2_b, m->eps, L.w_ff1, m->wdtype, nullptr, nullptr, s->hidden, hdt, 1,
-                              M, m->ffn_dim, d, stream)))
+        if ((rc = acmi_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, stream))) return rc;
+        if ((rc = acmi_linear(s->xn, ACMI_A_TILED, nullptr, nullptr, 0.f, L.w_ff1, m->wdtype, L.b_ff1, nullptr, s->hidden,
+                              ACMI_OUT_TILED, 1, M, m->ffn_dim, d, stream)))
             return rc;
-        if ((rc = acmi_linear(s->hidden, hdt, nullptr, nullptr, 0.f, L.w_ff2, m->wdtype, nullptr, s->x, s->x, ACMI_F32, 0, M, d,
-                              m->ffn_dim, stream)))
+        if ((rc = acmi_linear(s->hidden, ACMI_A_TILED, nullptr, nullptr, 0.f, L.w_ff2, m->wdtype, nullptr, s->x, s->x,
+                              ACMI_OUT_F32, 0, M, d, m->ffn_dim, stream)))
             return rc;
     }
     if (mode == ACMI_STEP_DECODE) {
-        if ((rc = acmi_linear(s->x, ACMI_F32, m->out_norm_g, m->out_norm_b, m->eps, m->w_head, m->wdtype, nullptr, nullptr,
-                              s->logits, ACMI_F32, 0, M, m->n_q * m->card, d, stream)))
+        if ((rc = acmi_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, stream))) return rc;
+        if ((rc = acmi_linear(s->xn, ACMI_A_TILED, nullptr, nullptr, 0.f, m->w_head, m->wdtype, m->b_head, nullptr,
+                              s->logits, ACMI_OUT_F32, 0, M, m->n_q * m->card, d, stream)))
             return rc;
         SampleArgs a = {};
         a.logits = s->logits; a.B = s->B; a.K = m->n_q; a.card = m->card; a.use_cfg = s->use_cfg;
         a.cfg_coef = s->cfg_coef; a.use_sampling = s->use_sampling; a.temp = s->temp; a.top_k = s->top_k;
-        a.top_p = s->top_p; a.seed = s->seed; a.step = 0; a.pos = s->pos; a.mixed_out = s->step_logits;
+        a.top_p = s->top_p; a.seed = s->seed; a.step = 0; a.pos = s->pos; a.advance = 1; a.mixed_out = s->step_logits;
         a.gen_sequence = s->gen_sequence; a.seq_mask = s->seq_mask; a.S = s->S; a.P = s->prepend ? s->n_prepend : 0;
-        if ((rc = launch_sample(a, st))) return rc;
+        return launch_sample(a, st);
     }
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, s->pos);
     return acmi_check_launch("advance_kernel");

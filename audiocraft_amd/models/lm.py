@@ -184,7 +184,12 @@ class LMModel(nn.Module):
         wd = self.weight_dtype
         keep: tp.List[torch.Tensor] = []
 
-        def W(t):
+        def W(t):  # nn.Linear weight [N, K] -> MFMA B-fragment order ("tiled weight", include/acmi.h)
+            tw = _C.TiledWeight(t.detach().to(dev), wd)
+            keep.append(tw)
+            return tw
+
+        def E(t):  # embedding tables stay row-major
             t = t.detach().to(device=dev, dtype=wd).contiguous()
             keep.append(t)
             return t
@@ -196,43 +201,49 @@ class LMModel(nn.Module):
             keep.append(t)
             return t
 
+        def folded(w, norm, own_bias=None):
+            """LN(x) W^T = standardise(x) (W diag(gamma))^T + W beta  ->  (tiled W diag(gamma), f32 bias)."""
+            w32 = w.detach().to(device=dev, dtype=torch.float32)
+            g = norm.weight.detach().to(device=dev, dtype=torch.float32)
+            b = norm.bias.detach().to(device=dev, dtype=torch.float32)
+            bias = w32 @ b
+            if own_bias is not None:
+                bias = bias + own_bias.detach().to(device=dev, dtype=torch.float32)
+            return W(w32 * g[None, :]), Fp(bias)
+
         d = self.dim
         layers = (_C.LMLayer * self.num_layers)()
         pk: dict = {'keep': keep, 'layers': layers, 'per_layer': []}
         for li, layer in enumerate(self.transformer.layers):
-            for b in (layer.self_attn.in_proj_bias, layer.self_attn.out_proj.bias, layer.linear1.bias,
-                      layer.linear2.bias):
+            for b in (layer.self_attn.out_proj.bias, layer.linear2.bias):
                 if b is not None and bool((b != 0).any()):
-                    raise NotImplementedError("transformer biases (bias_attn / bias_ff) are not wired into "
-                                              "acmi_lm_step; MusicGen checkpoints have none")
-            ent = {
-                'w_qkv': W(layer.self_attn.in_proj_weight), 'w_out': W(layer.self_attn.out_proj.weight),
-                'w_ff1': W(layer.linear1.weight), 'w_ff2': W(layer.linear2.weight),
-                'ln1_g': Fp(layer.norm1.weight), 'ln1_b': Fp(layer.norm1.bias),
-                'ln2_g': Fp(layer.norm2.weight), 'ln2_b': Fp(layer.norm2.bias),
-            }
+                    raise NotImplementedError("out_proj / linear2 biases are not wired into acmi_lm_step; "
+                                              "MusicGen checkpoints have none (bias_attn = bias_ff = false)")
+            ent = {'w_out': W(layer.self_attn.out_proj.weight), 'w_ff2': W(layer.linear2.weight)}
+            ent['w_qkv'], ent['b_qkv'] = folded(layer.self_attn.in_proj_weight, layer.norm1, layer.self_attn.in_proj_bias)
+            ent['w_ff1'], ent['b_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
             if layer.cross_attention is not None:
-                ipw = layer.cross_attention.in_proj_weight
-                ent.update({'w_cq': W(ipw[:d]), 'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]),
-                            'w_cout': W(layer.cross_attention.out_proj.weight),
-                            'lnc_g': Fp(layer.norm_cross.weight), 'lnc_b': Fp(layer.norm_cross.bias)})
+                ca = layer.cross_attention
+                if ca.in_proj_bias is not None and bool((ca.in_proj_bias != 0).any()):
+                    raise NotImplementedError("cross-attention in_proj_bias is not wired into acmi_lm_step")
+                ipw = ca.in_proj_weight
+                ent['w_cq'], ent['b_cq'] = folded(ipw[:d], layer.norm_cross)
+                ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]), 'w_cout': W(ca.out_proj.weight)})
             L = layers[li]
-            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_ff1', 'w_ff2', 'ln1_g', 'ln1_b', 'lnc_g', 'lnc_b',
-                      'ln2_g', 'ln2_b'):
+            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
-        embs = [W(e.weight) for e in self.emb]
+        embs = [E(e.weight) for e in self.emb]
         emb_arr = (_C.vp * self.n_q)(*[e.data_ptr() for e in embs])
-        for lin in self.linears:
-            if lin.bias is not None and bool((lin.bias != 0).any()):
-                raise NotImplementedError("bias_proj heads are not wired into acmi_lm_step")
-        w_head = W(torch.cat([lin.weight for lin in self.linears], dim=0))
+        head_bias = None
+        if self.linears[0].bias is not None:
+            head_bias = torch.cat([lin.bias for lin in self.linears], dim=0)
+        w_head, b_head = folded(torch.cat([lin.weight for lin in self.linears], dim=0), self.out_norm, head_bias)
         half = d // 2
         # divisor table of create_sin_embedding, computed exactly like the reference does
-        # (transformer.py:83-88: f32 tensor ops on the host)
+        # (transformer.py:83-88: f32 tensor ops on the host); cos/sin are evaluated on the device
         adim = torch.arange(half, dtype=torch.float32)
-        pos_freq = Fp(torch.full([], self.max_period, dtype=torch.float32) ** (adim / (half - 1)))
-        og, ob = Fp(self.out_norm.weight), Fp(self.out_norm.bias)
+        pos_freq = Fp(torch.full([], self.max_period, dtype=torch.float32) ** (adim / max(half - 1, 1)))
         desc = _C.LMModelDesc()
         desc.dim, desc.num_heads, desc.num_layers, desc.ffn_dim = d, self.num_heads, self.num_layers, self.ffn_dim
         desc.n_q, desc.card = self.n_q, self.card
@@ -241,9 +252,9 @@ class LMModel(nn.Module):
         desc.eps, desc.positional_scale = 1e-5, self.positional_scale
         desc.layers = C.cast(layers, C.POINTER(_C.LMLayer))
         desc.emb = C.cast(emb_arr, C.POINTER(_C.vp))
-        desc.pos_freq, desc.out_norm_g, desc.out_norm_b = pos_freq.data_ptr(), og.data_ptr(), ob.data_ptr()
-        desc.w_head = w_head.data_ptr()
-        pk.update({'desc': desc, 'emb_arr': emb_arr})
+        desc.pos_table = None
+        desc.w_head, desc.b_head = w_head.data_ptr(), b_head.data_ptr()
+        pk.update({'desc': desc, 'emb_arr': emb_arr, 'w_head': w_head, 'b_head': b_head, 'pos_freq': pos_freq})
         self._packed = pk
         self._run = None
         return pk
@@ -272,9 +283,11 @@ class LMModel(nn.Module):
                 L.ck_cache, L.cv_cache = run['ck'][li].data_ptr(), run['cv'][li].data_ptr()
         run['x'] = torch.zeros(Beff, d, **f32)
         run['q'] = torch.zeros(Beff, d, **f32)
-        run['att'] = torch.zeros(Beff, d, **f32)
-        hdt = torch.bfloat16 if self.weight_dtype == torch.bfloat16 else torch.float32
-        run['hidden'] = torch.zeros(Beff, self.ffn_dim, device=dev, dtype=hdt)
+        # activations that feed a GEMM directly live in A-fragment order, zero padded
+        run['xn'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
+        run['att'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
+        run['hidden'] = _C.tiled_activation_buffer(Beff, self.ffn_dim, self.weight_dtype, dev)
+        run['pos_table'] = _C.pos_table(pk['pos_freq'], Tmax, d)
         run['logits'] = torch.zeros(Beff, self.n_q * self.card, **f32)
         run['step_logits'] = torch.zeros(B, self.n_q, self.card, **f32)
         run['pos'] = torch.zeros(4, device=dev, dtype=torch.int32)
@@ -293,6 +306,7 @@ class LMModel(nn.Module):
         st.prepend = None if prepend is None else prepend.data_ptr()
         st.pos = run['pos'].data_ptr()
         st.x, st.q, st.att = run['x'].data_ptr(), run['q'].data_ptr(), run['att'].data_ptr()
+        st.xn = run['xn'].data_ptr()
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None
         st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)
@@ -410,6 +424,7 @@ class LMModel(nn.Module):
         state = self._make_state(run, B, use_cfg, Tmax, Lc, S, prepend, return_logits, use_sampling, temp, top_k,
                                  top_p, coef, seed)
         desc = self._packed['desc']
+        desc.pos_table = run['pos_table'].data_ptr()
         run['gen_sequence'].copy_(gen_sequence)
         run['seq_mask'].copy_(mask.to(torch.uint8))
         run['pos'].zero_()
@@ -460,8 +475,10 @@ class LMModel(nn.Module):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
             g.capture_begin()
-            _C.lm_step(desc, state, _C.STEP_DECODE)
-            g.capture_end()
+            try:
+                _C.lm_step(desc, state, _C.STEP_DECODE)
+            finally:
+                g.capture_end()
         torch.cuda.current_stream().wait_stream(s)
         self._graph_keepalive = (g, desc, state)
         return g
@@ -482,6 +499,7 @@ class LMModel(nn.Module):
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
         state = self._make_state(run, B, False, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
         desc = self._packed['desc']
+        desc.pos_table = run['pos_table'].data_ptr()
         seq = torch.full((B, K, S + 1), -1, dtype=torch.long, device=dev)
         seq[..., :S] = sequence.to(dev)
         run['gen_sequence'].copy_(seq)

@@ -134,7 +134,11 @@ class BaseConditioner(nn.Module):
         assert D == self.dim
         flat = embeds.to(device=dev, dtype=torch.float32).reshape(B * L, D).contiguous()
         out = torch.empty(B * L, self.output_dim, device=dev, dtype=torch.float32)
-        _C.linear(flat, w.detach().float().contiguous(), out, bias=self.output_proj.bias.detach().float().contiguous())
+        tw = self.__dict__.get('_tiled')
+        if tw is None or tw[0] != (w.data_ptr(), w._version):
+            tw = ((w.data_ptr(), w._version), _C.TiledWeight(w.detach().float(), torch.float32))
+            self.__dict__['_tiled'] = tw
+        _C.linear(flat, tw[1], out, bias=self.output_proj.bias.detach().float().contiguous())
         mask = mask.to(dev)
         out = out.view(B, L, self.output_dim) * mask.unsqueeze(-1).to(out.dtype)
         return out, mask

@@ -1,0 +1,257 @@
+"""Benchmark of the generation hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+metric  : audio seconds generated / wall-second (real-time factor), MusicGen-medium 30 s @ 32 kHz
+workload: BASELINE.json configs[2] -- MusicGen-medium (1.5B) bf16 weights + bf16 KV cache, batch 8
+          prompts x 30 s PER GPU (weak scaling), CFG on (16 rows), top-k 250 sampling, 1503
+          autoregressive positions, then EnCodec-32k decode of the [8, 4, 1500] tokens to [8, 1, 960000].
+          Random-init weights of that architecture, synthetic T5 stand-in (16 x 768 per prompt): no
+          checkpoints exist offline.
+step    : one full generate (conditioning given -> tokens -> waveform on device).  N > 1: rank 0
+          builds + broadcasts the global conditioning, every rank generates its 8 prompts, tokens are
+          all-gathered (both collectives are inside the timed region).
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = lin_kernel (weight-streaming skinny GEMM, HBM bound): algorithmic
+               weight bytes of one decode position / number of lin_kernel launches, divided by the
+               average launch duration measured here with HIP events over one decode position's worth
+               of launches (all layers, real shapes) on the launch stream.
+  cpu_baseline the oracle (a port of the reference's CPU algorithm, incl. its torch.cat KV cache)
+               timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def lm_algorithmic_bytes(lm, B_eff: int, n_positions: int, Lc: int, prefix: int = 0):
+    """per position W = bw*(14|12)*d^2*L + bw*4*d*card, KV read 2*B_eff*d*L*bk*t,
+    KV write 2*B_eff*d*L*bk, cross-KV 2*B_eff*Lc*d*L*bk."""
+    d, L, card, K = lm.dim, lm.num_layers, lm.card, lm.n_q
+    bw = 2 if lm.weight_dtype == torch.bfloat16 else 4
+    bk = 2 if lm.kv_dtype == torch.bfloat16 else 4
+    per_layer = (14 if lm.has_cross_attention else 12) * d * d
+    w_step = bw * (per_layer * L + K * d * card)
+    kv_total = sum(2 * B_eff * d * L * bk * (prefix + t + 1) for t in range(n_positions))
+    kv_write = 2 * B_eff * d * L * bk * n_positions
+    cross = 2 * B_eff * Lc * d * L * bk * n_positions if lm.has_cross_attention else 0
+    return dict(w_step=w_step, total=w_step * n_positions + kv_total + kv_write + cross)
+
+
+def measure_lin_kernel(model, B_eff: int, reps: int = 3):
+    """Average lin_kernel launch duration over one decode position's worth of launches (HIP events on the
+    launch stream), and the algorithmic bytes those launches stream."""
+    from audiocraft_amd import _C
+    lm = model.lm
+    pk = lm._packed
+    dev = lm.device
+    d, ffn, wd = lm.dim, lm.ffn_dim, lm.weight_dtype
+    x = torch.randn(B_eff, d, device=dev)
+    att = _C.tile_matrix(torch.randn(B_eff, d, device=dev), wd)
+    hid = _C.tile_matrix(torch.randn(B_eff, ffn, device=dev), wd)
+    qkv = torch.empty(B_eff, 3 * d, device=dev)
+    o = torch.empty(B_eff, d, device=dev)
+    h = _C.tiled_activation_buffer(B_eff, ffn, wd, dev)
+    logits = torch.empty(B_eff, lm.n_q * lm.card, device=dev)
+    w_head = pk['w_head']
+    launches = 0
+    nbytes = 0
+
+    def one_position():
+        # the same launches acmi_lm_step issues for one position (same shapes, operand layouts and weights)
+        nonlocal launches, nbytes
+        for ent in pk['per_layer']:
+            seq = [(att, ent['w_qkv'], qkv, ent['b_qkv'], 0, None, None), (att, ent['w_out'], o, None, 0, None, o)]
+            if 'w_cq' in ent:
+                seq += [(att, ent['w_cq'], o, ent['b_cq'], 0, None, None), (att, ent['w_cout'], o, None, 0, None, o)]
+            seq += [(att, ent['w_ff1'], h, ent['b_ff1'], 1, _C.OUT_TILED, None), (hid, ent['w_ff2'], o, None, 0, None, o)]
+            for a, w, out, bias, act, om, res in seq:
+                _C.linear(a, w, out, bias=bias, act=act, a_tiled=True, M=B_eff, out_mode=om, residual=res)
+                launches += 1
+                nbytes += w.N * w.K * w.data.element_size()
+        _C.linear(att, w_head, logits, bias=pk['b_head'], a_tiled=True, M=B_eff)
+        launches += 1
+        nbytes += w_head.N * w_head.K * w_head.data.element_size()
+
+    one_position()  # warm
+    torch.cuda.synchronize()
+    # capture the position's launches into a hipGraph so that the host (python + ctypes, ~10 us per call) is
+    # out of the measurement, exactly like in generate(); HIP events bracket the replays on the launch stream
+    launches = nbytes = 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        try:
+            one_position()
+        finally:
+            graph.capture_end()
+        graph.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(side)
+        side.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    ms = e0.elapsed_time(e1)
+    return dict(avg_us=ms * 1e3 / (launches * reps), bytes_per_launch=nbytes / launches, launches_per_position=launches)
+
+
+def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, sample_steps: int = 10):
+    """The oracle (kind "port": restatement of the reference CPU algorithm) on the host cores, on a bounded
+    sample: `sample_steps` early-context decode positions at the full batch + EnCodec decode of 1 s of
+    audio at the full batch; extrapolated linearly to the whole generate.  Early-context positions are
+    the CHEAPEST ones of the reference (its per-step cost grows with context through the torch.cat KV
+    cache), so the extrapolation over-states the CPU's real-time factor."""
+    from oracle import codec as ocodec
+    from oracle import lm as olm
+    # torch's default intra-op pool (= physical cores it detects); oversubscribing SMT threads makes the
+    # M=16-row GEMMs of a decode position slower, not faster
+    cores = torch.get_num_threads()
+    log = lambda msg: print(f"[cpu_baseline {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)  # noqa: E731
+    log(f"{cores} threads; copying weights to the host")
+    lm = model.lm
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=lm.dim, num_heads=lm.num_heads, num_layers=lm.num_layers, n_q=lm.n_q, card=lm.card,
+                      cross_attention=lm.has_cross_attention)
+    g = torch.Generator().manual_seed(0)
+    cross = torch.randn(2 * B, Lc, lm.dim, generator=g)
+    cross[B:] = 0
+    n_pos = int(duration * model.frame_rate) + 3
+    log("oracle warm-up position")
+    olm.generate(sd, oc, None, B, cross, max_gen_len=int(duration * model.frame_rate), top_k=top_k, max_steps=1)
+    log(f"timing {sample_steps} positions")
+    t0 = time.perf_counter()
+    olm.generate(sd, oc, None, B, cross, max_gen_len=int(duration * model.frame_rate), top_k=top_k,
+                 max_steps=sample_steps)
+    t_step = (time.perf_counter() - t0) / sample_steps
+    log(f"{t_step * 1e3:.0f} ms/position; EnCodec decode sample")
+    del sd
+    csd = {k: v.detach().float().cpu() for k, v in model.compression_model.state_dict().items()}
+    cc = ocodec.CodecConfig(channels=1, dimension=128, n_filters=64, n_residual_layers=1, ratios=[8, 5, 4, 4],
+                            causal=False, pad_mode='constant', lstm=2, norm='weight_norm', n_q=4, bins=2048,
+                            sample_rate=32000, frame_rate=50)
+    codes = torch.randint(0, 2048, (B, 4, 50), generator=g)
+    t0 = time.perf_counter()
+    ocodec.encodec_decode(csd, cc, codes, fast_lstm=True)
+    t_codec_1s = time.perf_counter() - t0
+    wall = t_step * n_pos + t_codec_1s * duration
+    return dict(value=B * duration / wall, unit='audio-s / wall-s', cores=cores, kind='port',
+                sample=f"{sample_steps} decode positions at context<= {sample_steps} (B={B}, CFG rows {2 * B}) "
+                       f"= {t_step * 1e3:.0f} ms/position x {n_pos} positions + EnCodec decode of 1 s "
+                       f"({t_codec_1s:.2f} s) x {duration:.0f}; linear extrapolation, optimistic for the CPU")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--model', default='facebook/musicgen-medium')
+    ap.add_argument('--batch', type=int, default=8, help='prompts per GPU')
+    ap.add_argument('--duration', type=float, default=30.0)
+    ap.add_argument('--top-k', type=int, default=250)
+    ap.add_argument('--text-len', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from audiocraft_amd import distributed as adist
+    from audiocraft_amd.models.musicgen import MusicGen
+    rank, world, local_rank = adist.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    model = MusicGen.get_random_init(args.model, dev, torch.bfloat16, text_len=args.text_len, seed=0)
+    model.set_generation_params(use_sampling=True, top_k=args.top_k, duration=args.duration)
+    B = args.batch
+    B_global = B * world
+    T = int(args.duration * model.frame_rate)
+    descriptions = [f"synthetic prompt {i}" for i in range(B_global)]
+
+    def step(i):
+        tokens, wav = adist.generate_sharded(model, descriptions if rank == 0 else None, B_global, T,
+                                             decode=True, base_seed=1000 * i)
+        return tokens, wav
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    vlog = lambda msg: print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)  # noqa: E731
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
+        step(i)
+        torch.cuda.synchronize()
+        if rank == 0:
+            vlog(f"warmup step {i}: {time.perf_counter() - t_w:.2f} s")
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tokens, wav = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert tokens.shape == (B_global, 4, T) and wav.shape == (B, 1, T * 640)
+    assert int(tokens.min()) >= 0 and int(tokens.max()) < 2048 and bool(torch.isfinite(wav).all())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B_global * args.duration * args.steps / elapsed
+    out = {
+        "metric": "audio seconds generated / wall-sec (real-time factor), MusicGen-medium 30 s @ 32 kHz",
+        "value": round(value, 3), "unit": "audio-s / wall-s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, synthetic T5 stand-in)",
+        "config": {"workload": f"{args.model} bf16, batch {B} prompts x {args.duration:.0f} s per GPU, CFG, "
+                               f"top-k {args.top_k}, {T + 3} AR positions + EnCodec-32k decode "
+                               "(BASELINE.json configs[2])",
+                   "global_batch": B_global, "seq_len": T, "parallelism": f"dp{world} (prompt sharding)"},
+    }
+    if rank == 0:
+        lm = model.lm
+        n_pos = T + 3
+        alg = lm_algorithmic_bytes(lm, 2 * B, n_pos, args.text_len)
+        out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes": alg['total'],
+                                "achieved": round(alg['total'] * args.steps / elapsed / 1e9, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg['total'] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "whole generate incl. EnCodec decode and collectives"}
+        if not args.no_roofline:
+            r = measure_lin_kernel(model, 2 * B)
+            ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
+            out["roofline"] = {"kernel": "lin_kernel (weight-streaming skinny GEMM)", "bound": "hbm",
+                               "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(r['avg_us'], 3),
+                               "launches_per_position": r['launches_per_position']}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, B, args.duration, args.text_len, args.top_k)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -104,20 +104,37 @@ size_t acmi_lstm_work_floats(int B, int H);
 
 /* ------------------------------------------------------------------------------------------
  * MusicGen LM decode step
- * ------------------------------------------------------------------------------------------ */
+ * ------------------------------------------------------------------------------------------
+ *
+ * Operand layouts of the skinny GEMM (M = CFG batch rows, weights streamed once per call):
+ *
+ *   "tiled weight"  W[N, K] (nn.Linear layout, out x in) is stored as 1 KB MFMA B-fragments:
+ *       element type E (bf16: 2 B, f32: 4 B), e = 16 / sizeof(E) elements per lane, KT = 4 * e
+ *       columns per tile (bf16: 32, f32: 16); N and K zero-padded to multiples of 16 / KT:
+ *           Wt[nt][kc][lane][j],  lane = kg * 16 + n,  holds  W[nt*16 + n][kc*KT + kg*e + j]
+ *       so that the fragment a wave needs is ONE fully coalesced 64-lane x 16-byte load.
+ *   "tiled activation"  A[M, K] in the same element type, as MFMA A-fragments:
+ *           At[mt][kc][lane][j],  lane = kg * 16 + m,  holds  A[mt*16 + m][kc*KT + kg*e + j]
+ *       (rows / columns beyond M / K must be zero).  Producers on the path (attention output, FFN
+ *       hidden) write this layout directly; row-major f32 activations (the residual stream) are
+ *       staged through LDS by the consumer, which is also where the LayerNorm is applied.
+ */
 
 typedef struct {
-    /* StreamingTransformerLayer parameters (audiocraft/modules/transformer.py:454-574); weight
-     * matrices are [out_features, in_features] row-major in `wdtype`; norms / biases f32. */
+    /* StreamingTransformerLayer parameters (audiocraft/modules/transformer.py:454-574); matrices are
+     * "tiled weights" in `wdtype`.  The affine part of each LayerNorm is folded on the host into the
+     * matrix that consumes it:  LN(x) W^T = ((x - mean) * rstd) (W diag(gamma))^T + W beta,  so
+     * w_qkv / w_cq / w_ff1 hold W diag(gamma) and b_qkv / b_cq / b_ff1 hold W beta (+ the layer's own
+     * bias if it has one), f32; the kernels only standardise the rows. */
     const void* w_qkv;      /* self_attn.in_proj_weight   [3d, d] */
     const void* w_out;      /* self_attn.out_proj.weight  [d, d] */
     const void* w_cq;       /* cross_attention.in_proj_weight[:d]  [d, d]  (NULL if no cross-attn) */
     const void* w_cout;     /* cross_attention.out_proj.weight     [d, d] */
     const void* w_ff1;      /* linear1.weight [ffn, d] */
     const void* w_ff2;      /* linear2.weight [d, ffn] */
-    const float* ln1_g; const float* ln1_b;
-    const float* lnc_g; const float* lnc_b;
-    const float* ln2_g; const float* ln2_b;
+    const float* b_qkv;     /* [3d]  norm1      folded */
+    const float* b_cq;      /* [d]   norm_cross folded */
+    const float* b_ff1;     /* [ffn] norm2      folded */
     void* k_cache;          /* [Beff, H, Tmax, hd] in `kvdtype` (past_keys,  transformer.py:266-298) */
     void* v_cache;          /* [Beff, H, Tmax, hd] */
     const void* ck_cache;   /* cross-attention keys   [Beff, H, Lc, hd] in `kvdtype`, projected once */
@@ -126,36 +143,37 @@ typedef struct {
 
 typedef struct {
     int dim, num_heads, num_layers, ffn_dim, n_q, card;
-    int wdtype;             /* ACMI_F32 | ACMI_BF16: matrices */
+    int wdtype;             /* ACMI_F32 | ACMI_BF16: matrices (and tiled activations) */
     int kvdtype;            /* ACMI_F32 | ACMI_BF16: KV caches */
     int cross_attention;    /* layers have norm_cross + cross_attention (text models) */
     float eps;              /* LayerNorm eps (1e-5, transformer.py:54-67) */
     float positional_scale; /* StreamingTransformer positional_scale */
     const acmi_lm_layer* layers;    /* host array [num_layers] */
-    const void* const* emb;         /* host array [n_q] of device ptrs: emb.k.weight [card+1, d] in wdtype */
-    const float* pos_freq;          /* [d/2] f32: max_period ** (i / (d/2 - 1)) (transformer.py:83-88) */
-    const float* out_norm_g; const float* out_norm_b;
-    const void* w_head;             /* linears.{k}.weight stacked [n_q * card, d] in wdtype */
+    const void* const* emb;         /* host array [n_q] of device ptrs: emb.k.weight [card+1, d] row-major, wdtype */
+    const float* pos_table;         /* [Tmax, d] f32 sinusoidal table from acmi_pos_table */
+    const void* w_head;             /* linears.{k}.weight stacked [n_q * card, d] x diag(out_norm.weight), tiled */
+    const float* b_head;            /* [n_q * card] = W_head out_norm.bias (+ head biases) */
 } acmi_lm_model;
 
 typedef struct {
     int Beff;               /* rows run through the transformer: 2B with CFG ([cond; uncond]), else B */
     int B;                  /* samples */
     int use_cfg;
-    int Tmax;               /* KV cache capacity (positions) */
+    int Tmax;               /* KV cache capacity (positions) = rows of pos_table */
     int Lc;                 /* cross-attention source length (0 if none) */
     int n_prepend;          /* P: rows of `prepend` consumed as inputs before the first token step */
     int S;                  /* pattern sequence length (T + max_delay + 1) */
     int64_t* gen_sequence;  /* [B, K, S] int64; -1 = not generated yet (lm.py:523-534) */
     const uint8_t* seq_mask;/* [K, S] pattern validity mask (codebooks_patterns.py:138-151) */
     const float* prepend;   /* [Beff, P, d] f32 prepended condition rows (conditioners.py:1739-1741) or NULL */
-    int* pos;               /* device int[4]: pos[0] = current position index g (advanced by the step) */
-    /* activations / scratch, all f32 unless noted; sizes given for M = Beff rows */
-    float* x;               /* [M, d]   residual stream */
-    float* q;               /* [M, d] */
-    float* att;             /* [M, d] */
-    void* hidden;           /* [M, ffn] in wdtype-compatible activation type (bf16 when wdtype bf16, else f32) */
-    float* logits;          /* [M, n_q * card] */
+    int* pos;               /* device int[4]: pos[0] = current position index g (advanced by the step),
+                               pos[1] = scratch ticket counter (must be 0 between steps) */
+    float* x;               /* [Beff, d] f32 residual stream */
+    float* q;               /* [Beff, d] f32 */
+    void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x */
+    void* att;              /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised */
+    void* hidden;           /* tiled activation [ceil(Beff/16)*16, ffn_pad] in wdtype, zero-initialised */
+    float* logits;          /* [Beff, n_q * card] f32 */
     float* step_logits;     /* optional [B, n_q, card] copy of the CFG-mixed logits of this step, or NULL */
     /* sampling (lm.py:402-418, utils/utils.py:88-122) */
     int use_sampling; float temp; int top_k; float top_p; float cfg_coef;
@@ -172,22 +190,44 @@ typedef struct {
  * incremented at the end. */
 int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int mode, void* stream);
 
-/* Individual operators of the step, exposed for parity tests and for the one-off cross-attention
- * K/V projection (the reference re-projects them every step, transformer.py:344-361).
- *   out[M, N] = act(LN(x)[M, K] @ W[N, K]^T + bias[N]) + residual[M, N]
- *   (ln_g == NULL: no LayerNorm; bias / residual may be NULL)
- * act: 0 none, 1 exact GELU.  out_dtype / a_dtype: ACMI_F32 | ACMI_BF16. */
-int acmi_linear(const void* a, int a_dtype, const float* ln_g, const float* ln_b, float eps,
-                const void* w, int wdtype, const float* bias, const float* residual, void* out, int out_dtype,
+/* create_sin_embedding (transformer.py:70-89) for positions 0..T-1: table[t, :d/2] = cos(t / f_i),
+ * table[t, d/2:] = sin(t / f_i), f_i = freq[i] = max_period ** (i / (d/2 - 1)) supplied by the host
+ * exactly as the reference computes it. */
+int acmi_pos_table(const float* freq, float* table, int T, int d, void* stream);
+
+/* Row standardisation ((x - mean) / sqrt(var + eps), two-pass statistics, no affine part) of a
+ * row-major f32 matrix x [M, K] into a zero-initialised tiled activation in `wdtype`: the LayerNorm
+ * prologue of the decode step's GEMMs (nn.LayerNorm, transformer.py:54-67), whose affine part is
+ * folded into the consuming matrix.  K % 4 == 0, K <= 2048. */
+int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream);
+
+/* Operand descriptors of acmi_linear */
+#define ACMI_A_ROWMAJOR_F32 0 /* a [M, K] f32 row-major, staged through LDS (+ optional LayerNorm) */
+#define ACMI_A_TILED 1        /* a = tiled activation in the weight's element type */
+#define ACMI_A_ROWMAJOR_F32_NORM 2 /* as 0, rows standardised ((x - mean) / sqrt(var + eps)) while staging */
+#define ACMI_OUT_F32 0        /* out [M, N] f32 row-major */
+#define ACMI_OUT_BF16 1       /* out [M, N] bf16 row-major */
+#define ACMI_OUT_TILED 2      /* out = tiled activation (element type of w), pad region untouched */
+
+/* The skinny GEMM of the decode step, exposed for parity tests, for the one-off cross-attention K/V
+ * projection (the reference re-projects them every step, transformer.py:344-361) and for the
+ * conditioners' output_proj (conditioners.py:355-360):
+ *   out[M, N] = act(LN?(a)[M, K] @ W[N, K]^T + bias[N]) + residual[M, N]
+ * w: tiled weight in wdtype.  ln_g / ln_b (both or neither, only with ACMI_A_ROWMAJOR_F32, K <= 2048): full
+ * LayerNorm with affine parameters applied in the kernel (the decode step uses the folded form instead).
+ * bias [N] / residual [M, N] f32 row-major or NULL.  act: 0 none, 1 exact (erf) GELU. */
+int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps,
+                const void* w, int wdtype, const float* bias, const float* residual, void* out, int out_mode,
                 int act, int M, int N, int K, void* stream);
 
 /* Single-query attention over a [Beff, H, Tcap, hd] cache, positions [0, len): the
  * F.scaled_dot_product_attention call of transformer.py:412-414 for one new step.
- * q [Beff, H*hd] f32 -> out [Beff, H*hd] f32.  len_dev (device int*) overrides len when not NULL
+ * q [Beff, H*hd] f32 -> out: [Beff, H*hd] f32 row-major (out_mode ACMI_OUT_F32) or a tiled activation
+ * in `out_dtype` (out_mode ACMI_OUT_TILED).  len_dev (device int*) overrides len when not NULL
  * (length = *len_dev + len_bias). */
-int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, float* out,
-                     int Beff, int H, int hd, int Tcap, int len, const int* len_dev, int len_bias,
-                     void* stream);
+int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, void* out,
+                     int out_mode, int out_dtype, int Beff, int H, int hd, int Tcap, int len,
+                     const int* len_dev, int len_bias, void* stream);
 
 /* Scatter rows [Beff, L, H*hd] f32 into a [Beff, H, Tcap, hd] cache at positions [t0, t0+L). */
 int acmi_kv_store(const float* src, void* cache, int kvdtype, int Beff, int H, int hd, int Tcap,

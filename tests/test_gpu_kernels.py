@@ -160,12 +160,14 @@ def test_lstm_vs_oracle(C, B, H, T, layers):
 # ------------------------------------------------------------------------------------------ LM operators
 
 @pytest.mark.parametrize('M,N,K', [(16, 4608, 1536), (2, 3072, 1024), (16, 1536, 6144), (32, 1536, 1536),
-                                    (5, 96, 32), (16, 8192, 1536), (7, 40, 24), (40, 2048, 2048)])
+                                    (5, 96, 32), (16, 8192, 1536), (7, 40, 24), (40, 2048, 2048), (16, 1536, 768)])
 @pytest.mark.parametrize('wdt', ['f32', 'bf16'])
-@pytest.mark.parametrize('ln', [False, True])
-def test_linear_vs_torch(C, M, N, K, wdt, ln):
-    if ln and K > 2048:
-        pytest.skip("LayerNorm-fused inputs are model-dim sized")
+@pytest.mark.parametrize('mode', ['rowmajor', 'rowmajor_ln', 'rowmajor_std', 'tiled_in', 'tiled_out'])
+def test_linear_vs_torch(C, M, N, K, wdt, mode):
+    """out = gelu(LN?(a) @ W^T + bias) + residual for every operand layout of acmi_linear."""
+    if mode != 'tiled_in' and K > 2048:
+        pytest.skip("row-major (LDS staged) activations are model-dim sized")
+    dt = torch.bfloat16 if wdt == 'bf16' else torch.float32
     g = torch.Generator().manual_seed(M * N + K)
     a = torch.randn(M, K, generator=g) * 1.5 + 0.3
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -173,20 +175,38 @@ def test_linear_vs_torch(C, M, N, K, wdt, ln):
     bet = 0.1 * torch.randn(K, generator=g)
     bias = 0.1 * torch.randn(N, generator=g)
     res = torch.randn(M, N, generator=g)
-    wq = w.bfloat16() if wdt == 'bf16' else w
+    wq = w.to(dt).float()
+    ln = mode == 'rowmajor_ln'
     xin = F.layer_norm(a, (K,), gam, bet, 1e-5) if ln else a
+    if mode == 'rowmajor_std':
+        xin = F.layer_norm(a, (K,), None, None, 1e-5)
+    if mode == 'tiled_in':
+        xin = xin.to(dt).float()   # the producer already rounded the activation to the weight type
     ref = F.gelu(xin.double() @ wq.double().t() + bias.double()).float() + res
-    out = torch.empty(M, N, device='cuda')
-    C.linear(a.cuda(), wq.cuda(), out, ln_g=gam.cuda() if ln else None, ln_b=bet.cuda() if ln else None,
-             bias=bias.cuda(), residual=res.cuda(), act=1)
+    tw = C.TiledWeight(w.cuda(), dt)
+    kw = dict(bias=bias.cuda(), residual=res.cuda(), act=1)
+    if mode == 'tiled_in':
+        out = torch.empty(M, N, device='cuda')
+        C.linear(C.tile_matrix(a.cuda(), dt), tw, out, a_tiled=True, M=M, **kw)
+    elif mode == 'tiled_out':
+        buf = C.tiled_activation_buffer(M, N, dt, 'cuda')
+        C.linear(a.cuda(), tw, buf, out_mode=C.OUT_TILED, **kw)
+        out = C.untile_matrix(buf, M, N).float()
+        # rows beyond M of the zero-initialised buffer must stay untouched
+        assert C.untile_matrix(buf, buf.shape[0] * 16, buf.shape[1] * buf.shape[4] * 4)[M:].abs().sum() == 0
+    else:
+        out = torch.empty(M, N, device='cuda')
+        C.linear(a.cuda(), tw, out, ln_g=gam.cuda() if ln else None, ln_b=bet.cuda() if ln else None,
+                 standardize=mode == 'rowmajor_std', **kw)
     r = rel(out.cpu(), ref)
-    # f32: exact-f32 MFMA chain; bf16: activations rounded to bf16 (2^-9 relative per element)
-    tol = 2e-6 if wdt == 'f32' else 4e-3
+    # f32: exact-f32 MFMA chain; bf16: activations (and a tiled output) rounded to bf16, 2^-9 relative each
+    tol = 2e-6 if wdt == 'f32' else 5e-3
     assert r < tol, f"rel-L2 {r}"
 
 
 @pytest.mark.parametrize('Beff,H,hd,Tcap,length', [(16, 24, 64, 1504, 1503), (2, 16, 64, 600, 1), (4, 4, 8, 40, 13),
-                                                    (3, 2, 16, 100, 100), (2, 2, 32, 70, 65), (2, 3, 128, 300, 257)])
+                                                    (3, 2, 16, 100, 100), (2, 2, 32, 70, 65), (2, 3, 128, 300, 257),
+                                                    (2, 4, 4, 20, 7), (20, 2, 16, 33, 33)])
 @pytest.mark.parametrize('kvdt', [torch.float32, torch.bfloat16])
 def test_attn_decode_vs_oracle(C, Beff, H, hd, Tcap, length, kvdt):
     g = torch.Generator().manual_seed(Tcap + length)
@@ -203,6 +223,35 @@ def test_attn_decode_vs_oracle(C, Beff, H, hd, Tcap, length, kvdt):
     out2 = torch.empty_like(out)
     C.attn_decode(q.cuda(), k.cuda(), v.cuda(), out2, 0, len_dev=ld, len_bias=1)
     assert torch.equal(out, out2)
+    # tiled (A-fragment) output, both element types
+    for dt in (torch.float32, torch.bfloat16):
+        buf = C.tiled_activation_buffer(Beff, H * hd, dt, 'cuda')
+        C.attn_decode(q.cuda(), k.cuda(), v.cuda(), buf, length, out_tiled=True)
+        assert torch.equal(C.untile_matrix(buf, Beff, H * hd), out.to(dt))
+
+
+@pytest.mark.parametrize('M,K', [(16, 1536), (3, 32), (33, 2048), (16, 1024)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_ln_tile_vs_torch(C, M, K, dt):
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * 2 + 0.7
+    ref = F.layer_norm(x, (K,), None, None, 1e-5)
+    buf = C.tiled_activation_buffer(M, K, dt, 'cuda')
+    C.ln_tile(x.cuda(), buf)
+    got = C.untile_matrix(buf, M, K).float().cpu()
+    tol = 2e-6 if dt == torch.float32 else 4e-3
+    assert (got - ref).abs().max().item() < tol * 4
+    full = C.untile_matrix(buf, buf.shape[0] * 16, buf.shape[1] * buf.shape[4] * 4)
+    assert full[M:].abs().sum() == 0 and full[:, K:].abs().sum() == 0
+
+
+def test_pos_table_vs_oracle(C):
+    d, T = 1536, 1800
+    half = d // 2
+    freq = torch.full([], 10000.0) ** (torch.arange(half, dtype=torch.float32) / (half - 1))
+    got = C.pos_table(freq.cuda(), T, d).cpu()
+    ref = olm.create_sin_embedding(torch.arange(T).view(1, -1, 1), d)[0]
+    assert (got - ref).abs().max().item() < 2e-6
 
 
 def test_sample_greedy_and_cfg(C):
