@@ -72,7 +72,7 @@ _conv1d = _sig('acmi_conv1d', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp])
 _lstm_layer = _sig('acmi_lstm_layer', [vp, vp, vp, vp, vp, i32, i32, i32, vp])
 _lstm_work = _sig('acmi_lstm_work_floats', [i32, i32], C.c_size_t)
 _lm_step = _sig('acmi_lm_step', [C.POINTER(LMModelDesc), C.POINTER(LMState), i32, vp])
-_linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp])
+_linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp])
 _attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
 _pos_table = _sig('acmi_pos_table', [vp, vp, i32, i32, vp])
 _ln_tile = _sig('acmi_ln_tile', [vp, vp, i32, i32, i32, f32, vp])
@@ -199,7 +199,7 @@ def tiled_activation_buffer(M: int, K: int, dtype: torch.dtype, device) -> torch
 
 
 def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, residual=None, act=0,
-           a_tiled=False, out_mode=None, M=None, standardize=False):
+           a_tiled=False, out_mode=None, M=None, standardize=False, prefetch: 'TiledWeight' = None):
     """out[M, N] = act(LN?(a)[M, K] @ W[N, K]^T + bias) + residual, see acmi_linear.
     a: row-major f32 [M, K] (a_tiled=False) or a tiled activation buffer (a_tiled=True, pass M)."""
     if a_tiled:
@@ -211,7 +211,9 @@ def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, re
         out_mode = OUT_BF16 if out.dtype == torch.bfloat16 else OUT_F32
     a_mode = A_TILED if a_tiled else (A_ROWMAJOR_F32_NORM if standardize else A_ROWMAJOR_F32)
     check(_linear(ptr(a), a_mode, ptr(ln_g), ptr(ln_b), eps, ptr(w.data),
-                  dtype_code(w.dtype), ptr(bias), ptr(residual), ptr(out), out_mode, act, M, w.N, w.K, stream()),
+                  dtype_code(w.dtype), ptr(bias), ptr(residual), ptr(out), out_mode, act, M, w.N, w.K,
+                  ptr(prefetch.data) if prefetch is not None else None, prefetch.N if prefetch is not None else 0,
+                  prefetch.K if prefetch is not None else 0, stream()),
           'acmi_linear')
     return out
 

@@ -72,16 +72,22 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     def one_position():
         # the same launches acmi_lm_step issues for one position (same shapes, operand layouts and weights)
         nonlocal launches, nbytes
-        for ent in pk['per_layer']:
-            seq = [(att, ent['w_qkv'], qkv, ent['b_qkv'], 0, None, None), (att, ent['w_out'], o, None, 0, None, o)]
-            if 'w_cq' in ent:
-                seq += [(att, ent['w_cq'], o, ent['b_cq'], 0, None, None), (att, ent['w_cout'], o, None, 0, None, o)]
-            seq += [(att, ent['w_ff1'], h, ent['b_ff1'], 1, _C.OUT_TILED, None), (hid, ent['w_ff2'], o, None, 0, None, o)]
-            for a, w, out, bias, act, om, res in seq:
-                _C.linear(a, w, out, bias=bias, act=act, a_tiled=True, M=B_eff, out_mode=om, residual=res)
+        L = pk['per_layer']
+        for li, ent in enumerate(L):
+            nq = L[li + 1]['w_qkv'] if li + 1 < len(L) else w_head
+            cross = 'w_cq' in ent
+            seq = [(att, ent['w_qkv'], qkv, ent['b_qkv'], 0, None, None, ent['w_out']),
+                   (att, ent['w_out'], o, None, 0, None, o, ent['w_cq'] if cross else ent['w_ff1'])]
+            if cross:
+                seq += [(att, ent['w_cq'], o, ent['b_cq'], 0, None, None, ent['w_cout']),
+                        (att, ent['w_cout'], o, None, 0, None, o, ent['w_ff1'])]
+            seq += [(att, ent['w_ff1'], h, ent['b_ff1'], 1, _C.OUT_TILED, None, None),
+                    (hid, ent['w_ff2'], o, None, 0, None, o, nq)]
+            for a, w, out, bias, act, om, res, pf in seq:
+                _C.linear(a, w, out, bias=bias, act=act, a_tiled=True, M=B_eff, out_mode=om, residual=res, prefetch=pf)
                 launches += 1
                 nbytes += w.N * w.K * w.data.element_size()
-        _C.linear(att, w_head, logits, bias=pk['b_head'], a_tiled=True, M=B_eff)
+        _C.linear(att, w_head, logits, bias=pk['b_head'], a_tiled=True, M=B_eff, prefetch=L[0]['w_qkv'])
         launches += 1
         nbytes += w_head.N * w_head.K * w_head.data.element_size()
 

@@ -215,10 +215,14 @@ int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps,
  *   out[M, N] = act(LN?(a)[M, K] @ W[N, K]^T + bias[N]) + residual[M, N]
  * w: tiled weight in wdtype.  ln_g / ln_b (both or neither, only with ACMI_A_ROWMAJOR_F32, K <= 2048): full
  * LayerNorm with affine parameters applied in the kernel (the decode step uses the folded form instead).
- * bias [N] / residual [M, N] f32 row-major or NULL.  act: 0 none, 1 exact (erf) GELU. */
+ * bias [N] / residual [M, N] f32 row-major or NULL.  act: 0 none, 1 exact (erf) GELU.
+ * prefetch_w (or NULL): tiled weight [prefetch_N, prefetch_K] (same wdtype) of the GEMM that will run next;
+ * with a tiled activation, 4 of the workgroup's 16 waves pull it into L2 while the other 12 compute, so
+ * that the next launch streams from L2 instead of paying HBM latency again (a hint: no effect on results). */
 int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps,
                 const void* w, int wdtype, const float* bias, const float* residual, void* out, int out_mode,
-                int act, int M, int N, int K, void* stream);
+                int act, int M, int N, int K, const void* prefetch_w, int prefetch_N, int prefetch_K,
+                void* stream);
 
 /* Single-query attention over a [Beff, H, Tcap, hd] cache, positions [0, len): the
  * F.scaled_dot_product_attention call of transformer.py:412-414 for one new step.
