@@ -1,0 +1,205 @@
+"""CPU suite (-m "not gpu"): host logic of the product package + the C ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import patterns as opat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, 'include', 'acmi.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(acmi_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from audiocraft_amd import _C
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(_C.lib, n), f"include/acmi.h declares {n} but libacmi.so does not export it"
+    assert set(_C.EXPORTS) == set(names)
+    assert _C.version() == 100
+
+
+def test_argument_validation_without_gpu():
+    """Error paths never touch the device: negative return code + thread-local message."""
+    from audiocraft_amd import _C
+    lib = _C.lib
+    rc = lib.acmi_rvq_decode(None, None, None, 1, 16, 4, 64, 32, None)
+    assert rc == -1 and b'K=64' in lib.acmi_last_error()
+    rc = lib.acmi_rvq_encode(None, None, None, None, 1, 100, 4, 4, 32, None)
+    assert rc == -1 and b'dimension 100' in lib.acmi_last_error()
+    d = _C.ConvDesc()
+    d.B, d.Cin, d.Tin, d.Cout, d.Tout, d.ksize, d.stride, d.dilation = 1, 4, 10, 6, 10, 3, 1, 1
+    d.shuffle = 4  # 6 % 4 != 0
+    rc = lib.acmi_conv1d(ctypes.byref(d), None, None, None, None, None, None)
+    assert rc == -1 and b'shuffle' in lib.acmi_last_error()
+    assert lib.acmi_lm_step(None, None, 0, None) == -1
+    assert lib.acmi_ln_tile(None, None, 0, 4, 4096, ctypes.c_float(1e-5), None) == -1
+    assert _C.lstm_work_floats(3, 8) == 72
+
+
+def test_tiling_roundtrip():
+    from audiocraft_amd import _C
+    w = torch.randn(40, 70)
+    for dt in (torch.float32, torch.bfloat16):
+        t = _C.tile_matrix(w, dt)
+        assert t.shape[0] == 3 and t.shape[3] == 16
+        assert torch.equal(_C.untile_matrix(t, 40, 70), w.to(dt))
+        # documented layout: T[rt][kc][kg*16 + r][j] = w[rt*16 + r][kc*KT + kg*e + j]
+        e = t.shape[4]
+        assert t[1, 1, 3, 5, 1] == w.to(dt)[16 + 5, 1 * 4 * e + 3 * e + 1]
+
+
+# ------------------------------------------------------------------------------------------ patterns
+
+@pytest.mark.parametrize('T,delays', [(7, None), (1, None), (12, [0, 1, 2, 3]), (9, [0, 0, 1, 3]), (5, [0, 0, 0, 0])])
+def test_pattern_matches_naive_loops(T, delays):
+    """reference tests/modules/test_codebooks_patterns.py:107-246: gathers == naive python loops."""
+    from audiocraft_amd.modules.codebooks_patterns import DelayedPatternProvider
+    K = 4
+    p = DelayedPatternProvider(K, delays).get_pattern(T)
+    z = torch.randint(0, 100, (3, K, T))
+    v, idx, m = p.build_pattern_sequence(z, 777)
+    v2, m2 = opat.build_pattern_sequence(z, 777, delays)
+    assert torch.equal(v, v2) and torch.equal(m, m2)
+    assert v.shape[-1] == T + max(delays or range(K)) + 1 == p.num_sequence_steps + 1
+    back, _, bm = p.revert_pattern_sequence(v, -1)
+    b2, bm2 = opat.revert_pattern_sequence(v2, -1, T, delays)
+    assert torch.equal(back, b2) and torch.equal(bm, bm2) and torch.equal(back, z)
+    # truncated sequences revert with the special token where steps are missing
+    back_t, _, bm_t = p.revert_pattern_sequence(v[..., :T], -1)
+    b3, bm3 = opat.revert_pattern_sequence(v2[..., :T], -1, T, delays)
+    assert torch.equal(back_t, b3) and torch.equal(bm_t, bm3)
+    for t in range(T):
+        assert p.get_first_step_with_timesteps(t) == opat.first_step_with_timestep(K, T, t, delays)
+    assert p.get_first_step_with_timesteps(T) is None
+    # layout view agrees with the closed form
+    lay = opat.delayed_layout(K, T, delays)
+    assert [[tuple(c) for c in s] for s in p.layout] == lay
+    # logits revert: [B, card, K, S] -> [B, card, K, T]; position t of codebook q comes from step t + delay
+    S = v.shape[-1]
+    logits = torch.randn(2, 5, K, S)
+    lv, _, lm = p.revert_pattern_logits(logits, float('nan'))
+    dl = delays or list(range(K))
+    for q in range(K):
+        for t in range(T):
+            if t + dl[q] < S - 1 + 1 and t + dl[q] < S:
+                assert lm[q, t] == (t + dl[q] < S)
+                if lm[q, t]:
+                    assert torch.equal(lv[:, :, q, t], logits[:, :, q, t + dl[q]])
+
+
+def test_pattern_valid_steps_only():
+    from audiocraft_amd.modules.codebooks_patterns import DelayedPatternProvider
+    p = DelayedPatternProvider(4).get_pattern(6)
+    z = torch.arange(2 * 4 * 6).view(2, 4, 6)
+    v, _, m = p.build_pattern_sequence(z, 99, keep_only_valid_steps=True)
+    assert v.shape[-1] == 7 and len(p.valid_layout) == 7
+    assert torch.equal(v, p.build_pattern_sequence(z, 99)[0][..., :7])
+
+
+# ------------------------------------------------------------------------------------------ conditioning
+
+def test_cfg_dropout_and_fuser_order():
+    from audiocraft_amd.modules.conditioners import (ClassifierFreeGuidanceDropout, ConditionFuser,
+                                                     ConditioningAttributes, WavCondition)
+    c = ConditioningAttributes(text={'description': 'hello'})
+    c.wav['self_wav'] = WavCondition(torch.randn(1, 1, 50), torch.tensor([50]), [32000], [None], [0.])
+    null = ClassifierFreeGuidanceDropout(p=1.0)([c])
+    assert c.text['description'] == 'hello' and c.wav['self_wav'].wav.shape[-1] == 50   # deep-copied
+    assert null[0].text['description'] is None
+    assert null[0].wav['self_wav'].wav.shape == (1, 1, 1) and int(null[0].wav['self_wav'].length) == 0
+    assert ClassifierFreeGuidanceDropout(p=0.0)([c])[0] is c
+    flat = c.to_flat_dict()
+    assert ConditioningAttributes.from_flat_dict(flat).text == c.text
+    # reference fuser loop (conditioners.py:1730-1748): later 'prepend' conditions go in FRONT
+    fuser = ConditionFuser({'prepend': ['self_wav', 'description'], 'cross': []})
+    d = {'description': (torch.ones(2, 3, 4), torch.ones(2, 3)), 'self_wav': (2 * torch.ones(2, 5, 4), torch.ones(2, 5))}
+    prepend, cross = fuser.fuse(d)
+    assert cross is None and prepend.shape == (2, 8, 4)
+    assert (prepend[:, :5] == 2).all() and (prepend[:, 5:] == 1).all()
+    fuser = ConditionFuser({'cross': ['description']})
+    prepend, cross = fuser.fuse({'description': d['description']})
+    assert prepend is None and cross.shape == (2, 3, 4)
+    with pytest.raises(AssertionError):
+        fuser.fuse(d)
+
+
+def test_wav_collation_pads_to_longest():
+    from audiocraft_amd.modules.conditioners import (ChromaStemConditioner, ConditioningAttributes,
+                                                     ConditioningProvider, WavCondition)
+    prov = ConditioningProvider({'self_wav': ChromaStemConditioner(8, 32000, 12, 14, 30.)})
+    a = ConditioningAttributes()
+    a.wav['self_wav'] = WavCondition(torch.ones(1, 2, 40), torch.tensor([40]), [32000], [None], [0.])
+    b = ConditioningAttributes()
+    b.wav['self_wav'] = WavCondition(torch.zeros(1, 1, 1), torch.tensor([0]), [32000], [None], [None])
+    tok = prov.tokenize([a, b])
+    w = tok['self_wav']
+    assert w.wav.shape == (2, 1, 40) and w.length.tolist() == [40, 0]
+    assert (w.wav[0] == 1).all() and (w.wav[1] == 0).all()
+    assert prov.conditioners['self_wav'].chroma_len == 235    # 30 s * 32 kHz / 4096 + 1
+
+
+def test_models_refuse_to_run_without_gpu():
+    from audiocraft_amd.models import builders
+    lm = builders.get_debug_lm_model('cpu')
+    with pytest.raises(RuntimeError, match="MI355X"):
+        ct = {'description': (torch.zeros(2, 3, 16), torch.ones(2, 3, dtype=torch.int64))}
+        lm.generate(None, [], num_samples=1, max_gen_len=4, condition_tensors=ct)
+    assert [k for k in lm.state_dict() if k.startswith('transformer.layers.0.')] == [
+        'transformer.layers.0.self_attn.in_proj_weight', 'transformer.layers.0.self_attn.out_proj.weight',
+        'transformer.layers.0.linear1.weight', 'transformer.layers.0.linear2.weight',
+        'transformer.layers.0.norm1.weight', 'transformer.layers.0.norm1.bias',
+        'transformer.layers.0.norm2.weight', 'transformer.layers.0.norm2.bias',
+        'transformer.layers.0.cross_attention.in_proj_weight', 'transformer.layers.0.cross_attention.out_proj.weight',
+        'transformer.layers.0.norm_cross.weight', 'transformer.layers.0.norm_cross.bias']
+
+
+def test_state_dict_keys_match_reference_golden():
+    """Checkpoint compatibility: our module trees expose exactly the reference's parameter names."""
+    from conftest import load_golden
+    from audiocraft_amd.models import builders
+    cfg, sd, _ = load_golden('lm_text')
+    lm = builders.get_lm_model(dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'],
+                                    n_q=cfg['n_q'], card=cfg['card'],
+                                    conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': cfg['cond_dim']}},
+                                    fuser={'cross': ['description']}), 'cpu', torch.float32)
+    assert set(lm.state_dict().keys()) == set(sd.keys())
+    for k, v in lm.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    cfg, sd, _ = load_golden('codec_causal')
+    sk = dict(channels=cfg['channels'], dimension=cfg['dimension'], n_filters=cfg['n_filters'],
+              n_residual_layers=cfg['n_residual_layers'], ratios=cfg['ratios'], norm=cfg['norm'], causal=True,
+              pad_mode=cfg['pad_mode'], true_skip=cfg['true_skip'], lstm=cfg['lstm'])
+    m = builders.get_compression_model(dict(seanet=sk, rvq=dict(n_q=cfg['n_q'], bins=cfg['bins']), sample_rate=1200,
+                                            frame_rate=75, channels=1, causal=True), 'cpu')
+    assert set(m.state_dict().keys()) == set(sd.keys())
+
+
+def test_loader_roundtrip(tmp_path):
+    """Reference export format (utils/export.py:58-79) -> loaders.load_lm_model (construction on CPU only)."""
+    from audiocraft_amd.models import builders, loaders
+    xp = {'transformer_lm': {'dim': 16, 'num_heads': 4, 'num_layers': 2, 'hidden_scale': 4, 'n_q': 4, 'card': 400},
+          'conditioners': {'description': {'model': 't5', 't5': {'name': 't5-small'}}},
+          'fuser': {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []},
+          'codebooks_pattern': {'modeling': 'delay', 'delay': {'delays': [0, 1, 2, 3]}},
+          'classifier_free_guidance': {'inference_coef': '${cfgc}'}, 'cfgc': 2.5}
+    cfg = loaders.lm_cfg_from_xp(loaders.parse_cfg(xp))
+    assert cfg['cfg_coef'] == 2.5 and cfg['conditioners']['description']['name'] == 't5-small'
+    lm = builders.get_lm_model(cfg, 'cpu', torch.float32)
+    path = tmp_path / 'state_dict.bin'
+    loaders.export_lm(lm, str(path), xp)
+    lm2 = loaders.load_lm_model(str(tmp_path), device='cpu', weight_dtype=torch.float32)
+    for (k1, v1), (k2, v2) in zip(lm.state_dict().items(), lm2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    with pytest.raises(FileNotFoundError):
+        loaders.load_lm_model('facebook/musicgen-small', device='cpu')
