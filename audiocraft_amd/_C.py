@@ -51,7 +51,7 @@ class LMModelDesc(C.Structure):
 class LMState(C.Structure):
     _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
                 ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
-                ('x', vp), ('q', vp), ('xn', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
+                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64)]
 
@@ -76,12 +76,22 @@ _linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i
 _attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
 _pos_table = _sig('acmi_pos_table', [vp, vp, i32, i32, vp])
 _ln_tile = _sig('acmi_ln_tile', [vp, vp, i32, i32, i32, f32, vp])
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [('a', vp), ('a_mode', i32), ('ln_g', vp), ('ln_b', vp), ('eps', f32), ('a_stats', vp),
+                ('a_stats_np', i32), ('a_stats_cnt', i32), ('w', vp), ('wdtype', i32), ('bias', vp), ('residual', vp),
+                ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('M', i32), ('N', i32), ('K', i32),
+                ('prefetch_w', vp), ('prefetch_N', i32), ('prefetch_K', i32)]
+
+
+_linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
 _kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, i32, f32, u64, u64, vp])
 
 EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
-           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile']
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex']
 
 
 def version() -> int:
@@ -152,7 +162,7 @@ def lstm_work_floats(B, H) -> int:
     return int(_lstm_work(B, H))
 
 
-A_ROWMAJOR_F32, A_TILED, A_ROWMAJOR_F32_NORM = 0, 1, 2
+A_ROWMAJOR_F32, A_TILED, A_ROWMAJOR_F32_NORM, A_ROWMAJOR_F32_STATS = 0, 1, 2, 3
 OUT_F32, OUT_BF16, OUT_TILED = 0, 1, 2
 
 
@@ -215,6 +225,19 @@ def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, re
                   ptr(prefetch.data) if prefetch is not None else None, prefetch.N if prefetch is not None else 0,
                   prefetch.K if prefetch is not None else 0, stream()),
           'acmi_linear')
+    return out
+
+
+def linear_ex(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0, cnt=0, stats_out=None, bias=None,
+              residual=None, act=0, eps=1e-5):
+    """Descriptor form (acmi_linear_ex): statistics hand-off between producer and consumer GEMMs."""
+    d = LinearDesc()
+    d.a, d.a_mode, d.eps = ptr(a), a_mode, eps
+    d.a_stats, d.a_stats_np, d.a_stats_cnt = ptr(a_stats), np_, cnt
+    d.w, d.wdtype, d.bias, d.residual = ptr(w.data), dtype_code(w.dtype), ptr(bias), ptr(residual)
+    d.out, d.out_mode, d.act, d.stats_out = ptr(out), out_mode, act, ptr(stats_out)
+    d.M, d.N, d.K = M, w.N, w.K
+    check(_linear_ex(C.byref(d), stream()), 'acmi_linear_ex')
     return out
 
 

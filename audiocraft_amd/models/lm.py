@@ -284,6 +284,7 @@ class LMModel(nn.Module):
         run['x'] = torch.zeros(Beff, d, **f32)
         run['q'] = torch.zeros(Beff, d, **f32)
         # activations that feed a GEMM directly live in A-fragment order, zero padded
+        run['stats'] = torch.zeros(max(1, d // 16), Beff, 2, **f32)
         run['xn'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['att'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['hidden'] = _C.tiled_activation_buffer(Beff, self.ffn_dim, self.weight_dtype, dev)
@@ -306,6 +307,7 @@ class LMModel(nn.Module):
         st.prepend = None if prepend is None else prepend.data_ptr()
         st.pos = run['pos'].data_ptr()
         st.x, st.q, st.att = run['x'].data_ptr(), run['q'].data_ptr(), run['att'].data_ptr()
+        st.stats = run['stats'].data_ptr()
         st.xn = run['xn'].data_ptr()
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None

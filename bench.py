@@ -62,7 +62,10 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     att = _C.tile_matrix(torch.randn(B_eff, d, device=dev), wd)
     hid = _C.tile_matrix(torch.randn(B_eff, ffn, device=dev), wd)
     qkv = torch.empty(B_eff, 3 * d, device=dev)
-    o = torch.empty(B_eff, d, device=dev)
+    o = torch.zeros(B_eff, d, device=dev)
+    o2 = torch.empty(B_eff, d, device=dev)
+    stats = torch.zeros(max(1, d // 16), B_eff, 2, device=dev)
+    stats[0, :, 1] = float(d)
     h = _C.tiled_activation_buffer(B_eff, ffn, wd, dev)
     logits = torch.empty(B_eff, lm.n_q * lm.card, device=dev)
     w_head = pk['w_head']
@@ -73,21 +76,28 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
         # the same launches acmi_lm_step issues for one position (same shapes, operand layouts and weights)
         nonlocal launches, nbytes
         L = pk['per_layer']
+        np_, cnt = 1, d
         for li, ent in enumerate(L):
-            nq = L[li + 1]['w_qkv'] if li + 1 < len(L) else w_head
-            cross = 'w_cq' in ent
-            seq = [(att, ent['w_qkv'], qkv, ent['b_qkv'], 0, None, None, ent['w_out']),
-                   (att, ent['w_out'], o, None, 0, None, o, ent['w_cq'] if cross else ent['w_ff1'])]
-            if cross:
-                seq += [(att, ent['w_cq'], o, ent['b_cq'], 0, None, None, ent['w_cout']),
-                        (att, ent['w_cout'], o, None, 0, None, o, ent['w_ff1'])]
-            seq += [(att, ent['w_ff1'], h, ent['b_ff1'], 1, _C.OUT_TILED, None, None),
-                    (hid, ent['w_ff2'], o, None, 0, None, o, nq)]
-            for a, w, out, bias, act, om, res, pf in seq:
-                _C.linear(a, w, out, bias=bias, act=act, a_tiled=True, M=B_eff, out_mode=om, residual=res, prefetch=pf)
-                launches += 1
-                nbytes += w.N * w.K * w.data.element_size()
-        _C.linear(att, w_head, logits, bias=pk['b_head'], a_tiled=True, M=B_eff, prefetch=L[0]['w_qkv'])
+            def stats_lin(w, out, bias, act=0, om=_C.OUT_F32):
+                _C.linear_ex(x, w, out, B_eff, _C.A_ROWMAJOR_F32_STATS, om, a_stats=stats, np_=np_, cnt=cnt, bias=bias, act=act)
+
+            def tiled_lin(a, w):
+                _C.linear_ex(a, w, o, B_eff, _C.A_TILED, _C.OUT_F32, stats_out=stats, residual=o)
+
+            stats_lin(ent['w_qkv'], qkv, ent['b_qkv'])
+            tiled_lin(att, ent['w_out'])
+            np_, cnt = d // 16, 16
+            ws = [ent['w_qkv'], ent['w_out']]
+            if 'w_cq' in ent:
+                stats_lin(ent['w_cq'], o2, ent['b_cq'])
+                tiled_lin(att, ent['w_cout'])
+                ws += [ent['w_cq'], ent['w_cout']]
+            stats_lin(ent['w_ff1'], h, ent['b_ff1'], act=1, om=_C.OUT_TILED)
+            tiled_lin(hid, ent['w_ff2'])
+            ws += [ent['w_ff1'], ent['w_ff2']]
+            launches += len(ws)
+            nbytes += sum(w.N * w.K * w.data.element_size() for w in ws)
+        stats_lin(w_head, logits, pk['b_head'])
         launches += 1
         nbytes += w_head.N * w_head.K * w_head.data.element_size()
 

@@ -170,6 +170,7 @@ typedef struct {
                                pos[1] = scratch ticket counter (must be 0 between steps) */
     float* x;               /* [Beff, d] f32 residual stream */
     float* q;               /* [Beff, d] f32 */
+    float* stats;           /* [max(1, d/16)][Beff][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
     void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x */
     void* att;              /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised */
     void* hidden;           /* tiled activation [ceil(Beff/16)*16, ffn_pad] in wdtype, zero-initialised */
@@ -205,6 +206,9 @@ int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps,
 #define ACMI_A_ROWMAJOR_F32 0 /* a [M, K] f32 row-major, staged through LDS (+ optional LayerNorm) */
 #define ACMI_A_TILED 1        /* a = tiled activation in the weight's element type */
 #define ACMI_A_ROWMAJOR_F32_NORM 2 /* as 0, rows standardised ((x - mean) / sqrt(var + eps)) while staging */
+#define ACMI_A_ROWMAJOR_F32_STATS 3 /* a [M, K] f32 row-major whose per-row LayerNorm statistics were emitted by
+                                       the kernel that produced it (a_stats, see acmi_linear_desc): rows are
+                                       standardised in a wave-private staging step, no separate LayerNorm launch */
 #define ACMI_OUT_F32 0        /* out [M, N] f32 row-major */
 #define ACMI_OUT_BF16 1       /* out [M, N] bf16 row-major */
 #define ACMI_OUT_TILED 2      /* out = tiled activation (element type of w), pad region untouched */
@@ -223,6 +227,26 @@ int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b,
                 const void* w, int wdtype, const float* bias, const float* residual, void* out, int out_mode,
                 int act, int M, int N, int K, const void* prefetch_w, int prefetch_N, int prefetch_K,
                 void* stream);
+
+/* Descriptor form of acmi_linear with the producer/consumer LayerNorm-statistics hand-off:
+ *   stats_out (or NULL): this GEMM writes, for every output row m and every workgroup b (16 output
+ *     features each, N % 16 == 0), the pair (mean_b, M2_b = sum (v - mean_b)^2) of its final outputs to
+ *     stats_out[(b * M + m) * 2 .. +1]  ->  N / 16 partials of 16 elements per row;
+ *   a_stats / a_stats_np / a_stats_cnt with ACMI_A_ROWMAJOR_F32_STATS: the consumer combines `np`
+ *     equal-count partials (Chan: mean = avg mean_b, M2 = sum M2_b + cnt (mean_b - mean)^2; np * cnt == K,
+ *     np <= 128) into mean / rstd per row and standardises the rows while building its A fragments. */
+typedef struct {
+    const void* a; int a_mode;
+    const float* ln_g; const float* ln_b; float eps;
+    const float* a_stats; int a_stats_np; int a_stats_cnt;
+    const void* w; int wdtype;
+    const float* bias; const float* residual;
+    void* out; int out_mode; int act;
+    float* stats_out;
+    int M, N, K;
+    const void* prefetch_w; int prefetch_N; int prefetch_K;
+} acmi_linear_desc;
+int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
 
 /* Single-query attention over a [Beff, H, Tcap, hd] cache, positions [0, len): the
  * F.scaled_dot_product_attention call of transformer.py:412-414 for one new step.

@@ -230,6 +230,44 @@ def test_attn_decode_vs_oracle(C, Beff, H, hd, Tcap, length, kvdt):
         assert torch.equal(C.untile_matrix(buf, Beff, H * hd), out.to(dt))
 
 
+@pytest.mark.parametrize('M,d,N2', [(16, 1536, 4608), (2, 1024, 3072), (5, 32, 96), (20, 2048, 512), (16, 16, 48)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_linear_statistics_handoff(C, M, d, N2, dt):
+    """x1 = x0 + A W1^T written with per-row (mean, M2) partials; the next GEMM standardises x1 from them:
+    out = LN_noaffine(x1) W2^T + b  (the LayerNorm in front of every GEMM of the decode step)."""
+    g = torch.Generator().manual_seed(M + d)
+    K1 = 64
+    a = torch.randn(M, K1, generator=g)
+    w1 = torch.randn(d, K1, generator=g) / math.sqrt(K1)
+    x0 = torch.randn(M, d, generator=g) * 2 + 0.5
+    w2 = torch.randn(N2, d, generator=g) / math.sqrt(d)
+    b2 = 0.1 * torch.randn(N2, generator=g)
+    x1_ref = x0 + a.to(dt).float() @ w1.to(dt).float().t()
+    ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t() + b2
+    x = x0.cuda().clone()
+    stats = torch.zeros(d // 16, M, 2, device='cuda')
+    C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w1.cuda(), dt), x, M, C.A_TILED, C.OUT_F32,
+                stats_out=stats, residual=x)
+    assert rel(x.cpu(), x1_ref) < (2e-6 if dt == torch.float32 else 1e-5)
+    # the partials reproduce the row statistics
+    mean_b, m2_b = stats[..., 0].cpu(), stats[..., 1].cpu()
+    mean = mean_b.mean(0)
+    var = (m2_b + 16 * (mean_b - mean) ** 2).sum(0) / d
+    assert torch.allclose(mean, x1_ref.mean(1), atol=1e-5)
+    assert torch.allclose(var, x1_ref.var(1, unbiased=False), rtol=1e-4)
+    out = torch.empty(M, N2, device='cuda')
+    C.linear_ex(x, C.TiledWeight(w2.cuda(), dt), out, M, C.A_ROWMAJOR_F32_STATS, C.OUT_F32, a_stats=stats,
+                np_=d // 16, cnt=16, bias=b2.cuda())
+    r = rel(out.cpu(), ref)
+    assert r < (3e-6 if dt == torch.float32 else 5e-3), f"rel-L2 {r}"
+    # single exact partial per row (what embed_kernel emits)
+    s1 = torch.stack([x1_ref.mean(1), ((x1_ref - x1_ref.mean(1, keepdim=True)) ** 2).sum(1)], dim=-1)[None].contiguous().cuda()
+    out2 = torch.empty(M, N2, device='cuda')
+    C.linear_ex(x, C.TiledWeight(w2.cuda(), dt), out2, M, C.A_ROWMAJOR_F32_STATS, C.OUT_F32, a_stats=s1, np_=1, cnt=d,
+                bias=b2.cuda())
+    assert rel(out2.cpu(), ref) < (3e-6 if dt == torch.float32 else 5e-3)
+
+
 @pytest.mark.parametrize('M,K', [(16, 1536), (3, 32), (33, 2048), (16, 1024)])
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_ln_tile_vs_torch(C, M, K, dt):
