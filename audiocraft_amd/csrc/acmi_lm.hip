@@ -50,7 +50,13 @@ struct LinArgs {
     float* q_out; void* k_cache; void* v_cache; int kv_bf16; int H, hd, Tcap, d; const int* pos;
 };
 
-template <typename WT> struct WTr { static constexpr int EPL = 16 / (int)sizeof(WT); static constexpr int KT = 4 * EPL; };
+template <typename WT> struct WTr {
+    static constexpr int EPL = 16 / (int)sizeof(WT);  // elements per lane of a fragment
+    static constexpr int KT = 4 * EPL;                // K columns per fragment tile
+    static constexpr int LPR = KT / 4;                // statistics mode: lanes per activation row (one float4 each)
+    static constexpr int RPI = 64 / LPR;              //                  rows covered by one load instruction
+    static constexpr int NJ = 16 / RPI;               //                  load instructions per 16-row tile
+};
 
 __device__ __forceinline__ u32x4 ld_frag_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
 
@@ -182,6 +188,30 @@ extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K,
     return acmi_check_launch("ln_tile_kernel");
 }
 
+// Statistics mode (AM 2): branch-free loads (clamped addresses, values masked later) of this wave's share of
+// the (mean, M2) partials of row m0 + wave and of its TPW activation tiles of the 16-row block at m0.
+template <typename WT, int TPW>
+__device__ __forceinline__ void stats_loads(const LinArgs& p, int m0, int wave, int lane, float (&pm)[2], float (&pq)[2],
+                                            float4 (&xa)[TPW > 0 ? TPW : 1][WTr<WT>::NJ]) {
+    constexpr int KT = WTr<WT>::KT, LPR = WTr<WT>::LPR, RPI = WTr<WT>::RPI, NJ = WTr<WT>::NJ;
+    const int mrow = min(m0 + wave, p.M - 1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int pi = min(lane + 64 * u, p.a_np - 1);
+        const float2 t = *reinterpret_cast<const float2*>(p.a_stats + ((size_t)pi * p.M + mrow) * 2);
+        pm[u] = t.x; pq[u] = t.y;
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kc = wave + i * 16;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = min(m0 + lane / LPR + RPI * j, p.M - 1), col = kc * KT + (lane % LPR) * 4;
+            xa[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.a) + (size_t)row * p.K + col);
+        }
+    }
+}
+
 // N weight fragments (HBM, non-temporal) and N activation fragments (L2) requested back to back, then N MFMAs:
 // branch-free so the compiler can count vmcnt instead of draining at control-flow joins.
 template <typename WT, int N>
@@ -195,7 +225,7 @@ __device__ __forceinline__ void mma_chunk(const u32x4* wt, const u32x4* at, int 
     for (int i = 0; i < N; ++i) mma_frag(av[i], bv[i], acc, WT());
 }
 
-template <typename WT, int AM>
+template <typename WT, int AM, int TPW>
 __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
     constexpr bool A_TILED = AM == 1;
     constexpr int EPL = WTr<WT>::EPL, KT = WTr<WT>::KT;
@@ -223,77 +253,53 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
         }
     }
 
+    // statistics mode: everything the first 16-row block needs is requested here, in the order it is consumed
+    // (vmcnt retires in order): statistics partials, activation tiles, then the weight fragments from HBM
+    float spm[2], spq[2];
+    float4 sxa[TPW > 0 ? TPW : 1][WTr<WT>::NJ];
+    u32x4 swv[TPW > 0 ? TPW : 1];
+    if (AM == 2) {
+        stats_loads<WT, TPW>(p, 0, wave, lane, spm, spq, sxa);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) swv[i] = ld_frag_nt(wt + (size_t)(wave + i * 16) * 64);
+    }
+
     for (int m0 = 0; m0 < p.M; m0 += 16) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (AM == 2) {
-            // Row-major f32 activation whose LayerNorm statistics arrive as per-row (mean, M2) partials from
-            // the kernel that produced it.  Load order matters (vmcnt retires in order): partials, then this
-            // wave's activation tiles, then (first pass) the weight fragments from HBM.
-            constexpr int LPR = KT / 4, RPI = 64 / LPR, NJ = 16 / RPI;  // lanes per row, rows per load, loads per tile
+            // Row-major f32 activation whose LayerNorm statistics arrive as per-row (mean, M2) partials from the
+            // kernel that produced it: combine them (one row per wave), standardise this wave's tiles through a
+            // wave-private LDS tile (no workgroup barrier besides the one that publishes mean / rstd).
+            constexpr int LPR = WTr<WT>::LPR, RPI = WTr<WT>::RPI, NJ = WTr<WT>::NJ;
             float* sstat = reinterpret_cast<float*>(As);                // [16][2] mean, rstd
             unsigned char* wbuf = As + 128 + (size_t)wave * 1280;       // this wave's [16][80 B] tile
-            const int mrow = m0 + wave;                                  // the row whose statistics this wave combines
-            float pm[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int pi = lane + 64 * u;
-                if (mrow < p.M && pi < p.a_np) {
-                    const float2 t = *reinterpret_cast<const float2*>(p.a_stats + ((size_t)pi * p.M + mrow) * 2);
-                    pm[u] = t.x; pq[u] = t.y;
-                }
-            }
-            float4 xa[TMAX][NJ];
-#pragma unroll
-            for (int i = 0; i < TMAX; ++i) {
-                const int kc = wave + i * nw;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int row = m0 + lane / LPR + RPI * j, col = kc * KT + (lane % LPR) * 4;
-                    xa[i][j] = (kc < NKC && row < p.M && col < p.K)
-                                   ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.a) + (size_t)row * p.K + col)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-            if (m0 == 0) {
-#pragma unroll
-                for (int i = 0; i < TMAX; ++i) {
-                    const int kc = wave + i * nw;
-                    if (kc < NKC) wv[i] = ld_frag_nt(wt + (size_t)kc * 64);
-                    else wv[i] = u32x4{0u, 0u, 0u, 0u};
-                }
-            }
+            if (m0 != 0) stats_loads<WT, TPW>(p, m0, wave, lane, spm, spq, sxa);
             // Chan combination of equal-count partials: mean = avg(mean_b), M2 = sum(M2_b + cnt (mean_b - mean)^2)
-            const float mean = wave_sum(pm[0] + pm[1]) / (float)p.a_np;
-            float q2 = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (lane + 64 * u < p.a_np) { const float dlt = pm[u] - mean; q2 += pq[u] + (float)p.a_cnt * dlt * dlt; }
+            const bool v0 = lane < p.a_np, v1 = lane + 64 < p.a_np;
+            const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.a_np;
+            const float d0 = spm[0] - mean, d1 = spm[1] - mean;
+            const float q2 = (v0 ? spq[0] + (float)p.a_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.a_cnt * d1 * d1 : 0.f);
             const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.K + p.eps);
-            if (lane == 0 && wave < 16) { sstat[wave * 2] = mean; sstat[wave * 2 + 1] = rstd; }
+            if (lane == 0) { sstat[wave * 2] = mean; sstat[wave * 2 + 1] = rstd; }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < TMAX; ++i) {
-                const int kc = wave + i * nw;
-                if (kc < NKC) {
+            for (int i = 0; i < TPW; ++i) {
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int rl = lane / LPR + RPI * j, col = kc * KT + (lane % LPR) * 4;
-                        const float mu = sstat[rl * 2], rs = sstat[rl * 2 + 1];
-                        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (m0 + rl < p.M && col < p.K)
-                            y = make_float4((xa[i][j].x - mu) * rs, (xa[i][j].y - mu) * rs, (xa[i][j].z - mu) * rs,
-                                            (xa[i][j].w - mu) * rs);
-                        unsigned char* dst = wbuf + rl * 80 + (lane % LPR) * 4 * sizeof(WT);
-                        if (sizeof(WT) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
-                        else *reinterpret_cast<float4*>(dst) = y;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const u32x4 av = *reinterpret_cast<const u32x4*>(wbuf + nl * 80 + kg * 16);
-                    __builtin_amdgcn_wave_barrier();
-                    mma_frag(av, wv[i], acc, WT());
+                for (int j = 0; j < NJ; ++j) {
+                    const int rl = lane / LPR + RPI * j;
+                    const float mu = sstat[rl * 2], rs = (m0 + rl < p.M) ? sstat[rl * 2 + 1] : 0.f;  // rows >= M -> 0
+                    const float y0 = (sxa[i][j].x - mu) * rs, y1 = (sxa[i][j].y - mu) * rs;
+                    const float y2 = (sxa[i][j].z - mu) * rs, y3 = (sxa[i][j].w - mu) * rs;
+                    unsigned char* dst = wbuf + rl * 80 + (lane % LPR) * 4 * sizeof(WT);
+                    if (sizeof(WT) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+                    else *reinterpret_cast<float4*>(dst) = make_float4(y0, y1, y2, y3);
                 }
+                __builtin_amdgcn_wave_barrier();
+                const u32x4 av = *reinterpret_cast<const u32x4*>(wbuf + nl * 80 + kg * 16);
+                __builtin_amdgcn_wave_barrier();
+                mma_frag(av, swv[i], acc, WT());
             }
-            __syncthreads();  // sstat is rewritten by the next 16-row tile
+            __syncthreads();  // sstat is rewritten by the next 16-row block
         } else if (AM == 0) {
             const int Kpad = NKC * KT;
             for (int r = wave; r < 16; r += nw) {
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
     }
 }
 
-template <typename WT, int AM>
+template <typename WT, int AM, int TPW = 0>
 static int launch_lin_t(LinArgs& a, hipStream_t st) {
     constexpr int KT = WTr<WT>::KT;
     constexpr bool A_TILED = AM == 1;
@@ -417,8 +423,7 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     } else if (AM == 2) {
         a.pf_ptr = nullptr;
         nw = 16;
-        constexpr int tmax = sizeof(WT) == 2 ? 4 : 8;
-        ACMI_REQUIRE(a.K % 4 == 0 && a.NKC <= 16 * tmax, "acmi_linear: statistics-mode activation needs K %% 4 == 0 and K <= 2048 (K=%d)", a.K);
+        ACMI_REQUIRE(a.K % KT == 0 && a.NKC == 16 * TPW, "acmi_linear: statistics mode needs K = %d * {1..4} (K=%d)", 16 * KT, a.K);
         ACMI_REQUIRE(a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 128 && a.a_np * a.a_cnt == a.K,
                      "acmi_linear: bad statistics partials (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
         a.RS = 0;
@@ -432,7 +437,7 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WT, AM>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WT, AM, TPW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
             return ACMI_ELAUNCH;
@@ -441,7 +446,7 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     }
     a.nwc = nw;
     ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
-    hipLaunchKernelGGL((lin_kernel<WT, AM>), dim3((a.N + 15) / 16), dim3((nw + npf) * 64), lds, st, a);
+    hipLaunchKernelGGL((lin_kernel<WT, AM, TPW>), dim3((a.N + 15) / 16), dim3((nw + npf) * 64), lds, st, a);
     return acmi_check_launch("lin_kernel");
 }
 
@@ -450,9 +455,25 @@ static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
     const int am = a.a_tiled ? 1 : (a.a_stats ? 2 : 0);
-    if (wdtype == ACMI_BF16)
-        return am == 1 ? launch_lin_t<bf16_t, 1>(a, st) : (am == 2 ? launch_lin_t<bf16_t, 2>(a, st) : launch_lin_t<bf16_t, 0>(a, st));
-    return am == 1 ? launch_lin_t<float, 1>(a, st) : (am == 2 ? launch_lin_t<float, 2>(a, st) : launch_lin_t<float, 0>(a, st));
+    if (am == 2) {  // statistics mode: K = 16 * KT * {1, 2, 3, 4 (, 6, 8 for f32)} <= 2048
+        const int kt = wdtype == ACMI_BF16 ? 32 : 16;
+        const int tpw = (a.K % (16 * kt) == 0) ? a.K / (16 * kt) : 0;
+#define ACMI_STATS_CASE(T) case T: return wdtype == ACMI_BF16 ? launch_lin_t<bf16_t, 2, T>(a, st) : launch_lin_t<float, 2, T>(a, st);
+        switch (tpw) {
+            ACMI_STATS_CASE(1) ACMI_STATS_CASE(2) ACMI_STATS_CASE(3) ACMI_STATS_CASE(4)
+            case 6: if (wdtype != ACMI_BF16) return launch_lin_t<float, 2, 6>(a, st); break;
+            case 8: if (wdtype != ACMI_BF16) return launch_lin_t<float, 2, 8>(a, st); break;
+            default: break;
+        }
+        {
+            acmi_set_error("acmi_linear: statistics mode needs K = %d * {1,2,3,4%s} <= 2048 (K=%d)", 16 * kt,
+                           wdtype == ACMI_BF16 ? "" : ",6,8", a.K);
+            return ACMI_EINVAL;
+        }
+#undef ACMI_STATS_CASE
+    }
+    if (wdtype == ACMI_BF16) return am == 1 ? launch_lin_t<bf16_t, 1>(a, st) : launch_lin_t<bf16_t, 0>(a, st);
+    return am == 1 ? launch_lin_t<float, 1>(a, st) : launch_lin_t<float, 0>(a, st);
 }
 
 extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream);
@@ -982,7 +1003,8 @@ static bool use_stats_mode(const acmi_lm_model* m) {
         mode = (e && e[0] == 's') ? 1 : 0;
     }
     const int kt = m->wdtype == ACMI_BF16 ? 32 : 16;
-    return mode == 1 && m->dim % (16 * kt) == 0;
+    const int tpw = m->dim % (16 * kt) == 0 ? m->dim / (16 * kt) : 0;
+    return mode == 1 && (tpw >= 1 && (tpw <= 4 || (m->wdtype != ACMI_BF16 && (tpw == 6 || tpw == 8))));
 }
 
 // internal helper of the step: one GEMM of the chain

@@ -208,7 +208,8 @@ int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps,
 #define ACMI_A_ROWMAJOR_F32_NORM 2 /* as 0, rows standardised ((x - mean) / sqrt(var + eps)) while staging */
 #define ACMI_A_ROWMAJOR_F32_STATS 3 /* a [M, K] f32 row-major whose per-row LayerNorm statistics were emitted by
                                        the kernel that produced it (a_stats, see acmi_linear_desc): rows are
-                                       standardised in a wave-private staging step, no separate LayerNorm launch */
+                                       standardised in a wave-private staging step, no separate LayerNorm launch.
+                                       K must be 16 * KT * n <= 2048 (bf16: 512 n, n <= 4; f32: 256 n, n in 1..4, 6, 8) */
 #define ACMI_OUT_F32 0        /* out [M, N] f32 row-major */
 #define ACMI_OUT_BF16 1       /* out [M, N] bf16 row-major */
 #define ACMI_OUT_TILED 2      /* out = tiled activation (element type of w), pad region untouched */
