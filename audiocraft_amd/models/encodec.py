@@ -173,3 +173,85 @@ class EncodecModel(CompressionModel):
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor):
         return self.quantizer.decode(codes)
+
+
+class InterleaveStereoCompressionModel(CompressionModel):
+    """Stereo on top of a mono codec (reference audiocraft/models/encodec.py:397-506): left / right are
+    encoded independently and their codebooks interleaved ([B, K, T] x 2 -> [B, 2K, T], left first per level);
+    `per_timestep=True` interleaves along time instead.  Pure host logic over `EncodecModel`."""
+
+    def __init__(self, model: CompressionModel, per_timestep: bool = False):
+        super().__init__()
+        self.model = model
+        self.per_timestep = per_timestep
+        assert self.model.channels == 1, "Wrapped model is expected to be for monophonic audio"
+
+    @property
+    def total_codebooks(self):
+        return self.model.total_codebooks
+
+    @property
+    def num_codebooks(self):
+        """With K the virtual number of codebooks: the wrapped model runs K // 2 per channel."""
+        return self.model.num_codebooks if self.per_timestep else self.model.num_codebooks * 2
+
+    def set_num_codebooks(self, n: int):
+        if not self.per_timestep:
+            assert n % 2 == 0
+            n //= 2
+        self.model.set_num_codebooks(n)
+
+    @property
+    def num_virtual_steps(self) -> float:
+        return 2 if self.per_timestep else 1
+
+    @property
+    def frame_rate(self) -> float:
+        return self.model.frame_rate * self.num_virtual_steps
+
+    @property
+    def sample_rate(self) -> int:
+        return self.model.sample_rate
+
+    @property
+    def channels(self) -> int:
+        return 2
+
+    @property
+    def cardinality(self):
+        return self.model.cardinality
+
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        raise NotImplementedError("Not supported, use encode and decode.")
+
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        B, C, T = x.shape
+        assert C == self.channels, f"Expecting stereo audio but audio num channels is {C}"
+        codes, scale = self.model.encode(x.reshape(B * C, 1, T))          # [(B C), K, T']
+        K, Tp = codes.shape[1], codes.shape[2]
+        codes = codes.view(B, C, K, Tp)
+        if self.per_timestep:
+            codes = codes.permute(0, 2, 3, 1).reshape(B, K, Tp * C)       # b k (t c)
+        else:
+            codes = codes.permute(0, 2, 1, 3).reshape(B, K * C, Tp)       # b (k c) t
+        return codes.contiguous(), None if scale is None else scale.view(B, C)
+
+    def get_left_right_codes(self, codes: torch.Tensor) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        B = codes.shape[0]
+        if self.per_timestep:
+            c = codes.view(B, codes.shape[1], -1, 2).permute(0, 3, 1, 2)  # b k (t c) -> b c k t
+        else:
+            c = codes.view(B, -1, 2, codes.shape[2]).permute(0, 2, 1, 3)  # b (k c) t -> b c k t
+        return c[:, 0].contiguous(), c[:, 1].contiguous()
+
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        B, K, T = codes.shape
+        assert T % self.num_virtual_steps == 0 and K == self.num_codebooks
+        left, right = self.get_left_right_codes(codes)
+        both = torch.cat([left, right], dim=0)
+        sc = None if scale is None else torch.cat([scale[:, 0], scale[:, 1]], dim=0).reshape(-1, 1)
+        out = self.model.decode(both, sc)                                 # [2B, 1, T']
+        return torch.cat([out[:B], out[B:]], dim=1)
+
+    def decode_latent(self, codes: torch.Tensor):
+        raise NotImplementedError("Not supported by interleaved stereo wrapped models.")

@@ -516,3 +516,41 @@ class LMModel(nn.Module):
             _C.lm_step(desc, state, _C.STEP_DECODE)
             outs.append(run['step_logits'].clone())  # the sampler only writes slots still at -1
         return torch.stack(outs, dim=2)
+
+    # ------------------------------------------------------------------------------------- reference forward API
+    @torch.no_grad()
+    def forward(self, sequence: torch.Tensor, conditions: tp.List[ConditioningAttributes] = [],
+                condition_tensors: tp.Optional[ConditionTensors] = None, stage: int = -1) -> torch.Tensor:
+        """`LMModel.forward` of the reference (lm.py:221-268): pattern sequence [B, K, S] -> logits
+        [B, K, S, card].  Evaluated causally position by position through the decode kernels
+        (streaming == batch); conditions are encoded here when `condition_tensors` is not given
+        (no CFG / attribute dropout: inference only)."""
+        if condition_tensors is None:
+            tokenized = self.condition_provider.tokenize(conditions)
+            condition_tensors = self.condition_provider(tokenized)
+        else:
+            assert not conditions, "Shouldn't pass both conditions and condition_tensors."
+        return self.forward_steps(sequence, condition_tensors)
+
+    @torch.no_grad()
+    def compute_predictions(self, codes: torch.Tensor, conditions: tp.List[ConditioningAttributes] = [],
+                            condition_tensors: tp.Optional[ConditionTensors] = None, stage: int = -1,
+                            keep_only_valid_steps: bool = True):
+        """`LMModel.compute_predictions` (lm.py:270-321): codes [B, K, T] -> (logits [B, K, T, card]
+        re-aligned with the codes, mask [B, K, T] of valid positions)."""
+        B, K, T = codes.shape
+        codes = codes.contiguous()
+        pattern = self.pattern_provider.get_pattern(T)
+        sequence_codes, _, _ = pattern.build_pattern_sequence(codes, self.special_token_id,
+                                                              keep_only_valid_steps=keep_only_valid_steps)
+        logits = self.forward(sequence_codes, conditions, condition_tensors, stage=stage)  # [B, K, S, card]
+        logits = logits.permute(0, 3, 1, 2)                                                 # [B, card, K, S]
+        logits, _, logits_mask = pattern.revert_pattern_logits(logits, float('nan'),
+                                                               keep_only_valid_steps=keep_only_valid_steps)
+        logits = logits.permute(0, 2, 3, 1)                                                 # [B, K, T, card]
+        return LMOutput(logits, logits_mask[None, :, :].expand(B, -1, -1))
+
+
+class LMOutput(tp.NamedTuple):
+    logits: torch.Tensor  # [B, K, T, card], already re-aligned with the input codes
+    mask: torch.Tensor    # [B, K, T]

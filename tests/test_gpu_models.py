@@ -210,3 +210,45 @@ def test_lm_sampling_generate_is_well_formed():
     assert torch.equal(toks, toks2)
     toks3 = lm.generate(None, conds, max_gen_len=30, use_sampling=True, top_k=50, seed=2)
     assert not torch.equal(toks, toks3)
+
+
+def test_compute_predictions_matches_oracle():
+    """LMModel.compute_predictions (lm.py:270-321): logits re-aligned with the codes + validity mask."""
+    cfg, sd, a = load_golden('lm_text')
+    lm = build_lm(cfg, sd)
+    ones = torch.ones(a['cross_src'].shape[:2], dtype=torch.int64)
+    ct = {'description': (a['cross_src'].cuda(), ones.cuda())}
+    g = torch.Generator().manual_seed(9)
+    codes = torch.randint(0, cfg['card'], (6, 4, 7), generator=g)
+    out = lm.compute_predictions(codes.cuda(), [], ct)
+    assert out.logits.shape == (6, 4, 7, cfg['card']) and out.mask.shape == (6, 4, 7)
+    seq, mask = __import__('oracle.patterns', fromlist=['x']).build_pattern_sequence(codes, cfg['card'])
+    ref = olm.lm_forward(sd, lm_cfg(cfg), seq[..., :8], a['cross_src'])   # valid steps only: T + 1
+    for q in range(4):       # position t of codebook q is predicted at sequence step t + q (delay pattern)
+        for t in range(7):
+            if t + q < 8:
+                assert out.mask[0, q, t]
+                assert torch.allclose(out.logits[:, q, t].cpu(), ref[:, q, t + q], atol=1e-4, rtol=1e-3)
+            else:
+                assert not out.mask[0, q, t] and torch.isnan(out.logits[:, q, t]).all()
+
+
+def test_musicgen_small_architecture_greedy_parity():
+    """BASELINE.json configs[1] at reduced length: MusicGen-small architecture (d=1024, 24 layers, 16 heads,
+    cross-attention), 1 prompt, greedy, fp32 mode -> tokens identical to the oracle, logits rel-L2 <= 1e-4."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(0)
+    lm = builders.get_lm_model(builders.musicgen_lm_cfg('small', text_len=12), 'cuda', torch.float32)
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=1024, num_heads=16, num_layers=24, n_q=4, card=2048, cross_attention=True)
+    g = torch.Generator().manual_seed(2)
+    cross = torch.randn(2, 12, 1024, generator=g)
+    cross[1:] = 0
+    ct = {'description': (cross.cuda(), torch.ones(2, 12, dtype=torch.int64).cuda())}
+    T = 24
+    toks, lg = lm.generate(None, [], num_samples=1, max_gen_len=T, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    ref_t, ref_l = olm.generate(sd, oc, None, 1, cross, max_gen_len=T, use_sampling=False, return_logits=True)
+    assert torch.equal(toks.cpu(), ref_t)
+    r = rel(lg.cpu(), ref_l)
+    assert r < 1e-4, f"logits rel-L2 {r}"

@@ -203,3 +203,44 @@ def test_loader_roundtrip(tmp_path):
         assert k1 == k2 and torch.equal(v1, v2)
     with pytest.raises(FileNotFoundError):
         loaders.load_lm_model('facebook/musicgen-small', device='cpu')
+
+
+def test_stereo_interleave_wrapper():
+    """InterleaveStereoCompressionModel (reference encodec.py:397-506): '(b c) k t -> b (k c) t' and the
+    per-timestep variant, checked on a stand-in mono codec (layout was cross-checked against the reference class)."""
+    from audiocraft_amd.models.encodec import CompressionModel, InterleaveStereoCompressionModel
+
+    class Mono(CompressionModel):
+        channels, frame_rate, sample_rate, cardinality, num_codebooks, total_codebooks = 1, 50, 32000, 2048, 4, 4
+
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def encode(self, x):
+            T = x.shape[-1] // 4
+            return (x[:, 0, :T * 4:4].abs() * 1000).long()[:, None].repeat(1, 4, 1) + torch.arange(4).view(1, 4, 1), None
+
+        def decode(self, codes, scale=None):
+            return codes.float().sum(1, keepdim=True).repeat_interleave(4, dim=-1)
+
+        def set_num_codebooks(self, n): pass
+        def forward(self, x): pass
+        def decode_latent(self, c): pass
+
+    x = torch.randn(3, 2, 40)
+    mono = Mono()
+    left, _ = mono.encode(x[:, :1])
+    right, _ = mono.encode(x[:, 1:])
+    st = InterleaveStereoCompressionModel(mono)
+    codes, scale = st.encode(x)
+    assert scale is None and codes.shape == (3, 8, 10) and st.num_codebooks == 8 and st.channels == 2
+    assert torch.equal(codes[:, 0::2], left) and torch.equal(codes[:, 1::2], right)
+    l2, r2 = st.get_left_right_codes(codes)
+    assert torch.equal(l2, left) and torch.equal(r2, right)
+    wav = st.decode(codes)
+    assert wav.shape == (3, 2, 40) and torch.equal(wav[:, :1], mono.decode(left))
+    st = InterleaveStereoCompressionModel(mono, per_timestep=True)
+    codes, _ = st.encode(x)
+    assert codes.shape == (3, 4, 20) and st.frame_rate == 100 and st.num_codebooks == 4
+    assert torch.equal(codes[..., 0::2], left) and torch.equal(codes[..., 1::2], right)
+    assert torch.equal(st.decode(codes)[:, 1:], mono.decode(right))
