@@ -224,9 +224,9 @@ def test_compute_predictions_matches_oracle():
     assert out.logits.shape == (6, 4, 7, cfg['card']) and out.mask.shape == (6, 4, 7)
     seq, mask = __import__('oracle.patterns', fromlist=['x']).build_pattern_sequence(codes, cfg['card'])
     ref = olm.lm_forward(sd, lm_cfg(cfg), seq[..., :8], a['cross_src'])   # valid steps only: T + 1
-    for q in range(4):       # position t of codebook q is predicted at sequence step t + q (delay pattern)
-        for t in range(7):
-            if t + q < 8:
+    for q in range(4):       # position t of codebook q is predicted by the model output at step t + q (delay
+        for t in range(7):   # pattern); the output of the last valid step has no target and is dropped
+            if t + q < 7:
                 assert out.mask[0, q, t]
                 assert torch.allclose(out.logits[:, q, t].cpu(), ref[:, q, t + q], atol=1e-4, rtol=1e-3)
             else:
