@@ -214,18 +214,24 @@ __device__ __forceinline__ void stats_loads(const LinArgs& p, int m0, int wave, 
 
 // N weight fragments (HBM, non-temporal) and N activation fragments (L2) requested back to back, then N MFMAs:
 // branch-free so the compiler can count vmcnt instead of draining at control-flow joins.
-template <typename WT, int N>
-__device__ __forceinline__ void mma_chunk(const u32x4* wt, const u32x4* at, int kc0, int nw, f32x4& acc) {
-    u32x4 bv[N], av[N];
+template <typename WT, int N, int MT>
+__device__ __forceinline__ void mma_chunk(const u32x4* wt, const u32x4* at, size_t mt_stride, int mt_valid, int kc0,
+                                          int nw, f32x4 (&acc)[MT]) {
+    u32x4 bv[N], av[MT][N];
 #pragma unroll
     for (int i = 0; i < N; ++i) bv[i] = ld_frag_nt(wt + (size_t)(kc0 + i * nw) * 64);
 #pragma unroll
-    for (int i = 0; i < N; ++i) av[i] = at[(size_t)(kc0 + i * nw) * 64];
+    for (int u = 0; u < MT; ++u)
 #pragma unroll
-    for (int i = 0; i < N; ++i) mma_frag(av[i], bv[i], acc, WT());
+        for (int i = 0; i < N; ++i)  // blocks beyond M re-read the last valid one (their results are dropped)
+            av[u][i] = at[(size_t)min(u, mt_valid - 1) * mt_stride + (size_t)(kc0 + i * nw) * 64];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) mma_frag(av[u][i], bv[i], acc[u], WT());
 }
 
-template <typename WT, int AM, int TPW>
+template <typename WT, int AM, int TPW, int MT>
 __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
     constexpr bool A_TILED = AM == 1;
     constexpr int EPL = WTr<WT>::EPL, KT = WTr<WT>::KT;
@@ -264,8 +270,13 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
         for (int i = 0; i < TPW; ++i) swv[i] = ld_frag_nt(wt + (size_t)(wave + i * 16) * 64);
     }
 
-    for (int m0 = 0; m0 < p.M; m0 += 16) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // MT 16-row blocks of the activation share every weight fragment (tiled path; MT = 1 otherwise)
+    for (int mg = 0; mg < p.M; mg += 16 * MT) {
+        f32x4 accs[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int m0 = mg;
+        f32x4& acc = accs[0];
         if (AM == 2) {
             // Row-major f32 activation whose LayerNorm statistics arrive as per-row (mean, M2) partials from the
             // kernel that produced it: combine them (one row per wave), standardise this wave's tiles through a
@@ -322,14 +333,17 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
         } else if (wave < nw) {
             // all of this wave's weight fragments (<= TPRE, 1 KB each) are requested from HBM before anything
             // else; the activation fragments (L2 hits) queue behind them and are consumed in order
-            const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)(m0 >> 4) * NKC * 64 + lane;
-            const int nfull = NKC / nw;  // fragments every wave owns; greedy straight-line chunks of 8 / 4 / 2 / 1
+            const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)(mg >> 4) * NKC * 64 + lane;
+            const size_t mts = (size_t)NKC * 64;  // fragments between consecutive 16-row blocks (pad rows are zero)
+            const int mtv = min(MT, (p.M - mg + 15) >> 4);
+            constexpr int C8 = 8 / MT, C4 = 4 / MT > 0 ? 4 / MT : 1, C2 = 2 / MT > 0 ? 2 / MT : 1;
+            const int nfull = NKC / nw;  // fragments every wave owns; greedy straight-line chunks
             int kc = wave, rem = nfull;
-            while (rem >= 8) { mma_chunk<WT, 8>(wt, at, kc, nw, acc); kc += 8 * nw; rem -= 8; }
-            if (rem >= 4) { mma_chunk<WT, 4>(wt, at, kc, nw, acc); kc += 4 * nw; rem -= 4; }
-            if (rem >= 2) { mma_chunk<WT, 2>(wt, at, kc, nw, acc); kc += 2 * nw; rem -= 2; }
-            if (rem >= 1) { mma_chunk<WT, 1>(wt, at, kc, nw, acc); kc += nw; }
-            if (kc < NKC) mma_chunk<WT, 1>(wt, at, kc, nw, acc);  // ragged tail (NKC % nw != 0)
+            while (rem >= C8) { mma_chunk<WT, C8, MT>(wt, at, mts, mtv, kc, nw, accs); kc += C8 * nw; rem -= C8; }
+            if (C4 < C8 && rem >= C4) { mma_chunk<WT, C4, MT>(wt, at, mts, mtv, kc, nw, accs); kc += C4 * nw; rem -= C4; }
+            if (C2 < C4 && rem >= C2) { mma_chunk<WT, C2, MT>(wt, at, mts, mtv, kc, nw, accs); kc += C2 * nw; rem -= C2; }
+            while (rem >= 1) { mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs); kc += nw; rem -= 1; }
+            if (kc < NKC) mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs);  // ragged tail (NKC % nw != 0)
         } else if (m0 == 0 && p.pf_ptr != nullptr) {
             // L2 prefetch waves: touch one dword per 128-B line of the NEXT GEMM's weight rows.  Chunk c (the
             // fragments of consumer workgroup c) is pulled by workgroup c mod gridDim: with a grid that is a
@@ -345,10 +359,14 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
             if (sink == 0x9e3779b9u && p.pf_chunks < 0) p.q_out[0] = (float)sink;  // never true
         }
 
-        // ---- deterministic cross-wave reduction + epilogue
+        // ---- deterministic cross-wave reduction + epilogue, one 16-row block at a time
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+        const int m0 = mg + 16 * u;
+        if (m0 >= p.M) break;
         if (wave < nw) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = acc[r];
+            for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = accs[u][r];
         }
         __syncthreads();
         for (int t = threadIdx.x; t < 256; t += blockDim.x) {
@@ -399,10 +417,11 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
             }
         }
         __syncthreads();
+        }
     }
 }
 
-template <typename WT, int AM, int TPW = 0>
+template <typename WT, int AM, int TPW = 0, int MT = 1>
 static int launch_lin_t(LinArgs& a, hipStream_t st) {
     constexpr int KT = WTr<WT>::KT;
     constexpr bool A_TILED = AM == 1;
@@ -437,7 +456,7 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WT, AM, TPW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WT, AM, TPW, MT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
             return ACMI_ELAUNCH;
@@ -446,7 +465,7 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     }
     a.nwc = nw;
     ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
-    hipLaunchKernelGGL((lin_kernel<WT, AM, TPW>), dim3((a.N + 15) / 16), dim3((nw + npf) * 64), lds, st, a);
+    hipLaunchKernelGGL((lin_kernel<WT, AM, TPW, MT>), dim3((a.N + 15) / 16), dim3((nw + npf) * 64), lds, st, a);
     return acmi_check_launch("lin_kernel");
 }
 
@@ -472,8 +491,13 @@ static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
         }
 #undef ACMI_STATS_CASE
     }
-    if (wdtype == ACMI_BF16) return am == 1 ? launch_lin_t<bf16_t, 1>(a, st) : launch_lin_t<bf16_t, 0>(a, st);
-    return am == 1 ? launch_lin_t<float, 1>(a, st) : launch_lin_t<float, 0>(a, st);
+    if (am == 1) {  // tiled activation: 1, 2 or 4 16-row blocks share each weight fragment
+        const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
+        if (wdtype == ACMI_BF16)
+            return mt == 4 ? launch_lin_t<bf16_t, 1, 0, 4>(a, st) : (mt == 2 ? launch_lin_t<bf16_t, 1, 0, 2>(a, st) : launch_lin_t<bf16_t, 1>(a, st));
+        return mt == 4 ? launch_lin_t<float, 1, 0, 4>(a, st) : (mt == 2 ? launch_lin_t<float, 1, 0, 2>(a, st) : launch_lin_t<float, 1>(a, st));
+    }
+    return wdtype == ACMI_BF16 ? launch_lin_t<bf16_t, 0>(a, st) : launch_lin_t<float, 0>(a, st);
 }
 
 extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream);

@@ -160,7 +160,8 @@ def test_lstm_vs_oracle(C, B, H, T, layers):
 # ------------------------------------------------------------------------------------------ LM operators
 
 @pytest.mark.parametrize('M,N,K', [(16, 4608, 1536), (2, 3072, 1024), (16, 1536, 6144), (32, 1536, 1536),
-                                    (5, 96, 32), (16, 8192, 1536), (7, 40, 24), (40, 2048, 2048), (16, 1536, 768)])
+                                    (5, 96, 32), (16, 8192, 1536), (7, 40, 24), (40, 2048, 2048), (16, 1536, 768),
+                                    (64, 1536, 1536), (70, 96, 64), (33, 64, 6144)])
 @pytest.mark.parametrize('wdt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['rowmajor', 'rowmajor_ln', 'rowmajor_std', 'tiled_in', 'tiled_out'])
 def test_linear_vs_torch(C, M, N, K, wdt, mode):
