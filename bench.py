@@ -119,6 +119,26 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     return dict(avg_us=ms * 1e3 / (launches * reps), bytes_per_launch=nbytes / launches, launches_per_position=launches)
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per lin_kernel launch from the committed rocprofv3 PMC passes over the same launch chain
+    (profiles/r*_lin_chain_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, scripts/dbg_chain.py):
+    FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half size
+    (MI355X_MICROARCH.md, HBM section), hence the x2.  None if no PMC summary is present."""
+    import csv
+    import glob
+    vals = {}
+    for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_lin_chain_pmc_{name}.csv')))
+        if not files:
+            return None
+        for row in csv.DictReader(open(files[-1])):
+            if 'lin_kernel' in row['kernel'] and row['counter'] == name:
+                vals[name] = float(row['mean_per_dispatch'])
+    if len(vals) != 2:
+        return None
+    return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
+
+
 def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, sample_steps: int = 10):
     """The oracle (kind "port": restatement of the reference CPU algorithm) on the host cores, on a bounded
     sample: `sample_steps` early-context decode positions at the full batch + EnCodec decode of 1 s of
@@ -261,7 +281,7 @@ def main():
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
             out["roofline"] = {"kernel": "lin_kernel (weight-streaming skinny GEMM)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(),
                                "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(r['avg_us'], 3),
                                "launches_per_position": r['launches_per_position']}
         if world == 1 and not args.no_cpu_baseline:
