@@ -5,6 +5,7 @@ API mirror of `audiocraft.models.encodec.CompressionModel` / `EncodecModel`
 channels / frame_rate / sample_rate / cardinality / num_codebooks / total_codebooks properties.
 The HF / DAC / stereo-interleave wrappers of the reference are outside this path.
 """
+import math
 import typing as tp
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
@@ -20,66 +21,50 @@ from ..quantization.vq import BaseQuantizer
 class QuantizedResult:
     x: torch.Tensor
     codes: torch.Tensor
-    bandwidth: torch.Tensor
+    bandwidth: torch.Tensor          # kb/s
     penalty: tp.Optional[torch.Tensor] = None
 
 
+def _abstract_property(name: str, doc: str):
+    def getter(self):
+        raise NotImplementedError(f"{type(self).__name__} must define `{name}`")
+    getter.__isabstractmethod__ = True
+    return property(getter, doc=doc)
+
+
 class CompressionModel(ABC, nn.Module):
-    """Base API for all compression models that aim at being used as audio tokenizers (encodec.py:28-85)."""
+    """Audio tokenizer interface (reference `CompressionModel`, encodec.py:28-85): `encode(x[B, C, T]) ->
+    (codes[B, K, T'], scale | None)`, `decode(codes, scale) -> wav[B, C, T]`, `decode_latent(codes)`,
+    `forward(x) -> QuantizedResult`, `set_num_codebooks(n)` and the read-only properties below."""
+
+    channels = _abstract_property('channels', "audio channels")
+    frame_rate = _abstract_property('frame_rate', "token frames per second")
+    sample_rate = _abstract_property('sample_rate', "audio sample rate")
+    cardinality = _abstract_property('cardinality', "entries per codebook")
+    num_codebooks = _abstract_property('num_codebooks', "codebooks in use")
+    total_codebooks = _abstract_property('total_codebooks', "codebooks available")
 
     @abstractmethod
-    def forward(self, x: torch.Tensor) -> QuantizedResult:
-        ...
+    def forward(self, x: torch.Tensor) -> QuantizedResult: ...
 
     @abstractmethod
-    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
-        ...
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]: ...
 
     @abstractmethod
-    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
-        ...
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None): ...
 
     @abstractmethod
-    def decode_latent(self, codes: torch.Tensor):
-        ...
-
-    @property
-    @abstractmethod
-    def channels(self) -> int:
-        ...
-
-    @property
-    @abstractmethod
-    def frame_rate(self) -> float:
-        ...
-
-    @property
-    @abstractmethod
-    def sample_rate(self) -> int:
-        ...
-
-    @property
-    @abstractmethod
-    def cardinality(self) -> int:
-        ...
-
-    @property
-    @abstractmethod
-    def num_codebooks(self) -> int:
-        ...
-
-    @property
-    @abstractmethod
-    def total_codebooks(self) -> int:
-        ...
+    def decode_latent(self, codes: torch.Tensor): ...
 
     @abstractmethod
-    def set_num_codebooks(self, n: int):
-        ...
+    def set_num_codebooks(self, n: int): ...
 
 
 class EncodecModel(CompressionModel):
-    """SEANet encoder + RVQ + SEANet decoder (encodec.py:125-259)."""
+    """SEANet encoder -> residual vector quantizer -> SEANet decoder on the waveform (reference
+    `EncodecModel`, encodec.py:125-259).  `renormalize=True` (divide by the mono RMS before encoding,
+    multiply back after decoding; encodec.py:186-204) is kept for completeness -- no MusicGen codec uses
+    it -- and runs as three elementwise torch ops."""
     frame_rate: float = 0
     sample_rate: int = 0
     channels: int = 0
@@ -87,92 +72,66 @@ class EncodecModel(CompressionModel):
     def __init__(self, encoder: nn.Module, decoder: nn.Module, quantizer: BaseQuantizer, frame_rate: int,
                  sample_rate: int, channels: int, causal: bool = False, renormalize: bool = False):
         super().__init__()
-        self.encoder = encoder
-        self.decoder = decoder
-        self.quantizer = quantizer
-        self.frame_rate = frame_rate
-        self.sample_rate = sample_rate
-        self.channels = channels
-        self.renormalize = renormalize
-        self.causal = causal
-        if self.causal:
-            assert not self.renormalize, 'Causal model does not support renormalize'
+        assert not (causal and renormalize), 'Causal model does not support renormalize'
+        self.encoder, self.decoder, self.quantizer = encoder, decoder, quantizer
+        self.frame_rate, self.sample_rate, self.channels = frame_rate, sample_rate, channels
+        self.causal, self.renormalize = causal, renormalize
         self.eval()
 
+    # folded weights are cached inside the conv / quantizer modules: drop them whenever parameters change
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        result = super().load_state_dict(state_dict, strict=strict, **kw)
         invalidate_prepared(self)
-        return out
+        return result
 
-    def _apply(self, fn, *a, **kw):
-        out = super()._apply(fn, *a, **kw)
+    def _apply(self, fn, *args, **kw):
+        result = super()._apply(fn, *args, **kw)
         invalidate_prepared(self)
-        return out
+        return result
 
-    @property
-    def total_codebooks(self):
-        return self.quantizer.total_codebooks
-
-    @property
-    def num_codebooks(self):
-        return self.quantizer.num_codebooks
+    total_codebooks = property(lambda self: self.quantizer.total_codebooks)
+    num_codebooks = property(lambda self: self.quantizer.num_codebooks)
+    cardinality = property(lambda self: self.quantizer.bins)
 
     def set_num_codebooks(self, n: int):
         self.quantizer.set_num_codebooks(n)
 
-    @property
-    def cardinality(self):
-        return self.quantizer.bins
-
     def preprocess(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
-        scale: tp.Optional[torch.Tensor]
-        if self.renormalize:  # encodec.py:186-196 (not used by the MusicGen codecs)
-            mono = x.mean(dim=1, keepdim=True)
-            volume = mono.pow(2).mean(dim=2, keepdim=True).sqrt()
-            scale = 1e-8 + volume
-            x = x / scale
-            scale = scale.view(-1, 1)
-        else:
-            scale = None
-        return x, scale
+        if not self.renormalize:
+            return x, None
+        rms = x.mean(dim=1, keepdim=True).pow(2).mean(dim=2, keepdim=True).sqrt()
+        scale = 1e-8 + rms
+        return x / scale, scale.view(-1, 1)
 
     def postprocess(self, x: torch.Tensor, scale: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
-        if scale is not None:
-            assert self.renormalize
-            x = x * scale.view(-1, 1, 1)
-        return x
-
-    @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> QuantizedResult:
-        assert x.dim() == 3
-        length = x.shape[-1]
-        x, scale = self.preprocess(x)
-        emb = self.encoder(x)
-        codes = self.quantizer.encode(emb)
-        out = self.decoder(self.quantizer.decode(codes))
-        assert out.shape[-1] >= length, (out.shape[-1], length)
-        out = self.postprocess(out[..., :length], scale)
-        import math
-        bw = torch.tensor(codes.shape[1] * math.log2(self.cardinality) * self.frame_rate / 1000).to(out)
-        return QuantizedResult(out, codes, bw)
+        if scale is None:
+            return x
+        assert self.renormalize
+        return x * scale.view(-1, 1, 1)
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
         assert x.dim() == 3
         x, scale = self.preprocess(x)
-        emb = self.encoder(x)
-        codes = self.quantizer.encode(emb)
-        return codes, scale
-
-    @torch.no_grad()
-    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
-        emb = self.decode_latent(codes)
-        out = self.decoder(emb)
-        return self.postprocess(out, scale)
+        return self.quantizer.encode(self.encoder(x)), scale
 
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor):
         return self.quantizer.decode(codes)
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        # the result keeps the encoder's extra right padding; callers trim to the length they expect
+        return self.postprocess(self.decoder(self.decode_latent(codes)), scale)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        assert x.dim() == 3
+        codes, scale = self.encode(x)
+        out = self.decode(codes, scale)
+        assert out.shape[-1] >= x.shape[-1], (out.shape[-1], x.shape[-1])
+        kbps = codes.shape[1] * math.log2(self.cardinality) * self.frame_rate / 1000
+        return QuantizedResult(out[..., :x.shape[-1]], codes, torch.tensor(kbps).to(out))
 
 
 class InterleaveStereoCompressionModel(CompressionModel):
