@@ -51,7 +51,7 @@ class LMModelDesc(C.Structure):
 class LMState(C.Structure):
     _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
                 ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
-                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
+                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('slab', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64)]
 
@@ -81,17 +81,18 @@ _ln_tile = _sig('acmi_ln_tile', [vp, vp, i32, i32, i32, f32, vp])
 class LinearDesc(C.Structure):
     _fields_ = [('a', vp), ('a_mode', i32), ('ln_g', vp), ('ln_b', vp), ('eps', f32), ('a_stats', vp),
                 ('a_stats_np', i32), ('a_stats_cnt', i32), ('w', vp), ('wdtype', i32), ('bias', vp), ('residual', vp),
-                ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('M', i32), ('N', i32), ('K', i32),
+                ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('ksplit', i32), ('M', i32), ('N', i32), ('K', i32),
                 ('prefetch_w', vp), ('prefetch_N', i32), ('prefetch_K', i32)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
+_ln_tile_reduce = _sig('acmi_ln_tile_reduce', [vp, vp, i32, vp, i32, i32, i32, f32, vp])
 _kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, i32, f32, u64, u64, vp])
 
 EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
-           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex']
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce']
 
 
 def version() -> int:
@@ -229,13 +230,13 @@ def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, re
 
 
 def linear_ex(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0, cnt=0, stats_out=None, bias=None,
-              residual=None, act=0, eps=1e-5):
+              residual=None, act=0, eps=1e-5, ksplit=1):
     """Descriptor form (acmi_linear_ex): statistics hand-off between producer and consumer GEMMs."""
     d = LinearDesc()
     d.a, d.a_mode, d.eps = ptr(a), a_mode, eps
     d.a_stats, d.a_stats_np, d.a_stats_cnt = ptr(a_stats), np_, cnt
     d.w, d.wdtype, d.bias, d.residual = ptr(w.data), dtype_code(w.dtype), ptr(bias), ptr(residual)
-    d.out, d.out_mode, d.act, d.stats_out = ptr(out), out_mode, act, ptr(stats_out)
+    d.out, d.out_mode, d.act, d.stats_out, d.ksplit = ptr(out), out_mode, act, ptr(stats_out), ksplit
     d.M, d.N, d.K = M, w.N, w.K
     check(_linear_ex(C.byref(d), stream()), 'acmi_linear_ex')
     return out
@@ -254,6 +255,14 @@ def ln_tile(x: torch.Tensor, out: torch.Tensor, eps: float = 1e-5):
     """x [M, K] f32 -> standardised rows in the tiled activation buffer `out`."""
     M, K = x.shape
     check(_ln_tile(ptr(x), ptr(out), dtype_code(out.dtype), M, K, eps, stream()), 'acmi_ln_tile')
+    return out
+
+
+def ln_tile_reduce(x: torch.Tensor, slabs: torch.Tensor, out: torch.Tensor, eps: float = 1e-5):
+    """x [M, K] += sum of slabs [S, M, K] (in place), then standardised rows into the tiled buffer `out`."""
+    M, K = x.shape
+    check(_ln_tile_reduce(ptr(x), ptr(slabs), slabs.shape[0], ptr(out), dtype_code(out.dtype), M, K, eps, stream()),
+          'acmi_ln_tile_reduce')
     return out
 
 

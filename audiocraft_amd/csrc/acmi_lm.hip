@@ -43,6 +43,7 @@ struct LinArgs {
     int NKC;      // K tiles
     int NKC_out;  // K tiles of a tiled output (its K is this GEMM's N)
     int RS;       // LDS row pitch (bytes) of the staged activation
+    int ksplit;   // tiled path: workgroups per n-tile; > 1 => raw partial sums go to slabs out[ks][M][N] (f32)
     int nwc;      // compute waves (the rest of the workgroup are L2-prefetch waves)
     const void* pf_ptr; int pf_chunks; int pf_chunk_bytes;  // next GEMM's tiled weight to pull into L2 (or NULL)
     int dbg;      // experiment switch (ACMI_DBG env), 0 in production
@@ -144,12 +145,26 @@ __device__ __forceinline__ void norm_store_row(float4 (&v)[ACMI_STAGE_JMAX], int
 // the consuming matrix (see acmi_lm_layer).  Doing this once per LayerNorm instead of once per GEMM
 // workgroup takes ~5 us of redundant VALU + LDS staging off the critical path of every GEMM workgroup.
 template <typename WT>
-__global__ __launch_bounds__(64) void ln_tile_kernel(const float* __restrict__ x, WT* __restrict__ out, int M, int K,
-                                                     int nkc, float eps) {
+__global__ __launch_bounds__(64) void ln_tile_kernel(float* __restrict__ x, WT* __restrict__ out, int M, int K, int nkc,
+                                                     float eps, const float* __restrict__ slabs, int nslabs) {
     const int m = blockIdx.x, lane = threadIdx.x;
     if (m >= M) return;
     float4 v[ACMI_STAGE_JMAX];
     load_row(x + (size_t)m * K, K, lane, v);
+    if (nslabs > 0) {
+        // the producer GEMM was split over K: finish it here (fixed order => deterministic) and write the row back
+        for (int sidx = 0; sidx < nslabs; ++sidx) {
+            float4 t[ACMI_STAGE_JMAX];
+            load_row(slabs + ((size_t)sidx * M + m) * K, K, lane, t);
+#pragma unroll
+            for (int j = 0; j < ACMI_STAGE_JMAX; ++j) { v[j].x += t[j].x; v[j].y += t[j].y; v[j].z += t[j].z; v[j].w += t[j].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+            const int k = (lane + 64 * j) * 4;
+            if (k < K) *reinterpret_cast<float4*>(x + (size_t)m * K + k) = v[j];
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < ACMI_STAGE_JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -176,16 +191,26 @@ __global__ __launch_bounds__(64) void ln_tile_kernel(const float* __restrict__ x
     }
 }
 
-extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream) {
+static int launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps, const float* slabs, int nslabs,
+                          hipStream_t st) {
     ACMI_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && K <= 2048, "acmi_ln_tile: needs K %% 4 == 0 and K <= 2048 (K=%d)", K);
-    hipStream_t st = (hipStream_t)stream;
     if (wdtype == ACMI_BF16)
         hipLaunchKernelGGL(ln_tile_kernel<bf16_t>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<bf16_t*>(out), M, K,
-                           (K + 31) / 32, eps);
+                           (K + 31) / 32, eps, slabs, nslabs);
     else
         hipLaunchKernelGGL(ln_tile_kernel<float>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<float*>(out), M, K,
-                           (K + 15) / 16, eps);
+                           (K + 15) / 16, eps, slabs, nslabs);
     return acmi_check_launch("ln_tile_kernel");
+}
+
+extern "C" int acmi_ln_tile_reduce(float* x, const float* slabs, int nslabs, void* out, int wdtype, int M, int K, float eps,
+                                   void* stream) {
+    ACMI_REQUIRE(nslabs >= 0 && (nslabs == 0 || slabs != nullptr), "acmi_ln_tile_reduce: bad slabs");
+    return launch_ln_tile(x, out, wdtype, M, K, eps, slabs, nslabs, (hipStream_t)stream);
+}
+
+extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream) {
+    return launch_ln_tile(const_cast<float*>(x), out, wdtype, M, K, eps, nullptr, 0, (hipStream_t)stream);
 }
 
 // Statistics mode (AM 2): branch-free loads (clamped addresses, values masked later) of this wave's share of
@@ -216,10 +241,21 @@ __device__ __forceinline__ void stats_loads(const LinArgs& p, int m0, int wave, 
 // branch-free so the compiler can count vmcnt instead of draining at control-flow joins.
 template <typename WT, int N, int MT>
 __device__ __forceinline__ void mma_chunk(const u32x4* wt, const u32x4* at, size_t mt_stride, int mt_valid, int kc0,
-                                          int nw, f32x4 (&acc)[MT]) {
+                                          int nw, f32x4 (&acc)[MT], int dbg = 0) {
     u32x4 bv[N], av[MT][N];
+    if (dbg == 6 || dbg == 7) {  // ablation: no weight loads
 #pragma unroll
-    for (int i = 0; i < N; ++i) bv[i] = ld_frag_nt(wt + (size_t)(kc0 + i * nw) * 64);
+        for (int i = 0; i < N; ++i) bv[i] = u32x4{1u, 2u, 3u, 4u};
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) bv[i] = ld_frag_nt(wt + (size_t)(kc0 + i * nw) * 64);
+    }
+    if (dbg == 4 || dbg == 7) {  // ablation: no activation loads
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int i = 0; i < N; ++i) av[u][i] = u32x4{5u, 6u, 7u, 8u};
+    } else
 #pragma unroll
     for (int u = 0; u < MT; ++u)
 #pragma unroll
@@ -242,9 +278,11 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
     float* red = reinterpret_cast<float*>(smem);       // [nw][256]
     unsigned char* As = smem + (size_t)nw * 1024;      // AM 0: [16][RS] staged activation; AM 2: stats + per-wave tiles
     const int nl = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int ksp = A_TILED ? p.ksplit : 1;
+    const int ntile = blockIdx.x / ksp, kslice = blockIdx.x - ntile * ksp;
+    const int n0 = ntile * 16;
     const int NKC = p.NKC;
-    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)blockIdx.x * NKC * 64 + lane;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64 + lane;
     const int tpos = p.qkv ? *p.pos : 0;
 
     u32x4 wv[TMAX];
@@ -337,13 +375,15 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
             const size_t mts = (size_t)NKC * 64;  // fragments between consecutive 16-row blocks (pad rows are zero)
             const int mtv = min(MT, (p.M - mg + 15) >> 4);
             constexpr int C8 = 8 / MT, C4 = 4 / MT > 0 ? 4 / MT : 1, C2 = 2 / MT > 0 ? 2 / MT : 1;
-            const int nfull = NKC / nw;  // fragments every wave owns; greedy straight-line chunks
-            int kc = wave, rem = nfull;
-            while (rem >= C8) { mma_chunk<WT, C8, MT>(wt, at, mts, mtv, kc, nw, accs); kc += C8 * nw; rem -= C8; }
-            if (C4 < C8 && rem >= C4) { mma_chunk<WT, C4, MT>(wt, at, mts, mtv, kc, nw, accs); kc += C4 * nw; rem -= C4; }
-            if (C2 < C4 && rem >= C2) { mma_chunk<WT, C2, MT>(wt, at, mts, mtv, kc, nw, accs); kc += C2 * nw; rem -= C2; }
-            while (rem >= 1) { mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs); kc += nw; rem -= 1; }
-            if (kc < NKC) mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs);  // ragged tail (NKC % nw != 0)
+            const int kcs = NKC / ksp, kbeg = kslice * kcs;  // this workgroup's K slice (host guarantees divisibility)
+            const int kend = kbeg + kcs;
+            const int nfull = kcs / nw;  // fragments every wave owns; greedy straight-line chunks
+            int kc = kbeg + wave, rem = nfull;
+            while (rem >= C8) { mma_chunk<WT, C8, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += C8 * nw; rem -= C8; }
+            if (C4 < C8 && rem >= C4) { mma_chunk<WT, C4, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += C4 * nw; rem -= C4; }
+            if (C2 < C4 && rem >= C2) { mma_chunk<WT, C2, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += C2 * nw; rem -= C2; }
+            while (rem >= 1) { mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += nw; rem -= 1; }
+            if (kc < kend) mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg);  // ragged tail (kcs % nw != 0)
         } else if (m0 == 0 && p.pf_ptr != nullptr) {
             // L2 prefetch waves: touch one dword per 128-B line of the NEXT GEMM's weight rows.  Chunk c (the
             // fragments of consumer workgroup c) is pulled by workgroup c mod gridDim: with a grid that is a
@@ -364,6 +404,10 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
         for (int u = 0; u < MT; ++u) {
         const int m0 = mg + 16 * u;
         if (m0 >= p.M) break;
+        if (p.dbg == 5) {  // ablation: no reduction / epilogue (keep the accumulators alive)
+            if (accs[u][0] == 123.456f) p.q_out[0] = accs[u][1];
+            continue;
+        }
         if (wave < nw) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = accs[u][r];
@@ -377,6 +421,10 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
             const int gm = m0 + mm, gn = n0 + nn;
             const bool valid = gm < p.M && gn < p.N;
             size_t oi = 0;
+            if (ksp > 1) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
+                if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
+                continue;
+            }
             if (valid) {
                 if (p.bias) v += p.bias[gn];
                 if (!p.qkv) {
@@ -431,6 +479,13 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     int npf = 0;
     size_t lds;
     if (A_TILED) {
+        // Waves are not free: the dispatcher starts ~1.25 waves / ns, so a 288-workgroup x 16-wave launch spends
+        // ~3.7 us just starting waves (measured by ablation: the same launch with no loads at all takes 6.2 us,
+        // 3.8 us with 96 workgroups).  With the loads of a wave issued as straight-line chunks of 8 fragments,
+        // 6-8 fragments per wave keep as many bytes in flight with a third of the waves: 9.1 -> 6.9 us (QKV).
+        if (a.ksplit < 1 || a.NKC % a.ksplit != 0) a.ksplit = 1;
+        nw = (a.NKC / a.ksplit + 7) / 8;
+        if (nw > 8) nw = 8;
         if (a.pf_ptr != nullptr && a.pf_chunks > 0) {  // 4 of the 16 waves become prefetch waves
             npf = 4;
             if (nw > 12) nw = 12;
@@ -465,13 +520,16 @@ static int launch_lin_t(LinArgs& a, hipStream_t st) {
     }
     a.nwc = nw;
     ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
-    hipLaunchKernelGGL((lin_kernel<WT, AM, TPW, MT>), dim3((a.N + 15) / 16), dim3((nw + npf) * 64), lds, st, a);
+    const int ks = A_TILED ? a.ksplit : 1;
+    ACMI_REQUIRE(ks == 1 || (!a.qkv && a.stats_out == nullptr), "acmi_linear: split-K is incompatible with QKV scatter / stats_out");
+    hipLaunchKernelGGL((lin_kernel<WT, AM, TPW, MT>), dim3(((a.N + 15) / 16) * ks), dim3((nw + npf) * 64), lds, st, a);
     return acmi_check_launch("lin_kernel");
 }
 
 static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     { const char* e = getenv("ACMI_DBG"); a.dbg = e ? atoi(e) : 0; }
     ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.ksplit < 1) a.ksplit = 1;
     ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
     const int am = a.a_tiled ? 1 : (a.a_stats ? 2 : 0);
     if (am == 2) {  // statistics mode: K = 16 * KT * {1, 2, 3, 4 (, 6, 8 for f32)} <= 2048
@@ -539,7 +597,7 @@ extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream) {
         ACMI_REQUIRE(c.a_stats != nullptr, "acmi_linear: ACMI_A_ROWMAJOR_F32_STATS needs a_stats");
         p.a_stats = c.a_stats; p.a_np = c.a_stats_np; p.a_cnt = c.a_stats_cnt;
     }
-    p.stats_out = c.stats_out;
+    p.stats_out = c.stats_out; p.ksplit = c.ksplit;
     p.w = c.w; p.bias = c.bias; p.residual = c.residual; p.out = c.out; p.out_mode = c.out_mode; p.act = c.act;
     p.M = c.M; p.N = c.N; p.K = c.K;
     return launch_lin(p, c.wdtype, (hipStream_t)stream);
@@ -1034,14 +1092,17 @@ static bool use_stats_mode(const acmi_lm_model* m) {
 // internal helper of the step: one GEMM of the chain
 static int step_lin(const acmi_lm_model* m, const acmi_lm_state* s, hipStream_t st, const void* a, int a_mode,
                     int np, int cnt, const void* w, const float* bias, const float* residual, void* out, int out_mode,
-                    int act, float* stats_out, int N, int K) {
+                    int act, float* stats_out, int N, int K, int& pending_slabs) {
+    // pending_slabs: slabs of a split-K linear2 waiting to be folded into x by the next LayerNorm kernel
     LinArgs p = {};
     p.a = a; p.a_tiled = a_mode == ACMI_A_TILED;
     if (a_mode == ACMI_A_ROWMAJOR_F32_STATS) {
         if (use_stats_mode(m)) {
             p.a_stats = s->stats; p.a_np = np; p.a_cnt = cnt; p.eps = m->eps;
         } else {  // separate standardisation kernel + tiled GEMM
-            int rc = acmi_ln_tile(reinterpret_cast<const float*>(a), s->xn, m->wdtype, s->Beff, K, m->eps, (void*)st);
+            int rc = launch_ln_tile(const_cast<float*>(reinterpret_cast<const float*>(a)), s->xn, m->wdtype, s->Beff, K,
+                                    m->eps, s->slab, pending_slabs, st);
+            pending_slabs = 0;
             if (rc) return rc;
             p.a = s->xn; p.a_tiled = 1;
         }
@@ -1072,6 +1133,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
 
     // Every kernel that writes the residual stream x also writes the (mean, M2) partials of its rows, so the
     // LayerNorm in front of the next GEMM costs no launch: (np, cnt) describes the partials currently valid.
+    int pending = 0;  // split-K slabs waiting for the next LayerNorm kernel
     int np = 1, cnt = d;
     const int npg = d / 16;  // partials written by a d-feature GEMM (one per 16-feature workgroup)
     for (int li = 0; li < m->num_layers; ++li) {
@@ -1081,7 +1143,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         if (use_stats_mode(m)) {
             a.a = s->x; a.a_stats = s->stats; a.a_np = np; a.a_cnt = cnt; a.eps = m->eps;
         } else {
-            if ((rc = acmi_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, stream))) return rc;
+            if ((rc = launch_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, s->slab, pending, st))) return rc;
+            pending = 0;
             a.a = s->xn; a.a_tiled = 1;
         }
         a.w = L.w_qkv; a.bias = L.b_qkv; a.M = M; a.N = 3 * d; a.K = d; a.qkv = 1;
@@ -1092,22 +1155,40 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         if ((rc = acmi_attn_decode(s->q, L.k_cache, L.v_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H, hd,
                                    s->Tmax, 0, s->pos, 1, stream)))
             return rc;
-        if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_out, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d))) return rc;
+        if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_out, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
         np = npg; cnt = 16;
         if (m->cross_attention) {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache, "acmi_lm_step: cross-attention caches missing");
-            if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_cq, L.b_cq, nullptr, s->q, ACMI_OUT_F32, 0, nullptr, d, d))) return rc;
+            if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_cq, L.b_cq, nullptr, s->q, ACMI_OUT_F32, 0, nullptr, d, d, pending))) return rc;
             if ((rc = acmi_attn_decode(s->q, L.ck_cache, L.cv_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H,
                                        hd, s->Lc, s->Lc, nullptr, 0, stream)))
                 return rc;
-            if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_cout, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d))) return rc;
+            if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_cout, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
         }
-        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_ff1, L.b_ff1, nullptr, s->hidden, ACMI_OUT_TILED, 1, nullptr, F, d))) return rc;
-        if ((rc = step_lin(m, s, st, s->hidden, TL, 0, 0, L.w_ff2, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, F))) return rc;
+        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_ff1, L.b_ff1, nullptr, s->hidden, ACMI_OUT_TILED, 1, nullptr, F, d, pending))) return rc;
+        // linear2 has only d/16 n-tiles (96 workgroups for d = 1536) against a 4d-deep K.  Optional
+        // (ACMI_FFN2_SPLIT=1): split K three ways so that every CU streams weights, the partial slabs being
+        // summed into x by the LayerNorm kernel that follows.  Measured on MusicGen-medium B=8: 3.55 vs
+        // 3.37 ms / position -- the faster GEMM is more than paid back by the slab traffic on the LayerNorm's
+        // critical path -- so it is off by default.
+        static const bool split_enabled = getenv("ACMI_FFN2_SPLIT") != nullptr && getenv("ACMI_FFN2_SPLIT")[0] == '1';
+        const int kt = wbf ? 32 : 16;
+        const bool last = li + 1 == m->num_layers;
+        const bool split = split_enabled && !use_stats_mode(m) && s->slab != nullptr && ((F + kt - 1) / kt) % 3 == 0 && d % 16 == 0 &&
+                           (!last || mode == ACMI_STEP_DECODE);
+        if (split) {
+            LinArgs f2 = {};
+            f2.a = s->hidden; f2.a_tiled = 1; f2.w = L.w_ff2; f2.out = s->slab; f2.out_mode = ACMI_OUT_F32;
+            f2.M = M; f2.N = d; f2.K = F; f2.ksplit = 3;
+            if ((rc = launch_lin(f2, m->wdtype, st))) return rc;
+            pending = 3;
+        } else if ((rc = step_lin(m, s, st, s->hidden, TL, 0, 0, L.w_ff2, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, F, pending))) {
+            return rc;
+        }
     }
     if (mode == ACMI_STEP_DECODE) {
         if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, m->w_head, m->b_head, nullptr, s->logits, ACMI_OUT_F32, 0, nullptr,
-                           m->n_q * m->card, d)))
+                           m->n_q * m->card, d, pending)))
             return rc;
         SampleArgs a = {};
         a.logits = s->logits; a.B = s->B; a.K = m->n_q; a.card = m->card; a.use_cfg = s->use_cfg;

@@ -286,6 +286,7 @@ class LMModel(nn.Module):
         # activations that feed a GEMM directly live in A-fragment order, zero padded
         run['stats'] = torch.zeros(max(1, d // 16), Beff, 2, **f32)
         run['xn'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
+        run['slab'] = torch.zeros(3, Beff, d, **f32)
         run['att'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['hidden'] = _C.tiled_activation_buffer(Beff, self.ffn_dim, self.weight_dtype, dev)
         run['pos_table'] = _C.pos_table(pk['pos_freq'], Tmax, d)
@@ -309,6 +310,7 @@ class LMModel(nn.Module):
         st.x, st.q, st.att = run['x'].data_ptr(), run['q'].data_ptr(), run['att'].data_ptr()
         st.stats = run['stats'].data_ptr()
         st.xn = run['xn'].data_ptr()
+        st.slab = run['slab'].data_ptr()
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None
         st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)

@@ -172,6 +172,7 @@ typedef struct {
     float* q;               /* [Beff, d] f32 */
     float* stats;           /* [max(1, d/16)][Beff][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
     void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x */
+    float* slab;            /* [3][Beff][d] f32 split-K partial sums of linear2 (or NULL: no split) */
     void* att;              /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised */
     void* hidden;           /* tiled activation [ceil(Beff/16)*16, ffn_pad] in wdtype, zero-initialised */
     float* logits;          /* [Beff, n_q * card] f32 */
@@ -201,6 +202,11 @@ int acmi_pos_table(const float* freq, float* table, int T, int d, void* stream);
  * prologue of the decode step's GEMMs (nn.LayerNorm, transformer.py:54-67), whose affine part is
  * folded into the consuming matrix.  K % 4 == 0, K <= 2048. */
 int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream);
+
+/* Same, preceded by the deterministic (fixed-order) reduction of a split-K producer:
+ * x[M, K] += slabs[0] + ... + slabs[nslabs-1]   (written back to x), then standardise into `out`. */
+int acmi_ln_tile_reduce(float* x, const float* slabs, int nslabs, void* out, int wdtype, int M, int K, float eps,
+                        void* stream);
 
 /* Operand descriptors of acmi_linear */
 #define ACMI_A_ROWMAJOR_F32 0 /* a [M, K] f32 row-major, staged through LDS (+ optional LayerNorm) */
@@ -244,6 +250,10 @@ typedef struct {
     const float* bias; const float* residual;
     void* out; int out_mode; int act;
     float* stats_out;
+    int ksplit;             /* tiled activation only: > 1 splits K over `ksplit` workgroups per 16-feature tile
+                               (K tiles % ksplit == 0, else ignored); `out` then receives RAW partial sums as
+                               f32 slabs out[ks][M][N] -- no bias / act / residual -- to be summed by the consumer
+                               (acmi_ln_tile_reduce) */
     int M, N, K;
     const void* prefetch_w; int prefetch_N; int prefetch_K;
 } acmi_linear_desc;

@@ -286,6 +286,30 @@ def test_ln_tile_vs_torch(C, M, K, dt):
     assert full[M:].abs().sum() == 0 and full[:, K:].abs().sum() == 0
 
 
+@pytest.mark.parametrize('M,N,K,S', [(16, 1536, 6144, 3), (5, 64, 192, 2), (33, 128, 1024, 4)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_split_k_slabs_and_reduce(C, M, N, K, S, dt):
+    """split-K GEMM -> raw partial slabs; acmi_ln_tile_reduce folds them into x (deterministically) and standardises."""
+    g = torch.Generator().manual_seed(N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    x0 = torch.randn(M, N, generator=g)
+    ref_x = x0 + a.to(dt).float() @ w.to(dt).float().t()
+    slabs = torch.zeros(S, M, N, device='cuda')
+    C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w.cuda(), dt), slabs, M, C.A_TILED, C.OUT_F32, ksplit=S)
+    assert rel(slabs.sum(0).cpu() + x0, ref_x) < (2e-6 if dt == torch.float32 else 1e-5)
+    assert slabs[S - 1].abs().sum() > 0
+    x = x0.cuda().clone()
+    buf = C.tiled_activation_buffer(M, N, dt, 'cuda')
+    C.ln_tile_reduce(x, slabs, buf)
+    assert rel(x.cpu(), ref_x) < (2e-6 if dt == torch.float32 else 1e-5)
+    got = C.untile_matrix(buf, M, N).float().cpu()
+    assert (got - F.layer_norm(ref_x, (N,), None, None, 1e-5)).abs().max() < (2e-5 if dt == torch.float32 else 2e-2)
+    x2 = x0.cuda().clone()
+    C.ln_tile_reduce(x2, slabs, buf)
+    assert torch.equal(x, x2)   # fixed summation order
+
+
 def test_pos_table_vs_oracle(C):
     d, T = 1536, 1800
     half = d // 2
