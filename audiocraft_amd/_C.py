@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
 
 class LMLayer(C.Structure):
     _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_ff1', vp), ('w_ff2', vp),
-                ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp),
+                ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp)]
 
 
@@ -45,13 +45,13 @@ class LMModelDesc(C.Structure):
     _fields_ = [('dim', i32), ('num_heads', i32), ('num_layers', i32), ('ffn_dim', i32), ('n_q', i32),
                 ('card', i32), ('wdtype', i32), ('kvdtype', i32), ('cross_attention', i32), ('eps', f32),
                 ('positional_scale', f32), ('layers', C.POINTER(LMLayer)), ('emb', C.POINTER(vp)),
-                ('pos_table', vp), ('w_head', vp), ('b_head', vp)]
+                ('pos_table', vp), ('w_head', vp), ('b_head', vp), ('cs_head', vp)]
 
 
 class LMState(C.Structure):
     _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
                 ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
-                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('slab', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
+                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('slab', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64)]
 
@@ -72,7 +72,7 @@ _conv1d = _sig('acmi_conv1d', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp])
 _lstm_layer = _sig('acmi_lstm_layer', [vp, vp, vp, vp, vp, i32, i32, i32, vp])
 _lstm_work = _sig('acmi_lstm_work_floats', [i32, i32], C.c_size_t)
 _lm_step = _sig('acmi_lm_step', [C.POINTER(LMModelDesc), C.POINTER(LMState), i32, vp])
-_linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp])
+_linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp])
 _attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
 _pos_table = _sig('acmi_pos_table', [vp, vp, i32, i32, vp])
 _ln_tile = _sig('acmi_ln_tile', [vp, vp, i32, i32, i32, f32, vp])
@@ -82,7 +82,7 @@ class LinearDesc(C.Structure):
     _fields_ = [('a', vp), ('a_mode', i32), ('ln_g', vp), ('ln_b', vp), ('eps', f32), ('a_stats', vp),
                 ('a_stats_np', i32), ('a_stats_cnt', i32), ('w', vp), ('wdtype', i32), ('bias', vp), ('residual', vp),
                 ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('ksplit', i32), ('M', i32), ('N', i32), ('K', i32),
-                ('prefetch_w', vp), ('prefetch_N', i32), ('prefetch_K', i32)]
+                ('a_lo', vp), ('colsum', vp), ('xt_hi', vp), ('xt_lo', vp)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
@@ -163,7 +163,7 @@ def lstm_work_floats(B, H) -> int:
     return int(_lstm_work(B, H))
 
 
-A_ROWMAJOR_F32, A_TILED, A_ROWMAJOR_F32_NORM, A_ROWMAJOR_F32_STATS = 0, 1, 2, 3
+A_ROWMAJOR_F32, A_TILED, A_ROWMAJOR_F32_NORM = 0, 1, 2
 OUT_F32, OUT_BF16, OUT_TILED = 0, 1, 2
 
 
@@ -210,7 +210,7 @@ def tiled_activation_buffer(M: int, K: int, dtype: torch.dtype, device) -> torch
 
 
 def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, residual=None, act=0,
-           a_tiled=False, out_mode=None, M=None, standardize=False, prefetch: 'TiledWeight' = None):
+           a_tiled=False, out_mode=None, M=None, standardize=False):
     """out[M, N] = act(LN?(a)[M, K] @ W[N, K]^T + bias) + residual, see acmi_linear.
     a: row-major f32 [M, K] (a_tiled=False) or a tiled activation buffer (a_tiled=True, pass M)."""
     if a_tiled:
@@ -222,22 +222,22 @@ def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, re
         out_mode = OUT_BF16 if out.dtype == torch.bfloat16 else OUT_F32
     a_mode = A_TILED if a_tiled else (A_ROWMAJOR_F32_NORM if standardize else A_ROWMAJOR_F32)
     check(_linear(ptr(a), a_mode, ptr(ln_g), ptr(ln_b), eps, ptr(w.data),
-                  dtype_code(w.dtype), ptr(bias), ptr(residual), ptr(out), out_mode, act, M, w.N, w.K,
-                  ptr(prefetch.data) if prefetch is not None else None, prefetch.N if prefetch is not None else 0,
-                  prefetch.K if prefetch is not None else 0, stream()),
+                  dtype_code(w.dtype), ptr(bias), ptr(residual), ptr(out), out_mode, act, M, w.N, w.K, stream()),
           'acmi_linear')
     return out
 
 
 def linear_ex(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0, cnt=0, stats_out=None, bias=None,
-              residual=None, act=0, eps=1e-5, ksplit=1):
-    """Descriptor form (acmi_linear_ex): statistics hand-off between producer and consumer GEMMs."""
+              residual=None, act=0, eps=1e-5, ksplit=1, a_lo=None, colsum=None, xt_hi=None, xt_lo=None):
+    """Descriptor form (acmi_linear_ex): statistics hand-off between producer and consumer GEMMs; with
+    `colsum` the folded LayerNorm on a raw tiled activation (a [, a_lo]); xt_hi / xt_lo: raw tiled copy of the output."""
     d = LinearDesc()
     d.a, d.a_mode, d.eps = ptr(a), a_mode, eps
     d.a_stats, d.a_stats_np, d.a_stats_cnt = ptr(a_stats), np_, cnt
     d.w, d.wdtype, d.bias, d.residual = ptr(w.data), dtype_code(w.dtype), ptr(bias), ptr(residual)
     d.out, d.out_mode, d.act, d.stats_out, d.ksplit = ptr(out), out_mode, act, ptr(stats_out), ksplit
     d.M, d.N, d.K = M, w.N, w.K
+    d.a_lo, d.colsum, d.xt_hi, d.xt_lo = ptr(a_lo), ptr(colsum), ptr(xt_hi), ptr(xt_lo)
     check(_linear_ex(C.byref(d), stream()), 'acmi_linear_ex')
     return out
 

@@ -34,6 +34,11 @@ struct LinArgs {
     const void* a; int a_tiled;
     const float* a_stats; int a_np; int a_cnt;  // per-row (mean, M2) partials of the row-major activation (stats mode)
     float* stats_out;                           // per-row (mean, M2) partials of this GEMM's output, [gridDim][M][2]
+    // "folded LayerNorm": a / a_lo hold the RAW activation as hi / lo fragments (x = hi + lo; f32 weights: hi
+    // only), colsum[n] = sum_k W'[n,k]; with the row statistics from a_stats the epilogue applies
+    //     LN(x) W'^T = rstd * (x W'^T - mean * colsum)
+    const void* a_lo; const float* colsum;
+    void* xt_hi; void* xt_lo; int xt_nkc;       // producer side: also write the output as raw hi / lo fragments
     int ln_mode; const float* ln_g; const float* ln_b; float eps;
     const void* w;
     const float* bias;
@@ -44,9 +49,7 @@ struct LinArgs {
     int NKC_out;  // K tiles of a tiled output (its K is this GEMM's N)
     int RS;       // LDS row pitch (bytes) of the staged activation
     int ksplit;   // tiled path: workgroups per n-tile; > 1 => raw partial sums go to slabs out[ks][M][N] (f32)
-    int nwc;      // compute waves (the rest of the workgroup are L2-prefetch waves)
-    const void* pf_ptr; int pf_chunks; int pf_chunk_bytes;  // next GEMM's tiled weight to pull into L2 (or NULL)
-    int dbg;      // experiment switch (ACMI_DBG env), 0 in production
+    int kcs, fpw; // tiled path: K tiles per split-K slice, fragments every wave owns (kcs / waves), set by the launcher
     int qkv;      // QKV scatter epilogue
     float* q_out; void* k_cache; void* v_cache; int kv_bf16; int H, hd, Tcap, d; const int* pos;
 };
@@ -213,205 +216,90 @@ extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K,
     return launch_ln_tile(const_cast<float*>(x), out, wdtype, M, K, eps, nullptr, 0, (hipStream_t)stream);
 }
 
-// Statistics mode (AM 2): branch-free loads (clamped addresses, values masked later) of this wave's share of
-// the (mean, M2) partials of row m0 + wave and of its TPW activation tiles of the 16-row block at m0.
-template <typename WT, int TPW>
-__device__ __forceinline__ void stats_loads(const LinArgs& p, int m0, int wave, int lane, float (&pm)[2], float (&pq)[2],
-                                            float4 (&xa)[TPW > 0 ? TPW : 1][WTr<WT>::NJ]) {
-    constexpr int KT = WTr<WT>::KT, LPR = WTr<WT>::LPR, RPI = WTr<WT>::RPI, NJ = WTr<WT>::NJ;
-    const int mrow = min(m0 + wave, p.M - 1);
+// Folded LayerNorm, row statistics: a "group" is 4 rows (16 lanes each); every lane fetches up to 8 of the
+// producer's equal-count (mean, M2) partials of its row (np <= 128), combined later with Chan's formula.
+__device__ __forceinline__ void rowstat_load(const float* __restrict__ stats, int np, int M, int row0, int lane,
+                                             float (&pm)[8], float (&pq)[8]) {
+    const int row = min(row0 + (lane >> 4), M - 1), jj = lane & 15;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int pi = min(lane + 64 * u, p.a_np - 1);
-        const float2 t = *reinterpret_cast<const float2*>(p.a_stats + ((size_t)pi * p.M + mrow) * 2);
-        pm[u] = t.x; pq[u] = t.y;
+    for (int i = 0; i < 8; ++i) {
+        const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)min(jj + 16 * i, np - 1) * M + row) * 2);
+        pm[i] = t.x; pq[i] = t.y;
+    }
+}
+__device__ __forceinline__ void rowstat_finish(const float (&pm)[8], const float (&pq)[8], int np, int cnt, int K, float eps,
+                                               int lane, float* __restrict__ dst /* [4][2] */) {
+    const int jj = lane & 15;
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm += (jj + 16 * i < np) ? pm[i] : 0.f;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+    const float mean = sm / (float)np;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float dlt = pm[i] - mean;
+        q2 += (jj + 16 * i < np) ? pq[i] + (float)cnt * dlt * dlt : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kc = wave + i * 16;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int row = min(m0 + lane / LPR + RPI * j, p.M - 1), col = kc * KT + (lane % LPR) * 4;
-            xa[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.a) + (size_t)row * p.K + col);
-        }
+    for (int off = 1; off < 16; off <<= 1) q2 += __shfl_xor(q2, off, 64);
+    if (jj == 0) {
+        dst[(lane >> 4) * 2] = mean;
+        dst[(lane >> 4) * 2 + 1] = 1.0f / sqrtf(q2 / (float)K + eps);
     }
 }
 
-// N weight fragments (HBM, non-temporal) and N activation fragments (L2) requested back to back, then N MFMAs:
-// branch-free so the compiler can count vmcnt instead of draining at control-flow joins.
-template <typename WT, int N, int MT>
-__device__ __forceinline__ void mma_chunk(const u32x4* wt, const u32x4* at, size_t mt_stride, int mt_valid, int kc0,
-                                          int nw, f32x4 (&acc)[MT], int dbg = 0) {
-    u32x4 bv[N], av[MT][N];
-    if (dbg == 6 || dbg == 7) {  // ablation: no weight loads
-#pragma unroll
-        for (int i = 0; i < N; ++i) bv[i] = u32x4{1u, 2u, 3u, 4u};
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) bv[i] = ld_frag_nt(wt + (size_t)(kc0 + i * nw) * 64);
-    }
-    if (dbg == 4 || dbg == 7) {  // ablation: no activation loads
-#pragma unroll
-        for (int u = 0; u < MT; ++u)
-#pragma unroll
-            for (int i = 0; i < N; ++i) av[u][i] = u32x4{5u, 6u, 7u, 8u};
-    } else
-#pragma unroll
-    for (int u = 0; u < MT; ++u)
-#pragma unroll
-        for (int i = 0; i < N; ++i)  // blocks beyond M re-read the last valid one (their results are dropped)
-            av[u][i] = at[(size_t)min(u, mt_valid - 1) * mt_stride + (size_t)(kc0 + i * nw) * 64];
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int u = 0; u < MT; ++u) mma_frag(av[u][i], bv[i], acc[u], WT());
-}
-
-template <typename WT, int AM, int TPW, int MT>
-__global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
-    constexpr bool A_TILED = AM == 1;
-    constexpr int EPL = WTr<WT>::EPL, KT = WTr<WT>::KT;
-    constexpr int TMAX = sizeof(WT) == 2 ? 4 : 8;  // staged path: fragments per wave held in registers (K <= 2048)
+// -----------------------------------------------------------------------------------------------------
+// lin_rowmajor_kernel: row-major f32 activation, staged (and optionally LayerNorm-ed) through LDS.
+// The general-purpose form: conditioner projections, the one-off cross-attention K / V projection, tests.
+// One workgroup = 16 output features; wave w stages rows w, w + nw, ... of each 16-row block and owns the K
+// fragments kc = w, w + nw, ... (<= TMAX of them, held in registers for all row blocks: K <= 2048).
+// -----------------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ __launch_bounds__(1024) void lin_rowmajor_kernel(const LinArgs p) {
+    constexpr int KT = WTr<WT>::KT;
+    constexpr int TMAX = sizeof(WT) == 2 ? 4 : 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nw = p.nwc;                              // compute waves; waves >= nw only prefetch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float* red = reinterpret_cast<float*>(smem);       // [nw][256]
-    unsigned char* As = smem + (size_t)nw * 1024;      // AM 0: [16][RS] staged activation; AM 2: stats + per-wave tiles
+    unsigned char* As = smem + (size_t)nw * 1024;      // [16][RS] staged activation
     const int nl = lane & 15, kg = lane >> 4;
-    const int ksp = A_TILED ? p.ksplit : 1;
-    const int ntile = blockIdx.x / ksp, kslice = blockIdx.x - ntile * ksp;
-    const int n0 = ntile * 16;
-    const int NKC = p.NKC;
-    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64 + lane;
-    const int tpos = p.qkv ? *p.pos : 0;
+    const int n0 = blockIdx.x * 16, NKC = p.NKC, Kpad = NKC * KT;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)blockIdx.x * NKC * 64 + lane;
 
-    u32x4 wv[TMAX];
+    // the first activation row is requested BEFORE the weight fragments: vmcnt retires in order, so the row
+    // must not queue behind HBM-latency weight loads
     float4 xv[ACMI_STAGE_JMAX];
-    if (AM == 0) {
-        load_row(wave < p.M && wave < 16 ? reinterpret_cast<const float*>(p.a) + (size_t)wave * p.K : nullptr, p.K, lane, xv);
+    load_row(wave < p.M && wave < 16 ? reinterpret_cast<const float*>(p.a) + (size_t)wave * p.K : nullptr, p.K, lane, xv);
+    u32x4 wv[TMAX];
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+        const int kc = wave + i * nw;
+        wv[i] = kc < NKC ? ld_frag_nt(wt + (size_t)kc * 64) : u32x4{0u, 0u, 0u, 0u};
+    }
+
+    for (int m0 = 0; m0 < p.M; m0 += 16) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = wave; r < 16; r += nw) {
+            const int m = m0 + r;
+            if (m0 != 0 || r != wave)
+                load_row(m < p.M ? reinterpret_cast<const float*>(p.a) + (size_t)m * p.K : nullptr, p.K, lane, xv);
+            norm_store_row<WT>(xv, p.K, Kpad, p.ln_mode, p.ln_g, p.ln_b, p.eps, As + (size_t)r * p.RS, lane);
+        }
+        __syncthreads();
+        const unsigned char* arow = As + (size_t)nl * p.RS + (size_t)kg * 16;
 #pragma unroll
         for (int i = 0; i < TMAX; ++i) {
             const int kc = wave + i * nw;
-            if (kc < NKC && p.dbg != 3) wv[i] = ld_frag_nt(wt + (size_t)kc * 64);
-            else wv[i] = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-
-    // statistics mode: everything the first 16-row block needs is requested here, in the order it is consumed
-    // (vmcnt retires in order): statistics partials, activation tiles, then the weight fragments from HBM
-    float spm[2], spq[2];
-    float4 sxa[TPW > 0 ? TPW : 1][WTr<WT>::NJ];
-    u32x4 swv[TPW > 0 ? TPW : 1];
-    if (AM == 2) {
-        stats_loads<WT, TPW>(p, 0, wave, lane, spm, spq, sxa);
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) swv[i] = ld_frag_nt(wt + (size_t)(wave + i * 16) * 64);
-    }
-
-    // MT 16-row blocks of the activation share every weight fragment (tiled path; MT = 1 otherwise)
-    for (int mg = 0; mg < p.M; mg += 16 * MT) {
-        f32x4 accs[MT];
-#pragma unroll
-        for (int u = 0; u < MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int m0 = mg;
-        f32x4& acc = accs[0];
-        if (AM == 2) {
-            // Row-major f32 activation whose LayerNorm statistics arrive as per-row (mean, M2) partials from the
-            // kernel that produced it: combine them (one row per wave), standardise this wave's tiles through a
-            // wave-private LDS tile (no workgroup barrier besides the one that publishes mean / rstd).
-            constexpr int LPR = WTr<WT>::LPR, RPI = WTr<WT>::RPI, NJ = WTr<WT>::NJ;
-            float* sstat = reinterpret_cast<float*>(As);                // [16][2] mean, rstd
-            unsigned char* wbuf = As + 128 + (size_t)wave * 1280;       // this wave's [16][80 B] tile
-            if (m0 != 0) stats_loads<WT, TPW>(p, m0, wave, lane, spm, spq, sxa);
-            // Chan combination of equal-count partials: mean = avg(mean_b), M2 = sum(M2_b + cnt (mean_b - mean)^2)
-            const bool v0 = lane < p.a_np, v1 = lane + 64 < p.a_np;
-            const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.a_np;
-            const float d0 = spm[0] - mean, d1 = spm[1] - mean;
-            const float q2 = (v0 ? spq[0] + (float)p.a_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.a_cnt * d1 * d1 : 0.f);
-            const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.K + p.eps);
-            if (lane == 0) { sstat[wave * 2] = mean; sstat[wave * 2 + 1] = rstd; }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int rl = lane / LPR + RPI * j;
-                    const float mu = sstat[rl * 2], rs = (m0 + rl < p.M) ? sstat[rl * 2 + 1] : 0.f;  // rows >= M -> 0
-                    const float y0 = (sxa[i][j].x - mu) * rs, y1 = (sxa[i][j].y - mu) * rs;
-                    const float y2 = (sxa[i][j].z - mu) * rs, y3 = (sxa[i][j].w - mu) * rs;
-                    unsigned char* dst = wbuf + rl * 80 + (lane % LPR) * 4 * sizeof(WT);
-                    if (sizeof(WT) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
-                    else *reinterpret_cast<float4*>(dst) = make_float4(y0, y1, y2, y3);
-                }
-                __builtin_amdgcn_wave_barrier();
-                const u32x4 av = *reinterpret_cast<const u32x4*>(wbuf + nl * 80 + kg * 16);
-                __builtin_amdgcn_wave_barrier();
-                mma_frag(av, swv[i], acc, WT());
+            if (kc < NKC) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(arow + (size_t)kc * 64);
+                mma_frag(av, wv[i], acc, WT());
             }
-            __syncthreads();  // sstat is rewritten by the next 16-row block
-        } else if (AM == 0) {
-            const int Kpad = NKC * KT;
-            for (int r = wave; r < 16; r += nw) {
-                const int m = m0 + r;
-                if (p.dbg == 2) continue;
-                if (m0 != 0 || r != wave)  // the first row of the first tile was requested before the weights
-                    load_row(m < p.M ? reinterpret_cast<const float*>(p.a) + (size_t)m * p.K : nullptr, p.K, lane, xv);
-                norm_store_row<WT>(xv, p.K, Kpad, p.dbg == 1 ? 0 : p.ln_mode, p.ln_g, p.ln_b, p.eps, As + (size_t)r * p.RS, lane);
-            }
-            __syncthreads();
-            const unsigned char* arow = As + (size_t)nl * p.RS + (size_t)kg * 16;
-#pragma unroll
-            for (int i = 0; i < TMAX; ++i) {
-                const int kc = wave + i * nw;
-                if (kc < NKC) {
-                    const u32x4 av = *reinterpret_cast<const u32x4*>(arow + (size_t)kc * 64);
-                    mma_frag(av, wv[i], acc, WT());
-                }
-            }
-        } else if (wave < nw) {
-            // all of this wave's weight fragments (<= TPRE, 1 KB each) are requested from HBM before anything
-            // else; the activation fragments (L2 hits) queue behind them and are consumed in order
-            const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)(mg >> 4) * NKC * 64 + lane;
-            const size_t mts = (size_t)NKC * 64;  // fragments between consecutive 16-row blocks (pad rows are zero)
-            const int mtv = min(MT, (p.M - mg + 15) >> 4);
-            constexpr int C8 = 8 / MT, C4 = 4 / MT > 0 ? 4 / MT : 1, C2 = 2 / MT > 0 ? 2 / MT : 1;
-            const int kcs = NKC / ksp, kbeg = kslice * kcs;  // this workgroup's K slice (host guarantees divisibility)
-            const int kend = kbeg + kcs;
-            const int nfull = kcs / nw;  // fragments every wave owns; greedy straight-line chunks
-            int kc = kbeg + wave, rem = nfull;
-            while (rem >= C8) { mma_chunk<WT, C8, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += C8 * nw; rem -= C8; }
-            if (C4 < C8 && rem >= C4) { mma_chunk<WT, C4, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += C4 * nw; rem -= C4; }
-            if (C2 < C4 && rem >= C2) { mma_chunk<WT, C2, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += C2 * nw; rem -= C2; }
-            while (rem >= 1) { mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg); kc += nw; rem -= 1; }
-            if (kc < kend) mma_chunk<WT, 1, MT>(wt, at, mts, mtv, kc, nw, accs, p.dbg);  // ragged tail (kcs % nw != 0)
-        } else if (m0 == 0 && p.pf_ptr != nullptr) {
-            // L2 prefetch waves: touch one dword per 128-B line of the NEXT GEMM's weight rows.  Chunk c (the
-            // fragments of consumer workgroup c) is pulled by workgroup c mod gridDim: with a grid that is a
-            // multiple of 8 this is the XCD (= L2) the consumer will run on (placement is a speed heuristic
-            // only).  The values are never used; `sink` only keeps the loads alive until the wave ends.
-            const int pw = wave - nw, npw = (int)(blockDim.x >> 6) - nw;
-            unsigned sink = 0u;
-            for (int c = blockIdx.x; c < p.pf_chunks; c += gridDim.x) {
-                const unsigned char* base = reinterpret_cast<const unsigned char*>(p.pf_ptr) + (size_t)c * p.pf_chunk_bytes;
-                for (int off = (pw * 64 + lane) * 128; off < p.pf_chunk_bytes; off += npw * 64 * 128)
-                    sink ^= *reinterpret_cast<const unsigned*>(base + off);
-            }
-            if (sink == 0x9e3779b9u && p.pf_chunks < 0) p.q_out[0] = (float)sink;  // never true
         }
-
-        // ---- deterministic cross-wave reduction + epilogue, one 16-row block at a time
+        // deterministic cross-wave reduction + epilogue
 #pragma unroll
-        for (int u = 0; u < MT; ++u) {
-        const int m0 = mg + 16 * u;
-        if (m0 >= p.M) break;
-        if (p.dbg == 5) {  // ablation: no reduction / epilogue (keep the accumulators alive)
-            if (accs[u][0] == 123.456f) p.q_out[0] = accs[u][1];
-            continue;
-        }
-        if (wave < nw) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = accs[u][r];
-        }
+        for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = acc[r];
         __syncthreads();
         for (int t = threadIdx.x; t < 256; t += blockDim.x) {
             const int nn = t & 15, mm = t >> 4;
@@ -419,18 +307,208 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
             float v = 0.f;
             for (int w = 0; w < nw; ++w) v += red[w * 256 + idx];
             const int gm = m0 + mm, gn = n0 + nn;
+            if (gm >= p.M || gn >= p.N) continue;
+            if (p.bias) v += p.bias[gn];
+            if (p.act == 1) v = gelu_exact(v);
+            const size_t oi = (size_t)gm * p.N + gn;
+            if (p.residual) v += p.residual[oi];
+            if (p.out_mode == ACMI_OUT_TILED) st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
+            else if (p.out_mode == ACMI_OUT_BF16) reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
+            else reinterpret_cast<float*>(p.out)[oi] = v;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename WT>
+static int launch_rowmajor(LinArgs& a, hipStream_t st) {
+    constexpr int KT = WTr<WT>::KT;
+    a.NKC = (a.K + KT - 1) / KT;
+    a.NKC_out = (a.N + KT - 1) / KT;
+    ACMI_REQUIRE(a.K % 4 == 0 && a.NKC * KT <= 2048, "acmi_linear: row-major activation needs K %% 4 == 0 and K <= 2048 (K=%d)", a.K);
+    ACMI_REQUIRE(a.stats_out == nullptr && a.xt_hi == nullptr && a.ksplit <= 1 && a.colsum == nullptr && !a.qkv,
+                 "acmi_linear: statistics / raw tiled outputs / split-K / folded LayerNorm need a tiled activation");
+    int nw = a.NKC < 16 ? a.NKC : 16;
+    if (nw < 4) nw = 4;
+    a.RS = a.NKC * KT * (int)sizeof(WT) + 16;
+    const size_t lds = (size_t)nw * 1024 + (size_t)16 * a.RS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_rowmajor_kernel<WT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
+            return ACMI_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lin_rowmajor_kernel<WT>), dim3((a.N + 15) / 16), dim3(nw * 64), lds, st, a);
+    return acmi_check_launch("lin_rowmajor_kernel");
+}
+
+// =====================================================================================================
+// lin_tiled_kernel: the decode step's GEMM  (tiled activation x tiled weight)
+// =====================================================================================================
+// One workgroup = 16 output features (x one K slice with split-K); its nw <= 8 waves own the K fragments
+// kc = wave, wave + nw, ...  Every wave requests everything it will ever need up front, in the order in which
+// it is consumed -- (weight fragment, activation fragments) pairs, then the LayerNorm row statistics, then the
+// epilogue operands of its thread -- because vmcnt retires in order and anything requested later (a cold bias
+// vector in the epilogue, say) is a full HBM round trip on the tail of the launch.  Absent operands are
+// replaced by the address of the wave's own first weight fragment (already in flight: no extra line, page or
+// hot spot), so the prologue is branch free.
+//   LN 0: plain   1: folded LayerNorm, single-term activation   2: folded LayerNorm, hi + lo activation
+struct TlExtras {
+    float pm[8], pq[8];     // LN > 0: (mean, M2) partials of this lane's statistics row
+    float bias, colsum, res;  // epilogue operands of this thread's first output element
+    int tpos;                 // QKV: the position the new K / V rows are stored at
+};
+
+template <typename WT, int MT, int LN, int C>
+__device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, const u32x4* __restrict__ at,
+                                         const u32x4* __restrict__ al, int mts, int mtv, int kc0, int nw,
+                                         const float* __restrict__ st_ptr, int st_stride, int np,
+                                         const float* __restrict__ pb, const float* __restrict__ pc,
+                                         const float* __restrict__ pr, const int* __restrict__ ppos, f32x4 (&acc)[MT],
+                                         TlExtras& ex) {
+    constexpr bool HL = LN == 2;
+    const int lane = threadIdx.x & 63;
+    u32x4 bv[C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int ko = (kc0 + i * nw) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
+        bv[i] = ld_frag_nt(wt + ko + lane);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {  // row blocks beyond M re-read the last valid one (their results are dropped)
+            const int off = min(u, mtv - 1) * mts + ko;
+            av[u][i] = (at + off)[lane];
+            if (HL) lv[u][i] = (al + off)[lane];
+        }
+    }
+    // (the asm keeps these loop-invariant loads here, behind the weight stream, instead of in front of the K loop)
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    st_ptr += opaque0; pb += opaque0; pc += opaque0; pr += opaque0; ppos += opaque0;
+    if (LN > 0) {
+        const int jj = (int)(threadIdx.x & 15);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 t = *reinterpret_cast<const float2*>(st_ptr + min(jj + 16 * i, np - 1) * st_stride);
+            ex.pm[i] = t.x; ex.pq[i] = t.y;
+        }
+    }
+    ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos;
+    __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            mma_frag(av[u][i], bv[i], acc[u], WT());
+            if (HL) mma_frag(lv[u][i], bv[i], acc[u], WT());
+        }
+}
+
+template <typename WT, int MT, int LN>
+__global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
+    constexpr int D = LN == 2 ? 2 : 1;
+    // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
+    // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
+    // VGPRs of a 2-waves-per-SIMD launch
+    constexpr int CQ = (LN > 0 ? 44 : 52) / (1 + MT * D);
+    constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
+    float* red = reinterpret_cast<float*>(smem);        // [MT][nw][256] partial accumulators
+    float* rowstat = red + (size_t)MT * nw * 256;       // [16 MT][2] mean, rstd
+    const int ksp = (int)gridDim.y;                     // split-K slices (grid.y)
+    const int ntile = blockIdx.x, kslice = blockIdx.y;
+    const int n0 = ntile * 16, NKC = p.NKC;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
+    const int mts = NKC * 64;                           // fragment lanes between consecutive 16-row blocks
+    const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
+    const float* own = reinterpret_cast<const float*>(wt + (size_t)(kbeg + min(wave, kcs - 1)) * 64 + lane);
+
+    // one group of MT 16-row blocks per workgroup (grid.z): no loop around the body, so that nothing of the
+    // epilogue is hoisted in front of the first load
+    {
+        const int mg = (int)blockIdx.z * 16 * MT;
+        const int mtv = min(MT, (p.M - mg + 15) >> 4);
+        f32x4 accs[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mg >> 4) * mts);
+        const u32x4* al = LN == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mg >> 4) * mts) : nullptr;
+        // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
+        const int ngroups = 4 * mtv;
+        const float* st_ptr = own;
+        if (LN > 0) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * 2;
+        // this thread's first epilogue element
+        const int e0 = (int)threadIdx.x, eu = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
+        const int egn = min(n0 + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
+        const float* pb = p.bias != nullptr ? p.bias + egn : own;
+        const float* pc = p.colsum != nullptr ? p.colsum + egn : own;
+        const float* pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
+        const int* ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+        TlExtras ex;
+
+        int kc = kbeg + wave, rem = p.fpw;              // fragments every wave owns (+ a ragged tail)
+#define ACMI_TL_RUN(Cn)                                                                                                 \
+        while (rem >= Cn) {                                                                                            \
+            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.M * 2, p.a_np, pb, pc, pr, ppos, accs, ex); \
+            kc += Cn * nw; rem -= Cn;                                                                                  \
+        }
+        if (CMAX >= 24) { ACMI_TL_RUN(24) }
+        if (CMAX >= 16) { ACMI_TL_RUN(16) }
+        if (CMAX >= 12) { ACMI_TL_RUN(12) }
+        if (CMAX >= 8) { ACMI_TL_RUN(8) }
+        if (CMAX >= 6) { ACMI_TL_RUN(6) }
+        if (CMAX >= 4) { ACMI_TL_RUN(4) }
+        ACMI_TL_RUN(2)
+        ACMI_TL_RUN(1)
+#undef ACMI_TL_RUN
+        if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
+            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.M * 2, p.a_np, pb, pc, pr, ppos, accs, ex);
+
+        // ---- deterministic cross-wave reduction through LDS
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)u * nw + wave) * 256 + lane * 4 + r] = accs[u][r];
+        if (LN > 0) {
+            // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
+            if (wave < ngroups) rowstat_finish(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8);
+            for (int g = wave + nw; g < ngroups; g += nw) {
+                rowstat_load(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
+                rowstat_finish(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8);
+            }
+        }
+        __syncthreads();
+
+        // ---- epilogue: one output element per thread and pass
+        for (int e = (int)threadIdx.x; e < 256 * mtv; e += (int)blockDim.x) {
+            const int u = e >> 8, mm = (e >> 4) & 15, nn = e & 15;
+            const bool first = e == (int)threadIdx.x;
+            const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
+            float v = 0.f;
+            for (int w = 0; w < nw; ++w) v += red[((size_t)u * nw + w) * 256 + idx];
+            const int gm = mg + 16 * u + mm, gn = n0 + nn;
             const bool valid = gm < p.M && gn < p.N;
-            size_t oi = 0;
             if (ksp > 1) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
                 if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
                 continue;
             }
+            size_t oi = 0;
             if (valid) {
-                if (p.bias) v += p.bias[gn];
+                if (LN > 0) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
+                    const float* rs = rowstat + (u * 16 + mm) * 2;
+                    v = rs[1] * (v - rs[0] * (first ? ex.colsum : p.colsum[gn]));
+                }
+                if (p.bias) v += first ? ex.bias : p.bias[gn];
                 if (!p.qkv) {
                     if (p.act == 1) v = gelu_exact(v);
                     oi = (size_t)gm * p.N + gn;
-                    if (p.residual) v += p.residual[oi];
+                    if (p.residual) v += first ? ex.res : p.residual[oi];
                 }
             }
             if (p.stats_out != nullptr) {
@@ -443,136 +521,94 @@ __global__ __launch_bounds__(1024) void lin_kernel(const LinArgs p) {
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) dq += __shfl_xor(dq, off, 64);
                 if (nn == 0 && gm < p.M)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)blockIdx.x * p.M + gm) * 2) = make_float2(mb, dq);
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)ntile * p.M + gm) * 2) = make_float2(mb, dq);
             }
-            if (valid) {
-                if (p.qkv) {
-                    const int part = gn / p.d, f = gn - part * p.d;
-                    if (part == 0) {
-                        p.q_out[(size_t)gm * p.d + f] = v;
-                    } else {
-                        const int h = f / p.hd, dd = f - h * p.hd;
-                        const size_t ci = (((size_t)gm * p.H + h) * p.Tcap + tpos) * p.hd + dd;
-                        void* cache = part == 1 ? p.k_cache : p.v_cache;
-                        if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v);
-                        else reinterpret_cast<float*>(cache)[ci] = v;
-                    }
+            if (!valid) continue;
+            if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
+                const size_t ti = tiled_index<WT>(gm, gn, p.xt_nkc);
+                if (sizeof(WT) == 2) {
+                    const bf16_t hi = f32_to_bf16(v);
+                    reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
+                    if (p.xt_lo != nullptr) reinterpret_cast<bf16_t*>(p.xt_lo)[ti] = f32_to_bf16(v - bf16_to_f32(hi));
                 } else {
-                    if (p.out_mode == ACMI_OUT_TILED) st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
-                    else if (p.out_mode == ACMI_OUT_BF16) reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
-                    else reinterpret_cast<float*>(p.out)[oi] = v;
+                    reinterpret_cast<float*>(p.xt_hi)[ti] = v;
                 }
             }
-        }
-        __syncthreads();
+            if (p.qkv) {
+                const int part = gn / p.d, f = gn - part * p.d;
+                if (part == 0) {
+                    p.q_out[(size_t)gm * p.d + f] = v;
+                } else {
+                    const int h = f / p.hd, dd = f - h * p.hd;
+                    const size_t ci = (((size_t)gm * p.H + h) * p.Tcap + ex.tpos) * p.hd + dd;
+                    void* cache = part == 1 ? p.k_cache : p.v_cache;
+                    if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v);
+                    else reinterpret_cast<float*>(cache)[ci] = v;
+                }
+            } else if (p.out_mode == ACMI_OUT_TILED) {
+                st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
+            } else if (p.out_mode == ACMI_OUT_BF16) {
+                reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
+            } else {
+                reinterpret_cast<float*>(p.out)[oi] = v;
+            }
         }
     }
 }
 
-template <typename WT, int AM, int TPW = 0, int MT = 1>
-static int launch_lin_t(LinArgs& a, hipStream_t st) {
+template <typename WT, int MT, int LN>
+static int launch_tiled_t(LinArgs& a, hipStream_t st) {
     constexpr int KT = WTr<WT>::KT;
-    constexpr bool A_TILED = AM == 1;
     a.NKC = (a.K + KT - 1) / KT;
     a.NKC_out = (a.N + KT - 1) / KT;
-    int nw = a.NKC < 16 ? a.NKC : 16;
-    int npf = 0;
-    size_t lds;
-    if (A_TILED) {
-        // Waves are not free: the dispatcher starts ~1.25 waves / ns, so a 288-workgroup x 16-wave launch spends
-        // ~3.7 us just starting waves (measured by ablation: the same launch with no loads at all takes 6.2 us,
-        // 3.8 us with 96 workgroups).  With the loads of a wave issued as straight-line chunks of 8 fragments,
-        // 6-8 fragments per wave keep as many bytes in flight with a third of the waves: 9.1 -> 6.9 us (QKV).
-        if (a.ksplit < 1 || a.NKC % a.ksplit != 0) a.ksplit = 1;
-        nw = (a.NKC / a.ksplit + 7) / 8;
-        if (nw > 8) nw = 8;
-        if (a.pf_ptr != nullptr && a.pf_chunks > 0) {  // 4 of the 16 waves become prefetch waves
-            npf = 4;
-            if (nw > 12) nw = 12;
-        }
-        { const char* e = getenv("ACMI_LIN_NW"); if (e && atoi(e) > 0 && atoi(e) < nw) nw = atoi(e); }
-        if (nw < 1) nw = 1;
-        a.RS = 0;
-        lds = (size_t)nw * 1024;
-    } else if (AM == 2) {
-        a.pf_ptr = nullptr;
-        nw = 16;
-        ACMI_REQUIRE(a.K % KT == 0 && a.NKC == 16 * TPW, "acmi_linear: statistics mode needs K = %d * {1..4} (K=%d)", 16 * KT, a.K);
-        ACMI_REQUIRE(a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 128 && a.a_np * a.a_cnt == a.K,
-                     "acmi_linear: bad statistics partials (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
-        a.RS = 0;
-        lds = (size_t)nw * 1024 + 128 + (size_t)nw * 1280;
-    } else {
-        a.pf_ptr = nullptr;
-        if (nw < 4) nw = 4;
-        ACMI_REQUIRE(a.K % 4 == 0 && a.NKC * KT <= 2048, "acmi_linear: row-major activation needs K %% 4 == 0 and K <= 2048 (K=%d)", a.K);
-        a.RS = a.NKC * KT * (int)sizeof(WT) + 16;
-        lds = (size_t)nw * 1024 + (size_t)16 * a.RS;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_kernel<WT, AM, TPW, MT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
-            return ACMI_ELAUNCH;
-        }
-        attr_set = true;
-    }
-    a.nwc = nw;
+    if (a.ksplit < 1 || a.NKC % a.ksplit != 0) a.ksplit = 1;
+    // Workgroup size.  (1) Waves are not free: the dispatcher starts ~1.25 waves / ns (a 288-workgroup x 16-wave
+    // launch with no loads at all takes 6.2 us), so a wave should own ~12 fragments or more, all of them
+    // requested before its first wait.  (2) The kernel needs > 128 VGPRs for that, i.e. a CU holds 8 waves:
+    // nw in {8, 4, 2, 1} packs 1, 2, 4, 8 workgroups per CU exactly, and the grid must fit the 256 CUs in ONE
+    // round (a 288-workgroup grid of 6-wave workgroups runs 256 + 32: the launch takes twice as long).
+    const int tiles = ((a.N + 15) / 16) * a.ksplit, frags = a.NKC / a.ksplit;
+    int nw = tiles <= 256 ? 8 : (tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1));
+    while (nw > 1 && frags < 12 * nw) nw >>= 1;
+    { static const char* e = getenv("ACMI_LIN_NW"); if (e && atoi(e) > 0 && atoi(e) < nw) nw = atoi(e); }
     ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
-    const int ks = A_TILED ? a.ksplit : 1;
-    ACMI_REQUIRE(ks == 1 || (!a.qkv && a.stats_out == nullptr), "acmi_linear: split-K is incompatible with QKV scatter / stats_out");
-    hipLaunchKernelGGL((lin_kernel<WT, AM, TPW, MT>), dim3(((a.N + 15) / 16) * ks), dim3((nw + npf) * 64), lds, st, a);
-    return acmi_check_launch("lin_kernel");
+    ACMI_REQUIRE(a.ksplit == 1 || (!a.qkv && a.stats_out == nullptr && a.xt_hi == nullptr),
+                 "acmi_linear: split-K is incompatible with QKV scatter / stats_out / xt_hi");
+    a.kcs = frags; a.fpw = frags / nw;
+    const size_t lds = (size_t)MT * nw * 1024 + (size_t)MT * 128;
+    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN>), dim3((a.N + 15) / 16, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)), dim3(nw * 64), lds, st, a);
+    return acmi_check_launch("lin_tiled_kernel");
+}
+
+template <typename WT>
+static int launch_tiled(LinArgs& a, hipStream_t st) {
+    const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);  // 1, 2 or 4 16-row blocks share each weight fragment
+    const int ln = a.colsum == nullptr ? 0 : (a.a_lo != nullptr ? 2 : 1);
+#define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv>(a, st);
+    ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2)
+    ACMI_TL_CASE(2, 0) ACMI_TL_CASE(2, 1) ACMI_TL_CASE(2, 2)
+    ACMI_TL_CASE(4, 0) ACMI_TL_CASE(4, 1) ACMI_TL_CASE(4, 2)
+#undef ACMI_TL_CASE
+    return ACMI_EINVAL;
 }
 
 static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
-    { const char* e = getenv("ACMI_DBG"); a.dbg = e ? atoi(e) : 0; }
     ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if (a.ksplit < 1) a.ksplit = 1;
     ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
-    const int am = a.a_tiled ? 1 : (a.a_stats ? 2 : 0);
-    if (am == 2) {  // statistics mode: K = 16 * KT * {1, 2, 3, 4 (, 6, 8 for f32)} <= 2048
-        const int kt = wdtype == ACMI_BF16 ? 32 : 16;
-        const int tpw = (a.K % (16 * kt) == 0) ? a.K / (16 * kt) : 0;
-#define ACMI_STATS_CASE(T) case T: return wdtype == ACMI_BF16 ? launch_lin_t<bf16_t, 2, T>(a, st) : launch_lin_t<float, 2, T>(a, st);
-        switch (tpw) {
-            ACMI_STATS_CASE(1) ACMI_STATS_CASE(2) ACMI_STATS_CASE(3) ACMI_STATS_CASE(4)
-            case 6: if (wdtype != ACMI_BF16) return launch_lin_t<float, 2, 6>(a, st); break;
-            case 8: if (wdtype != ACMI_BF16) return launch_lin_t<float, 2, 8>(a, st); break;
-            default: break;
-        }
-        {
-            acmi_set_error("acmi_linear: statistics mode needs K = %d * {1,2,3,4%s} <= 2048 (K=%d)", 16 * kt,
-                           wdtype == ACMI_BF16 ? "" : ",6,8", a.K);
-            return ACMI_EINVAL;
-        }
-#undef ACMI_STATS_CASE
-    }
-    if (am == 1) {  // tiled activation: 1, 2 or 4 16-row blocks share each weight fragment
-        const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);
-        if (wdtype == ACMI_BF16)
-            return mt == 4 ? launch_lin_t<bf16_t, 1, 0, 4>(a, st) : (mt == 2 ? launch_lin_t<bf16_t, 1, 0, 2>(a, st) : launch_lin_t<bf16_t, 1>(a, st));
-        return mt == 4 ? launch_lin_t<float, 1, 0, 4>(a, st) : (mt == 2 ? launch_lin_t<float, 1, 0, 2>(a, st) : launch_lin_t<float, 1>(a, st));
-    }
-    return wdtype == ACMI_BF16 ? launch_lin_t<bf16_t, 0>(a, st) : launch_lin_t<float, 0>(a, st);
+    ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 128 && a.a_np * a.a_cnt == a.K),
+                 "acmi_linear: folded LayerNorm needs a tiled activation and row statistics (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
+    ACMI_REQUIRE(a.colsum == nullptr || a.ksplit == 1, "acmi_linear: folded LayerNorm cannot be combined with split-K");
+    if (a.a_tiled) return wdtype == ACMI_BF16 ? launch_tiled<bf16_t>(a, st) : launch_tiled<float>(a, st);
+    return wdtype == ACMI_BF16 ? launch_rowmajor<bf16_t>(a, st) : launch_rowmajor<float>(a, st);
 }
 
 extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream);
 
-static void set_prefetch(LinArgs& p, int wdtype, const void* next_w, int next_N, int next_K) {
-    if (next_w == nullptr || next_N <= 0 || next_K <= 0) return;
-    const int kt = wdtype == ACMI_BF16 ? 32 : 16;
-    p.pf_ptr = next_w;
-    p.pf_chunks = (next_N + 15) / 16;                   // one chunk = the fragments of one consumer workgroup
-    p.pf_chunk_bytes = ((next_K + kt - 1) / kt) * 1024;
-}
-
 extern "C" int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps, const void* w,
                            int wdtype, const float* bias, const float* residual, void* out, int out_mode, int act, int M,
-                           int N, int K, const void* prefetch_w, int prefetch_N, int prefetch_K, void* stream) {
+                           int N, int K, void* stream) {
     LinArgs p = {};
-    set_prefetch(p, wdtype, prefetch_w, prefetch_N, prefetch_K);
     p.a = a; p.a_tiled = a_mode == ACMI_A_TILED;
     ACMI_REQUIRE(a_mode >= 0 && a_mode <= 2, "acmi_linear: bad a_mode %d", a_mode);
     ACMI_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "acmi_linear: ln_g and ln_b go together");
@@ -587,15 +623,18 @@ extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream) {
     ACMI_REQUIRE(dsc != nullptr, "acmi_linear_ex: null descriptor");
     const acmi_linear_desc& c = *dsc;
     LinArgs p = {};
-    set_prefetch(p, c.wdtype, c.prefetch_w, c.prefetch_N, c.prefetch_K);
-    ACMI_REQUIRE(c.a_mode >= 0 && c.a_mode <= 3, "acmi_linear: bad a_mode %d", c.a_mode);
+    ACMI_REQUIRE(c.a_mode >= 0 && c.a_mode <= 2, "acmi_linear: bad a_mode %d", c.a_mode);
     ACMI_REQUIRE((c.ln_g == nullptr) == (c.ln_b == nullptr), "acmi_linear: ln_g and ln_b go together");
     p.a = c.a; p.a_tiled = c.a_mode == ACMI_A_TILED;
     p.ln_mode = c.ln_g ? 2 : (c.a_mode == ACMI_A_ROWMAJOR_F32_NORM ? 1 : 0);
     p.ln_g = c.ln_g; p.ln_b = c.ln_b; p.eps = c.eps;
-    if (c.a_mode == ACMI_A_ROWMAJOR_F32_STATS) {
-        ACMI_REQUIRE(c.a_stats != nullptr, "acmi_linear: ACMI_A_ROWMAJOR_F32_STATS needs a_stats");
-        p.a_stats = c.a_stats; p.a_np = c.a_stats_np; p.a_cnt = c.a_stats_cnt;
+    if (c.colsum != nullptr) {
+        ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.a_stats != nullptr, "acmi_linear: colsum needs a tiled activation and a_stats");
+        p.a_stats = c.a_stats; p.a_np = c.a_stats_np; p.a_cnt = c.a_stats_cnt; p.colsum = c.colsum; p.a_lo = c.a_lo;
+    }
+    if (c.xt_hi != nullptr) {
+        p.xt_hi = c.xt_hi; p.xt_lo = c.xt_lo;
+        p.xt_nkc = (c.N + (c.wdtype == ACMI_BF16 ? 32 : 16) - 1) / (c.wdtype == ACMI_BF16 ? 32 : 16);
     }
     p.stats_out = c.stats_out; p.ksplit = c.ksplit;
     p.w = c.w; p.bias = c.bias; p.residual = c.residual; p.out = c.out; p.out_mode = c.out_mode; p.act = c.act;
@@ -636,7 +675,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < DPL; ++e) o[e] = 0.f;
 
-    for (int t0 = wave * CH; t0 < len; t0 += 4 * CH) {
+    const int nwv = blockDim.x >> 6;  // 1, 2 or 4 waves share the positions of this (row, head)
+    for (int t0 = wave * CH; t0 < len; t0 += nwv * CH) {
         // K and V of the whole chunk are requested together (2 * NI wide loads in flight per lane)
         rawv kr[NI], vr[NI];
 #pragma unroll
@@ -696,10 +736,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     if (lane == 0) { sm_m[wave] = m; sm_l[wave] = l; }
     __syncthreads();
     if (threadIdx.x < HD) {
-        float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float M = sm_m[0];
+        for (int w = 1; w < nwv; ++w) M = fmaxf(M, sm_m[w]);
         float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < nwv; ++w) {
             const float f = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - M);
             num += f * sm_o[w][threadIdx.x];
             den += f * sm_l[w];
@@ -720,7 +760,9 @@ template <typename KT>
 static int launch_attn_t(const float* q, const void* kc, const void* vc, void* out, int out_tiled, int out_bf16, int Beff,
                          int H, int hd, int Tcap, int len, const int* len_dev, int len_bias, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)hd);
-    dim3 grid(H, Beff), block(256);
+    static int attn_nw = -1;
+    if (attn_nw < 0) { const char* e = getenv("ACMI_ATTN_NW"); attn_nw = e ? atoi(e) : 4; if (attn_nw != 1 && attn_nw != 2) attn_nw = 4; }
+    dim3 grid(H, Beff), block(64 * attn_nw);
     const KT* k = reinterpret_cast<const KT*>(kc);
     const KT* v = reinterpret_cast<const KT*>(vc);
 #define ACMI_ATTN_CASE(HD)                                                                                      \
@@ -799,6 +841,7 @@ struct EmbedArgs {
     const int* pos;
     float* x; int d;
     float* stats;  // [1][M][2]: (mean, M2) of every produced row (one partial of d elements)
+    void* xt_hi; void* xt_lo; int xt_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
 };
 
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
@@ -826,6 +869,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
         }
         v += p.pos_scale * p.pos_table[(size_t)g * p.d + cch];
         p.x[(size_t)m * p.d + cch] = v;
+        if (p.xt_hi != nullptr) {
+            if (p.w_bf16) {
+                const size_t ti = tiled_index<bf16_t>(m, cch, p.xt_nkc);
+                const bf16_t hi = f32_to_bf16(v);
+                reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
+                if (p.xt_lo != nullptr) reinterpret_cast<bf16_t*>(p.xt_lo)[ti] = f32_to_bf16(v - bf16_to_f32(hi));
+            } else {
+                reinterpret_cast<float*>(p.xt_hi)[tiled_index<float>(m, cch, p.xt_nkc)] = v;
+            }
+        }
         loc[cnt] = v;
         sum += v;
     }
@@ -1074,31 +1127,48 @@ __global__ void advance_kernel(int* pos) { if (threadIdx.x == 0 && blockIdx.x ==
 // one decode position
 // =====================================================================================================
 
-// LayerNorm in front of a GEMM: either as a separate standardisation kernel writing tiled `xn` (default) or
-// consumed from producer statistics inside the GEMM (no extra launch; ACMI_LN_MODE=stats).  Measured on
-// MusicGen-medium, B=8: 3.62 vs 3.70 ms / position -- the launch saved is paid back by the longer
-// dependent chain inside the consuming workgroups, so the simpler form stays the default.
-static bool use_stats_mode(const acmi_lm_model* m) {
-    static int mode = -1;
-    if (mode < 0) {
+// LayerNorm in front of a GEMM, two interchangeable forms (ACMI_LN_MODE = fold | tile):
+//   tile   a separate standardisation kernel writes the tiled `xn` (one extra launch per LayerNorm);
+//   fold   the producers of x also emit it raw in fragment order (hi / lo), the consumer runs the plain tiled
+//          GEMM on it and applies rstd * (acc - mean * colsum) in its epilogue from the (mean, M2) partials the
+//          producer wrote next to x (no launch, no staging).  Default.
+// (A third form -- the consumer staging the row-major x through LDS and standardising it there -- measured
+// no faster than `tile` and was removed.)
+enum { LN_TILE = 0, LN_FOLD = 2 };
+enum { LN_X = 100 };  // step_lin: the activation is LayerNorm(x)
+static int ln_mode_of(const acmi_lm_model* m, const acmi_lm_state* s) {
+    static int want = -1;
+    if (want < 0) {
         const char* e = getenv("ACMI_LN_MODE");
-        mode = (e && e[0] == 's') ? 1 : 0;
+        want = (e && e[0] == 't') ? LN_TILE : LN_FOLD;
     }
-    const int kt = m->wdtype == ACMI_BF16 ? 32 : 16;
-    const int tpw = m->dim % (16 * kt) == 0 ? m->dim / (16 * kt) : 0;
-    return mode == 1 && (tpw >= 1 && (tpw <= 4 || (m->wdtype != ACMI_BF16 && (tpw == 6 || tpw == 8))));
+    if (want == LN_FOLD) {
+        const bool have = m->cs_head != nullptr && m->layers[0].cs_qkv != nullptr && m->layers[0].cs_ff1 != nullptr &&
+                          (m->wdtype != ACMI_BF16 || s->xlo != nullptr) && m->dim / 16 <= 128 && m->dim % 16 == 0;
+        return have ? LN_FOLD : LN_TILE;
+    }
+    return LN_TILE;
+}
+static bool fold_uses_lo() {  // experiment switch: ACMI_LN_LO=0 drops the low part of the bf16 pair
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACMI_LN_LO"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
 }
 
-// internal helper of the step: one GEMM of the chain
+// internal helper of the step: one GEMM of the chain.  a_mode LN_X = "LayerNorm(x) first"
+// (colsum: column sums of w for the folded form); stats_out != NULL = "this GEMM produces the residual stream".
 static int step_lin(const acmi_lm_model* m, const acmi_lm_state* s, hipStream_t st, const void* a, int a_mode,
-                    int np, int cnt, const void* w, const float* bias, const float* residual, void* out, int out_mode,
-                    int act, float* stats_out, int N, int K, int& pending_slabs) {
+                    int np, int cnt, const void* w, const float* bias, const float* colsum, const float* residual,
+                    void* out, int out_mode, int act, float* stats_out, int N, int K, int& pending_slabs) {
     // pending_slabs: slabs of a split-K linear2 waiting to be folded into x by the next LayerNorm kernel
+    const int lnm = ln_mode_of(m, s);
+    const int kt = m->wdtype == ACMI_BF16 ? 32 : 16;
     LinArgs p = {};
     p.a = a; p.a_tiled = a_mode == ACMI_A_TILED;
-    if (a_mode == ACMI_A_ROWMAJOR_F32_STATS) {
-        if (use_stats_mode(m)) {
-            p.a_stats = s->stats; p.a_np = np; p.a_cnt = cnt; p.eps = m->eps;
+    if (a_mode == LN_X) {
+        if (lnm == LN_FOLD) {
+            p.a = s->xn; p.a_lo = (m->wdtype == ACMI_BF16 && fold_uses_lo()) ? s->xlo : nullptr; p.a_tiled = 1;
+            p.a_stats = s->stats; p.a_np = np; p.a_cnt = cnt; p.eps = m->eps; p.colsum = colsum;
         } else {  // separate standardisation kernel + tiled GEMM
             int rc = launch_ln_tile(const_cast<float*>(reinterpret_cast<const float*>(a)), s->xn, m->wdtype, s->Beff, K,
                                     m->eps, s->slab, pending_slabs, st);
@@ -1106,6 +1176,9 @@ static int step_lin(const acmi_lm_model* m, const acmi_lm_state* s, hipStream_t 
             if (rc) return rc;
             p.a = s->xn; p.a_tiled = 1;
         }
+    }
+    if (stats_out != nullptr && lnm == LN_FOLD) {
+        p.xt_hi = s->xn; p.xt_lo = m->wdtype == ACMI_BF16 ? s->xlo : nullptr; p.xt_nkc = (N + kt - 1) / kt;
     }
     p.w = w; p.bias = bias; p.residual = residual; p.out = out; p.out_mode = out_mode; p.act = act;
     p.stats_out = stats_out; p.M = s->Beff; p.N = N; p.K = K;
@@ -1120,7 +1193,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     ACMI_REQUIRE(m->n_q <= 16, "acmi_lm_step: n_q=%d > 16", m->n_q);
     ACMI_REQUIRE(s->Beff == (s->use_cfg ? 2 * s->B : s->B), "acmi_lm_step: Beff/B mismatch");
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
-    const int ST = ACMI_A_ROWMAJOR_F32_STATS, TL = ACMI_A_TILED;
+    const int ST = LN_X, TL = ACMI_A_TILED;
     int rc;
 
     EmbedArgs e = {};
@@ -1128,6 +1201,9 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.K = m->n_q; e.S = s->S; e.card = m->card;
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
+    const int lnm = ln_mode_of(m, s);
+    const int kt = wbf ? 32 : 16;
+    if (lnm == LN_FOLD) { e.xt_hi = s->xn; e.xt_lo = wbf ? s->xlo : nullptr; e.xt_nkc = (d + kt - 1) / kt; }
     hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, st, e);
     if ((rc = acmi_check_launch("embed_kernel"))) return rc;
 
@@ -1140,8 +1216,9 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         const acmi_lm_layer& L = m->layers[li];
         // LN1 (folded) -> QKV ; K,V appended in place at position g, q to scratch
         LinArgs a = {};
-        if (use_stats_mode(m)) {
-            a.a = s->x; a.a_stats = s->stats; a.a_np = np; a.a_cnt = cnt; a.eps = m->eps;
+        if (lnm == LN_FOLD) {
+            a.a = s->xn; a.a_lo = (wbf && fold_uses_lo()) ? s->xlo : nullptr; a.a_tiled = 1;
+            a.a_stats = s->stats; a.a_np = np; a.a_cnt = cnt; a.eps = m->eps; a.colsum = L.cs_qkv;
         } else {
             if ((rc = launch_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, s->slab, pending, st))) return rc;
             pending = 0;
@@ -1155,26 +1232,25 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         if ((rc = acmi_attn_decode(s->q, L.k_cache, L.v_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H, hd,
                                    s->Tmax, 0, s->pos, 1, stream)))
             return rc;
-        if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_out, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
+        if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_out, nullptr, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
         np = npg; cnt = 16;
         if (m->cross_attention) {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache, "acmi_lm_step: cross-attention caches missing");
-            if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_cq, L.b_cq, nullptr, s->q, ACMI_OUT_F32, 0, nullptr, d, d, pending))) return rc;
+            if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_cq, L.b_cq, L.cs_cq, nullptr, s->q, ACMI_OUT_F32, 0, nullptr, d, d, pending))) return rc;
             if ((rc = acmi_attn_decode(s->q, L.ck_cache, L.cv_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H,
                                        hd, s->Lc, s->Lc, nullptr, 0, stream)))
                 return rc;
-            if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_cout, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
+            if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_cout, nullptr, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
         }
-        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_ff1, L.b_ff1, nullptr, s->hidden, ACMI_OUT_TILED, 1, nullptr, F, d, pending))) return rc;
+        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_ff1, L.b_ff1, L.cs_ff1, nullptr, s->hidden, ACMI_OUT_TILED, 1, nullptr, F, d, pending))) return rc;
         // linear2 has only d/16 n-tiles (96 workgroups for d = 1536) against a 4d-deep K.  Optional
         // (ACMI_FFN2_SPLIT=1): split K three ways so that every CU streams weights, the partial slabs being
         // summed into x by the LayerNorm kernel that follows.  Measured on MusicGen-medium B=8: 3.55 vs
         // 3.37 ms / position -- the faster GEMM is more than paid back by the slab traffic on the LayerNorm's
         // critical path -- so it is off by default.
         static const bool split_enabled = getenv("ACMI_FFN2_SPLIT") != nullptr && getenv("ACMI_FFN2_SPLIT")[0] == '1';
-        const int kt = wbf ? 32 : 16;
         const bool last = li + 1 == m->num_layers;
-        const bool split = split_enabled && !use_stats_mode(m) && s->slab != nullptr && ((F + kt - 1) / kt) % 3 == 0 && d % 16 == 0 &&
+        const bool split = split_enabled && lnm == LN_TILE && s->slab != nullptr && ((F + kt - 1) / kt) % 3 == 0 && d % 16 == 0 &&
                            (!last || mode == ACMI_STEP_DECODE);
         if (split) {
             LinArgs f2 = {};
@@ -1182,12 +1258,12 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             f2.M = M; f2.N = d; f2.K = F; f2.ksplit = 3;
             if ((rc = launch_lin(f2, m->wdtype, st))) return rc;
             pending = 3;
-        } else if ((rc = step_lin(m, s, st, s->hidden, TL, 0, 0, L.w_ff2, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, F, pending))) {
+        } else if ((rc = step_lin(m, s, st, s->hidden, TL, 0, 0, L.w_ff2, nullptr, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, F, pending))) {
             return rc;
         }
     }
     if (mode == ACMI_STEP_DECODE) {
-        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, m->w_head, m->b_head, nullptr, s->logits, ACMI_OUT_F32, 0, nullptr,
+        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, m->w_head, m->b_head, m->cs_head, nullptr, s->logits, ACMI_OUT_F32, 0, nullptr,
                            m->n_q * m->card, d, pending)))
             return rc;
         SampleArgs a = {};

@@ -202,14 +202,16 @@ class LMModel(nn.Module):
             return t
 
         def folded(w, norm, own_bias=None):
-            """LN(x) W^T = standardise(x) (W diag(gamma))^T + W beta  ->  (tiled W diag(gamma), f32 bias)."""
+            """LN(x) W^T = standardise(x) W'^T + W beta, W' = W diag(gamma)  ->  (tiled W', f32 bias W beta,
+            f32 column sums of the dtype-rounded W': standardise(x) W'^T = rstd (x W'^T - mean colsum))."""
             w32 = w.detach().to(device=dev, dtype=torch.float32)
             g = norm.weight.detach().to(device=dev, dtype=torch.float32)
             b = norm.bias.detach().to(device=dev, dtype=torch.float32)
             bias = w32 @ b
             if own_bias is not None:
                 bias = bias + own_bias.detach().to(device=dev, dtype=torch.float32)
-            return W(w32 * g[None, :]), Fp(bias)
+            wf = w32 * g[None, :]
+            return W(wf), Fp(bias), Fp(wf.to(wd).double().sum(dim=1).float())
 
         d = self.dim
         layers = (_C.LMLayer * self.num_layers)()
@@ -220,17 +222,18 @@ class LMModel(nn.Module):
                     raise NotImplementedError("out_proj / linear2 biases are not wired into acmi_lm_step; "
                                               "MusicGen checkpoints have none (bias_attn = bias_ff = false)")
             ent = {'w_out': W(layer.self_attn.out_proj.weight), 'w_ff2': W(layer.linear2.weight)}
-            ent['w_qkv'], ent['b_qkv'] = folded(layer.self_attn.in_proj_weight, layer.norm1, layer.self_attn.in_proj_bias)
-            ent['w_ff1'], ent['b_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
+            ent['w_qkv'], ent['b_qkv'], ent['cs_qkv'] = folded(layer.self_attn.in_proj_weight, layer.norm1, layer.self_attn.in_proj_bias)
+            ent['w_ff1'], ent['b_ff1'], ent['cs_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
             if layer.cross_attention is not None:
                 ca = layer.cross_attention
                 if ca.in_proj_bias is not None and bool((ca.in_proj_bias != 0).any()):
                     raise NotImplementedError("cross-attention in_proj_bias is not wired into acmi_lm_step")
                 ipw = ca.in_proj_weight
-                ent['w_cq'], ent['b_cq'] = folded(ipw[:d], layer.norm_cross)
+                ent['w_cq'], ent['b_cq'], ent['cs_cq'] = folded(ipw[:d], layer.norm_cross)
                 ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]), 'w_cout': W(ca.out_proj.weight)})
             L = layers[li]
-            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1'):
+            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv', 'cs_cq',
+                      'cs_ff1'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]
@@ -238,7 +241,7 @@ class LMModel(nn.Module):
         head_bias = None
         if self.linears[0].bias is not None:
             head_bias = torch.cat([lin.bias for lin in self.linears], dim=0)
-        w_head, b_head = folded(torch.cat([lin.weight for lin in self.linears], dim=0), self.out_norm, head_bias)
+        w_head, b_head, cs_head = folded(torch.cat([lin.weight for lin in self.linears], dim=0), self.out_norm, head_bias)
         half = d // 2
         # divisor table of create_sin_embedding, computed exactly like the reference does
         # (transformer.py:83-88: f32 tensor ops on the host); cos/sin are evaluated on the device
@@ -253,8 +256,9 @@ class LMModel(nn.Module):
         desc.layers = C.cast(layers, C.POINTER(_C.LMLayer))
         desc.emb = C.cast(emb_arr, C.POINTER(_C.vp))
         desc.pos_table = None
-        desc.w_head, desc.b_head = w_head.data_ptr(), b_head.data_ptr()
-        pk.update({'desc': desc, 'emb_arr': emb_arr, 'w_head': w_head, 'b_head': b_head, 'pos_freq': pos_freq})
+        desc.w_head, desc.b_head, desc.cs_head = w_head.data_ptr(), b_head.data_ptr(), cs_head.data_ptr()
+        pk.update({'desc': desc, 'emb_arr': emb_arr, 'w_head': w_head, 'b_head': b_head, 'cs_head': cs_head,
+                   'pos_freq': pos_freq})
         self._packed = pk
         self._run = None
         return pk
@@ -286,6 +290,7 @@ class LMModel(nn.Module):
         # activations that feed a GEMM directly live in A-fragment order, zero padded
         run['stats'] = torch.zeros(max(1, d // 16), Beff, 2, **f32)
         run['xn'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
+        run['xlo'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['slab'] = torch.zeros(3, Beff, d, **f32)
         run['att'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['hidden'] = _C.tiled_activation_buffer(Beff, self.ffn_dim, self.weight_dtype, dev)
@@ -309,7 +314,7 @@ class LMModel(nn.Module):
         st.pos = run['pos'].data_ptr()
         st.x, st.q, st.att = run['x'].data_ptr(), run['q'].data_ptr(), run['att'].data_ptr()
         st.stats = run['stats'].data_ptr()
-        st.xn = run['xn'].data_ptr()
+        st.xn, st.xlo = run['xn'].data_ptr(), run['xlo'].data_ptr()
         st.slab = run['slab'].data_ptr()
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None

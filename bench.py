@@ -58,39 +58,45 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     pk = lm._packed
     dev = lm.device
     d, ffn, wd = lm.dim, lm.ffn_dim, lm.weight_dtype
-    x = torch.randn(B_eff, d, device=dev)
-    att = _C.tile_matrix(torch.randn(B_eff, d, device=dev), wd)
-    xn = _C.tile_matrix(torch.randn(B_eff, d, device=dev), wd)
-    hid = _C.tile_matrix(torch.randn(B_eff, ffn, device=dev), wd)
+    rnd = lambda n: torch.randn(B_eff, n, device=dev)
+    att, hid = _C.tile_matrix(rnd(d), wd), _C.tile_matrix(rnd(ffn), wd)
+    # the residual stream: f32 row-major (x), raw in A-fragment order as a bf16 hi / lo pair (xh, xl) and its
+    # per-row (mean, M2) partials (stats), exactly what acmi_lm_step keeps (folded LayerNorm)
+    x, x0 = torch.zeros(B_eff, d, device=dev), rnd(d)   # x = x0 + a @ W^T keeps the synthetic stream bounded
+    xh = _C.tile_matrix(rnd(d), wd)
+    xl = _C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if wd == torch.bfloat16 else None
+    np_ = max(1, d // 16)
+    stats = torch.zeros(np_, B_eff, 2, device=dev)
+    stats[..., 1] = 16.0
+    q = torch.empty(B_eff, d, device=dev)
     qkv = torch.empty(B_eff, 3 * d, device=dev)
-    o = torch.zeros(B_eff, d, device=dev)
-    o2 = torch.empty(B_eff, d, device=dev)
-    stats = torch.zeros(max(1, d // 16), B_eff, 2, device=dev)
-    stats[0, :, 1] = float(d)
     h = _C.tiled_activation_buffer(B_eff, ffn, wd, dev)
     logits = torch.empty(B_eff, lm.n_q * lm.card, device=dev)
-    w_head = pk['w_head']
     launches = 0
     nbytes = 0
 
-    def one_position():
-        # the same launches acmi_lm_step issues for one position (same shapes, operand layouts and weights)
+    def gemm(w, out, out_mode, ln=None, bias=None, act=0, produce_x=False):
         nonlocal launches, nbytes
-        # (default LayerNorm mode: separate ln_tile_kernel writes the standardised activation in A-fragment
-        # order, so every GEMM of the chain takes a tiled activation)
-        for ent in pk['per_layer']:
-            seq = [(xn, ent['w_qkv'], qkv, ent['b_qkv'], 0, _C.OUT_F32, None), (att, ent['w_out'], o, None, 0, _C.OUT_F32, o)]
-            if 'w_cq' in ent:
-                seq += [(xn, ent['w_cq'], o2, ent['b_cq'], 0, _C.OUT_F32, None), (att, ent['w_cout'], o, None, 0, _C.OUT_F32, o)]
-            seq += [(xn, ent['w_ff1'], h, ent['b_ff1'], 1, _C.OUT_TILED, None), (hid, ent['w_ff2'], o, None, 0, _C.OUT_F32, o)]
-            for a, w, out, bias, act, om, res in seq:
-                _C.linear_ex(a, w, out, B_eff, _C.A_TILED, om, bias=bias, act=act, residual=res,
-                             stats_out=stats if res is not None else None)
-                launches += 1
-                nbytes += w.N * w.K * w.data.element_size()
-        _C.linear_ex(xn, w_head, logits, B_eff, _C.A_TILED, _C.OUT_F32, bias=pk['b_head'])
+        if ln is not None:   # LayerNorm(x) @ W'^T: raw fragments + statistics + column sums
+            _C.linear_ex(xh, w, out, B_eff, _C.A_TILED, out_mode, a_stats=stats, np_=np_, cnt=d // np_, bias=bias, act=act,
+                         a_lo=xl, colsum=ln)
+        elif produce_x:      # x += a @ W^T, also written as raw fragments and statistics partials
+            _C.linear_ex(att if w.K == d else hid, w, x, B_eff, _C.A_TILED, _C.OUT_F32, residual=x0, stats_out=stats,
+                         xt_hi=xh, xt_lo=xl)
         launches += 1
-        nbytes += w_head.N * w_head.K * w_head.data.element_size()
+        nbytes += w.N * w.K * w.data.element_size()
+
+    def one_position():
+        # the same GEMM launches acmi_lm_step issues for one position (same shapes, operand layouts, weights)
+        for ent in pk['per_layer']:
+            gemm(ent['w_qkv'], qkv, _C.OUT_F32, ln=ent['cs_qkv'], bias=ent['b_qkv'])
+            gemm(ent['w_out'], None, None, produce_x=True)
+            if 'w_cq' in ent:
+                gemm(ent['w_cq'], q, _C.OUT_F32, ln=ent['cs_cq'], bias=ent['b_cq'])
+                gemm(ent['w_cout'], None, None, produce_x=True)
+            gemm(ent['w_ff1'], h, _C.OUT_TILED, ln=ent['cs_ff1'], bias=ent['b_ff1'], act=1)
+            gemm(ent['w_ff2'], None, None, produce_x=True)
+        gemm(pk['w_head'], logits, _C.OUT_F32, ln=pk['cs_head'], bias=pk['b_head'])
 
     one_position()  # warm
     torch.cuda.synchronize()
@@ -132,7 +138,7 @@ def pmc_traffic_per_launch():
         if not files:
             return None
         for row in csv.DictReader(open(files[-1])):
-            if 'lin_kernel' in row['kernel'] and row['counter'] == name:
+            if 'lin_tiled_kernel' in row['kernel'] and row['counter'] == name:
                 vals[name] = float(row['mean_per_dispatch'])
     if len(vals) != 2:
         return None

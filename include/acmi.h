@@ -135,6 +135,13 @@ typedef struct {
     const float* b_qkv;     /* [3d]  norm1      folded */
     const float* b_cq;      /* [d]   norm_cross folded */
     const float* b_ff1;     /* [ffn] norm2      folded */
+    /* column sums of the (dtype-rounded) folded matrices, f32: cs[n] = sum_k W'[n, k].  With them the
+     * LayerNorm needs no kernel of its own: LN(x) W'^T = rstd * (x W'^T - mean * cs), the GEMM running on the
+     * RAW row (kept next to x in fragment order as a bf16 hi / lo pair) and the epilogue applying the row
+     * statistics its producer emitted.  All NULL = separate standardisation kernel (acmi_ln_tile). */
+    const float* cs_qkv;    /* [3d] */
+    const float* cs_cq;     /* [d] */
+    const float* cs_ff1;    /* [ffn] */
     void* k_cache;          /* [Beff, H, Tmax, hd] in `kvdtype` (past_keys,  transformer.py:266-298) */
     void* v_cache;          /* [Beff, H, Tmax, hd] */
     const void* ck_cache;   /* cross-attention keys   [Beff, H, Lc, hd] in `kvdtype`, projected once */
@@ -153,6 +160,7 @@ typedef struct {
     const float* pos_table;         /* [Tmax, d] f32 sinusoidal table from acmi_pos_table */
     const void* w_head;             /* linears.{k}.weight stacked [n_q * card, d] x diag(out_norm.weight), tiled */
     const float* b_head;            /* [n_q * card] = W_head out_norm.bias (+ head biases) */
+    const float* cs_head;           /* [n_q * card] column sums of w_head (see acmi_lm_layer.cs_*), or NULL */
 } acmi_lm_model;
 
 typedef struct {
@@ -171,7 +179,9 @@ typedef struct {
     float* x;               /* [Beff, d] f32 residual stream */
     float* q;               /* [Beff, d] f32 */
     float* stats;           /* [max(1, d/16)][Beff][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
-    void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x */
+    void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x
+                               (separate LayerNorm kernel) or the raw x / its bf16 high part (folded LayerNorm) */
+    void* xlo;              /* bf16 weights + folded LayerNorm: same shape as xn, low part x - bf16(x); else NULL */
     float* slab;            /* [3][Beff][d] f32 split-K partial sums of linear2 (or NULL: no split) */
     void* att;              /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised */
     void* hidden;           /* tiled activation [ceil(Beff/16)*16, ffn_pad] in wdtype, zero-initialised */
@@ -212,10 +222,6 @@ int acmi_ln_tile_reduce(float* x, const float* slabs, int nslabs, void* out, int
 #define ACMI_A_ROWMAJOR_F32 0 /* a [M, K] f32 row-major, staged through LDS (+ optional LayerNorm) */
 #define ACMI_A_TILED 1        /* a = tiled activation in the weight's element type */
 #define ACMI_A_ROWMAJOR_F32_NORM 2 /* as 0, rows standardised ((x - mean) / sqrt(var + eps)) while staging */
-#define ACMI_A_ROWMAJOR_F32_STATS 3 /* a [M, K] f32 row-major whose per-row LayerNorm statistics were emitted by
-                                       the kernel that produced it (a_stats, see acmi_linear_desc): rows are
-                                       standardised in a wave-private staging step, no separate LayerNorm launch.
-                                       K must be 16 * KT * n <= 2048 (bf16: 512 n, n <= 4; f32: 256 n, n in 1..4, 6, 8) */
 #define ACMI_OUT_F32 0        /* out [M, N] f32 row-major */
 #define ACMI_OUT_BF16 1       /* out [M, N] bf16 row-major */
 #define ACMI_OUT_TILED 2      /* out = tiled activation (element type of w), pad region untouched */
@@ -226,22 +232,18 @@ int acmi_ln_tile_reduce(float* x, const float* slabs, int nslabs, void* out, int
  *   out[M, N] = act(LN?(a)[M, K] @ W[N, K]^T + bias[N]) + residual[M, N]
  * w: tiled weight in wdtype.  ln_g / ln_b (both or neither, only with ACMI_A_ROWMAJOR_F32, K <= 2048): full
  * LayerNorm with affine parameters applied in the kernel (the decode step uses the folded form instead).
- * bias [N] / residual [M, N] f32 row-major or NULL.  act: 0 none, 1 exact (erf) GELU.
- * prefetch_w (or NULL): tiled weight [prefetch_N, prefetch_K] (same wdtype) of the GEMM that will run next;
- * with a tiled activation, 4 of the workgroup's 16 waves pull it into L2 while the other 12 compute, so
- * that the next launch streams from L2 instead of paying HBM latency again (a hint: no effect on results). */
+ * bias [N] / residual [M, N] f32 row-major or NULL.  act: 0 none, 1 exact (erf) GELU. */
 int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps,
                 const void* w, int wdtype, const float* bias, const float* residual, void* out, int out_mode,
-                int act, int M, int N, int K, const void* prefetch_w, int prefetch_N, int prefetch_K,
-                void* stream);
+                int act, int M, int N, int K, void* stream);
 
 /* Descriptor form of acmi_linear with the producer/consumer LayerNorm-statistics hand-off:
  *   stats_out (or NULL): this GEMM writes, for every output row m and every workgroup b (16 output
  *     features each, N % 16 == 0), the pair (mean_b, M2_b = sum (v - mean_b)^2) of its final outputs to
  *     stats_out[(b * M + m) * 2 .. +1]  ->  N / 16 partials of 16 elements per row;
- *   a_stats / a_stats_np / a_stats_cnt with ACMI_A_ROWMAJOR_F32_STATS: the consumer combines `np`
- *     equal-count partials (Chan: mean = avg mean_b, M2 = sum M2_b + cnt (mean_b - mean)^2; np * cnt == K,
- *     np <= 128) into mean / rstd per row and standardises the rows while building its A fragments. */
+ *   a_stats / a_stats_np / a_stats_cnt (with colsum, see below): the consumer combines `np` equal-count
+ *     partials (Chan: mean = avg mean_b, M2 = sum M2_b + cnt (mean_b - mean)^2; np * cnt == K, np <= 128)
+ *     into mean / rstd per row and applies the LayerNorm in its epilogue. */
 typedef struct {
     const void* a; int a_mode;
     const float* ln_g; const float* ln_b; float eps;
@@ -255,7 +257,14 @@ typedef struct {
                                f32 slabs out[ks][M][N] -- no bias / act / residual -- to be summed by the consumer
                                (acmi_ln_tile_reduce) */
     int M, N, K;
-    const void* prefetch_w; int prefetch_N; int prefetch_K;
+    /* folded LayerNorm (a_mode ACMI_A_TILED, a_stats and colsum given): `a` holds the RAW rows in fragment
+     * order (bf16 weights: a = bf16(x), a_lo = bf16(x - a) or NULL for a single-term activation; f32: a = x),
+     * colsum[n] = sum_k W[n, k]; the kernel returns act(rstd * (a W^T - mean * colsum) + bias) (+ residual)
+     * with mean / rstd per row from the a_stats partials (K elements per row in total). */
+    const void* a_lo; const float* colsum;
+    /* xt_hi (or NULL): the final outputs are ALSO written as a raw tiled activation [., N] in wdtype
+     * (bf16: xt_hi = bf16(v), xt_lo = bf16(v - xt_hi); f32: xt_hi = v, xt_lo unused) for such a consumer. */
+    void* xt_hi; void* xt_lo;
 } acmi_linear_desc;
 int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
 

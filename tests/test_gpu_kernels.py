@@ -234,8 +234,8 @@ def test_attn_decode_vs_oracle(C, Beff, H, hd, Tcap, length, kvdt):
 @pytest.mark.parametrize('M,d,N2', [(16, 1536, 4608), (2, 1024, 3072), (5, 512, 96), (20, 2048, 512), (16, 256, 48)])
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_linear_statistics_handoff(C, M, d, N2, dt):
-    """x1 = x0 + A W1^T written with per-row (mean, M2) partials; the next GEMM standardises x1 from them:
-    out = LN_noaffine(x1) W2^T + b  (the LayerNorm in front of every GEMM of the decode step)."""
+    """x1 = x0 + A W1^T written together with per-row (mean, M2) partials that reproduce the row statistics
+    (consumed by the folded LayerNorm of the next GEMM, see test_linear_folded_layernorm)."""
     g = torch.Generator().manual_seed(M + d)
     K1 = 64
     a = torch.randn(M, K1, generator=g)
@@ -256,19 +256,53 @@ def test_linear_statistics_handoff(C, M, d, N2, dt):
     var = (m2_b + 16 * (mean_b - mean) ** 2).sum(0) / d
     assert torch.allclose(mean, x1_ref.mean(1), atol=1e-5)
     assert torch.allclose(var, x1_ref.var(1, unbiased=False), rtol=1e-4)
-    if d % (256 if dt == torch.float32 else 512) != 0:
-        return   # statistics-mode consumer needs K = 16 * KT * n (documented in include/acmi.h); producer side checked
+
+
+@pytest.mark.parametrize('M,d,N2', [(16, 1536, 4608), (2, 1024, 3072), (5, 512, 96), (33, 2048, 512), (16, 48, 32), (64, 1536, 256)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_linear_folded_layernorm(C, M, d, N2, dt):
+    """Folded LayerNorm: the producer GEMM writes x1 = x0 + A W1^T three times -- f32 row-major, raw in fragment
+    order (bf16: hi / lo pair) and as (mean, M2) partials; the consumer runs the plain tiled GEMM on the raw
+    fragments and applies  rstd * (acc - mean * colsum) + b  in its epilogue."""
+    g = torch.Generator().manual_seed(M + d)
+    K1 = 64
+    a = torch.randn(M, K1, generator=g)
+    w1 = torch.randn(d, K1, generator=g) / math.sqrt(K1)
+    x0 = torch.randn(M, d, generator=g) * 2 + 0.5   # mean / std = 0.25: the cancellation in the epilogue is exercised
+    w2 = torch.randn(N2, d, generator=g) / math.sqrt(d)
+    b2 = 0.1 * torch.randn(N2, generator=g)
+    x1_ref = x0 + a.to(dt).float() @ w1.to(dt).float().t()
+    ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t() + b2
+    x = x0.cuda().clone()
+    stats = torch.zeros(d // 16, M, 2, device='cuda')
+    hi = C.tiled_activation_buffer(M, d, dt, 'cuda')
+    lo = C.tiled_activation_buffer(M, d, dt, 'cuda') if dt == torch.bfloat16 else None
+    C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w1.cuda(), dt), x, M, C.A_TILED, C.OUT_F32,
+                stats_out=stats, residual=x, xt_hi=hi, xt_lo=lo)
+    xh = C.untile_matrix(hi, M, d).float()
+    if dt == torch.bfloat16:
+        assert torch.equal(xh, x.to(dt).float())
+        xl = C.untile_matrix(lo, M, d).float()
+        assert torch.equal(xl, (x - xh).to(dt).float())
+        assert (xh + xl - x).abs().max() <= 2.0 ** -16 * x.abs().max()
+    else:
+        assert torch.equal(xh, x)
+    w2t = C.TiledWeight(w2.cuda(), dt)
+    colsum = w2.to(dt).double().sum(1).float().cuda()
     out = torch.empty(M, N2, device='cuda')
-    C.linear_ex(x, C.TiledWeight(w2.cuda(), dt), out, M, C.A_ROWMAJOR_F32_STATS, C.OUT_F32, a_stats=stats,
-                np_=d // 16, cnt=16, bias=b2.cuda())
+    C.linear_ex(hi, w2t, out, M, C.A_TILED, C.OUT_F32, a_stats=stats, np_=d // 16, cnt=16, bias=b2.cuda(), a_lo=lo,
+                colsum=colsum)
     r = rel(out.cpu(), ref)
-    assert r < (3e-6 if dt == torch.float32 else 5e-3), f"rel-L2 {r}"
-    # single exact partial per row (what embed_kernel emits)
+    assert r < (3e-6 if dt == torch.float32 else 2e-4), f"rel-L2 {r}"   # bf16: x carries 16 mantissa bits here
+    # one exact partial per row (what embed_kernel emits)
     s1 = torch.stack([x1_ref.mean(1), ((x1_ref - x1_ref.mean(1, keepdim=True)) ** 2).sum(1)], dim=-1)[None].contiguous().cuda()
     out2 = torch.empty(M, N2, device='cuda')
-    C.linear_ex(x, C.TiledWeight(w2.cuda(), dt), out2, M, C.A_ROWMAJOR_F32_STATS, C.OUT_F32, a_stats=s1, np_=1, cnt=d,
-                bias=b2.cuda())
-    assert rel(out2.cpu(), ref) < (3e-6 if dt == torch.float32 else 5e-3)
+    C.linear_ex(hi, w2t, out2, M, C.A_TILED, C.OUT_F32, a_stats=s1, np_=1, cnt=d, bias=b2.cuda(), a_lo=lo, colsum=colsum)
+    assert rel(out2.cpu(), ref) < (3e-6 if dt == torch.float32 else 2e-4)
+    if dt == torch.bfloat16:  # single-term activation (hi only): the accuracy of a bf16 LayerNorm output
+        out3 = torch.empty(M, N2, device='cuda')
+        C.linear_ex(hi, w2t, out3, M, C.A_TILED, C.OUT_F32, a_stats=stats, np_=d // 16, cnt=16, bias=b2.cuda(), colsum=colsum)
+        assert rel(out3.cpu(), ref) < 6e-3
 
 
 @pytest.mark.parametrize('M,K', [(16, 1536), (3, 32), (33, 2048), (16, 1024)])
