@@ -33,7 +33,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct LinArgs {
     const void* a; int a_tiled;
     const float* a_stats; int a_np; int a_cnt;  // per-row (mean, M2) partials of the row-major activation (stats mode)
-    float* stats_out;                           // per-row (mean, M2) partials of this GEMM's output, [gridDim][M][2]
+    float* stats_out;                           // per-row (mean, M2) partials of this GEMM's output, [M][N / 16][2]
     // "folded LayerNorm": a / a_lo hold the RAW activation as hi / lo fragments (x = hi + lo; f32 weights: hi
     // only), colsum[n] = sum_k W'[n,k]; with the row statistics from a_stats the epilogue applies
     //     LN(x) W'^T = rstd * (x W'^T - mean * colsum)
@@ -218,12 +218,14 @@ extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K,
 
 // Folded LayerNorm, row statistics: a "group" is 4 rows (16 lanes each); every lane fetches up to 8 of the
 // producer's equal-count (mean, M2) partials of its row (np <= 128), combined later with Chan's formula.
+// Layout stats[row][np][2]: the partials of a row are contiguous, so a wave's load touches 4 lines, not 64
+// (with [np][row][2] the gather cost ~2 us per consuming launch).
 __device__ __forceinline__ void rowstat_load(const float* __restrict__ stats, int np, int M, int row0, int lane,
                                              float (&pm)[8], float (&pq)[8]) {
     const int row = min(row0 + (lane >> 4), M - 1), jj = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)min(jj + 16 * i, np - 1) * M + row) * 2);
+    for (int i = 0; i < 8; ++i) {  // 16 consecutive partials of one row per 16 lanes: one 128-B line
+        const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)row * np + min(jj + 16 * i, np - 1)) * 2);
         pm[i] = t.x; pq[i] = t.y;
     }
 }
@@ -365,7 +367,7 @@ struct TlExtras {
 template <typename WT, int MT, int LN, int C>
 __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, const u32x4* __restrict__ at,
                                          const u32x4* __restrict__ al, int mts, int mtv, int kc0, int nw,
-                                         const float* __restrict__ st_ptr, int st_stride, int np,
+                                         const float* __restrict__ st_ptr, int np,
                                          const float* __restrict__ pb, const float* __restrict__ pc,
                                          const float* __restrict__ pr, const int* __restrict__ ppos, f32x4 (&acc)[MT],
                                          TlExtras& ex) {
@@ -391,7 +393,7 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
         const int jj = (int)(threadIdx.x & 15);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float2 t = *reinterpret_cast<const float2*>(st_ptr + min(jj + 16 * i, np - 1) * st_stride);
+            const float2 t = *reinterpret_cast<const float2*>(st_ptr + min(jj + 16 * i, np - 1) * 2);
             ex.pm[i] = t.x; ex.pq[i] = t.y;
         }
     }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
         // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
         const int ngroups = 4 * mtv;
         const float* st_ptr = own;
-        if (LN > 0) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * 2;
+        if (LN > 0) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
         // this thread's first epilogue element
         const int e0 = (int)threadIdx.x, eu = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
         const int egn = min(n0 + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
         int kc = kbeg + wave, rem = p.fpw;              // fragments every wave owns (+ a ragged tail)
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.M * 2, p.a_np, pb, pc, pr, ppos, accs, ex); \
+            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
             kc += Cn * nw; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
         ACMI_TL_RUN(1)
 #undef ACMI_TL_RUN
         if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
-            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.M * 2, p.a_np, pb, pc, pr, ppos, accs, ex);
+            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
 
         // ---- deterministic cross-wave reduction through LDS
 #pragma unroll
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) dq += __shfl_xor(dq, off, 64);
                 if (nn == 0 && gm < p.M)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)ntile * p.M + gm) * 2) = make_float2(mb, dq);
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * gridDim.x + ntile) * 2) = make_float2(mb, dq);
             }
             if (!valid) continue;
             if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
@@ -840,7 +842,7 @@ struct EmbedArgs {
     const float* pos_table; float pos_scale;
     const int* pos;
     float* x; int d;
-    float* stats;  // [1][M][2]: (mean, M2) of every produced row (one partial of d elements)
+    float* stats;  // [M][1][2]: (mean, M2) of every produced row (one partial of d elements)
     void* xt_hi; void* xt_lo; int xt_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
 };
 
@@ -852,19 +854,28 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     float loc[8];  // d <= 2048
     float sum = 0.f;
     int cnt = 0;
+    // the K tokens of this step, read once (inside the channel loop the stores to x would force a reload and
+    // serialise token -> embedding-row round trips: 17 -> 7 us)
+    int toks[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int64_t tok = (g >= p.P && k < p.K) ? p.gen_sequence[((size_t)b * p.K + k) * p.S + (g - p.P)] : 0;
+        if (tok < 0 || tok > p.card) tok = p.card;  // never happens for a well-formed sequence
+        toks[k] = (int)tok;
+    }
     for (int cch = threadIdx.x; cch < p.d; cch += blockDim.x, ++cnt) {
         float v;
         if (g < p.P) {
             v = p.prepend[((size_t)m * p.P + g) * p.d + cch];
         } else {
-            const int sidx = g - p.P;
             v = 0.f;
-            for (int k = 0; k < p.K; ++k) {
-                int64_t tok = p.gen_sequence[((size_t)b * p.K + k) * p.S + sidx];
-                if (tok < 0 || tok > p.card) tok = p.card;  // never happens for a well-formed sequence
-                const size_t ei = (size_t)tok * p.d + cch;
-                v += p.w_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(p.emb[k])[ei])
-                              : reinterpret_cast<const float*>(p.emb[k])[ei];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < p.K) {
+                    const size_t ei = (size_t)toks[k] * p.d + cch;
+                    v += p.w_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(p.emb[k])[ei])
+                                  : reinterpret_cast<const float*>(p.emb[k])[ei];
+                }
             }
         }
         v += p.pos_scale * p.pos_table[(size_t)g * p.d + cch];

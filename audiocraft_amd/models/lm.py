@@ -288,7 +288,7 @@ class LMModel(nn.Module):
         run['x'] = torch.zeros(Beff, d, **f32)
         run['q'] = torch.zeros(Beff, d, **f32)
         # activations that feed a GEMM directly live in A-fragment order, zero padded
-        run['stats'] = torch.zeros(max(1, d // 16), Beff, 2, **f32)
+        run['stats'] = torch.zeros(Beff, max(1, d // 16), 2, **f32)
         run['xn'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['xlo'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['slab'] = torch.zeros(3, Beff, d, **f32)

@@ -66,7 +66,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     xh = _C.tile_matrix(rnd(d), wd)
     xl = _C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if wd == torch.bfloat16 else None
     np_ = max(1, d // 16)
-    stats = torch.zeros(np_, B_eff, 2, device=dev)
+    stats = torch.zeros(B_eff, np_, 2, device=dev)
     stats[..., 1] = 16.0
     q = torch.empty(B_eff, d, device=dev)
     qkv = torch.empty(B_eff, 3 * d, device=dev)

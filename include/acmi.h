@@ -178,7 +178,7 @@ typedef struct {
                                pos[1] = scratch ticket counter (must be 0 between steps) */
     float* x;               /* [Beff, d] f32 residual stream */
     float* q;               /* [Beff, d] f32 */
-    float* stats;           /* [max(1, d/16)][Beff][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
+    float* stats;           /* [Beff][max(1, d/16)][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
     void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x
                                (separate LayerNorm kernel) or the raw x / its bf16 high part (folded LayerNorm) */
     void* xlo;              /* bf16 weights + folded LayerNorm: same shape as xn, low part x - bf16(x); else NULL */
@@ -240,7 +240,7 @@ int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b,
 /* Descriptor form of acmi_linear with the producer/consumer LayerNorm-statistics hand-off:
  *   stats_out (or NULL): this GEMM writes, for every output row m and every workgroup b (16 output
  *     features each, N % 16 == 0), the pair (mean_b, M2_b = sum (v - mean_b)^2) of its final outputs to
- *     stats_out[(b * M + m) * 2 .. +1]  ->  N / 16 partials of 16 elements per row;
+ *     stats_out[(m * (N / 16) + b) * 2 .. +1]  ->  N / 16 contiguous partials of 16 elements per row;
  *   a_stats / a_stats_np / a_stats_cnt (with colsum, see below): the consumer combines `np` equal-count
  *     partials (Chan: mean = avg mean_b, M2 = sum M2_b + cnt (mean_b - mean)^2; np * cnt == K, np <= 128)
  *     into mean / rstd per row and applies the LayerNorm in its epilogue. */

@@ -246,14 +246,14 @@ def test_linear_statistics_handoff(C, M, d, N2, dt):
     x1_ref = x0 + a.to(dt).float() @ w1.to(dt).float().t()
     ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t() + b2
     x = x0.cuda().clone()
-    stats = torch.zeros(d // 16, M, 2, device='cuda')
+    stats = torch.zeros(M, d // 16, 2, device='cuda')
     C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w1.cuda(), dt), x, M, C.A_TILED, C.OUT_F32,
                 stats_out=stats, residual=x)
     assert rel(x.cpu(), x1_ref) < (2e-6 if dt == torch.float32 else 1e-5)
     # the partials reproduce the row statistics
     mean_b, m2_b = stats[..., 0].cpu(), stats[..., 1].cpu()
-    mean = mean_b.mean(0)
-    var = (m2_b + 16 * (mean_b - mean) ** 2).sum(0) / d
+    mean = mean_b.mean(1)
+    var = (m2_b + 16 * (mean_b - mean[:, None]) ** 2).sum(1) / d
     assert torch.allclose(mean, x1_ref.mean(1), atol=1e-5)
     assert torch.allclose(var, x1_ref.var(1, unbiased=False), rtol=1e-4)
 
@@ -274,7 +274,7 @@ def test_linear_folded_layernorm(C, M, d, N2, dt):
     x1_ref = x0 + a.to(dt).float() @ w1.to(dt).float().t()
     ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t() + b2
     x = x0.cuda().clone()
-    stats = torch.zeros(d // 16, M, 2, device='cuda')
+    stats = torch.zeros(M, d // 16, 2, device='cuda')
     hi = C.tiled_activation_buffer(M, d, dt, 'cuda')
     lo = C.tiled_activation_buffer(M, d, dt, 'cuda') if dt == torch.bfloat16 else None
     C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w1.cuda(), dt), x, M, C.A_TILED, C.OUT_F32,
@@ -295,7 +295,7 @@ def test_linear_folded_layernorm(C, M, d, N2, dt):
     r = rel(out.cpu(), ref)
     assert r < (3e-6 if dt == torch.float32 else 2e-4), f"rel-L2 {r}"   # bf16: x carries 16 mantissa bits here
     # one exact partial per row (what embed_kernel emits)
-    s1 = torch.stack([x1_ref.mean(1), ((x1_ref - x1_ref.mean(1, keepdim=True)) ** 2).sum(1)], dim=-1)[None].contiguous().cuda()
+    s1 = torch.stack([x1_ref.mean(1), ((x1_ref - x1_ref.mean(1, keepdim=True)) ** 2).sum(1)], dim=-1)[:, None].contiguous().cuda()
     out2 = torch.empty(M, N2, device='cuda')
     C.linear_ex(hi, w2t, out2, M, C.A_TILED, C.OUT_F32, a_stats=s1, np_=1, cnt=d, bias=b2.cuda(), a_lo=lo, colsum=colsum)
     assert rel(out2.cpu(), ref) < (3e-6 if dt == torch.float32 else 2e-4)
