@@ -14,8 +14,8 @@ step    : one full generate (conditioning given -> tokens -> waveform on device)
           all-gathered (both collectives are inside the timed region).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = lin_kernel (weight-streaming skinny GEMM, HBM bound): algorithmic
-               weight bytes of one decode position / number of lin_kernel launches, divided by the
+  roofline     dominant kernel = lin_tiled_kernel (weight-streaming skinny GEMM, HBM bound): algorithmic
+               weight bytes of one decode position / number of its launches, divided by the
                average launch duration measured here with HIP events over one decode position's worth
                of launches (all layers, real shapes) on the launch stream.
   cpu_baseline the oracle (a port of the reference's CPU algorithm, incl. its torch.cat KV cache)
@@ -51,7 +51,7 @@ def lm_algorithmic_bytes(lm, B_eff: int, n_positions: int, Lc: int, prefix: int 
 
 
 def measure_lin_kernel(model, B_eff: int, reps: int = 3):
-    """Average lin_kernel launch duration over one decode position's worth of launches (HIP events on the
+    """Average lin_tiled_kernel launch duration over one decode position's worth of launches (HIP events on the
     launch stream), and the algorithmic bytes those launches stream."""
     from audiocraft_amd import _C
     lm = model.lm
@@ -126,7 +126,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per lin_kernel launch from the committed rocprofv3 PMC passes over the same launch chain
+    """HBM bytes per lin_tiled_kernel launch from the committed rocprofv3 PMC passes over the same launch chain
     (profiles/r*_lin_chain_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, scripts/dbg_chain.py):
     FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half size
     (MI355X_MICROARCH.md, HBM section), hence the x2.  None if no PMC summary is present."""
@@ -137,11 +137,14 @@ def pmc_traffic_per_launch():
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_lin_chain_pmc_{name}.csv')))
         if not files:
             return None
+        total = n = 0.0  # dispatch-weighted mean over the kernel's template variants (plain / folded LayerNorm)
         for row in csv.DictReader(open(files[-1])):
             if 'lin_tiled_kernel' in row['kernel'] and row['counter'] == name:
-                vals[name] = float(row['mean_per_dispatch'])
-    if len(vals) != 2:
-        return None
+                total += float(row['mean_per_dispatch']) * float(row['dispatches'])
+                n += float(row['dispatches'])
+        if n == 0:
+            return None
+        vals[name] = total / n
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
 
 
@@ -285,7 +288,7 @@ def main():
         if not args.no_roofline:
             r = measure_lin_kernel(model, 2 * B)
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "lin_kernel (weight-streaming skinny GEMM)", "bound": "hbm",
+            out["roofline"] = {"kernel": "lin_tiled_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(),
                                "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(r['avg_us'], 3),

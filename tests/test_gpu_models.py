@@ -90,6 +90,35 @@ def test_encodec_32khz_geometry_vs_oracle():
     assert (dec - dec_ref).abs().max().item() < 1e-4
 
 
+def test_encodec_24khz_geometry_config1():
+    """BASELINE.json configs[0] / SURVEY.md section 8(d) #1: EnCodec-24 kHz geometry (causal SEANet n_filters 32,
+    ratios [8,5,4,2], RVQ 32 x 1024 x 128), seeded random weights, input 0.1 * randn(1, 1, 240000) seed 1
+    -> codes [1, 32, 750].  Gates: RVQ indices bit exact on identical latents (all 32 stages), latents and
+    waveform within fp32 tolerance of the CPU oracle."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(0)
+    m = builders.get_compression_model(builders.ENCODEC_24KHZ, 'cuda')
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    c = ocodec.CodecConfig(channels=1, dimension=128, n_filters=32, n_residual_layers=1, ratios=[8, 5, 4, 2],
+                           causal=True, pad_mode='constant', lstm=2, norm='weight_norm', n_q=32, bins=1024,
+                           sample_rate=24000, frame_rate=75)
+    wav = 0.1 * torch.randn(1, 1, 240000, generator=torch.Generator().manual_seed(1))
+    lat_ref = ocodec.seanet_encoder(sd, c, wav, fast_lstm=True)
+    lat = m.encoder(wav.cuda()).cpu()
+    assert lat.shape == lat_ref.shape == (1, 128, 750)
+    assert rel(lat, lat_ref) < 2e-5
+    codes_ref = ocodec.rvq_encode(lat_ref, ocodec.codebooks_from_state(sd, 32))
+    assert codes_ref.shape == (1, 32, 750) and int(codes_ref.max()) < 1024
+    assert torch.equal(m.quantizer.encode(lat_ref.cuda()).cpu(), codes_ref)   # identical latents: bit exact
+    codes, scale = m.encode(wav.cuda())
+    assert scale is None and codes.shape == (1, 32, 750)
+    assert (codes[:, 0].cpu() == codes_ref[:, 0]).float().mean() > 0.97   # latents differ by fp32 round-off only
+    dec_ref = ocodec.encodec_decode(sd, c, codes_ref, fast_lstm=True)
+    dec = m.decode(codes_ref.cuda()).cpu()
+    assert dec.shape == dec_ref.shape == (1, 1, 240000)
+    assert (dec - dec_ref).abs().max().item() < 1e-4
+
+
 def test_encodec_random_lengths_roundtrip_shapes():
     """reference tests/models/test_encodec_model.py:37-46"""
     from audiocraft_amd.models import builders
