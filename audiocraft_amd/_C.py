@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
 
 
 class LMLayer(C.Structure):
-    _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_ff1', vp), ('w_ff2', vp),
+    _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_xcq', vp), ('w_ff1', vp), ('w_ff2', vp),
                 ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp)]
 
@@ -51,7 +51,7 @@ class LMModelDesc(C.Structure):
 class LMState(C.Structure):
     _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
                 ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
-                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('slab', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
+                ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64)]
 
@@ -82,17 +82,27 @@ class LinearDesc(C.Structure):
     _fields_ = [('a', vp), ('a_mode', i32), ('ln_g', vp), ('ln_b', vp), ('eps', f32), ('a_stats', vp),
                 ('a_stats_np', i32), ('a_stats_cnt', i32), ('w', vp), ('wdtype', i32), ('bias', vp), ('residual', vp),
                 ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('ksplit', i32), ('M', i32), ('N', i32), ('K', i32),
-                ('a_lo', vp), ('colsum', vp), ('xt_hi', vp), ('xt_lo', vp)]
+                ('a_lo', vp), ('colsum', vp), ('xt_hi', vp), ('xt_lo', vp), ('a_rbs', i32), ('a_lo_rbs', i32),
+                ('xt_rbs', i32), ('xt_lo_rbs', i32), ('lo_K', i32)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [('q', vp), ('k_cache', vp), ('v_cache', vp), ('kvdtype', i32), ('out', vp), ('out_mode', i32),
+                ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
+                ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('q_stats', vp), ('q_stats_np', i32),
+                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
+_linear_pair = _sig('acmi_linear_pair', [C.POINTER(LinearDesc), C.POINTER(LinearDesc), vp])
+_attn_ex = _sig('acmi_attn_decode_ex', [C.POINTER(AttnDesc), vp])
 _ln_tile_reduce = _sig('acmi_ln_tile_reduce', [vp, vp, i32, vp, i32, i32, i32, f32, vp])
 _kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, i32, f32, u64, u64, vp])
 
 EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
-           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce']
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
 
 def version() -> int:
@@ -227,27 +237,51 @@ def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, re
     return out
 
 
-def linear_ex(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0, cnt=0, stats_out=None, bias=None,
-              residual=None, act=0, eps=1e-5, ksplit=1, a_lo=None, colsum=None, xt_hi=None, xt_lo=None):
-    """Descriptor form (acmi_linear_ex): statistics hand-off between producer and consumer GEMMs; with
-    `colsum` the folded LayerNorm on a raw tiled activation (a [, a_lo]); xt_hi / xt_lo: raw tiled copy of the output."""
+def linear_desc(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0, cnt=0, stats_out=None, bias=None,
+                residual=None, act=0, eps=1e-5, ksplit=1, a_lo=None, colsum=None, xt_hi=None, xt_lo=None, a_rbs=0,
+                a_lo_rbs=0, xt_rbs=0, xt_lo_rbs=0, lo_K=0, K=None) -> LinearDesc:
+    """acmi_linear_desc (include/acmi.h).  K overrides w.K when the weight was tiled with a padded K.
+    The descriptor holds raw device pointers: the caller keeps the tensors alive until the launch."""
     d = LinearDesc()
     d.a, d.a_mode, d.eps = ptr(a), a_mode, eps
     d.a_stats, d.a_stats_np, d.a_stats_cnt = ptr(a_stats), np_, cnt
     d.w, d.wdtype, d.bias, d.residual = ptr(w.data), dtype_code(w.dtype), ptr(bias), ptr(residual)
     d.out, d.out_mode, d.act, d.stats_out, d.ksplit = ptr(out), out_mode, act, ptr(stats_out), ksplit
-    d.M, d.N, d.K = M, w.N, w.K
+    d.M, d.N, d.K = M, w.N, (w.K if K is None else K)
     d.a_lo, d.colsum, d.xt_hi, d.xt_lo = ptr(a_lo), ptr(colsum), ptr(xt_hi), ptr(xt_lo)
+    d.a_rbs, d.a_lo_rbs, d.xt_rbs, d.xt_lo_rbs, d.lo_K = a_rbs, a_lo_rbs, xt_rbs, xt_lo_rbs, lo_K
+    return d
+
+
+def linear_launch(d: LinearDesc):
     check(_linear_ex(C.byref(d), stream()), 'acmi_linear_ex')
+
+
+def linear_ex(a, w: TiledWeight, out, M, a_mode, out_mode, **kw):
+    """Descriptor form (acmi_linear_ex): statistics hand-off between producer and consumer GEMMs; with
+    `colsum` the folded LayerNorm on a raw tiled activation (a [, a_lo]); xt_hi / xt_lo: raw tiled copy of the output."""
+    linear_launch(linear_desc(a, w, out, M, a_mode, out_mode, **kw))
     return out
 
 
-def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False):
-    """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True)."""
+def linear_pair(plain: LinearDesc, xcat: LinearDesc):
+    """Two independent tiled GEMMs on the same rows in one launch (acmi_linear_pair)."""
+    check(_linear_pair(C.byref(plain), C.byref(xcat), stream()), 'acmi_linear_pair')
+
+
+def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False, out_rbs=0, out_col0=0,
+                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5):
+    """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True; out_rbs / out_col0
+    place the head outputs inside a wider buffer).  q_colsum: LayerNorm hook on q (acmi_attn_desc)."""
     Beff, H, Tcap, hd = k_cache.shape
-    check(_attn(ptr(q), ptr(k_cache), ptr(v_cache), dtype_code(k_cache.dtype), ptr(out),
-                OUT_TILED if out_tiled else OUT_F32, dtype_code(out.dtype), Beff, H, hd, Tcap, length,
-                ptr(len_dev), len_bias, stream()), 'acmi_attn_decode')
+    d = AttnDesc()
+    d.q, d.k_cache, d.v_cache, d.kvdtype = ptr(q), ptr(k_cache), ptr(v_cache), dtype_code(k_cache.dtype)
+    d.out, d.out_mode, d.out_dtype = ptr(out), (OUT_TILED if out_tiled else OUT_F32), dtype_code(out.dtype)
+    d.out_rbs, d.out_col0 = out_rbs, out_col0
+    d.Beff, d.H, d.hd, d.Tcap, d.len, d.len_dev, d.len_bias = Beff, H, hd, Tcap, length, ptr(len_dev), len_bias
+    d.q_stats, d.q_stats_np, d.q_stats_cnt, d.eps = ptr(q_stats), q_np, q_cnt, eps
+    d.q_colsum, d.q_bias = ptr(q_colsum), ptr(q_bias)
+    check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')
     return out
 
 

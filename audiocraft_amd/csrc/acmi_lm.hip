@@ -38,7 +38,10 @@ struct LinArgs {
     // only), colsum[n] = sum_k W'[n,k]; with the row statistics from a_stats the epilogue applies
     //     LN(x) W'^T = rstd * (x W'^T - mean * colsum)
     const void* a_lo; const float* colsum;
-    void* xt_hi; void* xt_lo; int xt_nkc;       // producer side: also write the output as raw hi / lo fragments
+    void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // producer side: also write the output as raw hi / lo fragments
+                                                // (K tiles per 16-row block of the two buffers)
+    int a_rbs, alo_rbs;                         // fragments (x 64 lanes) between 16-row blocks of a / a_lo (0: NKC)
+    int lo_split;                               // LN 3: only K fragments < lo_split have a lo term
     int ln_mode; const float* ln_g; const float* ln_b; float eps;
     const void* w;
     const float* bias;
@@ -358,6 +361,7 @@ static int launch_rowmajor(LinArgs& a, hipStream_t st) {
 // replaced by the address of the wave's own first weight fragment (already in flight: no extra line, page or
 // hot spot), so the prologue is branch free.
 //   LN 0: plain   1: folded LayerNorm, single-term activation   2: folded LayerNorm, hi + lo activation
+//      3: no LayerNorm, hi + lo activation for the first lo_split K fragments (x | a concatenated along K)
 struct TlExtras {
     float pm[8], pq[8];     // LN > 0: (mean, M2) partials of this lane's statistics row
     float bias, colsum, res;  // epilogue operands of this thread's first output element
@@ -366,12 +370,12 @@ struct TlExtras {
 
 template <typename WT, int MT, int LN, int C>
 __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, const u32x4* __restrict__ at,
-                                         const u32x4* __restrict__ al, int mts, int mtv, int kc0, int nw,
+                                         const u32x4* __restrict__ al, int mts, int mtl, int mtv, int kc0, int nw,
                                          const float* __restrict__ st_ptr, int np,
                                          const float* __restrict__ pb, const float* __restrict__ pc,
                                          const float* __restrict__ pr, const int* __restrict__ ppos, f32x4 (&acc)[MT],
                                          TlExtras& ex) {
-    constexpr bool HL = LN == 2;
+    constexpr bool HL = LN == 2 || LN == 3;
     const int lane = threadIdx.x & 63;
     u32x4 bv[C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
 #pragma unroll
@@ -380,16 +384,18 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
         bv[i] = ld_frag_nt(wt + ko + lane);
 #pragma unroll
         for (int u = 0; u < MT; ++u) {  // row blocks beyond M re-read the last valid one (their results are dropped)
-            const int off = min(u, mtv - 1) * mts + ko;
-            av[u][i] = (at + off)[lane];
-            if (HL) lv[u][i] = (al + off)[lane];
+            const int ub = min(u, mtv - 1);
+            av[u][i] = (at + (ub * mts + ko))[lane];
+            if (LN == 2) lv[u][i] = (al + (ub * mtl + ko))[lane];
+            if (LN == 3)  // fragments past lo_split have no lo term: re-read the last one (L1 hit), zeroed below
+                lv[u][i] = (al + (ub * mtl + min(kc0 + i * nw, p.lo_split - 1) * 64))[lane];
         }
     }
     // (the asm keeps these loop-invariant loads here, behind the weight stream, instead of in front of the K loop)
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
     st_ptr += opaque0; pb += opaque0; pc += opaque0; pr += opaque0; ppos += opaque0;
-    if (LN > 0) {
+    if (LN == 1 || LN == 2) {
         const int jj = (int)(threadIdx.x & 15);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -404,13 +410,15 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             mma_frag(av[u][i], bv[i], acc[u], WT());
+            if (LN == 3 && kc0 + i * nw >= p.lo_split) lv[u][i] = u32x4{0u, 0u, 0u, 0u};
             if (HL) mma_frag(lv[u][i], bv[i], acc[u], WT());
         }
 }
 
 template <typename WT, int MT, int LN>
-__global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
-    constexpr int D = LN == 2 ? 2 : 1;
+__device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const int kslice, const int ksp) {
+    constexpr int D = (LN == 2 || LN == 3) ? 2 : 1;
+    constexpr bool FOLD = LN == 1 || LN == 2;
     // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
     // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
     // VGPRs of a 2-waves-per-SIMD launch
@@ -421,11 +429,9 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
     float* red = reinterpret_cast<float*>(smem);        // [MT][nw][256] partial accumulators
     float* rowstat = red + (size_t)MT * nw * 256;       // [16 MT][2] mean, rstd
-    const int ksp = (int)gridDim.y;                     // split-K slices (grid.y)
-    const int ntile = blockIdx.x, kslice = blockIdx.y;
     const int n0 = ntile * 16, NKC = p.NKC;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
-    const int mts = NKC * 64;                           // fragment lanes between consecutive 16-row blocks
+    const int mts = p.a_rbs * 64, mtl = p.alo_rbs * 64;  // fragment lanes between consecutive 16-row blocks (a, a_lo)
     const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
     const float* own = reinterpret_cast<const float*>(wt + (size_t)(kbeg + min(wave, kcs - 1)) * 64 + lane);
 
@@ -438,11 +444,11 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
 #pragma unroll
         for (int u = 0; u < MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mg >> 4) * mts);
-        const u32x4* al = LN == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mg >> 4) * mts) : nullptr;
+        const u32x4* al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mg >> 4) * mtl) : nullptr;
         // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
         const int ngroups = 4 * mtv;
         const float* st_ptr = own;
-        if (LN > 0) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
+        if (FOLD) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
         // this thread's first epilogue element
         const int e0 = (int)threadIdx.x, eu = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
         const int egn = min(n0 + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
         int kc = kbeg + wave, rem = p.fpw;              // fragments every wave owns (+ a ragged tail)
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
+            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
             kc += Cn * nw; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -468,14 +474,14 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
         ACMI_TL_RUN(1)
 #undef ACMI_TL_RUN
         if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
-            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
+            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
 
         // ---- deterministic cross-wave reduction through LDS
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((size_t)u * nw + wave) * 256 + lane * 4 + r] = accs[u][r];
-        if (LN > 0) {
+        if (FOLD) {
             // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
 #pragma unroll
             for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
             }
             size_t oi = 0;
             if (valid) {
-                if (LN > 0) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
+                if (FOLD) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
                     const float* rs = rowstat + (u * 16 + mm) * 2;
                     v = rs[1] * (v - rs[0] * (first ? ex.colsum : p.colsum[gn]));
                 }
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) dq += __shfl_xor(dq, off, 64);
                 if (nn == 0 && gm < p.M)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * gridDim.x + ntile) * 2) = make_float2(mb, dq);
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> 4) + ntile) * 2) = make_float2(mb, dq);
             }
             if (!valid) continue;
             if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
@@ -531,7 +537,8 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
                 if (sizeof(WT) == 2) {
                     const bf16_t hi = f32_to_bf16(v);
                     reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
-                    if (p.xt_lo != nullptr) reinterpret_cast<bf16_t*>(p.xt_lo)[ti] = f32_to_bf16(v - bf16_to_f32(hi));
+                    if (p.xt_lo != nullptr)
+                        reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<WT>(gm, gn, p.xt_lo_nkc)] = f32_to_bf16(v - bf16_to_f32(hi));
                 } else {
                     reinterpret_cast<float*>(p.xt_hi)[ti] = v;
                 }
@@ -559,23 +566,54 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
 }
 
 template <typename WT, int MT, int LN>
-static int launch_tiled_t(LinArgs& a, hipStream_t st) {
+__global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
+    tl_body<WT, MT, LN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
+// (plain), the rest run p1 (LN 3: x | a concatenated along K, no LayerNorm).  Used for
+//   x1 = x0 + att W_out^T   and   r = [x0 | att] [W_cq' | W_cq' W_out]^T  (= x1 W_cq'^T, the cross-attention
+// query before its LayerNorm statistics are applied), see acmi_lm_step.
+template <typename WT, int MT, int LNB>
+__global__ __launch_bounds__(512) void lin_pair_kernel(const LinArgs p0, const LinArgs p1, const int tiles0) {
+    if ((int)blockIdx.x < tiles0) tl_body<WT, MT, 0>(p0, (int)blockIdx.x, 0, 1);
+    else tl_body<WT, MT, LNB>(p1, (int)blockIdx.x - tiles0, 0, 1);
+}
+
+// Workgroup size.  (1) Waves are not free: the dispatcher starts ~1.25 waves / ns (a 288-workgroup x 16-wave
+// launch with no loads at all takes 6.2 us), so a wave should own ~12 fragments or more, all of them requested
+// before its first wait.  (2) The kernel needs > 128 VGPRs for that, i.e. a CU holds 8 waves: nw in {8, 4, 2, 1}
+// packs 1, 2, 4, 8 workgroups per CU exactly, and the grid must fit the 256 CUs in ONE round (a 288-workgroup
+// grid of 6-wave workgroups runs 256 + 32: the launch takes twice as long).
+static int tiled_waves(int tiles, int frags) {
+    int nw = tiles <= 256 ? 8 : (tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1));
+    while (nw > 1 && frags < 12 * nw) nw >>= 1;
+    static const char* e = getenv("ACMI_LIN_NW");
+    if (e && atoi(e) > 0 && atoi(e) < nw) nw = atoi(e);
+    return nw;
+}
+
+template <typename WT>
+static int tiled_prepare(LinArgs& a) {
     constexpr int KT = WTr<WT>::KT;
     a.NKC = (a.K + KT - 1) / KT;
     a.NKC_out = (a.N + KT - 1) / KT;
     if (a.ksplit < 1 || a.NKC % a.ksplit != 0) a.ksplit = 1;
-    // Workgroup size.  (1) Waves are not free: the dispatcher starts ~1.25 waves / ns (a 288-workgroup x 16-wave
-    // launch with no loads at all takes 6.2 us), so a wave should own ~12 fragments or more, all of them
-    // requested before its first wait.  (2) The kernel needs > 128 VGPRs for that, i.e. a CU holds 8 waves:
-    // nw in {8, 4, 2, 1} packs 1, 2, 4, 8 workgroups per CU exactly, and the grid must fit the 256 CUs in ONE
-    // round (a 288-workgroup grid of 6-wave workgroups runs 256 + 32: the launch takes twice as long).
-    const int tiles = ((a.N + 15) / 16) * a.ksplit, frags = a.NKC / a.ksplit;
-    int nw = tiles <= 256 ? 8 : (tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1));
-    while (nw > 1 && frags < 12 * nw) nw >>= 1;
-    { static const char* e = getenv("ACMI_LIN_NW"); if (e && atoi(e) > 0 && atoi(e) < nw) nw = atoi(e); }
+    if (a.a_rbs <= 0) a.a_rbs = a.NKC;
+    if (a.alo_rbs <= 0) a.alo_rbs = a.lo_split > 0 ? a.lo_split : a.NKC;  // a lo buffer holds only the columns that have one
+    ACMI_REQUIRE(a.a_rbs >= a.NKC, "acmi_linear: a_rbs=%d < K tiles %d", a.a_rbs, a.NKC);
     ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
     ACMI_REQUIRE(a.ksplit == 1 || (!a.qkv && a.stats_out == nullptr && a.xt_hi == nullptr),
                  "acmi_linear: split-K is incompatible with QKV scatter / stats_out / xt_hi");
+    return ACMI_OK;
+}
+
+template <typename WT, int MT, int LN>
+static int launch_tiled_t(LinArgs& a, hipStream_t st) {
+    int rc = tiled_prepare<WT>(a);
+    if (rc) return rc;
+    const int tiles = ((a.N + 15) / 16) * a.ksplit, frags = a.NKC / a.ksplit;
+    const int nw = tiled_waves(tiles, frags);
     a.kcs = frags; a.fpw = frags / nw;
     const size_t lds = (size_t)MT * nw * 1024 + (size_t)MT * 128;
     hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN>), dim3((a.N + 15) / 16, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)), dim3(nw * 64), lds, st, a);
@@ -585,13 +623,39 @@ static int launch_tiled_t(LinArgs& a, hipStream_t st) {
 template <typename WT>
 static int launch_tiled(LinArgs& a, hipStream_t st) {
     const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);  // 1, 2 or 4 16-row blocks share each weight fragment
-    const int ln = a.colsum == nullptr ? 0 : (a.a_lo != nullptr ? 2 : 1);
+    const int ln = a.colsum == nullptr ? (a.lo_split > 0 ? 3 : 0) : (a.a_lo != nullptr ? 2 : 1);
 #define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv>(a, st);
-    ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2)
-    ACMI_TL_CASE(2, 0) ACMI_TL_CASE(2, 1) ACMI_TL_CASE(2, 2)
-    ACMI_TL_CASE(4, 0) ACMI_TL_CASE(4, 1) ACMI_TL_CASE(4, 2)
+    ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2) ACMI_TL_CASE(1, 3)
+    ACMI_TL_CASE(2, 0) ACMI_TL_CASE(2, 1) ACMI_TL_CASE(2, 2) ACMI_TL_CASE(2, 3)
+    ACMI_TL_CASE(4, 0) ACMI_TL_CASE(4, 1) ACMI_TL_CASE(4, 2) ACMI_TL_CASE(4, 3)
 #undef ACMI_TL_CASE
     return ACMI_EINVAL;
+}
+
+// p0 (plain tiled GEMM) and p1 (x | a concatenated along K, hi + lo for the x part) in one launch
+template <typename WT>
+static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
+    int rc;
+    if ((rc = tiled_prepare<WT>(p0)) || (rc = tiled_prepare<WT>(p1))) return rc;
+    ACMI_REQUIRE(p0.M == p1.M && p0.ksplit == 1 && p1.ksplit == 1 && !p0.qkv && !p1.qkv && p0.colsum == nullptr &&
+                 p1.colsum == nullptr && p0.a_lo == nullptr && (p1.a_lo == nullptr || (p1.lo_split > 0 && p1.lo_split <= p1.NKC)),
+                 "acmi_linear_pair: bad operands");
+    const bool hl = p1.a_lo != nullptr;  // f32 activations are a single term
+    const int t0 = (p0.N + 15) / 16, t1 = (p1.N + 15) / 16;
+    const int nw = tiled_waves(t0 + t1, p0.NKC > p1.NKC ? p0.NKC : p1.NKC);  // sized for the longer K
+    p0.kcs = p0.NKC; p0.fpw = p0.NKC / nw;
+    p1.kcs = p1.NKC; p1.fpw = p1.NKC / nw;
+    const int mt = p0.M > 32 ? 4 : (p0.M > 16 ? 2 : 1);
+    const size_t lds = (size_t)mt * nw * 1024 + (size_t)mt * 128;
+    const dim3 grid(t0 + t1, 1, (p0.M + 16 * mt - 1) / (16 * mt)), block(nw * 64);
+#define ACMI_PAIR_CASE(MTv)                                                                              \
+    if (mt == MTv) {                                                                                     \
+        if (hl) hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 3>), grid, block, lds, st, p0, p1, t0);      \
+        else hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 0>), grid, block, lds, st, p0, p1, t0);         \
+    }
+    ACMI_PAIR_CASE(1) ACMI_PAIR_CASE(2) ACMI_PAIR_CASE(4)
+#undef ACMI_PAIR_CASE
+    return acmi_check_launch("lin_pair_kernel");
 }
 
 static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
@@ -604,8 +668,6 @@ static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     if (a.a_tiled) return wdtype == ACMI_BF16 ? launch_tiled<bf16_t>(a, st) : launch_tiled<float>(a, st);
     return wdtype == ACMI_BF16 ? launch_rowmajor<bf16_t>(a, st) : launch_rowmajor<float>(a, st);
 }
-
-extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream);
 
 extern "C" int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps, const void* w,
                            int wdtype, const float* bias, const float* residual, void* out, int out_mode, int act, int M,
@@ -621,27 +683,53 @@ extern "C" int acmi_linear(const void* a, int a_mode, const float* ln_g, const f
     return launch_lin(p, wdtype, (hipStream_t)stream);
 }
 
-extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream) {
-    ACMI_REQUIRE(dsc != nullptr, "acmi_linear_ex: null descriptor");
-    const acmi_linear_desc& c = *dsc;
-    LinArgs p = {};
+static int desc_to_args(const acmi_linear_desc& c, LinArgs& p) {
     ACMI_REQUIRE(c.a_mode >= 0 && c.a_mode <= 2, "acmi_linear: bad a_mode %d", c.a_mode);
     ACMI_REQUIRE((c.ln_g == nullptr) == (c.ln_b == nullptr), "acmi_linear: ln_g and ln_b go together");
+    const int kt = c.wdtype == ACMI_BF16 ? 32 : 16;
     p.a = c.a; p.a_tiled = c.a_mode == ACMI_A_TILED;
     p.ln_mode = c.ln_g ? 2 : (c.a_mode == ACMI_A_ROWMAJOR_F32_NORM ? 1 : 0);
     p.ln_g = c.ln_g; p.ln_b = c.ln_b; p.eps = c.eps;
     if (c.colsum != nullptr) {
         ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.a_stats != nullptr, "acmi_linear: colsum needs a tiled activation and a_stats");
         p.a_stats = c.a_stats; p.a_np = c.a_stats_np; p.a_cnt = c.a_stats_cnt; p.colsum = c.colsum; p.a_lo = c.a_lo;
+    } else if (c.a_lo != nullptr) {  // hi + lo activation without LayerNorm (first lo_K columns)
+        ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.lo_K > 0 && c.lo_K <= c.K && c.lo_K % kt == 0,
+                     "acmi_linear: a_lo without colsum needs a tiled activation and lo_K %% %d == 0 (lo_K=%d)", kt, c.lo_K);
+        p.a_lo = c.a_lo; p.lo_split = c.lo_K / kt;
     }
+    p.a_rbs = c.a_rbs; p.alo_rbs = c.a_lo_rbs;
     if (c.xt_hi != nullptr) {
         p.xt_hi = c.xt_hi; p.xt_lo = c.xt_lo;
-        p.xt_nkc = (c.N + (c.wdtype == ACMI_BF16 ? 32 : 16) - 1) / (c.wdtype == ACMI_BF16 ? 32 : 16);
+        p.xt_nkc = c.xt_rbs > 0 ? c.xt_rbs : (c.N + kt - 1) / kt;
+        p.xt_lo_nkc = c.xt_lo_rbs > 0 ? c.xt_lo_rbs : (c.N + kt - 1) / kt;
+        ACMI_REQUIRE(p.xt_nkc >= (c.N + kt - 1) / kt && p.xt_lo_nkc >= (c.N + kt - 1) / kt,
+                     "acmi_linear: xt_rbs=%d / xt_lo_rbs=%d too small for N=%d", c.xt_rbs, c.xt_lo_rbs, c.N);
     }
     p.stats_out = c.stats_out; p.ksplit = c.ksplit;
     p.w = c.w; p.bias = c.bias; p.residual = c.residual; p.out = c.out; p.out_mode = c.out_mode; p.act = c.act;
     p.M = c.M; p.N = c.N; p.K = c.K;
-    return launch_lin(p, c.wdtype, (hipStream_t)stream);
+    return ACMI_OK;
+}
+
+extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream) {
+    ACMI_REQUIRE(dsc != nullptr, "acmi_linear_ex: null descriptor");
+    LinArgs p = {};
+    int rc = desc_to_args(*dsc, p);
+    if (rc) return rc;
+    return launch_lin(p, dsc->wdtype, (hipStream_t)stream);
+}
+
+extern "C" int acmi_linear_pair(const acmi_linear_desc* plain, const acmi_linear_desc* xcat, void* stream) {
+    ACMI_REQUIRE(plain != nullptr && xcat != nullptr, "acmi_linear_pair: null descriptor");
+    ACMI_REQUIRE(plain->wdtype == xcat->wdtype && plain->a_mode == ACMI_A_TILED && xcat->a_mode == ACMI_A_TILED,
+                 "acmi_linear_pair: both GEMMs take tiled activations of one element type");
+    LinArgs p0 = {}, p1 = {};
+    int rc;
+    if ((rc = desc_to_args(*plain, p0)) || (rc = desc_to_args(*xcat, p1))) return rc;
+    ACMI_REQUIRE(p0.M > 0 && p0.N > 0 && p0.K > 0 && p1.N > 0 && p1.K > 0, "acmi_linear_pair: empty problem");
+    return plain->wdtype == ACMI_BF16 ? launch_pair<bf16_t>(p0, p1, (hipStream_t)stream)
+                                      : launch_pair<float>(p0, p1, (hipStream_t)stream);
 }
 
 // =====================================================================================================
@@ -651,11 +739,22 @@ extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream) {
 __device__ __forceinline__ float raw_to_f32(bf16_t v) { return bf16_to_f32(v); }
 __device__ __forceinline__ float raw_to_f32(float v) { return v; }
 
+struct AttnArgs {
+    const float* q; const void* kc; const void* vc; void* out;
+    int out_tiled, out_bf16, out_rbs, out_col0;  // tiled output: K tiles per 16-row block, first column
+    int H, Tcap, len; const int* len_dev; int len_bias; float scale;
+    // optional LayerNorm hook on q (the cross-attention query arrives as x W'^T, see acmi_linear_pair):
+    //   q <- rstd[b] (q - mean[b] colsum) + bias, mean / rstd of row b from the (mean, M2) partials of x
+    const float* q_stats; int q_np, q_cnt, q_K; float q_eps; const float* q_colsum; const float* q_bias;
+};
+
 template <typename KT, int HD>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restrict__ q, const KT* __restrict__ kc,
-                                                          const KT* __restrict__ vc, void* __restrict__ out,
-                                                          int out_tiled, int out_bf16, int H, int Tcap, int len_arg,
-                                                          const int* len_dev, int len_bias, float scale) {
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
+    const float* __restrict__ q = p.q;
+    const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.kc);
+    const KT* __restrict__ vc = reinterpret_cast<const KT*>(p.vc);
+    const int H = p.H, Tcap = p.Tcap;
+    const float scale = p.scale;
     constexpr int DPL = HD >= 8 ? 8 : HD;  // dims per lane
     constexpr int LPP = HD / DPL;          // lanes per position
     constexpr int PPI = 64 / LPP;          // positions covered by one load instruction of a wave
@@ -665,11 +764,27 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
-    const int len = len_dev ? (*len_dev + len_bias) : len_arg;
+    const int len = p.len_dev ? (*p.len_dev + p.len_bias) : p.len;
 
     float qv[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * DPL + e];
+    // LayerNorm hook: everything it needs is requested here, consumed after the first K / V chunk is in flight
+    const bool qnorm = p.q_colsum != nullptr;
+    float qcs[DPL], qb[DPL], spm[2], spq[2];
+    if (qnorm) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            qcs[e] = p.q_colsum[h * HD + c * DPL + e];
+            qb[e] = p.q_bias != nullptr ? p.q_bias[h * HD + c * DPL + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // np <= 128 equal-count partials of row b, contiguous
+            const float2 t = *reinterpret_cast<const float2*>(p.q_stats + ((size_t)b * p.q_np + min(lane + 64 * i, p.q_np - 1)) * 2);
+            spm[i] = t.x; spq[i] = t.y;
+        }
+    }
+    bool q_pending = qnorm;
     const KT* kb = kc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
     const KT* vb = vc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
 
@@ -691,6 +806,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
 #pragma unroll
                 for (int e = 0; e < DPL; ++e) { kr[i][e] = 0; vr[i][e] = 0; }
             }
+        }
+        if (q_pending) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
+            const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
+            const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
+            const float d0 = spm[0] - mean, d1 = spm[1] - mean;
+            const float q2 = (v0 ? spq[0] + (float)p.q_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.q_cnt * d1 * d1 : 0.f);
+            const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.q_K + p.q_eps);
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - mean * qcs[e]) + qb[e];
+            q_pending = false;
         }
         float s[NI];
 #pragma unroll
@@ -748,30 +873,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* __restric
         }
         const float r = num / den;
         const int f = h * HD + threadIdx.x;
-        if (!out_tiled) {
-            reinterpret_cast<float*>(out)[(size_t)b * H * HD + f] = r;
-        } else if (out_bf16) {  // A-fragment order for the out-projection GEMM (include/acmi.h)
-            reinterpret_cast<bf16_t*>(out)[tiled_index<bf16_t>(b, f, (H * HD + 31) / 32)] = f32_to_bf16(r);
+        if (!p.out_tiled) {
+            reinterpret_cast<float*>(p.out)[(size_t)b * H * HD + f] = r;
+        } else if (p.out_bf16) {  // A-fragment order for the out-projection GEMM (include/acmi.h)
+            reinterpret_cast<bf16_t*>(p.out)[tiled_index<bf16_t>(b, p.out_col0 + f, p.out_rbs)] = f32_to_bf16(r);
         } else {
-            reinterpret_cast<float*>(out)[tiled_index<float>(b, f, (H * HD + 15) / 16)] = r;
+            reinterpret_cast<float*>(p.out)[tiled_index<float>(b, p.out_col0 + f, p.out_rbs)] = r;
         }
     }
 }
 
 template <typename KT>
-static int launch_attn_t(const float* q, const void* kc, const void* vc, void* out, int out_tiled, int out_bf16, int Beff,
-                         int H, int hd, int Tcap, int len, const int* len_dev, int len_bias, hipStream_t st) {
-    const float scale = 1.0f / sqrtf((float)hd);
+static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     static int attn_nw = -1;
     if (attn_nw < 0) { const char* e = getenv("ACMI_ATTN_NW"); attn_nw = e ? atoi(e) : 4; if (attn_nw != 1 && attn_nw != 2) attn_nw = 4; }
-    dim3 grid(H, Beff), block(64 * attn_nw);
-    const KT* k = reinterpret_cast<const KT*>(kc);
-    const KT* v = reinterpret_cast<const KT*>(vc);
-#define ACMI_ATTN_CASE(HD)                                                                                      \
-    case HD:                                                                                                    \
-        hipLaunchKernelGGL((attn_decode_kernel<KT, HD>), grid, block, 0, st, q, k, v, out, out_tiled, out_bf16, H, Tcap, \
-                           len, len_dev, len_bias, scale);                                                      \
-        break;
+    dim3 grid(a.H, Beff), block(64 * attn_nw);
+#define ACMI_ATTN_CASE(HD) case HD: hipLaunchKernelGGL((attn_decode_kernel<KT, HD>), grid, block, 0, st, a); break;
     switch (hd) {
         ACMI_ATTN_CASE(4)
         ACMI_ATTN_CASE(8)
@@ -787,18 +904,39 @@ static int launch_attn_t(const float* q, const void* kc, const void* vc, void* o
     return acmi_check_launch("attn_decode_kernel");
 }
 
+extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
+    ACMI_REQUIRE(dsc != nullptr, "acmi_attn_decode_ex: null descriptor");
+    const acmi_attn_desc& c = *dsc;
+    ACMI_REQUIRE(c.out_mode == ACMI_OUT_TILED || c.out_mode == ACMI_OUT_F32, "acmi_attn_decode: bad out_mode %d", c.out_mode);
+    ACMI_REQUIRE(c.Beff > 0 && c.H > 0 && c.Tcap > 0 && c.hd > 0, "acmi_attn_decode: bad shape");
+    ACMI_REQUIRE(c.len_dev != nullptr || (c.len > 0 && c.len <= c.Tcap), "acmi_attn_decode: len=%d out of (0, %d]", c.len, c.Tcap);
+    const int kt = c.out_dtype == ACMI_BF16 ? 32 : 16, nkc = (c.H * c.hd + kt - 1) / kt;
+    AttnArgs a = {};
+    a.q = c.q; a.kc = c.k_cache; a.vc = c.v_cache; a.out = c.out;
+    a.out_tiled = c.out_mode == ACMI_OUT_TILED; a.out_bf16 = c.out_dtype == ACMI_BF16;
+    a.out_rbs = c.out_rbs > 0 ? c.out_rbs : nkc; a.out_col0 = c.out_col0;
+    ACMI_REQUIRE(c.out_col0 >= 0 && c.out_col0 % kt == 0 && a.out_rbs * kt >= c.out_col0 + c.H * c.hd,
+                 "acmi_attn_decode: tiled output placement col0=%d rbs=%d does not hold %d columns", c.out_col0, a.out_rbs, c.H * c.hd);
+    a.H = c.H; a.Tcap = c.Tcap; a.len = c.len; a.len_dev = c.len_dev; a.len_bias = c.len_bias;
+    a.scale = 1.0f / sqrtf((float)c.hd);
+    if (c.q_colsum != nullptr) {
+        ACMI_REQUIRE(c.q_stats != nullptr && c.q_stats_np >= 1 && c.q_stats_np <= 128 && c.q_stats_np * c.q_stats_cnt > 0,
+                     "acmi_attn_decode: q LayerNorm hook needs 1..128 statistics partials");
+        a.q_stats = c.q_stats; a.q_np = c.q_stats_np; a.q_cnt = c.q_stats_cnt; a.q_K = c.q_stats_np * c.q_stats_cnt;
+        a.q_eps = c.eps; a.q_colsum = c.q_colsum; a.q_bias = c.q_bias;
+    }
+    return c.kvdtype == ACMI_BF16 ? launch_attn_t<bf16_t>(a, c.Beff, c.hd, (hipStream_t)stream)
+                                  : launch_attn_t<float>(a, c.Beff, c.hd, (hipStream_t)stream);
+}
+
 extern "C" int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, void* out,
                                 int out_mode, int out_dtype, int Beff, int H, int hd, int Tcap, int len,
                                 const int* len_dev, int len_bias, void* stream) {
-    const int out_tiled = out_mode == ACMI_OUT_TILED, out_bf16 = out_dtype == ACMI_BF16;
-    ACMI_REQUIRE(out_mode == ACMI_OUT_TILED || out_mode == ACMI_OUT_F32, "acmi_attn_decode: bad out_mode %d", out_mode);
-    ACMI_REQUIRE(Beff > 0 && H > 0 && Tcap > 0, "acmi_attn_decode: bad shape");
-    ACMI_REQUIRE(len_dev != nullptr || (len > 0 && len <= Tcap), "acmi_attn_decode: len=%d out of (0, %d]", len, Tcap);
-    if (kvdtype == ACMI_BF16)
-        return launch_attn_t<bf16_t>(q, k_cache, v_cache, out, out_tiled, out_bf16, Beff, H, hd, Tcap, len, len_dev,
-                                     len_bias, (hipStream_t)stream);
-    return launch_attn_t<float>(q, k_cache, v_cache, out, out_tiled, out_bf16, Beff, H, hd, Tcap, len, len_dev, len_bias,
-                                (hipStream_t)stream);
+    acmi_attn_desc c = {};
+    c.q = q; c.k_cache = k_cache; c.v_cache = v_cache; c.kvdtype = kvdtype; c.out = out; c.out_mode = out_mode;
+    c.out_dtype = out_dtype; c.Beff = Beff; c.H = H; c.hd = hd; c.Tcap = Tcap; c.len = len; c.len_dev = len_dev;
+    c.len_bias = len_bias;
+    return acmi_attn_decode_ex(&c, stream);
 }
 
 // scatter [Beff, L, H*hd] f32 rows into a [Beff, H, Tcap, hd] cache
@@ -843,7 +981,7 @@ struct EmbedArgs {
     const int* pos;
     float* x; int d;
     float* stats;  // [M][1][2]: (mean, M2) of every produced row (one partial of d elements)
-    void* xt_hi; void* xt_lo; int xt_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
+    void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
 };
 
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
@@ -885,7 +1023,8 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
                 const size_t ti = tiled_index<bf16_t>(m, cch, p.xt_nkc);
                 const bf16_t hi = f32_to_bf16(v);
                 reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
-                if (p.xt_lo != nullptr) reinterpret_cast<bf16_t*>(p.xt_lo)[ti] = f32_to_bf16(v - bf16_to_f32(hi));
+                if (p.xt_lo != nullptr)
+                    reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<bf16_t>(m, cch, p.xt_lo_nkc)] = f32_to_bf16(v - bf16_to_f32(hi));
             } else {
                 reinterpret_cast<float*>(p.xt_hi)[tiled_index<float>(m, cch, p.xt_nkc)] = v;
             }
@@ -1166,34 +1305,47 @@ static bool fold_uses_lo() {  // experiment switch: ACMI_LN_LO=0 drops the low p
     return v == 1;
 }
 
-// internal helper of the step: one GEMM of the chain.  a_mode LN_X = "LayerNorm(x) first"
-// (colsum: column sums of w for the folded form); stats_out != NULL = "this GEMM produces the residual stream".
-static int step_lin(const acmi_lm_model* m, const acmi_lm_state* s, hipStream_t st, const void* a, int a_mode,
-                    int np, int cnt, const void* w, const float* bias, const float* colsum, const float* residual,
-                    void* out, int out_mode, int act, float* stats_out, int N, int K, int& pending_slabs) {
-    // pending_slabs: slabs of a split-K linear2 waiting to be folded into x by the next LayerNorm kernel
-    const int lnm = ln_mode_of(m, s);
-    const int kt = m->wdtype == ACMI_BF16 ? 32 : 16;
+// ---- the step's GEMM chain ---------------------------------------------------------------------------
+// The residual stream x lives in four forms (include/acmi.h, acmi_lm_state): f32 row-major `x`, raw fragments
+// xh / xl (hi / lo) and the statistics partials.  StepCtx tracks which fragment buffers currently hold x.
+struct StepCtx {
+    const acmi_lm_model* m; const acmi_lm_state* s; hipStream_t st;
+    int lnm, kt, nkc_d, rbs;   // LayerNorm mode, K tile, K tiles of d, K tiles per row block of the xh buffers
+    void* xh; void* xl;        // fragments of the current x
+    int np, cnt;               // statistics partials of the current x: np partials of cnt elements
+};
+
+// out = act(LayerNorm(x) W'^T + bias): folded into the GEMM, or standardisation kernel + plain GEMM
+static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, const float* colsum, int N) {
+    const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
+    p.a_tiled = 1; p.w = w; p.bias = bias; p.M = s->Beff; p.N = N; p.K = m->dim;
+    if (c.lnm == LN_FOLD) {
+        p.a = c.xh; p.a_rbs = c.rbs; p.a_lo = (m->wdtype == ACMI_BF16 && fold_uses_lo()) ? c.xl : nullptr;
+        p.a_stats = s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
+    } else {
+        int rc = launch_ln_tile(s->x, c.xh, m->wdtype, s->Beff, m->dim, m->eps, nullptr, 0, c.st);
+        if (rc) return rc;
+        p.a = c.xh;
+    }
+    return launch_lin(p, m->wdtype, c.st);
+}
+
+// describes x <- x + a W^T (in place on the f32 copy), also emitted as fragments into (xh, xl) + statistics
+static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs, const void* w, int K, void* xh, void* xl) {
+    const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
+    p.a = a; p.a_tiled = 1; p.a_rbs = a_rbs; p.w = w; p.residual = s->x; p.out = s->x; p.out_mode = ACMI_OUT_F32;
+    p.M = s->Beff; p.N = m->dim; p.K = K;
+    if (c.lnm == LN_FOLD) {
+        p.stats_out = s->stats;
+        p.xt_hi = xh; p.xt_lo = m->wdtype == ACMI_BF16 ? xl : nullptr; p.xt_nkc = c.rbs; p.xt_lo_nkc = c.nkc_d;
+    }
+}
+static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K) {
     LinArgs p = {};
-    p.a = a; p.a_tiled = a_mode == ACMI_A_TILED;
-    if (a_mode == LN_X) {
-        if (lnm == LN_FOLD) {
-            p.a = s->xn; p.a_lo = (m->wdtype == ACMI_BF16 && fold_uses_lo()) ? s->xlo : nullptr; p.a_tiled = 1;
-            p.a_stats = s->stats; p.a_np = np; p.a_cnt = cnt; p.eps = m->eps; p.colsum = colsum;
-        } else {  // separate standardisation kernel + tiled GEMM
-            int rc = launch_ln_tile(const_cast<float*>(reinterpret_cast<const float*>(a)), s->xn, m->wdtype, s->Beff, K,
-                                    m->eps, s->slab, pending_slabs, st);
-            pending_slabs = 0;
-            if (rc) return rc;
-            p.a = s->xn; p.a_tiled = 1;
-        }
-    }
-    if (stats_out != nullptr && lnm == LN_FOLD) {
-        p.xt_hi = s->xn; p.xt_lo = m->wdtype == ACMI_BF16 ? s->xlo : nullptr; p.xt_nkc = (N + kt - 1) / kt;
-    }
-    p.w = w; p.bias = bias; p.residual = residual; p.out = out; p.out_mode = out_mode; p.act = act;
-    p.stats_out = stats_out; p.M = s->Beff; p.N = N; p.K = K;
-    return launch_lin(p, m->wdtype, st);
+    gemm_produce_x_args(c, p, a, 0, w, K, c.xh, c.xl);
+    int rc = launch_lin(p, c.m->wdtype, c.st);
+    c.np = c.m->dim / 16; c.cnt = 16;
+    return rc;
 }
 
 extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int mode, void* stream) {
@@ -1204,79 +1356,94 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     ACMI_REQUIRE(m->n_q <= 16, "acmi_lm_step: n_q=%d > 16", m->n_q);
     ACMI_REQUIRE(s->Beff == (s->use_cfg ? 2 * s->B : s->B), "acmi_lm_step: Beff/B mismatch");
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
-    const int ST = LN_X, TL = ACMI_A_TILED;
     int rc;
+
+    StepCtx c = {};
+    c.m = m; c.s = s; c.st = st; c.lnm = ln_mode_of(m, s);
+    c.kt = wbf ? 32 : 16; c.nkc_d = (d + c.kt - 1) / c.kt;
+    c.rbs = s->x_rbs > 0 ? s->x_rbs : c.nkc_d;
+    ACMI_REQUIRE(c.rbs >= c.nkc_d, "acmi_lm_step: x_rbs=%d < %d K tiles of d", c.rbs, c.nkc_d);
+    c.xh = s->xn; c.xl = s->xlo; c.np = 1; c.cnt = d;
+    // Cross-attention query without a launch of its own (include/acmi.h, acmi_linear_pair): needs the folded
+    // LayerNorm, the [W_cq' | W_cq' W_out] matrices, xh buffers wide enough for [x | att] and a second pair.
+    static const bool pair_enabled = !(getenv("ACMI_CROSS_FUSED") != nullptr && getenv("ACMI_CROSS_FUSED")[0] == '0');
+    const bool pair = pair_enabled && m->cross_attention && c.lnm == LN_FOLD && m->layers[0].w_xcq != nullptr &&
+                      s->xn2 != nullptr && (!wbf || s->xlo2 != nullptr) && s->r != nullptr && c.rbs >= 2 * c.nkc_d;
+    void* const xh2[2] = {s->xn, s->xn2};
+    void* const xl2[2] = {s->xlo, s->xlo2};
+    int cur = 0;
 
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.K = m->n_q; e.S = s->S; e.card = m->card;
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
-    const int lnm = ln_mode_of(m, s);
-    const int kt = wbf ? 32 : 16;
-    if (lnm == LN_FOLD) { e.xt_hi = s->xn; e.xt_lo = wbf ? s->xlo : nullptr; e.xt_nkc = (d + kt - 1) / kt; }
+    if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = wbf ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
     hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, st, e);
     if ((rc = acmi_check_launch("embed_kernel"))) return rc;
 
-    // Every kernel that writes the residual stream x also writes the (mean, M2) partials of its rows, so the
-    // LayerNorm in front of the next GEMM costs no launch: (np, cnt) describes the partials currently valid.
-    int pending = 0;  // split-K slabs waiting for the next LayerNorm kernel
-    int np = 1, cnt = d;
-    const int npg = d / 16;  // partials written by a d-feature GEMM (one per 16-feature workgroup)
     for (int li = 0; li < m->num_layers; ++li) {
         const acmi_lm_layer& L = m->layers[li];
-        // LN1 (folded) -> QKV ; K,V appended in place at position g, q to scratch
-        LinArgs a = {};
-        if (lnm == LN_FOLD) {
-            a.a = s->xn; a.a_lo = (wbf && fold_uses_lo()) ? s->xlo : nullptr; a.a_tiled = 1;
-            a.a_stats = s->stats; a.a_np = np; a.a_cnt = cnt; a.eps = m->eps; a.colsum = L.cs_qkv;
+        // norm1 -> QKV ; K, V appended in place at position g, q to scratch
+        {
+            LinArgs a = {};
+            a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
+            a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos;
+            if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
+        }
+        // self attention over positions [0, g]; output in A-fragment order for the out projection: into `att`,
+        // or next to x ([x | att], columns d_pad ..) when the out projection is paired with the cross query
+        acmi_attn_desc sa = {};
+        sa.q = s->q; sa.k_cache = L.k_cache; sa.v_cache = L.v_cache; sa.kvdtype = m->kvdtype;
+        sa.out_mode = ACMI_OUT_TILED; sa.out_dtype = m->wdtype; sa.Beff = M; sa.H = H; sa.hd = hd; sa.Tcap = s->Tmax;
+        sa.len_dev = s->pos; sa.len_bias = 1;
+        if (pair) { sa.out = c.xh; sa.out_rbs = c.rbs; sa.out_col0 = c.nkc_d * c.kt; }
+        else sa.out = s->att;
+        if ((rc = acmi_attn_decode_ex(&sa, stream))) return rc;
+
+        if (!m->cross_attention) {
+            if ((rc = gemm_produce_x(c, s->att, L.w_out, d))) return rc;
         } else {
-            if ((rc = launch_ln_tile(s->x, s->xn, m->wdtype, M, d, m->eps, s->slab, pending, st))) return rc;
-            pending = 0;
-            a.a = s->xn; a.a_tiled = 1;
-        }
-        a.w = L.w_qkv; a.bias = L.b_qkv; a.M = M; a.N = 3 * d; a.K = d; a.qkv = 1;
-        a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
-        a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos;
-        if ((rc = launch_lin(a, m->wdtype, st))) return rc;
-        // self attention over positions [0, g]; output already in A-fragment order for the out projection
-        if ((rc = acmi_attn_decode(s->q, L.k_cache, L.v_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H, hd,
-                                   s->Tmax, 0, s->pos, 1, stream)))
-            return rc;
-        if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_out, nullptr, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
-        np = npg; cnt = 16;
-        if (m->cross_attention) {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache, "acmi_lm_step: cross-attention caches missing");
-            if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_cq, L.b_cq, L.cs_cq, nullptr, s->q, ACMI_OUT_F32, 0, nullptr, d, d, pending))) return rc;
-            if ((rc = acmi_attn_decode(s->q, L.ck_cache, L.cv_cache, m->kvdtype, s->att, ACMI_OUT_TILED, m->wdtype, M, H,
-                                       hd, s->Lc, s->Lc, nullptr, 0, stream)))
-                return rc;
-            if ((rc = step_lin(m, s, st, s->att, TL, 0, 0, L.w_cout, nullptr, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, d, pending))) return rc;
+            acmi_attn_desc ca = {};
+            ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
+            ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.Beff = M; ca.H = H; ca.hd = hd; ca.Tcap = s->Lc;
+            ca.len = s->Lc;
+            if (pair) {
+                // ONE launch: x1 = x0 + att W_out^T (fragments of x1 into the other buffer pair: this launch
+                // still reads x0's) and r = [x0 | att] [W_cq' | W_cq' W_out]^T = x1 W_cq'^T
+                LinArgs p0 = {}, p1 = {};
+                const void* att_half = reinterpret_cast<const unsigned char*>(c.xh) + (size_t)c.nkc_d * 1024;  // K tile nkc_d
+                gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1]);
+                p1.a = c.xh; p1.a_tiled = 1; p1.a_rbs = c.rbs; p1.a_lo = wbf ? c.xl : nullptr; p1.alo_rbs = c.nkc_d;
+                p1.lo_split = wbf ? c.nkc_d : 0;
+                p1.w = L.w_xcq; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = 2 * c.nkc_d * c.kt;
+                if ((rc = wbf ? launch_pair<bf16_t>(p0, p1, st) : launch_pair<float>(p0, p1, st))) return rc;
+                cur ^= 1; c.xh = xh2[cur]; c.xl = xl2[cur]; c.np = d / 16; c.cnt = 16;
+                // the cross-attention kernel applies norm_cross to r from the statistics of x1
+                ca.q = s->r; ca.q_stats = s->stats; ca.q_stats_np = c.np; ca.q_stats_cnt = c.cnt; ca.eps = m->eps;
+                ca.q_colsum = L.cs_cq; ca.q_bias = L.b_cq;
+            } else {
+                if ((rc = gemm_produce_x(c, s->att, L.w_out, d))) return rc;
+                LinArgs a = {};
+                a.out = s->q; a.out_mode = ACMI_OUT_F32;
+                if ((rc = gemm_ln_x(c, a, L.w_cq, L.b_cq, L.cs_cq, d))) return rc;
+                ca.q = s->q;
+            }
+            if ((rc = acmi_attn_decode_ex(&ca, stream))) return rc;
+            if ((rc = gemm_produce_x(c, s->att, L.w_cout, d))) return rc;
         }
-        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, L.w_ff1, L.b_ff1, L.cs_ff1, nullptr, s->hidden, ACMI_OUT_TILED, 1, nullptr, F, d, pending))) return rc;
-        // linear2 has only d/16 n-tiles (96 workgroups for d = 1536) against a 4d-deep K.  Optional
-        // (ACMI_FFN2_SPLIT=1): split K three ways so that every CU streams weights, the partial slabs being
-        // summed into x by the LayerNorm kernel that follows.  Measured on MusicGen-medium B=8: 3.55 vs
-        // 3.37 ms / position -- the faster GEMM is more than paid back by the slab traffic on the LayerNorm's
-        // critical path -- so it is off by default.
-        static const bool split_enabled = getenv("ACMI_FFN2_SPLIT") != nullptr && getenv("ACMI_FFN2_SPLIT")[0] == '1';
-        const bool last = li + 1 == m->num_layers;
-        const bool split = split_enabled && lnm == LN_TILE && s->slab != nullptr && ((F + kt - 1) / kt) % 3 == 0 && d % 16 == 0 &&
-                           (!last || mode == ACMI_STEP_DECODE);
-        if (split) {
-            LinArgs f2 = {};
-            f2.a = s->hidden; f2.a_tiled = 1; f2.w = L.w_ff2; f2.out = s->slab; f2.out_mode = ACMI_OUT_F32;
-            f2.M = M; f2.N = d; f2.K = F; f2.ksplit = 3;
-            if ((rc = launch_lin(f2, m->wdtype, st))) return rc;
-            pending = 3;
-        } else if ((rc = step_lin(m, s, st, s->hidden, TL, 0, 0, L.w_ff2, nullptr, nullptr, s->x, s->x, ACMI_OUT_F32, 0, s->stats, d, F, pending))) {
-            return rc;
+        {   // norm2 -> linear1 + GELU -> hidden (A-fragment order) ; linear2 -> x
+            LinArgs a = {};
+            a.out = s->hidden; a.out_mode = ACMI_OUT_TILED; a.act = 1;
+            if ((rc = gemm_ln_x(c, a, L.w_ff1, L.b_ff1, L.cs_ff1, F))) return rc;
+            if ((rc = gemm_produce_x(c, s->hidden, L.w_ff2, F))) return rc;
         }
     }
     if (mode == ACMI_STEP_DECODE) {
-        if ((rc = step_lin(m, s, st, s->x, ST, np, cnt, m->w_head, m->b_head, m->cs_head, nullptr, s->logits, ACMI_OUT_F32, 0, nullptr,
-                           m->n_q * m->card, d, pending)))
-            return rc;
+        LinArgs hl = {};
+        hl.out = s->logits; hl.out_mode = ACMI_OUT_F32;
+        if ((rc = gemm_ln_x(c, hl, m->w_head, m->b_head, m->cs_head, m->n_q * m->card))) return rc;
         SampleArgs a = {};
         a.logits = s->logits; a.B = s->B; a.K = m->n_q; a.card = m->card; a.use_cfg = s->use_cfg;
         a.cfg_coef = s->cfg_coef; a.use_sampling = s->use_sampling; a.temp = s->temp; a.top_k = s->top_k;

@@ -230,10 +230,21 @@ class LMModel(nn.Module):
                     raise NotImplementedError("cross-attention in_proj_bias is not wired into acmi_lm_step")
                 ipw = ca.in_proj_weight
                 ent['w_cq'], ent['b_cq'], ent['cs_cq'] = folded(ipw[:d], layer.norm_cross)
+                # [W_cq' | W_cq' W_out]: x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T, so
+                # the cross-attention query rides in the out-projection launch (include/acmi.h, acmi_linear_pair);
+                # each block starts on a K-tile boundary of the [x | att] activation
+                kt = _C._tile_params(wd)[1]
+                dp = -(-d // kt) * kt
+                g_c = layer.norm_cross.weight.detach().to(device=dev, dtype=torch.float32)
+                wq = ipw[:d].detach().to(device=dev, dtype=torch.float32) * g_c[None, :]
+                xcq = torch.zeros(d, 2 * dp, device=dev, dtype=torch.float32)
+                xcq[:, :d] = wq
+                xcq[:, dp:dp + d] = wq @ layer.self_attn.out_proj.weight.detach().to(device=dev, dtype=torch.float32)
+                ent['w_xcq'] = W(xcq)
                 ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]), 'w_cout': W(ca.out_proj.weight)})
             L = layers[li]
-            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv', 'cs_cq',
-                      'cs_ff1'):
+            for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
+                      'cs_cq', 'cs_ff1'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]
@@ -289,9 +300,16 @@ class LMModel(nn.Module):
         run['q'] = torch.zeros(Beff, d, **f32)
         # activations that feed a GEMM directly live in A-fragment order, zero padded
         run['stats'] = torch.zeros(Beff, max(1, d // 16), 2, **f32)
-        run['xn'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
-        run['xlo'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
-        run['slab'] = torch.zeros(3, Beff, d, **f32)
+        # x as raw fragments: two (hi, lo) pairs, the hi buffers twice as wide so that the self-attention output
+        # sits next to x ([x | att], the operand of the paired out-projection / cross-query launch)
+        kt = _C._tile_params(self.weight_dtype)[1]
+        dp = -(-d // kt) * kt
+        for name in ('xn', 'xn2'):
+            run[name] = _C.tiled_activation_buffer(Beff, 2 * dp, self.weight_dtype, dev)
+        for name in ('xlo', 'xlo2'):
+            run[name] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
+        run['x_rbs'] = 2 * dp // kt
+        run['r'] = torch.zeros(Beff, d, **f32)
         run['att'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
         run['hidden'] = _C.tiled_activation_buffer(Beff, self.ffn_dim, self.weight_dtype, dev)
         run['pos_table'] = _C.pos_table(pk['pos_freq'], Tmax, d)
@@ -314,8 +332,8 @@ class LMModel(nn.Module):
         st.pos = run['pos'].data_ptr()
         st.x, st.q, st.att = run['x'].data_ptr(), run['q'].data_ptr(), run['att'].data_ptr()
         st.stats = run['stats'].data_ptr()
-        st.xn, st.xlo = run['xn'].data_ptr(), run['xlo'].data_ptr()
-        st.slab = run['slab'].data_ptr()
+        st.xn, st.xlo, st.xn2, st.xlo2 = (run[k].data_ptr() for k in ('xn', 'xlo', 'xn2', 'xlo2'))
+        st.x_rbs, st.r = run['x_rbs'], run['r'].data_ptr()
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None
         st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)

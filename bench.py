@@ -58,13 +58,20 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     pk = lm._packed
     dev = lm.device
     d, ffn, wd = lm.dim, lm.ffn_dim, lm.weight_dtype
-    rnd = lambda n: torch.randn(B_eff, n, device=dev)
-    att, hid = _C.tile_matrix(rnd(d), wd), _C.tile_matrix(rnd(ffn), wd)
-    # the residual stream: f32 row-major (x), raw in A-fragment order as a bf16 hi / lo pair (xh, xl) and its
-    # per-row (mean, M2) partials (stats), exactly what acmi_lm_step keeps (folded LayerNorm)
-    x, x0 = torch.zeros(B_eff, d, device=dev), rnd(d)   # x = x0 + a @ W^T keeps the synthetic stream bounded
-    xh = _C.tile_matrix(rnd(d), wd)
-    xl = _C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if wd == torch.bfloat16 else None
+    rnd = lambda n: torch.randn(B_eff, n, device=dev)  # noqa: E731
+    kt = 32 if wd == torch.bfloat16 else 16
+    dp = -(-d // kt) * kt
+    rbs = 2 * dp // kt
+    hid = _C.tile_matrix(rnd(ffn), wd)
+    catt = _C.tile_matrix(rnd(d), wd)                      # cross-attention output
+    # the residual stream: f32 row-major (x), raw in A-fragment order as a bf16 hi / lo pair, the hi buffer
+    # holding [x | self-attention output] side by side (two pairs: the paired launch reads one, writes the
+    # other) and its per-row (mean, M2) partials (stats): exactly what acmi_lm_step keeps
+    x, x0 = torch.zeros(B_eff, d, device=dev), rnd(d)       # x = x0 + a @ W^T keeps the synthetic stream bounded
+    cat = torch.zeros(B_eff, 2 * dp, device=dev)
+    cat[:, :d], cat[:, dp:dp + d] = rnd(d), rnd(d)
+    xh = [_C.tile_matrix(cat, wd), _C.tile_matrix(cat, wd)]
+    xl = [_C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if wd == torch.bfloat16 else None for _ in range(2)]
     np_ = max(1, d // 16)
     stats = torch.zeros(B_eff, np_, 2, device=dev)
     stats[..., 1] = 16.0
@@ -74,29 +81,54 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     logits = torch.empty(B_eff, lm.n_q * lm.card, device=dev)
     launches = 0
     nbytes = 0
+    cur = 0
 
-    def gemm(w, out, out_mode, ln=None, bias=None, act=0, produce_x=False):
+    def wbytes(w):
+        return w.N * w.K * w.data.element_size()
+
+    def consume(w, out, out_mode, colsum, bias, act=0):
+        # LayerNorm(x) @ W'^T: raw fragments + statistics + column sums
         nonlocal launches, nbytes
-        if ln is not None:   # LayerNorm(x) @ W'^T: raw fragments + statistics + column sums
-            _C.linear_ex(xh, w, out, B_eff, _C.A_TILED, out_mode, a_stats=stats, np_=np_, cnt=d // np_, bias=bias, act=act,
-                         a_lo=xl, colsum=ln)
-        elif produce_x:      # x += a @ W^T, also written as raw fragments and statistics partials
-            _C.linear_ex(att if w.K == d else hid, w, x, B_eff, _C.A_TILED, _C.OUT_F32, residual=x0, stats_out=stats,
-                         xt_hi=xh, xt_lo=xl)
+        _C.linear_ex(xh[cur], w, out, B_eff, _C.A_TILED, out_mode, a_stats=stats, np_=np_, cnt=d // np_, bias=bias, act=act,
+                     a_lo=xl[cur], colsum=colsum, a_rbs=rbs)
         launches += 1
-        nbytes += w.N * w.K * w.data.element_size()
+        nbytes += wbytes(w)
+
+    def produce_desc(a, w, a_rbs, dst):
+        return _C.linear_desc(a, w, x, B_eff, _C.A_TILED, _C.OUT_F32, residual=x0, stats_out=stats, xt_hi=xh[dst],
+                              xt_lo=xl[dst], a_rbs=a_rbs, xt_rbs=rbs)
+
+    def produce(a, w):
+        # x = x0 + a @ W^T, also written as raw fragments and statistics partials
+        nonlocal launches, nbytes
+        _C.linear_launch(produce_desc(a, w, 0, cur))
+        launches += 1
+        nbytes += wbytes(w)
 
     def one_position():
         # the same GEMM launches acmi_lm_step issues for one position (same shapes, operand layouts, weights)
+        nonlocal launches, nbytes, cur
         for ent in pk['per_layer']:
-            gemm(ent['w_qkv'], qkv, _C.OUT_F32, ln=ent['cs_qkv'], bias=ent['b_qkv'])
-            gemm(ent['w_out'], None, None, produce_x=True)
-            if 'w_cq' in ent:
-                gemm(ent['w_cq'], q, _C.OUT_F32, ln=ent['cs_cq'], bias=ent['b_cq'])
-                gemm(ent['w_cout'], None, None, produce_x=True)
-            gemm(ent['w_ff1'], h, _C.OUT_TILED, ln=ent['cs_ff1'], bias=ent['b_ff1'], act=1)
-            gemm(ent['w_ff2'], None, None, produce_x=True)
-        gemm(pk['w_head'], logits, _C.OUT_F32, ln=pk['cs_head'], bias=pk['b_head'])
+            consume(ent['w_qkv'], qkv, _C.OUT_F32, ent['cs_qkv'], ent['b_qkv'])
+            if 'w_xcq' in ent:
+                # out projection + cross-attention query in one launch (acmi_linear_pair)
+                att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
+                p0 = produce_desc(att_half, ent['w_out'], rbs, cur ^ 1)
+                p1 = _C.linear_desc(xh[cur], ent['w_xcq'], q, B_eff, _C.A_TILED, _C.OUT_F32, a_lo=xl[cur], a_rbs=rbs,
+                                    lo_K=dp if wd == torch.bfloat16 else 0)
+                _C.linear_pair(p0, p1)
+                launches += 1
+                nbytes += wbytes(ent['w_out']) + wbytes(ent['w_xcq'])
+                cur ^= 1
+                produce(catt, ent['w_cout'])
+            else:
+                att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
+                _C.linear_launch(produce_desc(att_half, ent['w_out'], rbs, cur))
+                launches += 1
+                nbytes += wbytes(ent['w_out'])
+            consume(ent['w_ff1'], h, _C.OUT_TILED, ent['cs_ff1'], ent['b_ff1'], act=1)
+            produce(hid, ent['w_ff2'])
+        consume(pk['w_head'], logits, _C.OUT_F32, pk['cs_head'], pk['b_head'])
 
     one_position()  # warm
     torch.cuda.synchronize()

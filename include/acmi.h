@@ -130,6 +130,9 @@ typedef struct {
     const void* w_out;      /* self_attn.out_proj.weight  [d, d] */
     const void* w_cq;       /* cross_attention.in_proj_weight[:d]  [d, d]  (NULL if no cross-attn) */
     const void* w_cout;     /* cross_attention.out_proj.weight     [d, d] */
+    const void* w_xcq;      /* [d, 2 d_pad] = [w_cq | w_cq W_out] (d_pad = d rounded up to the K tile; both blocks
+                               computed in f32 from the folded w_cq, then rounded): lets the cross-attention query
+                               ride in the out-projection launch (acmi_linear_pair); NULL = separate launch */
     const void* w_ff1;      /* linear1.weight [ffn, d] */
     const void* w_ff2;      /* linear2.weight [d, ffn] */
     const float* b_qkv;     /* [3d]  norm1      folded */
@@ -181,8 +184,11 @@ typedef struct {
     float* stats;           /* [Beff][max(1, d/16)][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
     void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x
                                (separate LayerNorm kernel) or the raw x / its bf16 high part (folded LayerNorm) */
-    void* xlo;              /* bf16 weights + folded LayerNorm: same shape as xn, low part x - bf16(x); else NULL */
-    float* slab;            /* [3][Beff][d] f32 split-K partial sums of linear2 (or NULL: no split) */
+    void* xlo;              /* bf16 weights + folded LayerNorm: tiled [., d_pad], low part x - bf16(x); else NULL */
+    int x_rbs;              /* K tiles per 16-row block of xn / xn2 (0 = d_pad / KT).  2 d_pad / KT or more makes room
+                               for the self-attention output next to x ([x | att]), which w_xcq needs */
+    void* xn2; void* xlo2;  /* second (xn, xlo) pair: the paired launch reads x0's fragments while writing x1's; or NULL */
+    float* r;               /* [Beff, d] f32: cross-attention query before its LayerNorm statistics are applied; or NULL */
     void* att;              /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised */
     void* hidden;           /* tiled activation [ceil(Beff/16)*16, ffn_pad] in wdtype, zero-initialised */
     float* logits;          /* [Beff, n_q * card] f32 */
@@ -265,8 +271,24 @@ typedef struct {
     /* xt_hi (or NULL): the final outputs are ALSO written as a raw tiled activation [., N] in wdtype
      * (bf16: xt_hi = bf16(v), xt_lo = bf16(v - xt_hi); f32: xt_hi = v, xt_lo unused) for such a consumer. */
     void* xt_hi; void* xt_lo;
+    /* Tiled activations wider than this GEMM's K / N (e.g. [x | att] side by side, 2d columns): K tiles
+     * between consecutive 16-row blocks of a / a_lo / xt_hi / xt_lo.  0 = exactly ceil(K / KT) (a_lo with lo_K:
+     * ceil(lo_K / KT)) resp. ceil(N / KT). */
+    int a_rbs, a_lo_rbs, xt_rbs, xt_lo_rbs;
+    /* a_lo WITHOUT colsum: hi + lo activation and no LayerNorm; only the first lo_K columns (a multiple of
+     * KT) have a lo term -- the [x | att] operand of acmi_linear_pair. */
+    int lo_K;
 } acmi_linear_desc;
 int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
+
+/* Two independent GEMMs on the same rows in ONE launch (one dependency edge of the decode chain less):
+ * `plain` is an ordinary tiled-activation GEMM (typically x1 = x0 + att W_out^T with stats_out / xt_hi),
+ * `xcat` runs on an activation concatenated along K with a lo term for its first lo_K columns.  In the
+ * decode step:  r = [x0 | att] [W_cq' | W_cq' W_out]^T = x1 W_cq'^T, the cross-attention query of
+ * transformer.py:344-349 before the LayerNorm statistics of x1 are applied (acmi_attn_decode_ex does that),
+ * which removes the cross-attention q projection as a launch of its own.  Neither GEMM may use split-K, a
+ * folded LayerNorm or the QKV scatter; both must have the same M and wdtype. */
+int acmi_linear_pair(const acmi_linear_desc* plain, const acmi_linear_desc* xcat, void* stream);
 
 /* Single-query attention over a [Beff, H, Tcap, hd] cache, positions [0, len): the
  * F.scaled_dot_product_attention call of transformer.py:412-414 for one new step.
@@ -276,6 +298,22 @@ int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
 int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, void* out,
                      int out_mode, int out_dtype, int Beff, int H, int hd, int Tcap, int len,
                      const int* len_dev, int len_bias, void* stream);
+
+/* Descriptor form: placement of a tiled output inside a wider tiled activation, and a LayerNorm hook on q. */
+typedef struct {
+    const float* q; const void* k_cache; const void* v_cache; int kvdtype;
+    void* out; int out_mode; int out_dtype;
+    int out_rbs;            /* tiled output: K tiles between 16-row blocks of `out` (0 = ceil(H*hd / KT)) */
+    int out_col0;           /* tiled output: first column (a multiple of KT), e.g. d for the att half of [x | att] */
+    int Beff, H, hd, Tcap, len; const int* len_dev; int len_bias;
+    /* q_colsum (or NULL): q holds x W'^T for the RAW row x (acmi_linear_pair); the kernel first applies
+     *   q <- rstd (q - mean * q_colsum) + q_bias      (q_colsum, q_bias: [H*hd] f32, q_bias may be NULL)
+     * with mean / rstd of row b combined from q_stats[b][np][2] ((mean, M2) partials of np * cnt elements): the
+     * LayerNorm (norm_cross, transformer.py:559-565) of the cross-attention query. */
+    const float* q_stats; int q_stats_np; int q_stats_cnt; float eps;
+    const float* q_colsum; const float* q_bias;
+} acmi_attn_desc;
+int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 
 /* Scatter rows [Beff, L, H*hd] f32 into a [Beff, H, Tcap, hd] cache at positions [t0, t0+L). */
 int acmi_kv_store(const float* src, void* cache, int kvdtype, int Beff, int H, int hd, int Tcap,

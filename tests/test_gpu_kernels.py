@@ -305,6 +305,101 @@ def test_linear_folded_layernorm(C, M, d, N2, dt):
         assert rel(out3.cpu(), ref) < 6e-3
 
 
+@pytest.mark.parametrize('M,d', [(16, 1536), (5, 512), (33, 1024), (16, 48), (64, 256)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_linear_pair_out_proj_and_cross_query(C, M, d, dt):
+    """acmi_linear_pair: x1 = x0 + att W_out^T (with statistics and raw fragments of x1 into a second buffer) and
+    r = [x0 | att] [W_cq | W_cq W_out]^T in ONE launch; r must equal x1 W_cq^T (the cross-attention query before
+    its LayerNorm), and a consumer of (x1 fragments, statistics) must see LayerNorm(x1)."""
+    g = torch.Generator().manual_seed(M * 7 + d)
+    kt = 32 if dt == torch.bfloat16 else 16
+    dp = -(-d // kt) * kt
+    x0 = torch.randn(M, d, generator=g) * 1.5 + 0.3
+    att = torch.randn(M, d, generator=g)
+    w_out = torch.randn(d, d, generator=g) / math.sqrt(d)
+    w_cq = torch.randn(d, d, generator=g) / math.sqrt(d)
+    # [x0 | att] side by side, x0 as hi (+ lo for bf16)
+    cat = torch.zeros(M, 2 * dp)
+    hi = x0.to(dt).float()
+    cat[:, :d] = hi
+    cat[:, dp:dp + d] = att
+    xa = C.tile_matrix(cat.cuda(), dt)
+    xl = C.tile_matrix((x0 - hi).cuda(), dt) if dt == torch.bfloat16 else None
+    xa2 = C.tiled_activation_buffer(M, 2 * dp, dt, 'cuda')
+    xl2 = C.tiled_activation_buffer(M, d, dt, 'cuda') if dt == torch.bfloat16 else None
+    rbs = 2 * dp // kt
+    w_xcq = torch.zeros(d, 2 * dp)
+    w_xcq[:, :d] = w_cq
+    w_xcq[:, dp:dp + d] = w_cq @ w_out
+    x = x0.cuda().clone()
+    stats = torch.zeros(M, d // 16, 2, device='cuda')
+    r = torch.zeros(M, d, device='cuda')
+    att_half = xa.view(-1)[(dp // kt) * 64 * (16 // xa.element_size()):]   # K tile dp/kt of row block 0
+    tw_out, tw_xcq = C.TiledWeight(w_out.cuda(), dt), C.TiledWeight(w_xcq.cuda(), dt)   # descriptors hold raw pointers
+    p0 = C.linear_desc(att_half, tw_out, x, M, C.A_TILED, C.OUT_F32, residual=x, stats_out=stats,
+                       xt_hi=xa2, xt_lo=xl2, a_rbs=rbs, xt_rbs=rbs)
+    p1 = C.linear_desc(xa, tw_xcq, r, M, C.A_TILED, C.OUT_F32, a_lo=xl, a_rbs=rbs,
+                       lo_K=dp if dt == torch.bfloat16 else 0)
+    C.linear_pair(p0, p1)
+    attq, woq = att.to(dt).float(), w_out.to(dt).float()
+    x1_ref = x0 + attq @ woq.t()
+    assert rel(x.cpu(), x1_ref) < (2e-6 if dt == torch.float32 else 1e-5)
+    # reference of r with the operands as rounded: (hi + lo) W_cq^T + att (W_cq W_out)^T
+    xin = x0 if dt == torch.float32 else hi + (x0 - hi).to(dt).float()
+    r_ref = xin @ w_cq.to(dt).float().t() + attq @ (w_cq @ w_out).to(dt).float().t()
+    assert rel(r.cpu(), r_ref) < (3e-6 if dt == torch.float32 else 1e-5)
+    # ... which is x1 W_cq^T up to the rounding of the fused matrix
+    assert rel(r.cpu(), x1_ref @ w_cq.t()) < (1e-5 if dt == torch.float32 else 8e-3)
+    # fragments of x1 landed in the second buffer's x half, the att half untouched (zero)
+    got = C.untile_matrix(xa2, M, 2 * dp).float().cpu()
+    assert torch.equal(got[:, :d], x.cpu().to(dt).float()) and got[:, d:].abs().sum() == 0
+    if dt == torch.bfloat16:
+        assert torch.equal(C.untile_matrix(xl2, M, d).float().cpu(), (x.cpu() - got[:, :d]).to(dt).float())
+    mean_b, m2_b = stats[..., 0].cpu(), stats[..., 1].cpu()
+    mean = mean_b.mean(1)
+    var = (m2_b + 16 * (mean_b - mean[:, None]) ** 2).sum(1) / d
+    assert torch.allclose(mean, x1_ref.mean(1), atol=1e-5) and torch.allclose(var, x1_ref.var(1, unbiased=False), rtol=1e-4)
+    # a folded-LayerNorm consumer reading x1 out of the wide buffer
+    w2 = torch.randn(64, d, generator=g) / math.sqrt(d)
+    out = torch.empty(M, 64, device='cuda')
+    C.linear_ex(xa2, C.TiledWeight(w2.cuda(), dt), out, M, C.A_TILED, C.OUT_F32, a_stats=stats, np_=d // 16, cnt=16,
+                a_lo=xl2, colsum=w2.to(dt).double().sum(1).float().cuda(), a_rbs=rbs)
+    ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t()
+    assert rel(out.cpu(), ref) < (3e-6 if dt == torch.float32 else 2e-4)
+
+
+@pytest.mark.parametrize('kvdt', [torch.float32, torch.bfloat16])
+def test_attention_query_layernorm_hook_and_placement(C, kvdt):
+    """acmi_attn_decode_ex: (1) q given as x W'^T of the raw row + statistics partials of x == attention on
+    rstd (q - mean colsum) + bias; (2) tiled output placed at a column offset of a wider [x | att] buffer."""
+    g = torch.Generator().manual_seed(11)
+    Beff, H, hd, Lc, dmodel = 6, 4, 64, 9, 256
+    d = H * hd
+    x = torch.randn(Beff, dmodel, generator=g) * 2 + 0.4
+    wq = torch.randn(d, dmodel, generator=g) / math.sqrt(dmodel)
+    bias = 0.1 * torch.randn(d, generator=g)
+    k = torch.randn(Beff, H, Lc, hd, generator=g).to(kvdt)
+    v = torch.randn(Beff, H, Lc, hd, generator=g).to(kvdt)
+    q_ref = F.layer_norm(x, (dmodel,), None, None, 1e-5) @ wq.t() + bias
+    out_ref = torch.empty(Beff, d, device='cuda')
+    C.attn_decode(q_ref.cuda(), k.cuda(), v.cuda(), out_ref, Lc)
+    # statistics as 16-element partials (what a producer GEMM emits)
+    xb = x.view(Beff, dmodel // 16, 16)
+    mb = xb.mean(-1)
+    stats = torch.stack([mb, ((xb - mb[..., None]) ** 2).sum(-1)], dim=-1).contiguous().cuda()
+    out = torch.empty(Beff, d, device='cuda')
+    C.attn_decode((x @ wq.t()).cuda(), k.cuda(), v.cuda(), out, Lc, q_stats=stats, q_np=dmodel // 16, q_cnt=16,
+                  q_colsum=wq.sum(1).cuda(), q_bias=bias.cuda())
+    assert rel(out.cpu(), out_ref.cpu()) < 1e-5
+    for dt in (torch.float32, torch.bfloat16):
+        kt = 32 if dt == torch.bfloat16 else 16
+        wide = C.tiled_activation_buffer(Beff, 3 * d, dt, 'cuda')
+        C.attn_decode(q_ref.cuda(), k.cuda(), v.cuda(), wide, Lc, out_tiled=True, out_rbs=3 * d // kt, out_col0=d)
+        full = C.untile_matrix(wide, Beff, 3 * d).float().cpu()
+        assert torch.equal(full[:, d:2 * d], out_ref.cpu().to(dt).float())
+        assert full[:, :d].abs().sum() == 0 and full[:, 2 * d:].abs().sum() == 0
+
+
 @pytest.mark.parametrize('M,K', [(16, 1536), (3, 32), (33, 2048), (16, 1024)])
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_ln_tile_vs_torch(C, M, K, dt):

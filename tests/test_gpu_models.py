@@ -192,8 +192,9 @@ def test_lm_melody_vs_reference_golden():
     assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
 
 
+@pytest.mark.parametrize('B', [3, 12, 20])   # CFG rows 6 / 24 / 40: 1, 2 and 4 (3 valid) 16-row blocks per GEMM
 @pytest.mark.parametrize('wdt,tol', [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
-def test_lm_midsize_vs_oracle(wdt, tol):
+def test_lm_midsize_vs_oracle(wdt, tol, B):
     """d=256, 4 layers, card 2048, cross attention: teacher-forced logits + greedy tokens vs the oracle."""
     from audiocraft_amd.models import builders
     torch.manual_seed(0)
@@ -210,16 +211,15 @@ def test_lm_midsize_vs_oracle(wdt, tol):
         sd = {k: (v.bfloat16().float() if v.dim() == 2 and 'output_proj' not in k else v) for k, v in sd.items()}
     oc = olm.LMConfig(dim=256, num_heads=4, num_layers=4, n_q=4, card=2048, cross_attention=True)
     g = torch.Generator().manual_seed(5)
-    B = 3
     cross = torch.randn(2 * B, 6, 256, generator=g)
     cross[B:] = 0
     ct = {'description': (cross.cuda(), torch.ones(2 * B, 6, dtype=torch.int64).cuda())}
-    seq = torch.randint(0, 2049, (2 * B, 4, 20), generator=g)
+    seq = torch.randint(0, 2049, (2 * B, 4, 20 if B == 3 else 8), generator=g)
     ref = olm.lm_forward(sd, oc, seq, cross)
     got = lm.forward_steps(seq.cuda(), ct).cpu()
     r = rel(got, ref)
     assert r < tol, f"teacher-forced logits rel-L2 {r} (tol {tol})"
-    if wdt == torch.float32:
+    if wdt == torch.float32 and B == 3:
         toks = lm.generate(None, [], num_samples=B, max_gen_len=16, use_sampling=False, condition_tensors=ct)
         ref_t = olm.generate(sd, oc, None, B, cross, max_gen_len=16, use_sampling=False)
         assert torch.equal(toks.cpu(), ref_t)

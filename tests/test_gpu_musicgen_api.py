@@ -98,7 +98,8 @@ def test_melody_model_with_chroma():
 
 def test_ln_modes_agree(monkeypatch):
     """LayerNorm folded into the consuming GEMM's epilogue (producer statistics + raw fragment-order row)
-    == separate standardisation kernel (tokens identical,
+    -- with the cross-attention query riding in the out-projection launch (default) or projected by its own
+    launch (ACMI_CROSS_FUSED=0) -- == separate standardisation kernel (tokens identical,
     logits within f32 round-off): run in a subprocess per mode because the mode is latched at first use."""
     import subprocess
     import sys
@@ -115,9 +116,9 @@ def test_ln_modes_agree(monkeypatch):
     outs = []
     import os
     import tempfile
-    for mode in ('tile', 'fold'):
+    for mode, fused in (('tile', '1'), ('fold', '1'), ('fold', '0')):
         f = tempfile.mktemp(suffix='.pt')
-        env = dict(os.environ, ACMI_LN_MODE=mode)
+        env = dict(os.environ, ACMI_LN_MODE=mode, ACMI_CROSS_FUSED=fused)
         subprocess.run([sys.executable, '-c', code, f], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
         outs.append(torch.load(f))
         os.remove(f)
