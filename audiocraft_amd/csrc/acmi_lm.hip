@@ -748,7 +748,7 @@ struct AttnArgs {
     const float* q_stats; int q_np, q_cnt, q_K; float q_eps; const float* q_colsum; const float* q_bias;
 };
 
-template <typename KT, int HD>
+template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const float* __restrict__ q = p.q;
     const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.kc);
@@ -770,13 +770,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = 0; e < DPL; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * DPL + e];
     // LayerNorm hook: everything it needs is requested here, consumed after the first K / V chunk is in flight
-    const bool qnorm = p.q_colsum != nullptr;
     float qcs[DPL], qb[DPL], spm[2], spq[2];
-    if (qnorm) {
+    if (QN) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
             qcs[e] = p.q_colsum[h * HD + c * DPL + e];
-            qb[e] = p.q_bias != nullptr ? p.q_bias[h * HD + c * DPL + e] : 0.f;
+            qb[e] = p.q_bias[h * HD + c * DPL + e];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // np <= 128 equal-count partials of row b, contiguous
@@ -784,7 +783,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             spm[i] = t.x; spq[i] = t.y;
         }
     }
-    bool q_pending = qnorm;
     const KT* kb = kc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
     const KT* vb = vc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
 
@@ -793,30 +791,31 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     for (int e = 0; e < DPL; ++e) o[e] = 0.f;
 
     const int nwv = blockDim.x >> 6;  // 1, 2 or 4 waves share the positions of this (row, head)
-    for (int t0 = wave * CH; t0 < len; t0 += nwv * CH) {
-        // K and V of the whole chunk are requested together (2 * NI wide loads in flight per lane)
-        rawv kr[NI], vr[NI];
+    // K and V of a whole chunk are requested together (2 * NI wide loads in flight per lane); the first chunk
+    // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x)
+    rawv kr[NI], vr[NI];
+    auto load_kv = [&](int t0) {
+        // branch free: lanes past the end re-read the last position (their scores are masked below); a per-lane
+        // zero fill would write the registers of loads still in flight and make every load wait for the previous
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int t = t0 + i * PPI + pp;
-            if (t < len) {
-                kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
-                vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
-            } else {
-#pragma unroll
-                for (int e = 0; e < DPL; ++e) { kr[i][e] = 0; vr[i][e] = 0; }
-            }
+            const int t = min(t0 + i * PPI + pp, len - 1);
+            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
+            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
         }
-        if (q_pending) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
-            const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
-            const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
-            const float d0 = spm[0] - mean, d1 = spm[1] - mean;
-            const float q2 = (v0 ? spq[0] + (float)p.q_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.q_cnt * d1 * d1 : 0.f);
-            const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.q_K + p.q_eps);
+        __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
+    };
+    load_kv(wave * CH);
+    if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
+        const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
+        const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
+        const float d0 = spm[0] - mean, d1 = spm[1] - mean;
+        const float q2 = (v0 ? spq[0] + (float)p.q_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.q_cnt * d1 * d1 : 0.f);
+        const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.q_K + p.q_eps);
 #pragma unroll
-            for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - mean * qcs[e]) + qb[e];
-            q_pending = false;
-        }
+        for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - mean * qcs[e]) + qb[e];
+    }
+    for (int t0 = wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
         float s[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -847,6 +846,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vr[i][e]), o[e]);
         }
         m = m_new;
+        if (t0 + nwv * CH < len) load_kv(t0 + nwv * CH);
     }
 #pragma unroll
     for (int off = LPP; off < 64; off <<= 1) {
@@ -887,8 +887,20 @@ template <typename KT>
 static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     static int attn_nw = -1;
     if (attn_nw < 0) { const char* e = getenv("ACMI_ATTN_NW"); attn_nw = e ? atoi(e) : 4; if (attn_nw != 1 && attn_nw != 2) attn_nw = 4; }
-    dim3 grid(a.H, Beff), block(64 * attn_nw);
-#define ACMI_ATTN_CASE(HD) case HD: hipLaunchKernelGGL((attn_decode_kernel<KT, HD>), grid, block, 0, st, a); break;
+    // waves per (row, head): 4 by default; a host-known short length (cross-attention) needs no more waves than
+    // it has 64-position chunks (bf16 cache, hd 64) -- idle waves still cost dispatch time
+    int nwv = attn_nw;
+    if (a.len_dev == nullptr) {
+        const int dpl = hd >= 8 ? 8 : hd, chunk = (sizeof(KT) == 2 ? 8 : 4) * (64 / (hd / dpl));
+        const int need = (a.len + chunk - 1) / chunk;
+        while (nwv > 1 && nwv / 2 >= need) nwv /= 2;
+    }
+    dim3 grid(a.H, Beff), block(64 * nwv);
+#define ACMI_ATTN_CASE(HD)                                                                              \
+    case HD:                                                                                            \
+        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false>), grid, block, 0, st, a);            \
+        break;
     switch (hd) {
         ACMI_ATTN_CASE(4)
         ACMI_ATTN_CASE(8)
@@ -923,7 +935,9 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
         ACMI_REQUIRE(c.q_stats != nullptr && c.q_stats_np >= 1 && c.q_stats_np <= 128 && c.q_stats_np * c.q_stats_cnt > 0,
                      "acmi_attn_decode: q LayerNorm hook needs 1..128 statistics partials");
         a.q_stats = c.q_stats; a.q_np = c.q_stats_np; a.q_cnt = c.q_stats_cnt; a.q_K = c.q_stats_np * c.q_stats_cnt;
-        a.q_eps = c.eps; a.q_colsum = c.q_colsum; a.q_bias = c.q_bias;
+        a.q_eps = c.eps; a.q_colsum = c.q_colsum;
+        a.q_bias = c.q_bias != nullptr ? c.q_bias : nullptr;
+        ACMI_REQUIRE(c.q_bias != nullptr, "acmi_attn_decode: q_bias is required with q_colsum (pass zeros for none)");
     }
     return c.kvdtype == ACMI_BF16 ? launch_attn_t<bf16_t>(a, c.Beff, c.hd, (hipStream_t)stream)
                                   : launch_attn_t<float>(a, c.Beff, c.hd, (hipStream_t)stream);

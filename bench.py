@@ -171,7 +171,7 @@ def pmc_traffic_per_launch():
             return None
         total = n = 0.0  # dispatch-weighted mean over the kernel's template variants (plain / folded LayerNorm)
         for row in csv.DictReader(open(files[-1])):
-            if 'lin_tiled_kernel' in row['kernel'] and row['counter'] == name:
+            if ('lin_tiled_kernel' in row['kernel'] or 'lin_pair_kernel' in row['kernel']) and row['counter'] == name:
                 total += float(row['mean_per_dispatch']) * float(row['dispatches'])
                 n += float(row['dispatches'])
         if n == 0:
@@ -320,7 +320,7 @@ def main():
         if not args.no_roofline:
             r = measure_lin_kernel(model, 2 * B)
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "lin_tiled_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
+            out["roofline"] = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(),
                                "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(r['avg_us'], 3),

@@ -307,7 +307,7 @@ typedef struct {
     int out_col0;           /* tiled output: first column (a multiple of KT), e.g. d for the att half of [x | att] */
     int Beff, H, hd, Tcap, len; const int* len_dev; int len_bias;
     /* q_colsum (or NULL): q holds x W'^T for the RAW row x (acmi_linear_pair); the kernel first applies
-     *   q <- rstd (q - mean * q_colsum) + q_bias      (q_colsum, q_bias: [H*hd] f32, q_bias may be NULL)
+     *   q <- rstd (q - mean * q_colsum) + q_bias      (q_colsum, q_bias: [H*hd] f32, both required)
      * with mean / rstd of row b combined from q_stats[b][np][2] ((mean, M2) partials of np * cnt elements): the
      * LayerNorm (norm_cross, transformer.py:559-565) of the cross-attention query. */
     const float* q_stats; int q_stats_np; int q_stats_cnt; float eps;
