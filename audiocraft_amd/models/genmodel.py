@@ -2,7 +2,8 @@
 
 API mirror of `audiocraft.models.genmodel.BaseGenModel` (reference audiocraft/models/genmodel.py:28-267):
 same public methods, properties and argument meaning.  The implementation is organised around one
-private driver (`_run`) that every `generate*` entry point funnels into, and there is no autocast
+private driver (`_run`) that every `generate*` entry point funnels into and one windowed token generator with
+a per-window hook, and there is no autocast
 context: precision is a property of the packed weights (`LMModel.weight_dtype`), not of a tracing mode.
 """
 import typing as tp
@@ -10,6 +11,7 @@ from abc import ABC, abstractmethod
 
 import torch
 
+from ..modules.conditioners import ConditioningAttributes
 from .encodec import CompressionModel
 from .lm import LMModel
 
@@ -77,13 +79,66 @@ class BaseGenModel(ABC):
     def get_pretrained(name: str, device=None):
         raise NotImplementedError("No base implementation for getting pretrained model")
 
-    @abstractmethod
-    def _prepare_tokens_and_attributes(self, descriptions, prompt):
-        """-> (list of ConditioningAttributes, prompt tokens [B, K, T0] or None)"""
+    # -- inputs and tokens (reference genmodel.py:109-133, 193-260) ------------------------------------
+    def _prepare_tokens_and_attributes(self, descriptions: tp.Sequence[tp.Optional[str]],
+                                       prompt: tp.Optional[torch.Tensor]):
+        """-> (one ConditioningAttributes per description, prompt tokens [B, K, T0] or None)."""
+        attributes = [ConditioningAttributes(text={'description': text}) for text in descriptions]
+        return attributes, self._encode_prompt(descriptions, prompt)
 
-    @abstractmethod
-    def _generate_tokens(self, attributes, prompt_tokens, progress: bool = False) -> torch.Tensor:
-        """-> tokens [B, K, T]"""
+    def _encode_prompt(self, descriptions, prompt: tp.Optional[torch.Tensor]) -> tp.Optional[torch.Tensor]:
+        if prompt is None:
+            return None
+        assert descriptions is None or len(descriptions) == len(prompt), "Prompt and nb. descriptions doesn't match"
+        prompt_tokens, scale = self.compression_model.encode(prompt.to(self.device))
+        assert scale is None
+        return prompt_tokens
+
+    def _lm_generate(self, prompt_tokens, attributes, n_frames: int, callback):
+        return self.lm.generate(prompt_tokens, attributes, callback=callback, max_gen_len=n_frames,
+                                **self.generation_params)
+
+    def _window_attributes(self, attributes: tp.List[ConditioningAttributes], t_start: float) -> None:
+        """Hook of the windowed generation: adapt the conditions to the window starting at `t_start` seconds
+        (MusicGen tiles the melody); the default conditions do not depend on time."""
+
+    def _generate_tokens(self, attributes: tp.List[ConditioningAttributes],
+                         prompt_tokens: tp.Optional[torch.Tensor], progress: bool = False) -> torch.Tensor:
+        """-> tokens [B, K, T].  Durations above `max_duration` are served by overlapping windows that advance by
+        `extend_stride` seconds, each prompted with the tail of the previous one."""
+        fps = self.frame_rate
+        total_frames = int(self.duration * fps)
+        if prompt_tokens is not None:
+            assert prompt_tokens.shape[-1] <= int(min(self.duration, self.max_duration) * fps), \
+                "Prompt is longer than audio to generate"
+        frames_done = 0  # frames produced by earlier windows (offsets the progress report)
+
+        def report(generated: int, to_generate: int):
+            generated += frames_done
+            if self._progress_callback is not None:
+                self._progress_callback(generated, to_generate)
+            else:
+                print(f'{generated: 6d} / {to_generate: 6d}', end='\r')
+
+        callback = report if progress else None
+        if self.duration <= self.max_duration:
+            return self._lm_generate(prompt_tokens, attributes, total_frames, callback)
+
+        assert self.extend_stride is not None, "Stride should be defined to generate beyond max_duration"
+        assert self.extend_stride < self.max_duration, "Cannot stride by more than max generation duration."
+        stride_frames = int(fps * self.extend_stride)
+        pieces = [] if prompt_tokens is None else [prompt_tokens]
+        prompt_len = 0 if prompt_tokens is None else prompt_tokens.shape[-1]
+        while frames_done + prompt_len < total_frames:
+            t_start = frames_done / fps
+            window_frames = int(min(self.duration - t_start, self.max_duration) * fps)
+            self._window_attributes(attributes, t_start)
+            window = self._lm_generate(prompt_tokens, attributes, window_frames, callback)
+            pieces.append(window if prompt_tokens is None else window[..., prompt_tokens.shape[-1]:])
+            prompt_tokens = window[..., stride_frames:]
+            prompt_len = prompt_tokens.shape[-1]
+            frames_done += stride_frames
+        return torch.cat(pieces, dim=-1)
 
     # -- single driver ------------------------------------------------------------------------------
     def _run(self, descriptions, prompt_wav, progress: bool, return_tokens: bool, expect_prompt: bool, **prep_kw):

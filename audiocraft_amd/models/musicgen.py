@@ -102,7 +102,8 @@ class MusicGen(BaseGenModel):
 
     def _prepare_tokens_and_attributes(self, descriptions: tp.Sequence[tp.Optional[str]],
                                        prompt: tp.Optional[torch.Tensor], melody_wavs: tp.Optional[MelodyList] = None):
-        """-> (attributes, prompt tokens); reference musicgen.py:193-249."""
+        """-> (attributes, prompt tokens); reference musicgen.py:193-249.  Every sample carries a `self_wav`
+        condition: its melody, or the null 1-sample wav."""
         if melody_wavs is not None:
             if 'self_wav' not in self.lm.condition_provider.conditioners:
                 raise RuntimeError("This model doesn't support melody conditioning. Use the `melody` model.")
@@ -114,60 +115,24 @@ class MusicGen(BaseGenModel):
             attr = ConditioningAttributes(text={'description': text})
             attr.wav['self_wav'] = self._wav_condition(None if melody_wavs is None else melody_wavs[i])
             attributes.append(attr)
-        prompt_tokens = None
-        if prompt is not None:
-            assert descriptions is None or len(descriptions) == len(prompt), "Prompt and nb. descriptions doesn't match"
-            prompt_tokens, scale = self.compression_model.encode(prompt.to(self.device))
-            assert scale is None
-        return attributes, prompt_tokens
+        return attributes, self._encode_prompt(descriptions, prompt)
 
-    # ------------------------------------------------------------------------------------- tokens
-    def _lm_generate(self, prompt_tokens, attributes, n_frames: int, callback):
-        return self.lm.generate(prompt_tokens, attributes, callback=callback, max_gen_len=n_frames,
-                                **self.generation_params)
+    # ------------------------------------------------------------------------------------- windows
+    def _generate_tokens(self, attributes, prompt_tokens, progress: bool = False) -> torch.Tensor:
+        self._melodies = [a.wav['self_wav'] for a in attributes]   # the un-tiled melodies of this call
+        try:
+            return super()._generate_tokens(attributes, prompt_tokens, progress)
+        finally:
+            self._melodies = None
 
-    def _generate_tokens(self, attributes: tp.List[ConditioningAttributes],
-                         prompt_tokens: tp.Optional[torch.Tensor], progress: bool = False) -> torch.Tensor:
-        fps = self.frame_rate
-        total_frames = int(self.duration * fps)
-        if prompt_tokens is not None:
-            assert prompt_tokens.shape[-1] <= int(min(self.duration, self.max_duration) * fps), \
-                "Prompt is longer than audio to generate"
-        frames_done = 0  # frames produced by earlier windows (offsets the progress report)
-
-        def report(generated: int, to_generate: int):
-            generated += frames_done
-            if self._progress_callback is not None:
-                self._progress_callback(generated, to_generate)
-            else:
-                print(f'{generated: 6d} / {to_generate: 6d}', end='\r')
-
-        callback = report if progress else None
-        if self.duration <= self.max_duration:
-            return self._lm_generate(prompt_tokens, attributes, total_frames, callback)
-
-        # ---- windowed generation: advance by `extend_stride`, re-prompt with the overlap
-        assert self.extend_stride is not None, "Stride should be defined to generate beyond max_duration"
-        assert self.extend_stride < self.max_duration, "Cannot stride by more than max generation duration."
-        stride_frames = int(fps * self.extend_stride)
-        melodies = [a.wav['self_wav'] for a in attributes]
-        pieces = [] if prompt_tokens is None else [prompt_tokens]
-        prompt_len = 0 if prompt_tokens is None else prompt_tokens.shape[-1]
-        while frames_done + prompt_len < total_frames:
-            t_start = frames_done / fps
-            window_frames = int(min(self.duration - t_start, self.max_duration) * fps)
-            for attr, mel in zip(attributes, melodies):
-                n = int(mel.length.item())
-                if n == 0:
-                    continue
-                # periodic extension of the melody so that this window sees max_duration seconds of it
-                want = int(self.max_duration * self.sample_rate)
-                idx = (int(t_start * self.sample_rate) + torch.arange(want, device=self.device)) % n
-                attr.wav['self_wav'] = WavCondition(mel[0][..., idx], torch.full_like(mel[1], want),
-                                                    [self.sample_rate] * mel[0].size(0), [None], [0.])
-            window = self._lm_generate(prompt_tokens, attributes, window_frames, callback)
-            pieces.append(window if prompt_tokens is None else window[..., prompt_tokens.shape[-1]:])
-            prompt_tokens = window[..., stride_frames:]
-            prompt_len = prompt_tokens.shape[-1]
-            frames_done += stride_frames
-        return torch.cat(pieces, dim=-1)
+    def _window_attributes(self, attributes: tp.List[ConditioningAttributes], t_start: float) -> None:
+        """Periodic extension of each melody so that the window starting at `t_start` sees `max_duration`
+        seconds of it (reference musicgen.py:309-324)."""
+        want = int(self.max_duration * self.sample_rate)
+        for attr, mel in zip(attributes, self._melodies):
+            n = int(mel.length.item())
+            if n == 0:
+                continue
+            idx = (int(t_start * self.sample_rate) + torch.arange(want, device=self.device)) % n
+            attr.wav['self_wav'] = WavCondition(mel[0][..., idx], torch.full_like(mel[1], want),
+                                                [self.sample_rate] * mel[0].size(0), [None], [0.])

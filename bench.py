@@ -312,11 +312,12 @@ def main():
         lm = model.lm
         n_pos = T + 3
         alg = lm_algorithmic_bytes(lm, 2 * B, n_pos, args.text_len)
-        out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes": alg['total'],
-                                "achieved": round(alg['total'] * args.steps / elapsed / 1e9, 1),
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(alg['total'] * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
-                                "note": "whole generate incl. EnCodec decode and collectives"}
+        job_bytes = alg['total'] * world   # every rank streams its own replica / KV shard
+        out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes": job_bytes,
+                                "achieved": round(job_bytes * args.steps / elapsed / 1e9, 1),
+                                "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                "frac": round(job_bytes * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                "note": "whole generate incl. EnCodec decode and collectives, all GPUs"}
         if not args.no_roofline:
             r = measure_lin_kernel(model, 2 * B)
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9

@@ -96,6 +96,42 @@ def test_melody_model_with_chroma():
         MusicGen.get_pretrained('debug', 'cuda').generate_with_chroma(['a'], melody[:1], 32000)
 
 
+# ---- AudioGen (reference tests/models/test_audiogen.py): same machinery, 16 kHz codec, 10 s windows, stride 2 s
+@pytest.fixture(scope='module')
+def ag():
+    from audiocraft_amd.models.audiogen import AudioGen
+    model = AudioGen.get_pretrained('debug', 'cuda')
+    model.set_generation_params(duration=2.0, extend_stride=2.)
+    return model
+
+
+def test_audiogen_base(ag):
+    assert ag.frame_rate == 25 and ag.sample_rate == 16000 and ag.audio_channels == 1
+    assert ag.max_duration == 10 and ag.generation_params['top_k'] == 250
+
+
+def test_audiogen_generate_and_continuation(ag):
+    wav = ag.generate(['youpi', 'lapin dort'])
+    assert list(wav.shape) == [2, 1, 32000] and bool(torch.isfinite(wav).all())
+    wav = ag.generate_continuation(torch.randn(3, 1, 16000), 16000)
+    assert list(wav.shape) == [3, 1, 32000]
+    wav, toks = ag.generate_continuation(torch.randn(2, 1, 16000), 16000, ['youpi', 'lapin dort'], return_tokens=True)
+    assert list(wav.shape) == [2, 1, 32000] and list(toks.shape) == [2, 4, 50]
+    with pytest.raises(AssertionError):
+        ag.generate_continuation(torch.randn(2, 1, 16000), 16000, ['youpi', 'lapin dort', 'one too many'])
+
+
+def test_audiogen_generate_long(ag):
+    ag.max_duration = 3.
+    ag.set_generation_params(duration=4., extend_stride=2.)
+    try:
+        wav = ag.generate(['youpi', 'lapin dort'])
+        assert list(wav.shape) == [2, 1, 16000 * 4]
+    finally:
+        ag.max_duration = 10.
+        ag.set_generation_params(duration=2.0, extend_stride=2.)
+
+
 def test_ln_modes_agree(monkeypatch):
     """LayerNorm folded into the consuming GEMM's epilogue (producer statistics + raw fragment-order row)
     -- with the cross-attention query riding in the out-projection launch (default) or projected by its own
