@@ -33,7 +33,19 @@ class AudioGen(BaseGenModel):
         lm = loaders.load_lm_model(name, device=device, weight_dtype=weight_dtype)
         assert 'self_wav' not in lm.condition_provider.conditioners, \
             "AudioGen do not support waveform conditioning for now"
-        return AudioGen(name, loaders.load_compression_model(name, device=device), lm, max_duration=10)
+        return AudioGen(name, loaders.load_compression_model(name, device=device), lm)
+
+    @staticmethod
+    def get_random_init(name: str = 'facebook/audiogen-medium', device='cuda', weight_dtype=None, text_len: int = 16,
+                        seed: int = 0):
+        """Architecture of the released model (1.5 B LM, 16 kHz EnCodec) with seeded random weights and a synthetic
+        text conditioner: neither checkpoints nor T5 weights exist offline."""
+        import torch
+        assert name == 'facebook/audiogen-medium', name
+        torch.manual_seed(seed)
+        lm = builders.get_lm_model(builders.audiogen_lm_cfg('medium', synthetic=True, text_len=text_len), device,
+                                   torch.bfloat16 if weight_dtype is None else weight_dtype)
+        return AudioGen(name, builders.get_compression_model(builders.ENCODEC_16KHZ, device), lm, max_duration=10)
 
     def set_generation_params(self, use_sampling: bool = True, top_k: int = 250, top_p: float = 0.0,
                               temperature: float = 1.0, duration: float = 10.0, cfg_coef: float = 3.0,

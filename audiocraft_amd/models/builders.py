@@ -36,6 +36,9 @@ ENCODEC_32KHZ = dict(
                 true_skip=True, compress=2, lstm=2, disable_norm_outer_blocks=0),
     rvq=dict(n_q=4, bins=2048), sample_rate=32000, frame_rate=50, channels=1, causal=False, renormalize=False)
 
+# config/model/encodec/encodec_large_nq4_s320.yaml over default.yaml (AudioGen's 16 kHz codec: hop 320 -> 50 fps)
+ENCODEC_16KHZ = dict(ENCODEC_32KHZ, seanet=dict(ENCODEC_32KHZ['seanet'], ratios=[8, 5, 4, 2]), sample_rate=16000)
+
 # config/model/encodec/encodec_base_causal.yaml ("encodec_24khz" geometry, BASELINE.json config #1)
 ENCODEC_24KHZ = dict(
     seanet=dict(channels=1, dimension=128, n_filters=32, n_residual_layers=1, ratios=[8, 5, 4, 2], activation='ELU',
@@ -105,9 +108,13 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
     return lm.to(device)
 
 
-def musicgen_lm_cfg(scale: str = 'small', melody: bool = False, synthetic: bool = True, text_len: int = 16) -> dict:
-    """Architecture of facebook/musicgen-{small,medium,large,melody}."""
-    cfg = dict(LM_SCALES[scale], n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0)
+def musicgen_lm_cfg(scale: str = 'small', melody: bool = False, synthetic: bool = True, text_len: int = 16,
+                    stereo: bool = False) -> dict:
+    """Architecture of facebook/musicgen-{small,medium,large,melody}[ -stereo ].  Stereo:
+    8 codebooks = left / right interleaved per RVQ level, each pair sharing its delay."""
+    cfg = dict(LM_SCALES[scale], n_q=8 if stereo else 4, card=2048, hidden_scale=4, cfg_coef=3.0)
+    if stereo:
+        cfg['codebooks_pattern'] = {'modeling': 'delay', 'delay': {'delays': [0, 0, 1, 1, 2, 2, 3, 3]}}
     emb = 'synthetic' if synthetic else None
     cfg['conditioners'] = {'description': {'kind': 't5', 'name': 't5-base', 'embedder': emb, 'length': text_len}}
     if melody:  # config/conditioner/chroma2music.yaml: prepend [self_wav, description], no cross-attention
@@ -116,6 +123,16 @@ def musicgen_lm_cfg(scale: str = 'small', melody: bool = False, synthetic: bool 
         cfg['fuser'] = {'prepend': ['self_wav', 'description']}
     else:       # config/conditioner/text2music.yaml
         cfg['fuser'] = {'cross': ['description']}
+    return cfg
+
+
+def audiogen_lm_cfg(scale: str = 'medium', synthetic: bool = True, text_len: int = 16) -> dict:
+    """Architecture of facebook/audiogen-medium: the MusicGen LM (config/model/lm/audiogen_lm.yaml) with
+    T5-large text conditioning through cross-attention (config/conditioner/text2sound.yaml)."""
+    cfg = dict(LM_SCALES[scale], n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0)
+    cfg['conditioners'] = {'description': {'kind': 't5', 'name': 't5-large', 'dim': 1024,
+                                           'embedder': 'synthetic' if synthetic else None, 'length': text_len}}
+    cfg['fuser'] = {'cross': ['description']}
     return cfg
 
 

@@ -12,7 +12,7 @@ from abc import ABC, abstractmethod
 import torch
 
 from ..modules.conditioners import ConditioningAttributes
-from .encodec import CompressionModel
+from .encodec import CompressionModel, InterleaveStereoCompressionModel
 from .lm import LMModel
 
 ProgressFn = tp.Callable[[int, int], None]
@@ -39,6 +39,17 @@ def convert_audio(wav: torch.Tensor, from_rate: float, to_rate: float, to_channe
     return wav
 
 
+def get_wrapped_compression_model(compression_model: CompressionModel, cfg: dict) -> CompressionModel:
+    """Stereo wrapper / codebook count requested by an experiment config (reference builders.py:338-351)."""
+    stereo = cfg.get('interleave_stereo_codebooks') or {}
+    if stereo.get('use'):
+        compression_model = InterleaveStereoCompressionModel(compression_model,
+                                                             per_timestep=bool(stereo.get('per_timestep', False)))
+    if cfg.get('compression_model_n_q') is not None:
+        compression_model.set_num_codebooks(cfg['compression_model_n_q'])
+    return compression_model
+
+
 class BaseGenModel(ABC):
     """Tokens-from-LM + audio-from-codec generator.
 
@@ -47,10 +58,16 @@ class BaseGenModel(ABC):
 
     def __init__(self, name: str, compression_model: CompressionModel, lm: LMModel,
                  max_duration: tp.Optional[float] = None):
+        self.name = name
+        # the LM of a released checkpoint carries the experiment config (`loaders.load_lm_model`): it says whether
+        # the codec is the stereo wrapper and what duration the model was trained on (reference genmodel.py:49-62)
+        self.cfg: tp.Optional[dict] = getattr(lm, 'cfg', None)
+        if self.cfg is not None:
+            compression_model = get_wrapped_compression_model(compression_model, self.cfg)
+            if max_duration is None:
+                max_duration = (self.cfg.get('dataset') or {}).get('segment_duration')
         if max_duration is None:
             raise ValueError("You must provide max_duration when building directly your GenModel")
-        self.name = name
-        self.cfg = None
         self.compression_model = compression_model.eval()
         self.lm = lm.eval()
         self.max_duration: float = float(max_duration)

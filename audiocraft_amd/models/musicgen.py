@@ -15,19 +15,20 @@ import torch
 
 from ..modules.conditioners import ConditioningAttributes, WavCondition
 from . import builders
-from .encodec import CompressionModel
+from .encodec import CompressionModel, InterleaveStereoCompressionModel
 from .genmodel import BaseGenModel, convert_audio
 from .lm import LMModel
 
 MelodyList = tp.List[tp.Optional[torch.Tensor]]
 MelodyType = tp.Union[torch.Tensor, MelodyList]
 
-# released architectures: name -> (LM scale, melody conditioning?)
+# released architectures: name -> (LM scale, melody conditioning?); a "-stereo-" name adds the stereo variant
 _ARCH = {
     'facebook/musicgen-small': ('small', False), 'facebook/musicgen-medium': ('medium', False),
     'facebook/musicgen-large': ('large', False), 'facebook/musicgen-melody': ('medium', True),
     'facebook/musicgen-melody-large': ('large', True),
 }
+_ARCH.update({k.replace('musicgen-', 'musicgen-stereo-'): v for k, v in list(_ARCH.items())})
 _SHORT_NAMES = {"small": "facebook/musicgen-small", "medium": "facebook/musicgen-medium",
                 "large": "facebook/musicgen-large", "melody": "facebook/musicgen-melody"}
 
@@ -51,7 +52,8 @@ class MusicGen(BaseGenModel):
                             max_duration=30)
         from . import loaders
         lm = loaders.load_lm_model(name, device=device, weight_dtype=weight_dtype)
-        return MusicGen(name, loaders.load_compression_model(name, device=device), lm, max_duration=30)
+        # max_duration and the stereo codec wrapper come from the checkpoint's experiment config (BaseGenModel)
+        return MusicGen(name, loaders.load_compression_model(name, device=device), lm)
 
     @staticmethod
     def get_random_init(name: str = 'facebook/musicgen-medium', device='cuda', weight_dtype=torch.bfloat16,
@@ -59,10 +61,14 @@ class MusicGen(BaseGenModel):
         """Architecture of a released model with seeded random weights and synthetic conditioners: what
         bench.py runs, since neither checkpoints nor T5 weights exist offline."""
         scale, melody = _ARCH[name]
+        stereo = '-stereo-' in name
         torch.manual_seed(seed)
-        lm = builders.get_lm_model(builders.musicgen_lm_cfg(scale, melody, synthetic=True, text_len=text_len),
-                                   device, weight_dtype)
-        return MusicGen(name, builders.get_compression_model(builders.ENCODEC_32KHZ, device), lm, max_duration=30)
+        lm = builders.get_lm_model(builders.musicgen_lm_cfg(scale, melody, synthetic=True, text_len=text_len,
+                                                            stereo=stereo), device, weight_dtype)
+        codec = builders.get_compression_model(builders.ENCODEC_32KHZ, device)
+        if stereo:  # left / right through the mono codec, codebooks interleaved (reference encodec.py:397-506)
+            codec = InterleaveStereoCompressionModel(codec)
+        return MusicGen(name, codec, lm, max_duration=30)
 
     # ------------------------------------------------------------------------------------- parameters
     def set_generation_params(self, use_sampling: bool = True, top_k: int = 250, top_p: float = 0.0,

@@ -96,6 +96,32 @@ def test_melody_model_with_chroma():
         MusicGen.get_pretrained('debug', 'cuda').generate_with_chroma(['a'], melody[:1], 32000)
 
 
+def test_stereo_musicgen_debug_geometry():
+    """Stereo MusicGen (reference encodec.py:397-506 + 8-codebook delay pattern [0,0,1,1,2,2,3,3]): left / right
+    through the mono codec, codebooks interleaved per RVQ level; generation and continuation give 2-channel audio."""
+    from audiocraft_amd.models import builders
+    from audiocraft_amd.models.encodec import InterleaveStereoCompressionModel
+    torch.manual_seed(0)
+    lm = builders.get_lm_model(dict(dim=32, num_heads=4, num_layers=2, n_q=8, card=400,
+                                    codebooks_pattern={'modeling': 'delay', 'delay': {'delays': [0, 0, 1, 1, 2, 2, 3, 3]}},
+                                    conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 16, 'length': 4}},
+                                    fuser={'cross': ['description']}), 'cuda', torch.float32)
+    codec = InterleaveStereoCompressionModel(builders.get_debug_compression_model('cuda'))
+    mg = MusicGen('stereo-debug', codec, lm, max_duration=30)
+    mg.set_generation_params(duration=2.0, extend_stride=2.)
+    assert mg.audio_channels == 2 and codec.num_codebooks == 8
+    wav, toks = mg.generate(['youpi', 'lapin dort'], return_tokens=True)
+    assert list(wav.shape) == [2, 2, 64000] and list(toks.shape) == [2, 8, 50] and bool(torch.isfinite(wav).all())
+    assert int(toks.min()) >= 0 and int(toks.max()) < 400
+    # the wrapper's decode of the interleaved codes == the mono codec on the de-interleaved halves
+    left, right = codec.model.decode(toks[:, 0::2]), codec.model.decode(toks[:, 1::2])
+    assert torch.equal(wav, torch.cat([left, right], dim=1))
+    wav = mg.generate_continuation(torch.randn(2, 2, 32000), 32000, ['a', 'b'])
+    assert list(wav.shape) == [2, 2, 64000]
+    wav = mg.generate_continuation(torch.randn(2, 1, 32000), 32000)   # mono prompt is replicated to both channels
+    assert list(wav.shape) == [2, 2, 64000]
+
+
 # ---- AudioGen (reference tests/models/test_audiogen.py): same machinery, 16 kHz codec, 10 s windows, stride 2 s
 @pytest.fixture(scope='module')
 def ag():

@@ -244,3 +244,25 @@ def test_stereo_interleave_wrapper():
     assert codes.shape == (3, 4, 20) and st.frame_rate == 100 and st.num_codebooks == 4
     assert torch.equal(codes[..., 0::2], left) and torch.equal(codes[..., 1::2], right)
     assert torch.equal(st.decode(codes)[:, 1:], mono.decode(right))
+
+
+def test_genmodel_reads_experiment_config_of_the_lm():
+    """BaseGenModel (reference genmodel.py:49-62, builders.py:338-351): an LM loaded from a released checkpoint
+    carries `cfg`; `interleave_stereo_codebooks.use` wraps the codec, `dataset.segment_duration` is max_duration."""
+    from audiocraft_amd.models import AudioGen, MusicGen, builders
+    from audiocraft_amd.models.encodec import InterleaveStereoCompressionModel
+    lm = builders.get_lm_model(dict(dim=16, num_heads=4, num_layers=1, n_q=8, card=400,
+                                    codebooks_pattern={'modeling': 'delay', 'delay': {'delays': [0, 0, 1, 1, 2, 2, 3, 3]}},
+                                    conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 16}},
+                                    fuser={'cross': ['description']}), 'cpu', torch.float32)
+    lm.cfg = {'interleave_stereo_codebooks': {'use': True, 'per_timestep': False}, 'compression_model_n_q': None,
+              'dataset': {'segment_duration': 30}}
+    mg = MusicGen('stereo-stub', builders.get_debug_compression_model('cpu'), lm)
+    assert isinstance(mg.compression_model, InterleaveStereoCompressionModel)
+    assert mg.audio_channels == 2 and mg.compression_model.num_codebooks == 8 and mg.max_duration == 30
+    del lm.cfg
+    with pytest.raises(ValueError):
+        MusicGen('no-duration', builders.get_debug_compression_model('cpu'), lm)
+    ag = AudioGen('plain', builders.get_debug_compression_model('cpu', sample_rate=16000), lm, max_duration=10)
+    assert ag.sample_rate == 16000 and ag.duration == 5 and ag.extend_stride == 2
+    assert builders.ENCODEC_16KHZ['seanet']['ratios'] == [8, 5, 4, 2] and builders.audiogen_lm_cfg()['dim'] == 1536
