@@ -99,7 +99,7 @@ def test_melody_model_with_chroma():
 def test_stereo_musicgen_debug_geometry():
     """Stereo MusicGen (reference encodec.py:397-506 + 8-codebook delay pattern [0,0,1,1,2,2,3,3]): left / right
     through the mono codec, codebooks interleaved per RVQ level; generation and continuation give 2-channel audio."""
-    from audiocraft_amd.models import builders
+    from audiocraft_amd.models import MusicGen, builders
     from audiocraft_amd.models.encodec import InterleaveStereoCompressionModel
     torch.manual_seed(0)
     lm = builders.get_lm_model(dict(dim=32, num_heads=4, num_layers=2, n_q=8, card=400,
