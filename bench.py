@@ -118,7 +118,9 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                                     lo_K=dp if wd == torch.bfloat16 else 0)
                 _C.linear_pair(p0, p1)
                 launches += 1
-                nbytes += wbytes(ent['w_out']) + wbytes(ent['w_xcq'])
+                # algorithmic bytes: W_out + W_cq as in SURVEY.md section 8(d); the launch really streams W_cq twice
+                # over ([W_cq' | W_cq' W_out], +d^2 elements per layer), which shows up in the PMC traffic instead
+                nbytes += wbytes(ent['w_out']) + wbytes(ent['w_cq'])
                 cur ^= 1
                 produce(catt, ent['w_cout'])
             else:
