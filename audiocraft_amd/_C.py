@@ -50,7 +50,7 @@ class LMModelDesc(C.Structure):
 
 class LMState(C.Structure):
     _fields_ = [('Beff', i32), ('B', i32), ('use_cfg', i32), ('Tmax', i32), ('Lc', i32), ('n_prepend', i32),
-                ('S', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
+                ('S', i32), ('n_pos', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
                 ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64)]
@@ -89,7 +89,7 @@ class LinearDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [('q', vp), ('k_cache', vp), ('v_cache', vp), ('kvdtype', i32), ('out', vp), ('out_mode', i32),
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
-                ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('q_stats', vp), ('q_stats_np', i32),
+                ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('cache_rows', i32), ('q_stats', vp), ('q_stats_np', i32),
                 ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp)]
 
 
@@ -273,12 +273,14 @@ def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_
                 q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5):
     """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True; out_rbs / out_col0
     place the head outputs inside a wider buffer).  q_colsum: LayerNorm hook on q (acmi_attn_desc)."""
-    Beff, H, Tcap, hd = k_cache.shape
+    cache_rows, H, Tcap, hd = k_cache.shape
+    Beff = q.shape[0]   # a multiple of cache_rows: n consecutive positions per cache row (prefill)
     d = AttnDesc()
     d.q, d.k_cache, d.v_cache, d.kvdtype = ptr(q), ptr(k_cache), ptr(v_cache), dtype_code(k_cache.dtype)
     d.out, d.out_mode, d.out_dtype = ptr(out), (OUT_TILED if out_tiled else OUT_F32), dtype_code(out.dtype)
     d.out_rbs, d.out_col0 = out_rbs, out_col0
     d.Beff, d.H, d.hd, d.Tcap, d.len, d.len_dev, d.len_bias = Beff, H, hd, Tcap, length, ptr(len_dev), len_bias
+    d.cache_rows = cache_rows
     d.q_stats, d.q_stats_np, d.q_stats_cnt, d.eps = ptr(q_stats), q_np, q_cnt, eps
     d.q_colsum, d.q_bias = ptr(q_colsum), ptr(q_bias)
     check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')

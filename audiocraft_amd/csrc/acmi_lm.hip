@@ -55,6 +55,7 @@ struct LinArgs {
     int kcs, fpw; // tiled path: K tiles per split-K slice, fragments every wave owns (kcs / waves), set by the launcher
     int qkv;      // QKV scatter epilogue
     float* q_out; void* k_cache; void* v_cache; int kv_bf16; int H, hd, Tcap, d; const int* pos;
+    int rpp;      // QKV scatter: rows per position (row gm = position gm / rpp of the call, cache row gm % rpp)
 };
 
 template <typename WT> struct WTr {
@@ -549,7 +550,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
                     p.q_out[(size_t)gm * p.d + f] = v;
                 } else {
                     const int h = f / p.hd, dd = f - h * p.hd;
-                    const size_t ci = (((size_t)gm * p.H + h) * p.Tcap + ex.tpos) * p.hd + dd;
+                    const int pidx = gm / p.rpp, brow = gm - pidx * p.rpp;  // several positions per call (prefill)
+                    const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + ex.tpos + pidx) * p.hd + dd;
                     void* cache = part == 1 ? p.k_cache : p.v_cache;
                     if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v);
                     else reinterpret_cast<float*>(cache)[ci] = v;
@@ -661,6 +663,7 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
 static int launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if (a.ksplit < 1) a.ksplit = 1;
+    if (a.rpp <= 0) a.rpp = a.M;
     ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
     ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 128 && a.a_np * a.a_cnt == a.K),
                  "acmi_linear: folded LayerNorm needs a tiled activation and row statistics (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
@@ -743,6 +746,7 @@ struct AttnArgs {
     const float* q; const void* kc; const void* vc; void* out;
     int out_tiled, out_bf16, out_rbs, out_col0;  // tiled output: K tiles per 16-row block, first column
     int H, Tcap, len; const int* len_dev; int len_bias; float scale;
+    int rpp;      // rows per position: query row b belongs to cache row b % rpp; with len_dev its length grows by b / rpp
     // optional LayerNorm hook on q (the cross-attention query arrives as x W'^T, see acmi_linear_pair):
     //   q <- rstd[b] (q - mean[b] colsum) + bias, mean / rstd of row b from the (mean, M2) partials of x
     const float* q_stats; int q_np, q_cnt, q_K; float q_eps; const float* q_colsum; const float* q_bias;
@@ -764,7 +768,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
-    const int len = p.len_dev ? (*p.len_dev + p.len_bias) : p.len;
+    const int b0 = b % p.rpp, pidx = b / p.rpp;   // several positions per call (prefill): cache row, position index
+    const int len = p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len;
 
     float qv[DPL];
 #pragma unroll
@@ -783,8 +788,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             spm[i] = t.x; spq[i] = t.y;
         }
     }
-    const KT* kb = kc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
-    const KT* vb = vc + ((size_t)b * H + h) * Tcap * HD + c * DPL;
+    const KT* kb = kc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
+    const KT* vb = vc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
 
     float m = -INFINITY, l = 0.f, o[DPL];
 #pragma unroll
@@ -930,6 +935,8 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
     ACMI_REQUIRE(c.out_col0 >= 0 && c.out_col0 % kt == 0 && a.out_rbs * kt >= c.out_col0 + c.H * c.hd,
                  "acmi_attn_decode: tiled output placement col0=%d rbs=%d does not hold %d columns", c.out_col0, a.out_rbs, c.H * c.hd);
     a.H = c.H; a.Tcap = c.Tcap; a.len = c.len; a.len_dev = c.len_dev; a.len_bias = c.len_bias;
+    a.rpp = c.cache_rows > 0 ? c.cache_rows : c.Beff;
+    ACMI_REQUIRE(c.Beff % a.rpp == 0, "acmi_attn_decode: %d query rows are not a multiple of %d cache rows", c.Beff, a.rpp);
     a.scale = 1.0f / sqrtf((float)c.hd);
     if (c.q_colsum != nullptr) {
         ACMI_REQUIRE(c.q_stats != nullptr && c.q_stats_np >= 1 && c.q_stats_np <= 128 && c.q_stats_np * c.q_stats_cnt > 0,
@@ -989,7 +996,7 @@ __device__ __forceinline__ float block_sum(float v, float* sval);
 
 struct EmbedArgs {
     const void* emb[16]; int w_bf16;
-    const int64_t* gen_sequence; int B, K, S, card;
+    const int64_t* gen_sequence; int B, Beff, K, S, card;
     const float* prepend; int P;
     const float* pos_table; float pos_scale;
     const int* pos;
@@ -1000,9 +1007,10 @@ struct EmbedArgs {
 
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     __shared__ float sred[4];
-    const int m = blockIdx.x;
-    const int g = *p.pos;
-    const int b = m % p.B;
+    const int m = blockIdx.x;              // row = position-of-the-call * Beff + CFG row
+    const int pidx = m / p.Beff, m0 = m - pidx * p.Beff;
+    const int g = *p.pos + pidx;
+    const int b = m0 % p.B;
     float loc[8];  // d <= 2048
     float sum = 0.f;
     int cnt = 0;
@@ -1018,7 +1026,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     for (int cch = threadIdx.x; cch < p.d; cch += blockDim.x, ++cnt) {
         float v;
         if (g < p.P) {
-            v = p.prepend[((size_t)m * p.P + g) * p.d + cch];
+            v = p.prepend[((size_t)m0 * p.P + g) * p.d + cch];
         } else {
             v = 0.f;
 #pragma unroll
@@ -1285,7 +1293,7 @@ extern "C" int acmi_sample(const float* logits, int64_t* tokens_out, float* mixe
     return launch_sample(a, (hipStream_t)stream);
 }
 
-__global__ void advance_kernel(int* pos) { if (threadIdx.x == 0 && blockIdx.x == 0) pos[0] += 1; }
+__global__ void advance_kernel(int* pos, int n) { if (threadIdx.x == 0 && blockIdx.x == 0) pos[0] += n; }
 
 // =====================================================================================================
 // one decode position
@@ -1327,17 +1335,18 @@ struct StepCtx {
     int lnm, kt, nkc_d, rbs;   // LayerNorm mode, K tile, K tiles of d, K tiles per row block of the xh buffers
     void* xh; void* xl;        // fragments of the current x
     int np, cnt;               // statistics partials of the current x: np partials of cnt elements
+    int rows;                  // rows of this call (Beff x positions)
 };
 
 // out = act(LayerNorm(x) W'^T + bias): folded into the GEMM, or standardisation kernel + plain GEMM
 static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, const float* colsum, int N) {
     const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
-    p.a_tiled = 1; p.w = w; p.bias = bias; p.M = s->Beff; p.N = N; p.K = m->dim;
+    p.a_tiled = 1; p.w = w; p.bias = bias; p.M = c.rows; p.N = N; p.K = m->dim;
     if (c.lnm == LN_FOLD) {
         p.a = c.xh; p.a_rbs = c.rbs; p.a_lo = (m->wdtype == ACMI_BF16 && fold_uses_lo()) ? c.xl : nullptr;
         p.a_stats = s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
     } else {
-        int rc = launch_ln_tile(s->x, c.xh, m->wdtype, s->Beff, m->dim, m->eps, nullptr, 0, c.st);
+        int rc = launch_ln_tile(s->x, c.xh, m->wdtype, c.rows, m->dim, m->eps, nullptr, 0, c.st);
         if (rc) return rc;
         p.a = c.xh;
     }
@@ -1348,7 +1357,7 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
 static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs, const void* w, int K, void* xh, void* xl) {
     const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
     p.a = a; p.a_tiled = 1; p.a_rbs = a_rbs; p.w = w; p.residual = s->x; p.out = s->x; p.out_mode = ACMI_OUT_F32;
-    p.M = s->Beff; p.N = m->dim; p.K = K;
+    p.M = c.rows; p.N = m->dim; p.K = K;
     if (c.lnm == LN_FOLD) {
         p.stats_out = s->stats;
         p.xt_hi = xh; p.xt_lo = m->wdtype == ACMI_BF16 ? xl : nullptr; p.xt_nkc = c.rbs; p.xt_lo_nkc = c.nkc_d;
@@ -1365,10 +1374,14 @@ static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K) {
 extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int mode, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ACMI_REQUIRE(m && s, "acmi_lm_step: null argument");
-    const int d = m->dim, H = m->num_heads, hd = d / H, M = s->Beff, F = m->ffn_dim;
+    // rows of this call: Beff per position; a PREFILL call may run several consecutive positions at once (row
+    // p * Beff + b = position pos[0] + p of CFG row b): K / V of all of them are in the cache before any attends
+    const int npos = (mode == ACMI_STEP_PREFILL && s->n_pos > 1) ? s->n_pos : 1;
+    const int d = m->dim, H = m->num_heads, hd = d / H, M = s->Beff * npos, F = m->ffn_dim;
     ACMI_REQUIRE(d % H == 0 && d % 16 == 0 && d <= 2048 && F % 4 == 0, "acmi_lm_step: bad dims d=%d H=%d", d, H);
     ACMI_REQUIRE(m->n_q <= 16, "acmi_lm_step: n_q=%d > 16", m->n_q);
     ACMI_REQUIRE(s->Beff == (s->use_cfg ? 2 * s->B : s->B), "acmi_lm_step: Beff/B mismatch");
+    ACMI_REQUIRE(mode == ACMI_STEP_PREFILL || s->n_pos <= 1, "acmi_lm_step: n_pos=%d only with ACMI_STEP_PREFILL", s->n_pos);
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
     int rc;
 
@@ -1377,7 +1390,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     c.kt = wbf ? 32 : 16; c.nkc_d = (d + c.kt - 1) / c.kt;
     c.rbs = s->x_rbs > 0 ? s->x_rbs : c.nkc_d;
     ACMI_REQUIRE(c.rbs >= c.nkc_d, "acmi_lm_step: x_rbs=%d < %d K tiles of d", c.rbs, c.nkc_d);
-    c.xh = s->xn; c.xl = s->xlo; c.np = 1; c.cnt = d;
+    c.xh = s->xn; c.xl = s->xlo; c.np = 1; c.cnt = d; c.rows = M;
     // Cross-attention query without a launch of its own (include/acmi.h, acmi_linear_pair): needs the folded
     // LayerNorm, the [W_cq' | W_cq' W_out] matrices, xh buffers wide enough for [x | att] and a second pair.
     static const bool pair_enabled = !(getenv("ACMI_CROSS_FUSED") != nullptr && getenv("ACMI_CROSS_FUSED")[0] == '0');
@@ -1389,7 +1402,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
 
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
-    e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.K = m->n_q; e.S = s->S; e.card = m->card;
+    e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.Beff = s->Beff; e.K = m->n_q; e.S = s->S; e.card = m->card;
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
     if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = wbf ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
@@ -1402,7 +1415,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         {
             LinArgs a = {};
             a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
-            a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos;
+            a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
             if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
         }
         // self attention over positions [0, g]; output in A-fragment order for the out projection: into `att`,
@@ -1410,7 +1423,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         acmi_attn_desc sa = {};
         sa.q = s->q; sa.k_cache = L.k_cache; sa.v_cache = L.v_cache; sa.kvdtype = m->kvdtype;
         sa.out_mode = ACMI_OUT_TILED; sa.out_dtype = m->wdtype; sa.Beff = M; sa.H = H; sa.hd = hd; sa.Tcap = s->Tmax;
-        sa.len_dev = s->pos; sa.len_bias = 1;
+        sa.len_dev = s->pos; sa.len_bias = 1; sa.cache_rows = s->Beff;
         if (pair) { sa.out = c.xh; sa.out_rbs = c.rbs; sa.out_col0 = c.nkc_d * c.kt; }
         else sa.out = s->att;
         if ((rc = acmi_attn_decode_ex(&sa, stream))) return rc;
@@ -1422,7 +1435,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             acmi_attn_desc ca = {};
             ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
             ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.Beff = M; ca.H = H; ca.hd = hd; ca.Tcap = s->Lc;
-            ca.len = s->Lc;
+            ca.len = s->Lc; ca.cache_rows = s->Beff;
             if (pair) {
                 // ONE launch: x1 = x0 + att W_out^T (fragments of x1 into the other buffer pair: this launch
                 // still reads x0's) and r = [x0 | att] [W_cq' | W_cq' W_out]^T = x1 W_cq'^T
@@ -1465,6 +1478,6 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         a.gen_sequence = s->gen_sequence; a.seq_mask = s->seq_mask; a.S = s->S; a.P = s->prepend ? s->n_prepend : 0;
         return launch_sample(a, st);
     }
-    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, s->pos);
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, s->pos, npos);
     return acmi_check_launch("advance_kernel");
 }

@@ -15,8 +15,8 @@ nothing between steps except replay (and the optional progress callback).
    mode) [out, in] matrices; the 4 output heads are stacked into one [K*card, d] matrix;
  * cross-attention keys/values are projected ONCE per generate() instead of every step
    (reference transformer.py:344-361 recomputes them);
- * prompt / prepended-condition prefill is run position by position through the same step
-   (streaming == batch, reference tests/modules/test_transformer.py:16-49).
+ * prompt / prepended-condition prefill runs through the same step, PREFILL_CHUNK consecutive positions per
+   call as extra rows (streaming == batch, reference tests/modules/test_transformer.py:16-49).
 """
 import ctypes as C
 import math
@@ -296,22 +296,25 @@ class LMModel(nn.Module):
             L.k_cache, L.v_cache = run['k'][li].data_ptr(), run['v'][li].data_ptr()
             if self.has_cross_attention:
                 L.ck_cache, L.cv_cache = run['ck'][li].data_ptr(), run['cv'][li].data_ptr()
-        run['x'] = torch.zeros(Beff, d, **f32)
-        run['q'] = torch.zeros(Beff, d, **f32)
+        # activation rows: one decode position = Beff rows; a prefill call runs PREFILL_CHUNK consecutive positions
+        # (prompt / prepended-condition rows) at once through the same kernels
+        rows = Beff * self.PREFILL_CHUNK
+        run['x'] = torch.zeros(rows, d, **f32)
+        run['q'] = torch.zeros(rows, d, **f32)
         # activations that feed a GEMM directly live in A-fragment order, zero padded
-        run['stats'] = torch.zeros(Beff, max(1, d // 16), 2, **f32)
+        run['stats'] = torch.zeros(rows, max(1, d // 16), 2, **f32)
         # x as raw fragments: two (hi, lo) pairs, the hi buffers twice as wide so that the self-attention output
         # sits next to x ([x | att], the operand of the paired out-projection / cross-query launch)
         kt = _C._tile_params(self.weight_dtype)[1]
         dp = -(-d // kt) * kt
         for name in ('xn', 'xn2'):
-            run[name] = _C.tiled_activation_buffer(Beff, 2 * dp, self.weight_dtype, dev)
+            run[name] = _C.tiled_activation_buffer(rows, 2 * dp, self.weight_dtype, dev)
         for name in ('xlo', 'xlo2'):
-            run[name] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
+            run[name] = _C.tiled_activation_buffer(rows, d, self.weight_dtype, dev)
         run['x_rbs'] = 2 * dp // kt
-        run['r'] = torch.zeros(Beff, d, **f32)
-        run['att'] = _C.tiled_activation_buffer(Beff, d, self.weight_dtype, dev)
-        run['hidden'] = _C.tiled_activation_buffer(Beff, self.ffn_dim, self.weight_dtype, dev)
+        run['r'] = torch.zeros(rows, d, **f32)
+        run['att'] = _C.tiled_activation_buffer(rows, d, self.weight_dtype, dev)
+        run['hidden'] = _C.tiled_activation_buffer(rows, self.ffn_dim, self.weight_dtype, dev)
         run['pos_table'] = _C.pos_table(pk['pos_freq'], Tmax, d)
         run['logits'] = torch.zeros(Beff, self.n_q * self.card, **f32)
         run['step_logits'] = torch.zeros(B, self.n_q, self.card, **f32)
@@ -458,10 +461,8 @@ class LMModel(nn.Module):
         if cross_src is not None:
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
 
-        # ---- prefill: prepended condition rows and prompt steps, position by position, no sampling
-        n_prefill = P + start_offset_sequence - 1
-        for _ in range(n_prefill):
-            _C.lm_step(desc, state, _C.STEP_PREFILL)
+        # ---- prefill: prepended condition rows and prompt steps, PREFILL_CHUNK positions per call, no sampling
+        self._prefill(desc, state, P + start_offset_sequence - 1)
 
         # ---- decode: one hipGraph replay per position
         n_steps = S - start_offset_sequence
@@ -510,6 +511,18 @@ class LMModel(nn.Module):
         self._graph_keepalive = (g, desc, state)
         return g
 
+    PREFILL_CHUNK = 8   # consecutive positions per prefill call (activation buffers hold Beff * PREFILL_CHUNK rows)
+
+    def _prefill(self, desc, state, n_positions: int):
+        """Run `n_positions` input-only positions (prepended conditions, prompt tokens): the same kernels as a
+        decode position, several consecutive positions per call as extra rows (acmi_lm_state.n_pos)."""
+        done = 0
+        while done < n_positions:
+            state.n_pos = min(self.PREFILL_CHUNK, n_positions - done)
+            _C.lm_step(desc, state, _C.STEP_PREFILL)
+            done += state.n_pos
+        state.n_pos = 1
+
     # ------------------------------------------------------------------------------------- teacher forcing
     @torch.no_grad()
     def forward_steps(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
@@ -534,8 +547,7 @@ class LMModel(nn.Module):
         run['pos'].zero_()
         if cross_src is not None:
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
-        for _ in range(P):
-            _C.lm_step(desc, state, _C.STEP_PREFILL)
+        self._prefill(desc, state, P)
         outs = []
         for i in range(S):
             _C.lm_step(desc, state, _C.STEP_DECODE)

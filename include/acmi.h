@@ -174,6 +174,9 @@ typedef struct {
     int Lc;                 /* cross-attention source length (0 if none) */
     int n_prepend;          /* P: rows of `prepend` consumed as inputs before the first token step */
     int S;                  /* pattern sequence length (T + max_delay + 1) */
+    int n_pos;              /* ACMI_STEP_PREFILL only: consecutive positions run by one call (0 / 1 = one).  Every
+                               activation buffer below then holds n_pos * Beff rows (row p * Beff + b = position
+                               pos[0] + p of CFG row b) and pos[0] advances by n_pos */
     int64_t* gen_sequence;  /* [B, K, S] int64; -1 = not generated yet (lm.py:523-534) */
     const uint8_t* seq_mask;/* [K, S] pattern validity mask (codebooks_patterns.py:138-151) */
     const float* prepend;   /* [Beff, P, d] f32 prepended condition rows (conditioners.py:1739-1741) or NULL */
@@ -198,7 +201,7 @@ typedef struct {
     uint64_t seed;
 } acmi_lm_state;
 
-#define ACMI_STEP_PREFILL 0 /* run the layers at position g, no head / sampling (prompt + prepend rows) */
+#define ACMI_STEP_PREFILL 0 /* run the layers at position g (.. g + n_pos - 1), no head / sampling (prompt + prepend rows) */
 #define ACMI_STEP_DECODE 1  /* layers + out_norm + heads + CFG + sampling + pattern write-back */
 
 /* One position of LMModel._sample_next_token / LMModel.forward / StreamingTransformer.forward in
@@ -306,6 +309,9 @@ typedef struct {
     int out_rbs;            /* tiled output: K tiles between 16-row blocks of `out` (0 = ceil(H*hd / KT)) */
     int out_col0;           /* tiled output: first column (a multiple of KT), e.g. d for the att half of [x | att] */
     int Beff, H, hd, Tcap, len; const int* len_dev; int len_bias;
+    int cache_rows;         /* rows of the K / V cache (0 = Beff).  Beff = n * cache_rows query rows: row b attends in cache
+                               row b % cache_rows and, with len_dev, over b / cache_rows more positions (n consecutive
+                               positions of a prompt in one call) */
     /* q_colsum (or NULL): q holds x W'^T for the RAW row x (acmi_linear_pair); the kernel first applies
      *   q <- rstd (q - mean * q_colsum) + q_bias      (q_colsum, q_bias: [H*hd] f32, both required)
      * with mean / rstd of row b combined from q_stats[b][np][2] ((mean, M2) partials of np * cnt elements): the
