@@ -1,0 +1,686 @@
+// Skinny GEMMs of the MusicGen LM decode step for gfx950 (CDNA4, wave64): lin_tiled_kernel / lin_pair_kernel
+// (tiled activation x tiled weight, LayerNorm folded into the epilogue), lin_rowmajor_kernel (row-major f32
+// activation staged through LDS) and ln_tile_kernel (LayerNorm as a kernel of its own).
+// Reference semantics: audiocraft/modules/transformer.py:315-451, 550-574 (every F.linear / nn.LayerNorm of a
+// layer), audiocraft/models/lm.py:260-262 (out_norm + heads).
+#include "acmi_lm_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+// =====================================================================================================
+// skinny GEMM   out[M,N] = act(LN?(a)[M,K] @ W[N,K]^T + bias) + residual
+//
+// One 16-feature n-tile per workgroup, K split across its waves.  Weights are stored as 1 KB MFMA
+// B-fragments (include/acmi.h "tiled weight"), so each fragment is ONE fully coalesced non-temporal
+// 64 x 16 B load.  Activations produced on the path (residual stream as raw hi / lo fragments, attention
+// output, FFN hidden) arrive already in A-fragment order and are loaded like the weights
+// (lin_tiled_kernel); row-major f32 activations are staged through LDS once per workgroup -- one wave per
+// row, which is also where an explicit LayerNorm runs -- and read back with ds_read_b128
+// (lin_rowmajor_kernel).  Cross-wave reduction through LDS in a fixed order (deterministic), then the
+// fused epilogue.
+// =====================================================================================================
+
+__device__ __forceinline__ u32x4 ld_frag_nt(const u32x4* p) { return __builtin_nontemporal_load(p); }
+
+__device__ __forceinline__ void mma_frag(const u32x4& a, const u32x4& b, f32x4& acc, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_frag(const u32x4& a, const u32x4& b, f32x4& acc, float) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Staging of one activation row by one wave: row load (issued by the caller BEFORE the weight fragments:
+// vmcnt retires in order, so the row must not queue behind HBM-latency weight loads), then LayerNorm
+// (ln_mode 1: standardise only -- the affine part is folded into the weights on the host; 2: affine here)
+// and the store to LDS in the weight's element type.
+#define ACMI_STAGE_JMAX 8  // Kpad <= 2048
+
+__device__ __forceinline__ void load_row(const float* __restrict__ xrow, int K, int lane, float4 (&v)[ACMI_STAGE_JMAX]) {
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+        const int k = (lane + 64 * j) * 4;
+        v[j] = (xrow != nullptr && k < K) ? *reinterpret_cast<const float4*>(xrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <typename WT>
+__device__ __forceinline__ void norm_store_row(float4 (&v)[ACMI_STAGE_JMAX], int K, int Kpad, int ln_mode,
+                                               const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                               unsigned char* dst, int lane) {
+    constexpr int JMAX = ACMI_STAGE_JMAX;
+    if (ln_mode != 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        const float mean = wave_sum(s) / (float)K;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            if ((lane + 64 * j) * 4 < K) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)K + eps);
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int k = (lane + 64 * j) * 4;
+            if (k < K) {
+                v[j].x = (v[j].x - mean) * rstd; v[j].y = (v[j].y - mean) * rstd;
+                v[j].z = (v[j].z - mean) * rstd; v[j].w = (v[j].w - mean) * rstd;
+                if (ln_mode == 2) {
+                    const float4 gg = *reinterpret_cast<const float4*>(g + k);
+                    const float4 bb = *reinterpret_cast<const float4*>(b + k);
+                    v[j].x = v[j].x * gg.x + bb.x; v[j].y = v[j].y * gg.y + bb.y;
+                    v[j].z = v[j].z * gg.z + bb.z; v[j].w = v[j].w * gg.w + bb.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int k = (lane + 64 * j) * 4;
+        if (k < Kpad) {
+            if (sizeof(WT) == 2)
+                *reinterpret_cast<uint2*>(dst + (size_t)k * 2) = make_uint2(pack_bf16x2(v[j].x, v[j].y), pack_bf16x2(v[j].z, v[j].w));
+            else
+                *reinterpret_cast<float4*>(dst + (size_t)k * 4) = v[j];
+        }
+    }
+}
+
+// Row standardisation as its own tiny kernel (one wave per row): x [M, K] f32 row-major ->
+// ((x - mean) * rstd) in A-fragment order, element type WT.  The affine part of the LayerNorm lives in
+// the consuming matrix (see acmi_lm_layer).  Doing this once per LayerNorm instead of once per GEMM
+// workgroup takes ~5 us of redundant VALU + LDS staging off the critical path of every GEMM workgroup.
+template <typename WT>
+__global__ __launch_bounds__(64) void ln_tile_kernel(float* __restrict__ x, WT* __restrict__ out, int M, int K, int nkc,
+                                                     float eps, const float* __restrict__ slabs, int nslabs) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if (m >= M) return;
+    float4 v[ACMI_STAGE_JMAX];
+    load_row(x + (size_t)m * K, K, lane, v);
+    if (nslabs > 0) {
+        // the producer GEMM was split over K: finish it here (fixed order => deterministic) and write the row back
+        for (int sidx = 0; sidx < nslabs; ++sidx) {
+            float4 t[ACMI_STAGE_JMAX];
+            load_row(slabs + ((size_t)sidx * M + m) * K, K, lane, t);
+#pragma unroll
+            for (int j = 0; j < ACMI_STAGE_JMAX; ++j) { v[j].x += t[j].x; v[j].y += t[j].y; v[j].z += t[j].z; v[j].w += t[j].w; }
+        }
+#pragma unroll
+        for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+            const int k = (lane + 64 * j) * 4;
+            if (k < K) *reinterpret_cast<float4*>(x + (size_t)m * K + k) = v[j];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum(s) / (float)K;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+        if ((lane + 64 * j) * 4 < K) {
+            const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+            s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)K + eps);
+#pragma unroll
+    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+        const int k = (lane + 64 * j) * 4;
+        if (k < K) {
+            const float y0 = (v[j].x - mean) * rstd, y1 = (v[j].y - mean) * rstd;
+            const float y2 = (v[j].z - mean) * rstd, y3 = (v[j].w - mean) * rstd;
+            WT* dst = out + tiled_index<WT>(m, k, nkc);  // 4 consecutive k stay inside one lane fragment
+            if (sizeof(WT) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+            else *reinterpret_cast<float4*>(dst) = make_float4(y0, y1, y2, y3);
+        }
+    }
+}
+
+int acmi_launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps, const float* slabs, int nslabs,
+                        hipStream_t st) {
+    ACMI_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && K <= 2048, "acmi_ln_tile: needs K %% 4 == 0 and K <= 2048 (K=%d)", K);
+    if (wdtype == ACMI_BF16)
+        hipLaunchKernelGGL(ln_tile_kernel<bf16_t>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<bf16_t*>(out), M, K,
+                           (K + 31) / 32, eps, slabs, nslabs);
+    else
+        hipLaunchKernelGGL(ln_tile_kernel<float>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<float*>(out), M, K,
+                           (K + 15) / 16, eps, slabs, nslabs);
+    return acmi_check_launch("ln_tile_kernel");
+}
+
+extern "C" int acmi_ln_tile_reduce(float* x, const float* slabs, int nslabs, void* out, int wdtype, int M, int K, float eps,
+                                   void* stream) {
+    ACMI_REQUIRE(nslabs >= 0 && (nslabs == 0 || slabs != nullptr), "acmi_ln_tile_reduce: bad slabs");
+    return acmi_launch_ln_tile(x, out, wdtype, M, K, eps, slabs, nslabs, (hipStream_t)stream);
+}
+
+extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream) {
+    return acmi_launch_ln_tile(const_cast<float*>(x), out, wdtype, M, K, eps, nullptr, 0, (hipStream_t)stream);
+}
+
+// Folded LayerNorm, row statistics: a "group" is 4 rows (16 lanes each); every lane fetches up to 8 of the
+// producer's equal-count (mean, M2) partials of its row (np <= 128), combined later with Chan's formula.
+// Layout stats[row][np][2]: the partials of a row are contiguous, so a wave's load touches 4 lines, not 64
+// (with [np][row][2] the gather cost ~2 us per consuming launch).
+__device__ __forceinline__ void rowstat_load(const float* __restrict__ stats, int np, int M, int row0, int lane,
+                                             float (&pm)[8], float (&pq)[8]) {
+    const int row = min(row0 + (lane >> 4), M - 1), jj = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // 16 consecutive partials of one row per 16 lanes: one 128-B line
+        const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)row * np + min(jj + 16 * i, np - 1)) * 2);
+        pm[i] = t.x; pq[i] = t.y;
+    }
+}
+__device__ __forceinline__ void rowstat_finish(const float (&pm)[8], const float (&pq)[8], int np, int cnt, int K, float eps,
+                                               int lane, float* __restrict__ dst /* [4][2] */) {
+    const int jj = lane & 15;
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm += (jj + 16 * i < np) ? pm[i] : 0.f;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+    const float mean = sm / (float)np;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float dlt = pm[i] - mean;
+        q2 += (jj + 16 * i < np) ? pq[i] + (float)cnt * dlt * dlt : 0.f;
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) q2 += __shfl_xor(q2, off, 64);
+    if (jj == 0) {
+        dst[(lane >> 4) * 2] = mean;
+        dst[(lane >> 4) * 2 + 1] = 1.0f / sqrtf(q2 / (float)K + eps);
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// lin_rowmajor_kernel: row-major f32 activation, staged (and optionally LayerNorm-ed) through LDS.
+// The general-purpose form: conditioner projections, the one-off cross-attention K / V projection, tests.
+// One workgroup = 16 output features; wave w stages rows w, w + nw, ... of each 16-row block and owns the K
+// fragments kc = w, w + nw, ... (<= TMAX of them, held in registers for all row blocks: K <= 2048).
+// -----------------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ __launch_bounds__(1024) void lin_rowmajor_kernel(const LinArgs p) {
+    constexpr int KT = WTr<WT>::KT;
+    constexpr int TMAX = sizeof(WT) == 2 ? 4 : 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float* red = reinterpret_cast<float*>(smem);       // [nw][256]
+    unsigned char* As = smem + (size_t)nw * 1024;      // [16][RS] staged activation
+    const int nl = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 16, NKC = p.NKC, Kpad = NKC * KT;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)blockIdx.x * NKC * 64 + lane;
+
+    // the first activation row is requested BEFORE the weight fragments: vmcnt retires in order, so the row
+    // must not queue behind HBM-latency weight loads
+    float4 xv[ACMI_STAGE_JMAX];
+    load_row(wave < p.M && wave < 16 ? reinterpret_cast<const float*>(p.a) + (size_t)wave * p.K : nullptr, p.K, lane, xv);
+    u32x4 wv[TMAX];
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+        const int kc = wave + i * nw;
+        wv[i] = kc < NKC ? ld_frag_nt(wt + (size_t)kc * 64) : u32x4{0u, 0u, 0u, 0u};
+    }
+
+    for (int m0 = 0; m0 < p.M; m0 += 16) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = wave; r < 16; r += nw) {
+            const int m = m0 + r;
+            if (m0 != 0 || r != wave)
+                load_row(m < p.M ? reinterpret_cast<const float*>(p.a) + (size_t)m * p.K : nullptr, p.K, lane, xv);
+            norm_store_row<WT>(xv, p.K, Kpad, p.ln_mode, p.ln_g, p.ln_b, p.eps, As + (size_t)r * p.RS, lane);
+        }
+        __syncthreads();
+        const unsigned char* arow = As + (size_t)nl * p.RS + (size_t)kg * 16;
+#pragma unroll
+        for (int i = 0; i < TMAX; ++i) {
+            const int kc = wave + i * nw;
+            if (kc < NKC) {
+                const u32x4 av = *reinterpret_cast<const u32x4*>(arow + (size_t)kc * 64);
+                mma_frag(av, wv[i], acc, WT());
+            }
+        }
+        // deterministic cross-wave reduction + epilogue
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * 256 + lane * 4 + r] = acc[r];
+        __syncthreads();
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+            const int nn = t & 15, mm = t >> 4;
+            const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
+            float v = 0.f;
+            for (int w = 0; w < nw; ++w) v += red[w * 256 + idx];
+            const int gm = m0 + mm, gn = n0 + nn;
+            if (gm >= p.M || gn >= p.N) continue;
+            if (p.bias) v += p.bias[gn];
+            if (p.act == 1) v = gelu_exact(v);
+            const size_t oi = (size_t)gm * p.N + gn;
+            if (p.residual) v += p.residual[oi];
+            if (p.out_mode == ACMI_OUT_TILED) st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
+            else if (p.out_mode == ACMI_OUT_BF16) reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
+            else reinterpret_cast<float*>(p.out)[oi] = v;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename WT>
+static int launch_rowmajor(LinArgs& a, hipStream_t st) {
+    constexpr int KT = WTr<WT>::KT;
+    a.NKC = (a.K + KT - 1) / KT;
+    a.NKC_out = (a.N + KT - 1) / KT;
+    ACMI_REQUIRE(a.K % 4 == 0 && a.NKC * KT <= 2048, "acmi_linear: row-major activation needs K %% 4 == 0 and K <= 2048 (K=%d)", a.K);
+    ACMI_REQUIRE(a.stats_out == nullptr && a.xt_hi == nullptr && a.ksplit <= 1 && a.colsum == nullptr && !a.qkv,
+                 "acmi_linear: statistics / raw tiled outputs / split-K / folded LayerNorm need a tiled activation");
+    int nw = a.NKC < 16 ? a.NKC : 16;
+    if (nw < 4) nw = 4;
+    a.RS = a.NKC * KT * (int)sizeof(WT) + 16;
+    const size_t lds = (size_t)nw * 1024 + (size_t)16 * a.RS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_rowmajor_kernel<WT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
+            return ACMI_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lin_rowmajor_kernel<WT>), dim3((a.N + 15) / 16), dim3(nw * 64), lds, st, a);
+    return acmi_check_launch("lin_rowmajor_kernel");
+}
+
+// =====================================================================================================
+// lin_tiled_kernel: the decode step's GEMM  (tiled activation x tiled weight)
+// =====================================================================================================
+// One workgroup = 16 output features (x one K slice with split-K); its nw <= 8 waves own the K fragments
+// kc = wave, wave + nw, ...  Every wave requests everything it will ever need up front, in the order in which
+// it is consumed -- (weight fragment, activation fragments) pairs, then the LayerNorm row statistics, then the
+// epilogue operands of its thread -- because vmcnt retires in order and anything requested later (a cold bias
+// vector in the epilogue, say) is a full HBM round trip on the tail of the launch.  Absent operands are
+// replaced by the address of the wave's own first weight fragment (already in flight: no extra line, page or
+// hot spot), so the prologue is branch free.
+//   LN 0: plain   1: folded LayerNorm, single-term activation   2: folded LayerNorm, hi + lo activation
+//      3: no LayerNorm, hi + lo activation for the first lo_split K fragments (x | a concatenated along K)
+struct TlExtras {
+    float pm[8], pq[8];     // LN > 0: (mean, M2) partials of this lane's statistics row
+    float bias, colsum, res;  // epilogue operands of this thread's first output element
+    int tpos;                 // QKV: the position the new K / V rows are stored at
+};
+
+template <typename WT, int MT, int LN, int C>
+__device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, const u32x4* __restrict__ at,
+                                         const u32x4* __restrict__ al, int mts, int mtl, int mtv, int kc0, int nw,
+                                         const float* __restrict__ st_ptr, int np,
+                                         const float* __restrict__ pb, const float* __restrict__ pc,
+                                         const float* __restrict__ pr, const int* __restrict__ ppos, f32x4 (&acc)[MT],
+                                         TlExtras& ex) {
+    constexpr bool HL = LN == 2 || LN == 3;
+    const int lane = threadIdx.x & 63;
+    u32x4 bv[C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int ko = (kc0 + i * nw) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
+        bv[i] = ld_frag_nt(wt + ko + lane);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {  // row blocks beyond M re-read the last valid one (their results are dropped)
+            const int ub = min(u, mtv - 1);
+            av[u][i] = (at + (ub * mts + ko))[lane];
+            if (LN == 2) lv[u][i] = (al + (ub * mtl + ko))[lane];
+            if (LN == 3)  // fragments past lo_split have no lo term: re-read the last one (L1 hit), zeroed below
+                lv[u][i] = (al + (ub * mtl + min(kc0 + i * nw, p.lo_split - 1) * 64))[lane];
+        }
+    }
+    // (the asm keeps these loop-invariant loads here, behind the weight stream, instead of in front of the K loop)
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    st_ptr += opaque0; pb += opaque0; pc += opaque0; pr += opaque0; ppos += opaque0;
+    if (LN == 1 || LN == 2) {
+        const int jj = (int)(threadIdx.x & 15);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float2 t = *reinterpret_cast<const float2*>(st_ptr + min(jj + 16 * i, np - 1) * 2);
+            ex.pm[i] = t.x; ex.pq[i] = t.y;
+        }
+    }
+    ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos;
+    __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            mma_frag(av[u][i], bv[i], acc[u], WT());
+            if (LN == 3 && kc0 + i * nw >= p.lo_split) lv[u][i] = u32x4{0u, 0u, 0u, 0u};
+            if (HL) mma_frag(lv[u][i], bv[i], acc[u], WT());
+        }
+}
+
+template <typename WT, int MT, int LN>
+__device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const int kslice, const int ksp) {
+    constexpr int D = (LN == 2 || LN == 3) ? 2 : 1;
+    constexpr bool FOLD = LN == 1 || LN == 2;
+    // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
+    // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
+    // VGPRs of a 2-waves-per-SIMD launch
+    constexpr int CQ = (LN > 0 ? 44 : 52) / (1 + MT * D);
+    constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
+    float* red = reinterpret_cast<float*>(smem);        // [MT][nw][256] partial accumulators
+    float* rowstat = red + (size_t)MT * nw * 256;       // [16 MT][2] mean, rstd
+    const int n0 = ntile * 16, NKC = p.NKC;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
+    const int mts = p.a_rbs * 64, mtl = p.alo_rbs * 64;  // fragment lanes between consecutive 16-row blocks (a, a_lo)
+    const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
+    const float* own = reinterpret_cast<const float*>(wt + (size_t)(kbeg + min(wave, kcs - 1)) * 64 + lane);
+
+    // one group of MT 16-row blocks per workgroup (grid.z): no loop around the body, so that nothing of the
+    // epilogue is hoisted in front of the first load
+    {
+        const int mg = (int)blockIdx.z * 16 * MT;
+        const int mtv = min(MT, (p.M - mg + 15) >> 4);
+        f32x4 accs[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mg >> 4) * mts);
+        const u32x4* al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mg >> 4) * mtl) : nullptr;
+        // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
+        const int ngroups = 4 * mtv;
+        const float* st_ptr = own;
+        if (FOLD) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
+        // this thread's first epilogue element
+        const int e0 = (int)threadIdx.x, eu = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
+        const int egn = min(n0 + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
+        const float* pb = p.bias != nullptr ? p.bias + egn : own;
+        const float* pc = p.colsum != nullptr ? p.colsum + egn : own;
+        const float* pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
+        const int* ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+        TlExtras ex;
+
+        int kc = kbeg + wave, rem = p.fpw;              // fragments every wave owns (+ a ragged tail)
+#define ACMI_TL_RUN(Cn)                                                                                                 \
+        while (rem >= Cn) {                                                                                            \
+            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
+            kc += Cn * nw; rem -= Cn;                                                                                  \
+        }
+        if (CMAX >= 24) { ACMI_TL_RUN(24) }
+        if (CMAX >= 16) { ACMI_TL_RUN(16) }
+        if (CMAX >= 12) { ACMI_TL_RUN(12) }
+        if (CMAX >= 8) { ACMI_TL_RUN(8) }
+        if (CMAX >= 6) { ACMI_TL_RUN(6) }
+        if (CMAX >= 4) { ACMI_TL_RUN(4) }
+        ACMI_TL_RUN(2)
+        ACMI_TL_RUN(1)
+#undef ACMI_TL_RUN
+        if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
+            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
+
+        // ---- deterministic cross-wave reduction through LDS
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)u * nw + wave) * 256 + lane * 4 + r] = accs[u][r];
+        if (FOLD) {
+            // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
+            if (wave < ngroups) rowstat_finish(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8);
+            for (int g = wave + nw; g < ngroups; g += nw) {
+                rowstat_load(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
+                rowstat_finish(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8);
+            }
+        }
+        __syncthreads();
+
+        // ---- epilogue: one output element per thread and pass
+        for (int e = (int)threadIdx.x; e < 256 * mtv; e += (int)blockDim.x) {
+            const int u = e >> 8, mm = (e >> 4) & 15, nn = e & 15;
+            const bool first = e == (int)threadIdx.x;
+            const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
+            float v = 0.f;
+            for (int w = 0; w < nw; ++w) v += red[((size_t)u * nw + w) * 256 + idx];
+            const int gm = mg + 16 * u + mm, gn = n0 + nn;
+            const bool valid = gm < p.M && gn < p.N;
+            if (ksp > 1) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
+                if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
+                continue;
+            }
+            size_t oi = 0;
+            if (valid) {
+                if (FOLD) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
+                    const float* rs = rowstat + (u * 16 + mm) * 2;
+                    v = rs[1] * (v - rs[0] * (first ? ex.colsum : p.colsum[gn]));
+                }
+                if (p.bias) v += first ? ex.bias : p.bias[gn];
+                if (!p.qkv) {
+                    if (p.act == 1) v = gelu_exact(v);
+                    oi = (size_t)gm * p.N + gn;
+                    if (p.residual) v += first ? ex.res : p.residual[oi];
+                }
+            }
+            if (p.stats_out != nullptr) {
+                // (mean, M2) of this workgroup's 16 output features per row, for the LayerNorm of the consumer
+                float sm = valid ? v : 0.f;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+                const float mb = sm * (1.0f / 16.0f);
+                float dq = valid ? (v - mb) * (v - mb) : 0.f;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) dq += __shfl_xor(dq, off, 64);
+                if (nn == 0 && gm < p.M)
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> 4) + ntile) * 2) = make_float2(mb, dq);
+            }
+            if (!valid) continue;
+            if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
+                const size_t ti = tiled_index<WT>(gm, gn, p.xt_nkc);
+                if (sizeof(WT) == 2) {
+                    const bf16_t hi = f32_to_bf16(v);
+                    reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
+                    if (p.xt_lo != nullptr)
+                        reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<WT>(gm, gn, p.xt_lo_nkc)] = f32_to_bf16(v - bf16_to_f32(hi));
+                } else {
+                    reinterpret_cast<float*>(p.xt_hi)[ti] = v;
+                }
+            }
+            if (p.qkv) {
+                const int part = gn / p.d, f = gn - part * p.d;
+                if (part == 0) {
+                    p.q_out[(size_t)gm * p.d + f] = v;
+                } else {
+                    const int h = f / p.hd, dd = f - h * p.hd;
+                    const int pidx = gm / p.rpp, brow = gm - pidx * p.rpp;  // several positions per call (prefill)
+                    const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + ex.tpos + pidx) * p.hd + dd;
+                    void* cache = part == 1 ? p.k_cache : p.v_cache;
+                    if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v);
+                    else reinterpret_cast<float*>(cache)[ci] = v;
+                }
+            } else if (p.out_mode == ACMI_OUT_TILED) {
+                st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
+            } else if (p.out_mode == ACMI_OUT_BF16) {
+                reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
+            } else {
+                reinterpret_cast<float*>(p.out)[oi] = v;
+            }
+        }
+    }
+}
+
+template <typename WT, int MT, int LN>
+__global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
+    tl_body<WT, MT, LN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
+// (plain), the rest run p1 (LN 3: x | a concatenated along K, no LayerNorm).  Used for
+//   x1 = x0 + att W_out^T   and   r = [x0 | att] [W_cq' | W_cq' W_out]^T  (= x1 W_cq'^T, the cross-attention
+// query before its LayerNorm statistics are applied), see acmi_lm_step.
+template <typename WT, int MT, int LNB>
+__global__ __launch_bounds__(512) void lin_pair_kernel(const LinArgs p0, const LinArgs p1, const int tiles0) {
+    if ((int)blockIdx.x < tiles0) tl_body<WT, MT, 0>(p0, (int)blockIdx.x, 0, 1);
+    else tl_body<WT, MT, LNB>(p1, (int)blockIdx.x - tiles0, 0, 1);
+}
+
+// Workgroup size.  (1) Waves are not free: the dispatcher starts ~1.25 waves / ns (a 288-workgroup x 16-wave
+// launch with no loads at all takes 6.2 us), so a wave should own ~12 fragments or more, all of them requested
+// before its first wait.  (2) The kernel needs > 128 VGPRs for that, i.e. a CU holds 8 waves: nw in {8, 4, 2, 1}
+// packs 1, 2, 4, 8 workgroups per CU exactly, and the grid must fit the 256 CUs in ONE round (a 288-workgroup
+// grid of 6-wave workgroups runs 256 + 32: the launch takes twice as long).
+static int tiled_waves(int tiles, int frags) {
+    int nw = tiles <= 256 ? 8 : (tiles <= 512 ? 4 : (tiles <= 1024 ? 2 : 1));
+    while (nw > 1 && frags < 12 * nw) nw >>= 1;
+    static const char* e = getenv("ACMI_LIN_NW");
+    if (e && atoi(e) > 0 && atoi(e) < nw) nw = atoi(e);
+    return nw;
+}
+
+template <typename WT>
+static int tiled_prepare(LinArgs& a) {
+    constexpr int KT = WTr<WT>::KT;
+    a.NKC = (a.K + KT - 1) / KT;
+    a.NKC_out = (a.N + KT - 1) / KT;
+    if (a.ksplit < 1 || a.NKC % a.ksplit != 0) a.ksplit = 1;
+    if (a.a_rbs <= 0) a.a_rbs = a.NKC;
+    if (a.alo_rbs <= 0) a.alo_rbs = a.lo_split > 0 ? a.lo_split : a.NKC;  // a lo buffer holds only the columns that have one
+    ACMI_REQUIRE(a.a_rbs >= a.NKC, "acmi_linear: a_rbs=%d < K tiles %d", a.a_rbs, a.NKC);
+    ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
+    ACMI_REQUIRE(a.ksplit == 1 || (!a.qkv && a.stats_out == nullptr && a.xt_hi == nullptr),
+                 "acmi_linear: split-K is incompatible with QKV scatter / stats_out / xt_hi");
+    return ACMI_OK;
+}
+
+template <typename WT, int MT, int LN>
+static int launch_tiled_t(LinArgs& a, hipStream_t st) {
+    int rc = tiled_prepare<WT>(a);
+    if (rc) return rc;
+    const int tiles = ((a.N + 15) / 16) * a.ksplit, frags = a.NKC / a.ksplit;
+    const int nw = tiled_waves(tiles, frags);
+    a.kcs = frags; a.fpw = frags / nw;
+    const size_t lds = (size_t)MT * nw * 1024 + (size_t)MT * 128;
+    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN>), dim3((a.N + 15) / 16, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)), dim3(nw * 64), lds, st, a);
+    return acmi_check_launch("lin_tiled_kernel");
+}
+
+template <typename WT>
+static int launch_tiled(LinArgs& a, hipStream_t st) {
+    const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);  // 1, 2 or 4 16-row blocks share each weight fragment
+    const int ln = a.colsum == nullptr ? (a.lo_split > 0 ? 3 : 0) : (a.a_lo != nullptr ? 2 : 1);
+#define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv>(a, st);
+    ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2) ACMI_TL_CASE(1, 3)
+    ACMI_TL_CASE(2, 0) ACMI_TL_CASE(2, 1) ACMI_TL_CASE(2, 2) ACMI_TL_CASE(2, 3)
+    ACMI_TL_CASE(4, 0) ACMI_TL_CASE(4, 1) ACMI_TL_CASE(4, 2) ACMI_TL_CASE(4, 3)
+#undef ACMI_TL_CASE
+    return ACMI_EINVAL;
+}
+
+// p0 (plain tiled GEMM) and p1 (x | a concatenated along K, hi + lo for the x part) in one launch
+template <typename WT>
+static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
+    int rc;
+    if ((rc = tiled_prepare<WT>(p0)) || (rc = tiled_prepare<WT>(p1))) return rc;
+    ACMI_REQUIRE(p0.M == p1.M && p0.ksplit == 1 && p1.ksplit == 1 && !p0.qkv && !p1.qkv && p0.colsum == nullptr &&
+                 p1.colsum == nullptr && p0.a_lo == nullptr && (p1.a_lo == nullptr || (p1.lo_split > 0 && p1.lo_split <= p1.NKC)),
+                 "acmi_linear_pair: bad operands");
+    const bool hl = p1.a_lo != nullptr;  // f32 activations are a single term
+    const int t0 = (p0.N + 15) / 16, t1 = (p1.N + 15) / 16;
+    const int nw = tiled_waves(t0 + t1, p0.NKC > p1.NKC ? p0.NKC : p1.NKC);  // sized for the longer K
+    p0.kcs = p0.NKC; p0.fpw = p0.NKC / nw;
+    p1.kcs = p1.NKC; p1.fpw = p1.NKC / nw;
+    const int mt = p0.M > 32 ? 4 : (p0.M > 16 ? 2 : 1);
+    const size_t lds = (size_t)mt * nw * 1024 + (size_t)mt * 128;
+    const dim3 grid(t0 + t1, 1, (p0.M + 16 * mt - 1) / (16 * mt)), block(nw * 64);
+#define ACMI_PAIR_CASE(MTv)                                                                              \
+    if (mt == MTv) {                                                                                     \
+        if (hl) hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 3>), grid, block, lds, st, p0, p1, t0);      \
+        else hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 0>), grid, block, lds, st, p0, p1, t0);         \
+    }
+    ACMI_PAIR_CASE(1) ACMI_PAIR_CASE(2) ACMI_PAIR_CASE(4)
+#undef ACMI_PAIR_CASE
+    return acmi_check_launch("lin_pair_kernel");
+}
+
+int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
+    ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.ksplit < 1) a.ksplit = 1;
+    if (a.rpp <= 0) a.rpp = a.M;
+    ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
+    ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 128 && a.a_np * a.a_cnt == a.K),
+                 "acmi_linear: folded LayerNorm needs a tiled activation and row statistics (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
+    ACMI_REQUIRE(a.colsum == nullptr || a.ksplit == 1, "acmi_linear: folded LayerNorm cannot be combined with split-K");
+    if (a.a_tiled) return wdtype == ACMI_BF16 ? launch_tiled<bf16_t>(a, st) : launch_tiled<float>(a, st);
+    return wdtype == ACMI_BF16 ? launch_rowmajor<bf16_t>(a, st) : launch_rowmajor<float>(a, st);
+}
+
+extern "C" int acmi_linear(const void* a, int a_mode, const float* ln_g, const float* ln_b, float eps, const void* w,
+                           int wdtype, const float* bias, const float* residual, void* out, int out_mode, int act, int M,
+                           int N, int K, void* stream) {
+    LinArgs p = {};
+    p.a = a; p.a_tiled = a_mode == ACMI_A_TILED;
+    ACMI_REQUIRE(a_mode >= 0 && a_mode <= 2, "acmi_linear: bad a_mode %d", a_mode);
+    ACMI_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "acmi_linear: ln_g and ln_b go together");
+    p.ln_mode = ln_g ? 2 : (a_mode == ACMI_A_ROWMAJOR_F32_NORM ? 1 : 0);
+    p.ln_g = ln_g; p.ln_b = ln_b; p.eps = eps;
+    p.w = w; p.bias = bias; p.residual = residual; p.out = out; p.out_mode = out_mode; p.act = act;
+    p.M = M; p.N = N; p.K = K;
+    return acmi_launch_lin(p, wdtype, (hipStream_t)stream);
+}
+
+int acmi_launch_pair(LinArgs& p0, LinArgs& p1, int wdtype, hipStream_t st) {
+    return wdtype == ACMI_BF16 ? launch_pair<bf16_t>(p0, p1, st) : launch_pair<float>(p0, p1, st);
+}
+
+static int desc_to_args(const acmi_linear_desc& c, LinArgs& p) {
+    ACMI_REQUIRE(c.a_mode >= 0 && c.a_mode <= 2, "acmi_linear: bad a_mode %d", c.a_mode);
+    ACMI_REQUIRE((c.ln_g == nullptr) == (c.ln_b == nullptr), "acmi_linear: ln_g and ln_b go together");
+    const int kt = c.wdtype == ACMI_BF16 ? 32 : 16;
+    p.a = c.a; p.a_tiled = c.a_mode == ACMI_A_TILED;
+    p.ln_mode = c.ln_g ? 2 : (c.a_mode == ACMI_A_ROWMAJOR_F32_NORM ? 1 : 0);
+    p.ln_g = c.ln_g; p.ln_b = c.ln_b; p.eps = c.eps;
+    if (c.colsum != nullptr) {
+        ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.a_stats != nullptr, "acmi_linear: colsum needs a tiled activation and a_stats");
+        p.a_stats = c.a_stats; p.a_np = c.a_stats_np; p.a_cnt = c.a_stats_cnt; p.colsum = c.colsum; p.a_lo = c.a_lo;
+    } else if (c.a_lo != nullptr) {  // hi + lo activation without LayerNorm (first lo_K columns)
+        ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.lo_K > 0 && c.lo_K <= c.K && c.lo_K % kt == 0,
+                     "acmi_linear: a_lo without colsum needs a tiled activation and lo_K %% %d == 0 (lo_K=%d)", kt, c.lo_K);
+        p.a_lo = c.a_lo; p.lo_split = c.lo_K / kt;
+    }
+    p.a_rbs = c.a_rbs; p.alo_rbs = c.a_lo_rbs;
+    if (c.xt_hi != nullptr) {
+        p.xt_hi = c.xt_hi; p.xt_lo = c.xt_lo;
+        p.xt_nkc = c.xt_rbs > 0 ? c.xt_rbs : (c.N + kt - 1) / kt;
+        p.xt_lo_nkc = c.xt_lo_rbs > 0 ? c.xt_lo_rbs : (c.N + kt - 1) / kt;
+        ACMI_REQUIRE(p.xt_nkc >= (c.N + kt - 1) / kt && p.xt_lo_nkc >= (c.N + kt - 1) / kt,
+                     "acmi_linear: xt_rbs=%d / xt_lo_rbs=%d too small for N=%d", c.xt_rbs, c.xt_lo_rbs, c.N);
+    }
+    p.stats_out = c.stats_out; p.ksplit = c.ksplit;
+    p.w = c.w; p.bias = c.bias; p.residual = c.residual; p.out = c.out; p.out_mode = c.out_mode; p.act = c.act;
+    p.M = c.M; p.N = c.N; p.K = c.K;
+    return ACMI_OK;
+}
+
+extern "C" int acmi_linear_ex(const acmi_linear_desc* dsc, void* stream) {
+    ACMI_REQUIRE(dsc != nullptr, "acmi_linear_ex: null descriptor");
+    LinArgs p = {};
+    int rc = desc_to_args(*dsc, p);
+    if (rc) return rc;
+    return acmi_launch_lin(p, dsc->wdtype, (hipStream_t)stream);
+}
+
+extern "C" int acmi_linear_pair(const acmi_linear_desc* plain, const acmi_linear_desc* xcat, void* stream) {
+    ACMI_REQUIRE(plain != nullptr && xcat != nullptr, "acmi_linear_pair: null descriptor");
+    ACMI_REQUIRE(plain->wdtype == xcat->wdtype && plain->a_mode == ACMI_A_TILED && xcat->a_mode == ACMI_A_TILED,
+                 "acmi_linear_pair: both GEMMs take tiled activations of one element type");
+    LinArgs p0 = {}, p1 = {};
+    int rc;
+    if ((rc = desc_to_args(*plain, p0)) || (rc = desc_to_args(*xcat, p1))) return rc;
+    ACMI_REQUIRE(p0.M > 0 && p0.N > 0 && p0.K > 0 && p1.N > 0 && p1.K > 0, "acmi_linear_pair: empty problem");
+    return acmi_launch_pair(p0, p1, plain->wdtype, (hipStream_t)stream);
+}

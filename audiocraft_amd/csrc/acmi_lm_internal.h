@@ -1,0 +1,55 @@
+// Internal interfaces shared by the translation units of the LM decode path (not part of the C ABI).
+//   acmi_gemm.hip  skinny GEMMs (tiled / paired / row-major), LayerNorm-as-a-kernel
+//   acmi_attn.hip  single-query attention over the KV cache, KV scatter
+//   acmi_lm.hip    embedding, sampler, acmi_lm_step
+#pragma once
+#include "acmi_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct LinArgs {
+    const void* a; int a_tiled;
+    const float* a_stats; int a_np; int a_cnt;  // per-row (mean, M2) partials of the activation's rows, [M][a_np][2]
+    float* stats_out;                           // per-row (mean, M2) partials of this GEMM's output, [M][N / 16][2]
+    // "folded LayerNorm": a / a_lo hold the RAW activation as hi / lo fragments (x = hi + lo; f32 weights: hi
+    // only), colsum[n] = sum_k W'[n,k]; with the row statistics from a_stats the epilogue applies
+    //     LN(x) W'^T = rstd * (x W'^T - mean * colsum)
+    const void* a_lo; const float* colsum;
+    void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // producer side: also write the output as raw hi / lo fragments
+                                                // (K tiles per 16-row block of the two buffers)
+    int a_rbs, alo_rbs;                         // fragments (x 64 lanes) between 16-row blocks of a / a_lo (0: NKC)
+    int lo_split;                               // LN 3: only K fragments < lo_split have a lo term
+    int ln_mode; const float* ln_g; const float* ln_b; float eps;
+    const void* w;
+    const float* bias;
+    const float* residual;
+    void* out; int out_mode; int act;
+    int M, N, K;
+    int NKC;      // K tiles
+    int NKC_out;  // K tiles of a tiled output (its K is this GEMM's N)
+    int RS;       // LDS row pitch (bytes) of the staged activation
+    int ksplit;   // tiled path: workgroups per n-tile; > 1 => raw partial sums go to slabs out[ks][M][N] (f32)
+    int kcs, fpw; // tiled path: K tiles per split-K slice, fragments every wave owns (kcs / waves), set by the launcher
+    int qkv;      // QKV scatter epilogue
+    float* q_out; void* k_cache; void* v_cache; int kv_bf16; int H, hd, Tcap, d; const int* pos;
+    int rpp;      // QKV scatter: rows per position (row gm = position gm / rpp of the call, cache row gm % rpp)
+};
+
+template <typename WT> struct WTr {
+    static constexpr int EPL = 16 / (int)sizeof(WT);  // elements per lane of a fragment
+    static constexpr int KT = 4 * EPL;                // K columns per fragment tile
+};
+
+// element index of (row, col) inside a tiled activation with `nkc` K tiles
+template <typename WT>
+__device__ __forceinline__ size_t tiled_index(int row, int col, int nkc) {
+    constexpr int EPL = WTr<WT>::EPL, KT = WTr<WT>::KT;
+    const int kc = col / KT, r = col - kc * KT;
+    return ((((size_t)(row >> 4) * nkc + kc) * 64 + (r / EPL) * 16 + (row & 15)) * EPL) + (r % EPL);
+}
+
+// launchers of acmi_gemm.hip used by acmi_lm_step
+int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st);                 // tiled or row-major activation
+int acmi_launch_pair(LinArgs& p0, LinArgs& p1, int wdtype, hipStream_t st);  // two tiled GEMMs, one launch
+int acmi_launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps, const float* slabs, int nslabs,
+                        hipStream_t st);
