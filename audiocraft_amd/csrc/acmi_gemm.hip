@@ -316,20 +316,22 @@ struct TlExtras {
     int tpos;                 // QKV: the position the new K / V rows are stored at
 };
 
-template <typename WT, int MT, int LN, int C>
+template <typename WT, int MT, int LN, int NT, int C>
 __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, const u32x4* __restrict__ at,
                                          const u32x4* __restrict__ al, int mts, int mtl, int mtv, int kc0, int nw,
                                          const float* __restrict__ st_ptr, int np,
                                          const float* __restrict__ pb, const float* __restrict__ pc,
-                                         const float* __restrict__ pr, const int* __restrict__ ppos, f32x4 (&acc)[MT],
-                                         TlExtras& ex) {
+                                         const float* __restrict__ pr, const int* __restrict__ ppos,
+                                         f32x4 (&acc)[NT * MT], TlExtras& ex) {
     constexpr bool HL = LN == 2 || LN == 3;
     const int lane = threadIdx.x & 63;
-    u32x4 bv[C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
+    const int wts = p.NKC * 64;  // fragment lanes between the NT adjacent n-tiles of this workgroup
+    u32x4 bv[NT][C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         const int ko = (kc0 + i * nw) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
-        bv[i] = ld_frag_nt(wt + ko + lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
 #pragma unroll
         for (int u = 0; u < MT; ++u) {  // row blocks beyond M re-read the last valid one (their results are dropped)
             const int ub = min(u, mtv - 1);
@@ -357,26 +359,33 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
     for (int i = 0; i < C; ++i)
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            mma_frag(av[u][i], bv[i], acc[u], WT());
             if (LN == 3 && kc0 + i * nw >= p.lo_split) lv[u][i] = u32x4{0u, 0u, 0u, 0u};
-            if (HL) mma_frag(lv[u][i], bv[i], acc[u], WT());
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                mma_frag(av[u][i], bv[t][i], acc[t * MT + u], WT());
+                if (HL) mma_frag(lv[u][i], bv[t][i], acc[t * MT + u], WT());
+            }
         }
 }
 
-template <typename WT, int MT, int LN>
-__device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const int kslice, const int ksp) {
+// NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
+// the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs (MT = 1 only).
+template <typename WT, int MT, int LN, int NT = 1>
+__device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, const int kslice, const int ksp) {
+    static_assert(NT == 1 || MT == 1, "wide tiles are built for one 16-row block");
+    const int ntile = wgtile * NT;   // first n-tile of this workgroup
     constexpr int D = (LN == 2 || LN == 3) ? 2 : 1;
     constexpr bool FOLD = LN == 1 || LN == 2;
     // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
     // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
     // VGPRs of a 2-waves-per-SIMD launch
-    constexpr int CQ = (LN > 0 ? 44 : 52) / (1 + MT * D);
+    constexpr int CQ = (LN > 0 ? 44 : 52) / (NT + MT * D);
     constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
-    float* red = reinterpret_cast<float*>(smem);        // [MT][nw][256] partial accumulators
-    float* rowstat = red + (size_t)MT * nw * 256;       // [16 MT][2] mean, rstd
+    float* red = reinterpret_cast<float*>(smem);        // [NT MT][nw][256] partial accumulators
+    float* rowstat = red + (size_t)NT * MT * nw * 256;  // [16 MT][2] mean, rstd
     const int n0 = ntile * 16, NKC = p.NKC;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
     const int mts = p.a_rbs * 64, mtl = p.alo_rbs * 64;  // fragment lanes between consecutive 16-row blocks (a, a_lo)
@@ -388,9 +397,9 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
     {
         const int mg = (int)blockIdx.z * 16 * MT;
         const int mtv = min(MT, (p.M - mg + 15) >> 4);
-        f32x4 accs[MT];
+        f32x4 accs[NT * MT];
 #pragma unroll
-        for (int u = 0; u < MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < NT * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mg >> 4) * mts);
         const u32x4* al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mg >> 4) * mtl) : nullptr;
         // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
@@ -398,8 +407,9 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
         const float* st_ptr = own;
         if (FOLD) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
         // this thread's first epilogue element
-        const int e0 = (int)threadIdx.x, eu = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
-        const int egn = min(n0 + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
+        const int e0 = (int)threadIdx.x, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
+        const int et = NT > 1 ? min(eq, NT - 1) : 0, eu = NT > 1 ? 0 : eq;   // (n-tile, row block) of that element
+        const int egn = min(n0 + 16 * et + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
         const float* pb = p.bias != nullptr ? p.bias + egn : own;
         const float* pc = p.colsum != nullptr ? p.colsum + egn : own;
         const float* pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
@@ -409,7 +419,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
         int kc = kbeg + wave, rem = p.fpw;              // fragments every wave owns (+ a ragged tail)
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            tl_chunk<WT, MT, LN, Cn>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
+            tl_chunk<WT, MT, LN, NT, Cn>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
             kc += Cn * nw; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -422,11 +432,11 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
         ACMI_TL_RUN(1)
 #undef ACMI_TL_RUN
         if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
-            tl_chunk<WT, MT, LN, 1>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
+            tl_chunk<WT, MT, LN, NT, 1>(p, wt, at, al, mts, mtl, mtv, kc, nw, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
 
         // ---- deterministic cross-wave reduction through LDS
 #pragma unroll
-        for (int u = 0; u < MT; ++u)
+        for (int u = 0; u < NT * MT; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[((size_t)u * nw + wave) * 256 + lane * 4 + r] = accs[u][r];
         if (FOLD) {
@@ -442,13 +452,13 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
         __syncthreads();
 
         // ---- epilogue: one output element per thread and pass
-        for (int e = (int)threadIdx.x; e < 256 * mtv; e += (int)blockDim.x) {
-            const int u = e >> 8, mm = (e >> 4) & 15, nn = e & 15;
+        for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += (int)blockDim.x) {
+            const int t = NT > 1 ? e >> 8 : 0, u = NT > 1 ? 0 : e >> 8, mm = (e >> 4) & 15, nn = e & 15;
             const bool first = e == (int)threadIdx.x;
             const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
             float v = 0.f;
-            for (int w = 0; w < nw; ++w) v += red[((size_t)u * nw + w) * 256 + idx];
-            const int gm = mg + 16 * u + mm, gn = n0 + nn;
+            for (int w = 0; w < nw; ++w) v += red[((size_t)(t * MT + u) * nw + w) * 256 + idx];
+            const int gm = mg + 16 * u + mm, gn = n0 + 16 * t + nn;
             const bool valid = gm < p.M && gn < p.N;
             if (ksp > 1) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
                 if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
@@ -477,7 +487,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) dq += __shfl_xor(dq, off, 64);
                 if (nn == 0 && gm < p.M)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> 4) + ntile) * 2) = make_float2(mb, dq);
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> 4) + ntile + t) * 2) = make_float2(mb, dq);
             }
             if (!valid) continue;
             if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
@@ -514,9 +524,9 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int ntile, const
     }
 }
 
-template <typename WT, int MT, int LN>
+template <typename WT, int MT, int LN, int NT>
 __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
-    tl_body<WT, MT, LN>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+    tl_body<WT, MT, LN, NT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
@@ -557,23 +567,34 @@ static int tiled_prepare(LinArgs& a) {
     return ACMI_OK;
 }
 
-template <typename WT, int MT, int LN>
+template <typename WT, int MT, int LN, int NT>
 static int launch_tiled_t(LinArgs& a, hipStream_t st) {
-    int rc = tiled_prepare<WT>(a);
-    if (rc) return rc;
-    const int tiles = ((a.N + 15) / 16) * a.ksplit, frags = a.NKC / a.ksplit;
-    const int nw = tiled_waves(tiles, frags);
+    const int wgs = ((a.N + 15) / 16 / NT) * a.ksplit, frags = a.NKC / a.ksplit;
+    const int nw = tiled_waves(wgs, frags * NT);
     a.kcs = frags; a.fpw = frags / nw;
-    const size_t lds = (size_t)MT * nw * 1024 + (size_t)MT * 128;
-    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN>), dim3((a.N + 15) / 16, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)), dim3(nw * 64), lds, st, a);
+    const size_t lds = (size_t)NT * MT * nw * 1024 + (size_t)MT * 128;
+    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT>), dim3((a.N + 15) / 16 / NT, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
+                       dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_tiled_kernel");
 }
 
 template <typename WT>
 static int launch_tiled(LinArgs& a, hipStream_t st) {
+    int rc = tiled_prepare<WT>(a);
+    if (rc) return rc;
     const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);  // 1, 2 or 4 16-row blocks share each weight fragment
     const int ln = a.colsum == nullptr ? (a.lo_split > 0 ? 3 : 0) : (a.a_lo != nullptr ? 2 : 1);
-#define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv>(a, st);
+    // wide (32-feature) workgroups when the 16-feature grid would not fit the 256 CUs in one workgroup each:
+    // the activation fragments, re-read by every workgroup, are then shared by two n-tiles
+    static const bool wide_ok = !(getenv("ACMI_LIN_WIDE") != nullptr && getenv("ACMI_LIN_WIDE")[0] == '0');
+    const int tiles = (a.N + 15) / 16;
+    if (wide_ok && mt == 1 && ln != 3 && a.ksplit == 1 && tiles > 256 && tiles % 2 == 0 && a.N % 16 == 0 &&
+        a.stats_out == nullptr && a.xt_hi == nullptr) {
+        if (ln == 0) return launch_tiled_t<WT, 1, 0, 2>(a, st);
+        if (ln == 1) return launch_tiled_t<WT, 1, 1, 2>(a, st);
+        return launch_tiled_t<WT, 1, 2, 2>(a, st);
+    }
+#define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv, 1>(a, st);
     ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2) ACMI_TL_CASE(1, 3)
     ACMI_TL_CASE(2, 0) ACMI_TL_CASE(2, 1) ACMI_TL_CASE(2, 2) ACMI_TL_CASE(2, 3)
     ACMI_TL_CASE(4, 0) ACMI_TL_CASE(4, 1) ACMI_TL_CASE(4, 2) ACMI_TL_CASE(4, 3)
