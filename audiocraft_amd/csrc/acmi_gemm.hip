@@ -369,10 +369,10 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 }
 
 // NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
-// the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs (MT = 1 only).
+// the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs.
 template <typename WT, int MT, int LN, int NT = 1>
 __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, const int kslice, const int ksp) {
-    static_assert(NT == 1 || MT == 1, "wide tiles are built for one 16-row block");
+    static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
     const int ntile = wgtile * NT;   // first n-tile of this workgroup
     constexpr int D = (LN == 2 || LN == 3) ? 2 : 1;
     constexpr bool FOLD = LN == 1 || LN == 2;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         if (FOLD) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
         // this thread's first epilogue element
         const int e0 = (int)threadIdx.x, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
-        const int et = NT > 1 ? min(eq, NT - 1) : 0, eu = NT > 1 ? 0 : eq;   // (n-tile, row block) of that element
+        const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
         const int egn = min(n0 + 16 * et + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
         const float* pb = p.bias != nullptr ? p.bias + egn : own;
         const float* pc = p.colsum != nullptr ? p.colsum + egn : own;
@@ -453,7 +453,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
 
         // ---- epilogue: one output element per thread and pass
         for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += (int)blockDim.x) {
-            const int t = NT > 1 ? e >> 8 : 0, u = NT > 1 ? 0 : e >> 8, mm = (e >> 4) & 15, nn = e & 15;
+            const int t = (e >> 8) % NT, u = (e >> 8) / NT, mm = (e >> 4) & 15, nn = e & 15;
             const bool first = e == (int)threadIdx.x;
             const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
             float v = 0.f;
@@ -573,6 +573,17 @@ static int launch_tiled_t(LinArgs& a, hipStream_t st) {
     const int nw = tiled_waves(wgs, frags * NT);
     a.kcs = frags; a.fpw = frags / nw;
     const size_t lds = (size_t)NT * MT * nw * 1024 + (size_t)MT * 128;
+    if (lds > 64 * 1024) {  // 2 n-tiles x 4 row blocks x 8 waves: just above the default dynamic LDS limit
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
+                return ACMI_ELAUNCH;
+            }
+            attr_set = true;
+        }
+    }
     hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT>), dim3((a.N + 15) / 16 / NT, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
                        dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_tiled_kernel");
@@ -588,11 +599,13 @@ static int launch_tiled(LinArgs& a, hipStream_t st) {
     // the activation fragments, re-read by every workgroup, are then shared by two n-tiles
     static const bool wide_ok = !(getenv("ACMI_LIN_WIDE") != nullptr && getenv("ACMI_LIN_WIDE")[0] == '0');
     const int tiles = (a.N + 15) / 16;
-    if (wide_ok && mt == 1 && ln != 3 && a.ksplit == 1 && tiles > 256 && tiles % 2 == 0 && a.N % 16 == 0 &&
+    if (wide_ok && ln != 3 && a.ksplit == 1 && tiles > 256 && tiles % 2 == 0 && a.N % 16 == 0 &&
         a.stats_out == nullptr && a.xt_hi == nullptr) {
-        if (ln == 0) return launch_tiled_t<WT, 1, 0, 2>(a, st);
-        if (ln == 1) return launch_tiled_t<WT, 1, 1, 2>(a, st);
-        return launch_tiled_t<WT, 1, 2, 2>(a, st);
+#define ACMI_TLW_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv, 2>(a, st);
+        ACMI_TLW_CASE(1, 0) ACMI_TLW_CASE(1, 1) ACMI_TLW_CASE(1, 2)
+        ACMI_TLW_CASE(2, 0) ACMI_TLW_CASE(2, 1) ACMI_TLW_CASE(2, 2)
+        ACMI_TLW_CASE(4, 0) ACMI_TLW_CASE(4, 1) ACMI_TLW_CASE(4, 2)
+#undef ACMI_TLW_CASE
     }
 #define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv, 1>(a, st);
     ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2) ACMI_TL_CASE(1, 3)

@@ -161,7 +161,7 @@ def test_lstm_vs_oracle(C, B, H, T, layers):
 
 @pytest.mark.parametrize('M,N,K', [(16, 4608, 1536), (2, 3072, 1024), (16, 1536, 6144), (32, 1536, 1536),
                                     (5, 96, 32), (16, 8192, 1536), (7, 40, 24), (40, 2048, 2048), (16, 1536, 768),
-                                    (64, 1536, 1536), (70, 96, 64), (33, 64, 6144)])
+                                    (64, 1536, 1536), (70, 96, 64), (33, 64, 6144), (32, 4608, 1536), (64, 8192, 256)])
 @pytest.mark.parametrize('wdt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['rowmajor', 'rowmajor_ln', 'rowmajor_std', 'tiled_in', 'tiled_out'])
 def test_linear_vs_torch(C, M, N, K, wdt, mode):
@@ -258,7 +258,8 @@ def test_linear_statistics_handoff(C, M, d, N2, dt):
     assert torch.allclose(var, x1_ref.var(1, unbiased=False), rtol=1e-4)
 
 
-@pytest.mark.parametrize('M,d,N2', [(16, 1536, 4608), (2, 1024, 3072), (5, 512, 96), (33, 2048, 512), (16, 48, 32), (64, 1536, 256)])
+@pytest.mark.parametrize('M,d,N2', [(16, 1536, 4608), (2, 1024, 3072), (5, 512, 96), (33, 2048, 512), (16, 48, 32), (64, 1536, 256),
+                                    (33, 1536, 4608), (64, 512, 8192)])   # the last two: wide tiles x 4 row blocks
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_linear_folded_layernorm(C, M, d, N2, dt):
     """Folded LayerNorm: the producer GEMM writes x1 = x0 + A W1^T three times -- f32 row-major, raw in fragment
