@@ -266,3 +266,53 @@ def test_genmodel_reads_experiment_config_of_the_lm():
     ag = AudioGen('plain', builders.get_debug_compression_model('cpu', sample_rate=16000), lm, max_duration=10)
     assert ag.sample_rate == 16000 and ag.duration == 5 and ag.extend_stride == 2
     assert builders.ENCODEC_16KHZ['seanet']['ratios'] == [8, 5, 4, 2] and builders.audiogen_lm_cfg()['dim'] == 1536
+
+
+def test_windowed_generation_matches_reference_trace():
+    """Durations above max_duration (reference genmodel.py:193-260, musicgen.py:290-337): the windows' (prompt length,
+    max_gen_len), the periodically tiled melody each one carries and the stitched tokens are those recorded from the
+    unmodified reference with a deterministic stand-in for `lm.generate` (tests/golden/make_windowing_golden.py)."""
+    import json
+    from audiocraft_amd.models import MusicGen
+    from audiocraft_amd.modules.conditioners import WavCondition
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'windowing.json')))
+    assert len(cases) >= 6
+    for c in cases:
+        mg = MusicGen.get_pretrained('debug', device='cpu')
+        mg.max_duration = c['max_duration']
+        mg.set_generation_params(duration=c['duration'], extend_stride=c['extend_stride'])
+        assert mg.frame_rate == c['frame_rate'] and mg.sample_rate == c['sample_rate']
+        calls = []
+
+        def generate(prompt, attributes, callback=None, max_gen_len=256, **kw):
+            B, T0 = len(attributes), 0 if prompt is None else prompt.shape[-1]
+            mel = []
+            for a in attributes:
+                w = a.wav['self_wav']
+                mel.append([int(w.length[0]), [round(float(v), 6) for v in w.wav.flatten()[:3]],
+                            round(float(w.wav.double().sum()), 4)])
+            calls.append({'prompt_len': T0, 'max_gen_len': int(max_gen_len), 'melody': mel})
+            out = torch.empty(B, 4, max_gen_len, dtype=torch.long)
+            if prompt is not None:
+                out[..., :T0] = prompt
+            out[..., T0:] = (torch.arange(T0, max_gen_len) * 7 + len(calls) * 13) % 400
+            return out
+
+        mg.lm.generate = generate
+        attributes, _ = mg._prepare_tokens_and_attributes(['a', 'b'], None)
+        if c['melody_len']:
+            for i, attr in enumerate(attributes):
+                m = torch.arange(c['melody_len'], dtype=torch.float32)[None] * (i + 1) * 1e-3
+                attr.wav['self_wav'] = WavCondition(m[None], torch.tensor([m.shape[-1]]), sample_rate=[mg.sample_rate],
+                                                    path=[None])
+        prompt = None
+        if c['prompt_len']:
+            prompt = (torch.arange(c['prompt_len'])[None, None] + torch.arange(4)[None, :, None]).repeat(2, 1, 1) % 400
+        tokens = mg._generate_tokens(attributes, prompt)
+        assert list(tokens.shape) == c['tokens_shape']
+        assert tokens[0, 0].tolist() == c['tokens_row']
+        assert len(calls) == len(c['calls'])
+        for got, ref in zip(calls, c['calls']):
+            assert (got['prompt_len'], got['max_gen_len']) == (ref['prompt_len'], ref['max_gen_len'])
+            for (gl, gh, gs), (rl, rh, rs) in zip(got['melody'], ref['melody']):
+                assert gl == rl and gh == pytest.approx(rh, abs=1e-5) and gs == pytest.approx(rs, rel=1e-6)
