@@ -207,7 +207,7 @@ def test_loader_roundtrip(tmp_path):
 
 def test_stereo_interleave_wrapper():
     """InterleaveStereoCompressionModel (reference encodec.py:397-506): '(b c) k t -> b (k c) t' and the
-    per-timestep variant, checked on a stand-in mono codec (layout was cross-checked against the reference class)."""
+    per-timestep variant, checked on a stand-in mono codec and against outputs of the reference class."""
     from audiocraft_amd.models.encodec import CompressionModel, InterleaveStereoCompressionModel
 
     class Mono(CompressionModel):
@@ -244,6 +244,17 @@ def test_stereo_interleave_wrapper():
     assert codes.shape == (3, 4, 20) and st.frame_rate == 100 and st.num_codebooks == 4
     assert torch.equal(codes[..., 0::2], left) and torch.equal(codes[..., 1::2], right)
     assert torch.equal(st.decode(codes)[:, 1:], mono.decode(right))
+    # and against the reference class itself (tests/golden/stereo.npz, recorded by tests/golden/make_host_golden.py
+    # from audiocraft.models.encodec.InterleaveStereoCompressionModel over the same stand-in codec)
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'stereo.npz'))
+    xg = torch.from_numpy(gold['x'])
+    for tag, per_timestep in (('k', False), ('t', True)):
+        st = InterleaveStereoCompressionModel(Mono(), per_timestep=per_timestep)
+        codes, _ = st.encode(xg)
+        assert torch.equal(codes, torch.from_numpy(gold[f'codes_{tag}']))
+        assert torch.equal(st.decode(codes), torch.from_numpy(gold[f'wav_{tag}']))
+        assert [st.num_codebooks, st.frame_rate, st.channels, st.total_codebooks] == gold[f'meta_{tag}'].tolist()
 
 
 def test_genmodel_reads_experiment_config_of_the_lm():
@@ -271,7 +282,7 @@ def test_genmodel_reads_experiment_config_of_the_lm():
 def test_windowed_generation_matches_reference_trace():
     """Durations above max_duration (reference genmodel.py:193-260, musicgen.py:290-337): the windows' (prompt length,
     max_gen_len), the periodically tiled melody each one carries and the stitched tokens are those recorded from the
-    unmodified reference with a deterministic stand-in for `lm.generate` (tests/golden/make_windowing_golden.py)."""
+    unmodified reference with a deterministic stand-in for `lm.generate` (tests/golden/make_host_golden.py)."""
     import json
     from audiocraft_amd.models import MusicGen
     from audiocraft_amd.modules.conditioners import WavCondition
