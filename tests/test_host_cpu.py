@@ -45,6 +45,24 @@ def test_argument_validation_without_gpu():
     assert lib.acmi_lm_step(None, None, 0, None) == -1
     assert lib.acmi_ln_tile(None, None, 0, 4, 4096, ctypes.c_float(1e-5), None) == -1
     assert _C.lstm_work_floats(3, 8) == 72
+    # descriptor entry points: null descriptors, contradictory operands, bad placement
+    assert lib.acmi_linear_ex(None, None) == -1 and lib.acmi_linear_pair(None, None, None) == -1
+    assert lib.acmi_attn_decode_ex(None, None) == -1
+    ld = _C.LinearDesc()
+    ld.a_mode, ld.wdtype, ld.M, ld.N, ld.K = _C.A_ROWMAJOR_F32, _C.BF16, 4, 32, 64
+    ld.colsum = 1  # folded LayerNorm asked for on a row-major activation
+    assert lib.acmi_linear_ex(ctypes.byref(ld), None) == -1 and b'colsum' in lib.acmi_last_error()
+    ld = _C.LinearDesc()
+    ld.a_mode, ld.wdtype, ld.M, ld.N, ld.K, ld.a_lo, ld.lo_K = _C.A_TILED, _C.BF16, 4, 32, 64, 1, 40  # 40 % 32 != 0
+    assert lib.acmi_linear_ex(ctypes.byref(ld), None) == -1 and b'lo_K' in lib.acmi_last_error()
+    ad = _C.AttnDesc()
+    ad.out_mode, ad.out_dtype, ad.Beff, ad.H, ad.hd, ad.Tcap, ad.len = _C.OUT_TILED, _C.BF16, 4, 2, 64, 8, 8
+    ad.out_col0, ad.out_rbs = 48, 8   # not a multiple of the K tile
+    assert lib.acmi_attn_decode_ex(ctypes.byref(ad), None) == -1 and b'placement' in lib.acmi_last_error()
+    ad.out_col0, ad.out_rbs, ad.cache_rows = 0, 0, 3   # 4 query rows over 3 cache rows
+    assert lib.acmi_attn_decode_ex(ctypes.byref(ad), None) == -1 and b'cache rows' in lib.acmi_last_error()
+    ad.cache_rows, ad.q_colsum = 0, 1   # LayerNorm hook without statistics
+    assert lib.acmi_attn_decode_ex(ctypes.byref(ad), None) == -1 and b'statistics' in lib.acmi_last_error()
 
 
 def test_tiling_roundtrip():
