@@ -345,3 +345,34 @@ def test_windowed_generation_matches_reference_trace():
             assert (got['prompt_len'], got['max_gen_len']) == (ref['prompt_len'], ref['max_gen_len'])
             for (gl, gh, gs), (rl, rh, rs) in zip(got['melody'], ref['melody']):
                 assert gl == rl and gh == pytest.approx(rh, abs=1e-5) and gs == pytest.approx(rs, rel=1e-6)
+
+
+def test_streamable_conv_geometry_and_constructor_checks():
+    """Host geometry of the conv wrappers (reference tests/modules/test_conv.py:152-203): output length of
+    StreamableConv1d = the reference's "last window is full" formula, StreamableConvTranspose1d's constructor
+    rejects trim_right_ratio outside [0, 1] or != 1 for non-causal layers; the SEANet hop follows."""
+    import math
+    import random
+    from audiocraft_amd.modules.seanet import SEANetEncoder, StreamableConv1d, StreamableConvTranspose1d
+
+    def ref_len(length, kernel_size, stride, dilation):
+        padding_total = (kernel_size - 1) * dilation - (stride - 1)
+        n_frames = (length - kernel_size + padding_total) / stride + 1
+        ideal_length = (math.ceil(n_frames) - 1) * stride + (kernel_size - padding_total)
+        return ideal_length // stride
+
+    rng = random.Random(0)
+    for _ in range(50):
+        T = rng.randrange(1, 100_000)
+        for causal in (False, True):
+            for k, s, d in [(4, 1, 1), (4, 2, 1), (3, 1, 3), (10, 5, 1), (3, 2, 3), (7, 1, 1), (16, 8, 1)]:
+                conv = StreamableConv1d(2, 1, kernel_size=k, stride=s, dilation=d, causal=causal, device='cpu')
+                assert conv.out_length(T) == ref_len(T, k, s, d), (T, k, s, d, causal)
+    with pytest.raises(AssertionError):
+        StreamableConvTranspose1d(2, 1, kernel_size=4, causal=False, trim_right_ratio=0.5, device='cpu')
+    with pytest.raises(AssertionError):
+        StreamableConvTranspose1d(2, 1, kernel_size=4, causal=True, trim_right_ratio=-1., device='cpu')
+    with pytest.raises(AssertionError):
+        StreamableConvTranspose1d(2, 1, kernel_size=4, causal=True, trim_right_ratio=2, device='cpu')
+    enc = SEANetEncoder(channels=1, dimension=16, n_filters=4, ratios=[8, 5, 4, 4], device='cpu')
+    assert enc.hop_length == 640
