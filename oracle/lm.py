@@ -174,6 +174,14 @@ def cfg_mix(all_logits: torch.Tensor, cfg_coef: float) -> torch.Tensor:
     return uncond + (cond - uncond) * cfg_coef
 
 
+def double_cfg_mix(all_logits: torch.Tensor, cfg_coef: float, cfg_coef_beta: float) -> torch.Tensor:
+    """lm.py:372-376 (MusicGen-Style double CFG): rows [text + wav; wav only; null] ->
+    uncond + coef * (wav + beta * (cond - wav) - uncond)."""
+    B = all_logits.shape[0] // 3
+    cond, wav, uncond = all_logits.split(B, dim=0)
+    return uncond + cfg_coef * (wav + cfg_coef_beta * (cond - wav) - uncond)
+
+
 def sample_next_token(logits: torch.Tensor, use_sampling: bool, temp: float, top_k: int, top_p: float,
                       generator=None) -> torch.Tensor:
     """lm.py:402-418 on logits [B, K, card] (last step) -> [B, K, 1]."""
@@ -195,14 +203,23 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
              cross_src: tp.Optional[torch.Tensor], prepend_src: tp.Optional[torch.Tensor] = None,
              max_gen_len: int = 256, use_sampling: bool = True, temp: float = 1.0, top_k: int = 250,
              top_p: float = 0.0, cfg_coef: tp.Optional[float] = None, remove_prompts: bool = False,
-             generator=None, callback=None, return_logits: bool = False, max_steps: tp.Optional[int] = None):
-    """LMModel.generate (audiocraft/models/lm.py:420-587), default one-forward CFG mode.
+             generator=None, callback=None, return_logits: bool = False, max_steps: tp.Optional[int] = None,
+             cfg_coef_beta: tp.Optional[float] = None, null_cross_src: tp.Optional[torch.Tensor] = None,
+             null_prepend_src: tp.Optional[torch.Tensor] = None):
+    """LMModel.generate (audiocraft/models/lm.py:420-587).
 
-    `cross_src` / `prepend_src` hold the already-batched `[cond; uncond]` condition tensors
-    ([2B, L, C]) when CFG is on; pass both as None for unconditional generation (no CFG).
+    Default one-forward CFG mode: `cross_src` / `prepend_src` hold the already-batched `[cond; uncond]` condition
+    tensors ([2B, L, C]); pass both as None for unconditional generation (no CFG).
+    `cfg_coef_beta` (double CFG, lm.py:362-376): the condition tensors hold `[text + wav; wav only; null]` (3B rows).
+    `null_cross_src` / `null_prepend_src` (two_step_cfg, lm.py:377-386): the conditional tensors hold B rows and
+    the unconditional pass runs separately on these, with its own condition length and streaming state; the mix
+    then uses the model's `cfg.cfg_coef` -- the reference ignores the `cfg_coef` argument on that branch.
     """
     coef = cfg.cfg_coef if cfg_coef is None else cfg_coef
     use_cfg = cross_src is not None or prepend_src is not None
+    two_step = null_cross_src is not None or null_prepend_src is not None
+    assert not (two_step and cfg_coef_beta is not None)
+    null_state = LMState(cfg.num_layers) if two_step else None
     K, special, unknown = cfg.n_q, cfg.card, -1
     if prompt is None:
         prompt = torch.zeros((num_samples, K, 0), dtype=torch.long)
@@ -221,10 +238,18 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
         if max_steps is not None and offset - start >= max_steps:
             break
         curr = gen_sequence[..., prev:offset]
-        seq = torch.cat([curr, curr], dim=0) if use_cfg else curr
-        logits = lm_forward(sd, cfg, seq, cross_src, prepend_src, state)
-        if use_cfg:
-            logits = cfg_mix(logits, coef)
+        if two_step:
+            cond = lm_forward(sd, cfg, curr, cross_src, prepend_src, state)
+            uncond = lm_forward(sd, cfg, curr, null_cross_src, null_prepend_src, null_state)
+            logits = uncond + (cond - uncond) * cfg.cfg_coef
+        elif cfg_coef_beta is not None:
+            logits = lm_forward(sd, cfg, torch.cat([curr, curr, curr], dim=0), cross_src, prepend_src, state)
+            logits = double_cfg_mix(logits, coef, cfg_coef_beta)
+        else:
+            seq = torch.cat([curr, curr], dim=0) if use_cfg else curr
+            logits = lm_forward(sd, cfg, seq, cross_src, prepend_src, state)
+            if use_cfg:
+                logits = cfg_mix(logits, coef)
         logits = logits[:, :, -1]  # [B, K, card]
         if return_logits:
             all_logits.append(logits)

@@ -98,3 +98,30 @@ def test_pattern_roundtrip_and_layout():
     assert torch.equal(back, z) and bmask.all()
     assert opat.first_step_with_timestep(4, 7, 0) == 1
     assert opat.first_step_with_timestep(4, 7, 3) == 4
+
+
+def test_lm_oracle_two_step_cfg_matches_reference():
+    """two_step_cfg=True (reference lm.py:377-386, 498-505): separate conditional / unconditional passes with their own
+    condition lengths (5 vs 1) and streaming states; the reference mixes with the MODEL's cfg_coef there, ignoring the
+    argument (the golden run passed cfg_coef=7 on purpose)."""
+    cfg, sd, a = load_golden('lm_two_step')
+    c = lm_cfg(cfg)
+    assert a['cross_src'].shape[1] == 5 and a['null_cross_src'].shape[1] == 1
+    toks, logits = olm.generate(sd, c, None, 3, a['cross_src'], max_gen_len=10, use_sampling=False, cfg_coef=7.0,
+                                null_cross_src=a['null_cross_src'], return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
+    assert torch.allclose(logits, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_lm_oracle_double_cfg_matches_reference():
+    """cfg_coef_beta (MusicGen-Style double CFG, reference lm.py:362-376, 490-496): rows [text + wav; wav only; null],
+    logits = u + coef (w + beta (c - w) - u)."""
+    cfg, sd, a = load_golden('lm_double_cfg')
+    c = lm_cfg(cfg)
+    B = a['prepend_src'].shape[0] // 3
+    toks, logits = olm.generate(sd, c, None, B, None, a['prepend_src'], max_gen_len=9, use_sampling=False,
+                                cfg_coef_beta=cfg['cfg_coef_beta'], return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    assert torch.allclose(logits, olm.double_cfg_mix(a['step_logits'], cfg['cfg_coef'], cfg['cfg_coef_beta']),
+                          atol=5e-5, rtol=1e-5)
