@@ -155,6 +155,8 @@ def rvq_encode(latents: torch.Tensor, codebooks: torch.Tensor, norms: torch.Tens
 def rvq_decode(codes: torch.Tensor, codebooks: torch.Tensor) -> torch.Tensor:
     B, K, T = codes.shape
     D = codebooks.shape[2]
+    if K > codebooks.shape[0]:   # the reference indexes self.layers[i] and raises (core_vq.py:398-404)
+        raise IndexError(f"rvq_decode: codes carry {K} codebooks, the quantizer holds {codebooks.shape[0]}")
     out = torch.empty(B, D, T, device=codes.device, dtype=torch.float32)
     check(_rvq_decode(ptr(codes), ptr(codebooks), ptr(out), B, D, T, K, codebooks.shape[1], stream()),
           'acmi_rvq_decode')

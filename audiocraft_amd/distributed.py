@@ -119,6 +119,9 @@ def generate_sharded(model, descriptions: tp.Optional[tp.Sequence[tp.Optional[st
     Sampling seeds are per rank (base_seed + rank, cf. reference utils/utils.py:203-223)."""
     rk, world = rank(), world_size()
     device = model.device
+    # every rank needs at least one prompt: a rank with an empty shard would skip generate() and leave the others
+    # blocked in the all-gather
+    assert B_global >= world, f"global batch {B_global} < world size {world}: launch fewer ranks"
     ct = None
     if rk == 0:
         assert descriptions is not None and len(descriptions) == B_global

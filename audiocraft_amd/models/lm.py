@@ -130,6 +130,7 @@ class LMModel(nn.Module):
         self._init_weights(weight_init, depthwise_init, zero_bias_init)
         self._packed: tp.Optional[dict] = None
         self._run: tp.Optional[dict] = None
+        self._graph_keepalive = None
         self.eval()
 
     # ------------------------------------------------------------------------------------- init
@@ -170,10 +171,20 @@ class LMModel(nn.Module):
     def device(self):
         return next(iter(self.parameters())).device
 
-    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+    def _invalidate(self):
+        """Drop the packed kernel weights, the run state and any captured graph (they hold raw device pointers)."""
         self._packed = None
         self._run = None
+        self._graph_keepalive = None
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._invalidate()
         return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _apply(self, fn, *args, **kw):   # .to() / .cuda() / .float(): parameters move, the packs must be rebuilt
+        result = super()._apply(fn, *args, **kw)
+        self._invalidate()
+        return result
 
     # ------------------------------------------------------------------------------------- packing
     def _pack(self):

@@ -82,6 +82,11 @@ def lm_cfg_from_xp(cfg: dict) -> dict:
                cfg_coef=cfg.get('classifier_free_guidance', {}).get('inference_coef', 3.0))
     conds = {}
     for name, c in (cfg.get('conditioners') or {}).items():
+        # `conditioners.args` (merge_text_conditions_p, drop_desc_p) is not a conditioner: the reference pops it
+        # (builders.py get_conditioner_provider: dict_cfg.pop('args', {})) and load_lm_model deletes its entries
+        # (loaders.py:118-120); null entries are conditioners switched off by the experiment config
+        if name == 'args' or c is None:
+            continue
         model = c['model']
         if model == 't5':
             conds[name] = {'kind': 't5', 'name': c['t5']['name']}
@@ -105,9 +110,19 @@ def load_lm_model(file_or_id: str, device='cuda', weight_dtype=None):
     if weight_dtype is None:
         weight_dtype = torch.bfloat16
     lm = builders.get_lm_model(lm_cfg_from_xp(cfg), device, weight_dtype)
-    lm.load_state_dict(pkg['best_state'])
+    state = _drop_third_party_buffers(pkg['best_state'])
+    lm.load_state_dict(state)
     lm.cfg = cfg
     return lm
+
+
+def _drop_third_party_buffers(state: dict) -> dict:
+    """The module tree mirrors only `output_proj` of each conditioner.  Released checkpoints may also carry buffers of
+    the third-party models the reference conditioners embed (e.g. `ChromaStemConditioner.chroma.spec.window`, a
+    persistent torchaudio buffer, or a fine-tuned T5): those stay behind the `embedder` boundary and are dropped
+    here, by name, so that the strict load below still catches every key that IS mirrored."""
+    pat = re.compile(r'^condition_provider\.conditioners\.[^.]+\.(?!output_proj\.)')
+    return {k: v for k, v in state.items() if not pat.match(k)}
 
 
 def compression_cfg_from_xp(cfg: dict) -> dict:

@@ -71,6 +71,7 @@ class ResidualVectorQuantizer(BaseQuantizer):
         self.bins = bins
         self.vq = _RVQ(n_q, dimension, bins, device)
         self._prep: tp.Optional[tp.Tuple[torch.Tensor, torch.Tensor]] = None
+        self.check_codes = True   # decode() raises on out-of-range code values like the reference's F.embedding
 
     def _codebooks(self):
         """Stacked [K, bins, D] codebooks + their squared norms (`embed.pow(2).sum(0)`, core_vq.py:169)."""
@@ -87,7 +88,14 @@ class ResidualVectorQuantizer(BaseQuantizer):
     def decode(self, codes: torch.Tensor) -> torch.Tensor:
         """codes [B, K, T] -> quantized latents [B, D, T] (reference vq.py:98-103)."""
         cb, _ = self._codebooks()
-        return _C.rvq_decode(codes.to(torch.int64).contiguous(), cb)
+        codes = codes.to(torch.int64).contiguous()
+        if codes.shape[1] > cb.shape[0]:
+            raise IndexError(f"decode: codes carry {codes.shape[1]} codebooks, the quantizer holds {cb.shape[0]}")
+        # F.embedding raises on an out-of-range index (core_vq.py:177-179); the kernel would clamp silently
+        # (e.g. the LM's special token `card` leaking into the codes), so check here: one tiny reduction per decode
+        if self.check_codes and codes.numel() and bool(((codes < 0) | (codes >= cb.shape[1])).any()):
+            raise IndexError(f"decode: code values outside [0, {cb.shape[1]})")
+        return _C.rvq_decode(codes, cb)
 
     @property
     def total_codebooks(self):
