@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libacmi.so')
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1
 STEP_PREFILL, STEP_DECODE = 0, 1
+CFG_NONE, CFG_PAIR, CFG_DOUBLE = 0, 1, 2
 
 
 class AcmiError(RuntimeError):
@@ -53,7 +54,7 @@ class LMState(C.Structure):
                 ('S', i32), ('n_pos', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
                 ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
-                ('seed', u64)]
+                ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -90,7 +91,7 @@ class AttnDesc(C.Structure):
     _fields_ = [('q', vp), ('k_cache', vp), ('v_cache', vp), ('kvdtype', i32), ('out', vp), ('out_mode', i32),
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
                 ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('cache_rows', i32), ('q_stats', vp), ('q_stats_np', i32),
-                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp)]
+                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
@@ -98,7 +99,7 @@ _linear_pair = _sig('acmi_linear_pair', [C.POINTER(LinearDesc), C.POINTER(Linear
 _attn_ex = _sig('acmi_attn_decode_ex', [C.POINTER(AttnDesc), vp])
 _ln_tile_reduce = _sig('acmi_ln_tile_reduce', [vp, vp, i32, vp, i32, i32, i32, f32, vp])
 _kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
-_sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, i32, f32, i32, f32, u64, u64, vp])
+_sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, f32, i32, f32, u64, u64, vp])
 
 EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
@@ -272,7 +273,7 @@ def linear_pair(plain: LinearDesc, xcat: LinearDesc):
 
 
 def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False, out_rbs=0, out_col0=0,
-                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5):
+                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5, len_rows=None):
     """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True; out_rbs / out_col0
     place the head outputs inside a wider buffer).  q_colsum: LayerNorm hook on q (acmi_attn_desc)."""
     cache_rows, H, Tcap, hd = k_cache.shape
@@ -285,6 +286,7 @@ def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_
     d.cache_rows = cache_rows
     d.q_stats, d.q_stats_np, d.q_stats_cnt, d.eps = ptr(q_stats), q_np, q_cnt, eps
     d.q_colsum, d.q_bias = ptr(q_colsum), ptr(q_bias)
+    d.len_rows = ptr(len_rows)
     check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')
     return out
 
@@ -317,11 +319,13 @@ def kv_store(src, cache, t0):
     check(_kv_store(ptr(src), ptr(cache), dtype_code(cache.dtype), Beff, H, hd, Tcap, t0, L, stream()), 'acmi_kv_store')
 
 
-def sample(logits, B, K, card, use_cfg, cfg_coef, use_sampling, temp, top_k, top_p, seed, step, want_mixed=False):
+def sample(logits, B, K, card, use_cfg, cfg_coef, use_sampling, temp, top_k, top_p, seed, step, want_mixed=False,
+           cfg_coef_beta=0.0):
+    """use_cfg: False / CFG_NONE, True / CFG_PAIR ([cond; uncond] rows) or CFG_DOUBLE ([cond; wav; uncond] rows)."""
     tokens = torch.empty(B, K, device=logits.device, dtype=torch.int64)
     mixed = torch.empty(B, K, card, device=logits.device, dtype=torch.float32) if want_mixed else None
-    check(_sample(ptr(logits), ptr(tokens), ptr(mixed), B, K, card, int(use_cfg), cfg_coef, int(use_sampling), temp,
-                  top_k, top_p, seed, step, stream()), 'acmi_sample')
+    check(_sample(ptr(logits), ptr(tokens), ptr(mixed), B, K, card, int(use_cfg), cfg_coef, cfg_coef_beta,
+                  int(use_sampling), temp, top_k, top_p, seed, step, stream()), 'acmi_sample')
     return tokens, mixed
 
 

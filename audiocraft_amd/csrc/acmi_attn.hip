@@ -17,6 +17,7 @@ struct AttnArgs {
     const float* q; const void* kc; const void* vc; void* out;
     int out_tiled, out_bf16, out_rbs, out_col0;  // tiled output: K tiles per 16-row block, first column
     int H, Tcap, len; const int* len_dev; int len_bias; float scale;
+    const int* len_rows;  // per-cache-row length (two_step_cfg: the two passes keep their own condition length), or NULL
     int rpp;      // rows per position: query row b belongs to cache row b % rpp; with len_dev its length grows by b / rpp
     // optional LayerNorm hook on q (the cross-attention query arrives as x W'^T, see acmi_linear_pair):
     //   q <- rstd[b] (q - mean[b] colsum) + bias, mean / rstd of row b from the (mean, M2) partials of x
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
     const int b0 = b % p.rpp, pidx = b / p.rpp;   // several positions per call (prefill): cache row, position index
-    const int len = p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len;
+    const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len)) : (p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len);
 
     float qv[DPL];
 #pragma unroll
@@ -205,7 +206,8 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
     a.out_rbs = c.out_rbs > 0 ? c.out_rbs : nkc; a.out_col0 = c.out_col0;
     ACMI_REQUIRE(c.out_col0 >= 0 && c.out_col0 % kt == 0 && a.out_rbs * kt >= c.out_col0 + c.H * c.hd,
                  "acmi_attn_decode: tiled output placement col0=%d rbs=%d does not hold %d columns", c.out_col0, a.out_rbs, c.H * c.hd);
-    a.H = c.H; a.Tcap = c.Tcap; a.len = c.len; a.len_dev = c.len_dev; a.len_bias = c.len_bias;
+    a.H = c.H; a.Tcap = c.Tcap; a.len = c.len; a.len_dev = c.len_dev; a.len_bias = c.len_bias; a.len_rows = c.len_rows;
+    ACMI_REQUIRE(c.len_rows == nullptr || (c.len_dev == nullptr && c.len > 0), "acmi_attn_decode: len_rows needs a host `len` bound");
     a.rpp = c.cache_rows > 0 ? c.cache_rows : c.Beff;
     ACMI_REQUIRE(c.Beff % a.rpp == 0, "acmi_attn_decode: %d query rows are not a multiple of %d cache rows", c.Beff, a.rpp);
     a.scale = 1.0f / sqrtf((float)c.hd);

@@ -109,8 +109,8 @@ extern "C" int acmi_pos_table(const float* freq, float* table, int T, int d, voi
 
 struct SampleArgs {
     const float* logits;  // [Beff, K*card]
-    int B, K, card, use_cfg;
-    float cfg_coef;
+    int B, K, card, use_cfg;   // use_cfg: ACMI_CFG_NONE | ACMI_CFG_PAIR | ACMI_CFG_DOUBLE
+    float cfg_coef, cfg_beta;
     int use_sampling; float temp; int top_k; float top_p;
     uint64_t seed; uint64_t step; int* pos;  // step counter = step + pos[0] when pos != NULL
     int advance;          // last block to finish does pos[0] += 1 (pos[1] is the ticket counter)
@@ -183,13 +183,19 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
     const int k = blockIdx.x, b = blockIdx.y;
     const int card = p.card;
     const float* cond = p.logits + ((size_t)b * p.K + k) * card;
-    const float* uncond = p.logits + ((size_t)(p.B + b) * p.K + k) * card;
+    // row groups: PAIR [cond; uncond], DOUBLE [cond (text + wav); wav; uncond]
+    const float* second = p.logits + ((size_t)(p.B + b) * p.K + k) * card;
+    const float* third = p.logits + ((size_t)(2 * p.B + b) * p.K + k) * card;
     const int gpos = p.pos ? p.pos[0] : 0;
     for (int i = threadIdx.x; i < card; i += blockDim.x) {
         float v = cond[i];
-        if (p.use_cfg) {  // uncond + (cond - uncond) * coef, rounded after every op like the reference (no fma)
-            const float u = uncond[i];
+        if (p.use_cfg == ACMI_CFG_PAIR) {  // uncond + (cond - uncond) * coef, rounded after every op like the reference (no fma)
+            const float u = second[i];
             v = __fadd_rn(u, __fmul_rn(__fsub_rn(v, u), p.cfg_coef));
+        } else if (p.use_cfg == ACMI_CFG_DOUBLE) {  // uncond + coef * (wav + beta * (cond - wav) - uncond), lm.py:372-376
+            const float w = second[i], u = third[i];
+            const float inner = __fsub_rn(__fadd_rn(w, __fmul_rn(p.cfg_beta, __fsub_rn(v, w))), u);
+            v = __fadd_rn(u, __fmul_rn(p.cfg_coef, inner));
         }
         vals[i] = v;
         if (p.mixed_out) p.mixed_out[((size_t)b * p.K + k) * card + i] = v;
@@ -307,10 +313,11 @@ static int launch_sample(const SampleArgs& a, hipStream_t st) {
 }
 
 extern "C" int acmi_sample(const float* logits, int64_t* tokens_out, float* mixed_out, int B, int K, int card,
-                           int use_cfg, float cfg_coef, int use_sampling, float temp, int top_k, float top_p,
-                           uint64_t seed, uint64_t step, void* stream) {
+                           int cfg_mode, float cfg_coef, float cfg_coef_beta, int use_sampling, float temp, int top_k,
+                           float top_p, uint64_t seed, uint64_t step, void* stream) {
+    ACMI_REQUIRE(cfg_mode >= ACMI_CFG_NONE && cfg_mode <= ACMI_CFG_DOUBLE, "acmi_sample: bad cfg_mode %d", cfg_mode);
     SampleArgs a = {};
-    a.logits = logits; a.B = B; a.K = K; a.card = card; a.use_cfg = use_cfg; a.cfg_coef = cfg_coef;
+    a.logits = logits; a.B = B; a.K = K; a.card = card; a.use_cfg = cfg_mode; a.cfg_coef = cfg_coef; a.cfg_beta = cfg_coef_beta;
     a.use_sampling = use_sampling; a.temp = temp; a.top_k = top_k; a.top_p = top_p; a.seed = seed; a.step = step;
     a.tokens_out = tokens_out; a.mixed_out = mixed_out;
     return launch_sample(a, (hipStream_t)stream);
@@ -403,7 +410,9 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     const int d = m->dim, H = m->num_heads, hd = d / H, M = s->Beff * npos, F = m->ffn_dim;
     ACMI_REQUIRE(d % H == 0 && d % 16 == 0 && d <= 2048 && F % 4 == 0, "acmi_lm_step: bad dims d=%d H=%d", d, H);
     ACMI_REQUIRE(m->n_q <= 16, "acmi_lm_step: n_q=%d > 16", m->n_q);
-    ACMI_REQUIRE(s->Beff == (s->use_cfg ? 2 * s->B : s->B), "acmi_lm_step: Beff/B mismatch");
+    ACMI_REQUIRE(s->use_cfg >= ACMI_CFG_NONE && s->use_cfg <= ACMI_CFG_DOUBLE, "acmi_lm_step: bad use_cfg %d", s->use_cfg);
+    ACMI_REQUIRE(s->Beff == s->B * (s->use_cfg + 1), "acmi_lm_step: Beff=%d is not B=%d x %d row groups", s->Beff, s->B,
+                 s->use_cfg + 1);
     ACMI_REQUIRE(mode == ACMI_STEP_PREFILL || s->n_pos <= 1, "acmi_lm_step: n_pos=%d only with ACMI_STEP_PREFILL", s->n_pos);
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
     int rc;
@@ -458,7 +467,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             acmi_attn_desc ca = {};
             ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
             ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.Beff = M; ca.H = H; ca.hd = hd; ca.Tcap = s->Lc;
-            ca.len = s->Lc; ca.cache_rows = s->Beff;
+            ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows;
             if (pair) {
                 // ONE launch: x1 = x0 + att W_out^T (fragments of x1 into the other buffer pair: this launch
                 // still reads x0's) and r = [x0 | att] [W_cq' | W_cq' W_out]^T = x1 W_cq'^T
@@ -496,7 +505,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         if ((rc = gemm_ln_x(c, hl, m->w_head, m->b_head, m->cs_head, m->n_q * m->card))) return rc;
         SampleArgs a = {};
         a.logits = s->logits; a.B = s->B; a.K = m->n_q; a.card = m->card; a.use_cfg = s->use_cfg;
-        a.cfg_coef = s->cfg_coef; a.use_sampling = s->use_sampling; a.temp = s->temp; a.top_k = s->top_k;
+        a.cfg_coef = s->cfg_coef; a.cfg_beta = s->cfg_coef_beta; a.use_sampling = s->use_sampling; a.temp = s->temp; a.top_k = s->top_k;
         a.top_p = s->top_p; a.seed = s->seed; a.step = 0; a.pos = s->pos; a.advance = 1; a.mixed_out = s->step_logits;
         a.gen_sequence = s->gen_sequence; a.seq_mask = s->seq_mask; a.S = s->S; a.P = s->prepend ? s->n_prepend : 0;
         return launch_sample(a, st);

@@ -21,6 +21,7 @@ nothing between steps except replay (and the optional progress callback).
 import ctypes as C
 import math
 import typing as tp
+from contextlib import contextmanager
 
 import torch
 from torch import nn
@@ -28,7 +29,7 @@ from torch import nn
 from .. import _C
 from ..modules.codebooks_patterns import CodebooksPatternProvider
 from ..modules.conditioners import (ClassifierFreeGuidanceDropout, ConditionFuser, ConditioningAttributes,
-                                    ConditioningProvider, ConditionType)
+                                    ConditioningProvider, ConditionType, _drop_description_condition)
 
 ConditionTensors = tp.Dict[str, ConditionType]
 
@@ -103,8 +104,6 @@ class LMModel(nn.Module):
                 raise NotImplementedError(f"{k} is not used by MusicGen and not implemented")
         if kwargs.get('kv_repeat', 1) != 1 or kwargs.get('qk_layer_norm', False):
             raise NotImplementedError("kv_repeat / qk_layer_norm are not used by MusicGen")
-        if two_step_cfg:
-            raise NotImplementedError("two_step_cfg (lm.py:378-387) is a 'next' row; MusicGen configs use one-step CFG")
         assert dim % num_heads == 0 and dim % 8 == 0
         self.cfg_coef = cfg_coef
         self.cfg_dropout = ClassifierFreeGuidanceDropout(p=cfg_dropout)
@@ -131,6 +130,8 @@ class LMModel(nn.Module):
         self._packed: tp.Optional[dict] = None
         self._run: tp.Optional[dict] = None
         self._graph_keepalive = None
+        self._stream = None
+        self._is_streaming = False
         self.eval()
 
     # ------------------------------------------------------------------------------------- init
@@ -176,6 +177,7 @@ class LMModel(nn.Module):
         self._packed = None
         self._run = None
         self._graph_keepalive = None
+        self._stream = None
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         self._invalidate()
@@ -286,14 +288,17 @@ class LMModel(nn.Module):
         return pk
 
     # ------------------------------------------------------------------------------------- run state
-    def _prepare_run(self, B: int, use_cfg: bool, Tmax: int, Lc: int, S: int):
-        """(Re)allocate KV caches / activations for this batch geometry; reused across generate() calls."""
+    def _prepare_run(self, B: int, use_cfg: int, Tmax: int, Lc: int, S: int):
+        """(Re)allocate KV caches / activations for this batch geometry; reused across generate() calls.
+        use_cfg: _C.CFG_NONE / CFG_PAIR / CFG_DOUBLE -> 1, 2 or 3 row groups of B rows."""
         pk = self._packed or self._pack()
+        use_cfg = int(use_cfg)
         key = (B, use_cfg, Tmax, Lc, S)
         if self._run is not None and self._run['key'] == key:
             return self._run
+        self._stream = None   # a stream holds pointers into the buffers replaced below
         dev = self.device
-        Beff = 2 * B if use_cfg else B
+        Beff = B * (use_cfg + 1)
         H, hd, d = self.num_heads, self.dim // self.num_heads, self.dim
         f32 = dict(device=dev, dtype=torch.float32)
         run: dict = {'key': key, 'Beff': Beff, 'graphs': {}}
@@ -330,14 +335,21 @@ class LMModel(nn.Module):
         run['logits'] = torch.zeros(Beff, self.n_q * self.card, **f32)
         run['step_logits'] = torch.zeros(B, self.n_q, self.card, **f32)
         run['pos'] = torch.zeros(4, device=dev, dtype=torch.int32)
+        run['cross_len_rows'] = torch.full((Beff,), max(Lc, 1), device=dev, dtype=torch.int32)
         run['gen_sequence'] = torch.zeros(B, self.n_q, S, device=dev, dtype=torch.int64)
         run['seq_mask'] = torch.zeros(self.n_q, S, device=dev, dtype=torch.uint8)
         self._run = run
         return run
 
     def _make_state(self, run, B, use_cfg, Tmax, Lc, S, prepend, record_logits, use_sampling, temp, top_k, top_p,
-                    cfg_coef, seed) -> _C.LMState:
+                    cfg_coef, seed, cfg_coef_beta: float = 0.0, cross_lens: tp.Optional[torch.Tensor] = None) -> _C.LMState:
         st = _C.LMState()
+        st.cfg_coef_beta = float(cfg_coef_beta)
+        if cross_lens is not None:   # per-row cross-attention length (two_step_cfg)
+            run['cross_len_rows'].copy_(cross_lens.to(torch.int32))
+            st.cross_len_rows = run['cross_len_rows'].data_ptr()
+        else:
+            st.cross_len_rows = None
         st.Beff, st.B, st.use_cfg, st.Tmax, st.Lc = run['Beff'], B, int(use_cfg), Tmax, Lc
         st.n_prepend = 0 if prepend is None else prepend.shape[1]
         st.S = S
@@ -369,12 +381,43 @@ class LMModel(nn.Module):
             _C.kv_store(tmp.view(Beff, Lc, d), run['cv'][li], 0)
 
     # ------------------------------------------------------------------------------------- conditions
-    def _cfg_condition_tensors(self, conditions: tp.List[ConditioningAttributes]) -> ConditionTensors:
-        """conditions + null conditions, batched as [cond; uncond] (lm.py:497-509)."""
+    def _cfg_condition_tensors(self, conditions: tp.List[ConditioningAttributes], cfg_coef_beta=None,
+                               two_step_cfg: bool = False):
+        """The condition tensors of the three CFG modes of the reference's generate (lm.py:486-511):
+        default      conditions + null conditions -> ONE batch [cond; uncond]                       (dict)
+        double CFG   conditions + wav-only conditions + null conditions -> [cond; wav; uncond]       (dict, 3B rows)
+        two_step_cfg conditions and null conditions encoded SEPARATELY, each with its own padding    (tuple of dicts)"""
         null_conditions = ClassifierFreeGuidanceDropout(p=1.0)(conditions)
-        conditions = conditions + null_conditions
-        tokenized = self.condition_provider.tokenize(conditions)
-        return self.condition_provider(tokenized)
+        provider = self.condition_provider
+        if cfg_coef_beta is not None:
+            allc = conditions + _drop_description_condition(conditions) + null_conditions
+            return provider(provider.tokenize(allc))
+        if two_step_cfg:
+            return (provider(provider.tokenize(conditions)), provider(provider.tokenize(null_conditions)))
+        return provider(provider.tokenize(conditions + null_conditions))
+
+    def _fuse_two_step(self, cond: ConditionTensors, null: ConditionTensors):
+        """two_step_cfg on the device: the reference runs the conditional and the unconditional forward one after the
+        other, each with its own condition tensors and its own streaming state (lm.py:377-387).  Rows are independent,
+        so the two passes are the two row groups of ONE step; what must be kept apart is the cross-attention source
+        length of each pass (padding is not masked in cross-attention: SURVEY.md section 7) -> per-row lengths."""
+        p_c, x_c = self.fuser.fuse(cond)
+        p_n, x_n = self.fuser.fuse(null)
+        cross_src, lens = None, None
+        if x_c is not None or x_n is not None:
+            assert x_c is not None and x_n is not None
+            Lc, Ln = x_c.shape[1], x_n.shape[1]
+            L = max(Lc, Ln)
+            pad = lambda t: torch.nn.functional.pad(t.float(), (0, 0, 0, L - t.shape[1]))  # noqa: E731
+            cross_src = torch.cat([pad(x_c), pad(x_n)], dim=0)
+            lens = torch.tensor([Lc] * x_c.shape[0] + [Ln] * x_n.shape[0], dtype=torch.int32)
+        prepend = None
+        if p_c is not None or p_n is not None:
+            if p_c is None or p_n is None or p_c.shape[1] != p_n.shape[1]:
+                raise NotImplementedError("two_step_cfg with prepended conditions of different lengths in the two passes: "
+                                          "the row groups would sit at different positions of the stream")
+            prepend = torch.cat([p_c.float(), p_n.float()], dim=0)
+        return prepend, cross_src, lens
 
     # ------------------------------------------------------------------------------------- generate
     @torch.no_grad()
@@ -393,41 +436,48 @@ class LMModel(nn.Module):
                  remove_prompts: bool = False,
                  check: bool = False,
                  callback: tp.Optional[tp.Callable[[int, int], None]] = None,
-                 condition_tensors: tp.Optional[ConditionTensors] = None,
+                 condition_tensors: tp.Optional[tp.Union[ConditionTensors, tp.Tuple[ConditionTensors, ConditionTensors]]] = None,
                  seed: tp.Optional[int] = None,
                  return_logits: bool = False,
                  use_graph: bool = True,
                  ) -> torch.Tensor:
-        """Same contract as the reference `LMModel.generate` (lm.py:420-587) -> LongTensor [B, K, T].
+        """Same contract as the reference `LMModel.generate` (lm.py:420-587) -> LongTensor [B, K, T], including its three
+        classifier-free-guidance modes: one batched forward on `[cond; uncond]` (default), `two_step_cfg` (separate
+        conditional / unconditional passes, mixed with the MODEL's cfg_coef like the reference does, lm.py:386) and
+        double CFG (`cfg_coef_beta`, rows `[text + wav; wav; null]`, lm.py:362-376).
 
-        Extra keyword-only conveniences (not in the reference): `condition_tensors` (already batched
-        `[cond; uncond]` output of the condition provider -- the multi-GPU path broadcasts these),
-        `seed` (device Philox stream; default drawn from torch's global generator), `return_logits`
-        (also return the CFG-mixed logits of every step, [B, K, steps, card]) and `use_graph`.
+        Extra keyword-only conveniences (not in the reference): `condition_tensors` (the already encoded conditions, as
+        `_cfg_condition_tensors` returns them for the mode in use -- the multi-GPU path broadcasts these), `seed` (device
+        Philox stream; default drawn from torch's global generator), `return_logits` (also return the CFG-mixed logits
+        of every step, [B, K, steps, card]) and `use_graph`.
         """
         assert not self.training, "generation shouldn't be used in training mode."
-        if cfg_coef_beta is not None:
-            raise NotImplementedError("double CFG (cfg_coef_beta, MusicGen-Style) is a 'next' row")
-        if two_step_cfg or (two_step_cfg is None and self.two_step_cfg):
-            raise NotImplementedError("two_step_cfg is a 'next' row")
         dev = self.device
+        two_step = self.two_step_cfg if two_step_cfg is None else two_step_cfg
+        cfg_conditions: tp.Any = {}
+        if condition_tensors is not None:
+            assert not conditions, "Shouldn't pass both conditions and condition_tensors."
+            cfg_conditions = condition_tensors
+        elif conditions:
+            cfg_conditions = self._cfg_condition_tensors(conditions, cfg_coef_beta, bool(two_step))
+        two_step = isinstance(cfg_conditions, tuple)
+        groups = 1
+        if two_step or cfg_conditions:
+            groups = 3 if (cfg_coef_beta is not None and not two_step) else 2
         if num_samples is None:
             if prompt is not None:
                 num_samples = prompt.shape[0]
             elif conditions:
                 num_samples = len(conditions)
-            elif condition_tensors:
-                num_samples = next(iter(condition_tensors.values()))[0].shape[0] // 2
+            elif two_step:
+                num_samples = next(iter(cfg_conditions[0].values()))[0].shape[0]
+            elif cfg_conditions:
+                num_samples = next(iter(cfg_conditions.values()))[0].shape[0] // groups
             else:
                 num_samples = 1
-        cfg_conditions: ConditionTensors = {}
-        if condition_tensors is not None:
-            assert not conditions, "Shouldn't pass both conditions and condition_tensors."
-            cfg_conditions = condition_tensors
-        elif conditions:
-            cfg_conditions = self._cfg_condition_tensors(conditions)
-        use_cfg = bool(cfg_conditions)
-        coef = self.cfg_coef if cfg_coef is None else cfg_coef
+        use_cfg = {1: _C.CFG_NONE, 2: _C.CFG_PAIR, 3: _C.CFG_DOUBLE}[groups]
+        # the two-step branch of the reference ignores the cfg_coef argument (lm.py:386)
+        coef = self.cfg_coef if (cfg_coef is None or two_step) else cfg_coef
 
         if prompt is None:
             assert num_samples > 0
@@ -448,11 +498,17 @@ class LMModel(nn.Module):
         S = gen_sequence.shape[-1]
 
         # fuse conditions: what is prepended to the token stream, what is cross-attended to
-        prepend, cross_src = self.fuser.fuse(cfg_conditions)
+        cross_lens = None
+        if two_step:
+            prepend, cross_src, cross_lens = self._fuse_two_step(*cfg_conditions)
+        else:
+            prepend, cross_src = self.fuser.fuse(cfg_conditions)
         if self.has_cross_attention:
             assert cross_src is not None, "this model cross-attends to a condition but none was given"
         else:
             assert cross_src is None, "this model has no cross-attention layers"
+        for t in (prepend, cross_src):
+            assert t is None or t.shape[0] == B * groups, f"condition rows {t.shape[0]} != {B} samples x {groups} row groups"
         P = 0 if prepend is None else prepend.shape[1]
         Lc = 0 if cross_src is None else cross_src.shape[1]
         Tmax = P + S  # positions g = 0 .. P + S - 2 are ever run
@@ -463,7 +519,8 @@ class LMModel(nn.Module):
         if prepend is not None:
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
         state = self._make_state(run, B, use_cfg, Tmax, Lc, S, prepend, return_logits, use_sampling, temp, top_k,
-                                 top_p, coef, seed)
+                                 top_p, coef, seed, cfg_coef_beta=0.0 if cfg_coef_beta is None else cfg_coef_beta,
+                                 cross_lens=cross_lens)
         desc = self._packed['desc']
         desc.pos_table = run['pos_table'].data_ptr()
         run['gen_sequence'].copy_(gen_sequence)
@@ -534,6 +591,108 @@ class LMModel(nn.Module):
             done += state.n_pos
         state.n_pos = 1
 
+    # ------------------------------------------------------------------------------------- streaming protocol
+    # `StreamingModule` of the reference (audiocraft/modules/streaming.py:20-119): `with lm.streaming():` makes successive
+    # `forward` calls continue one stream (KV caches, position offsets); the state is a dict of tensors with the
+    # reference's key names.  Here the state lives in the device buffers `acmi_lm_step` works on; the dict entries are
+    # VIEWS of them (the caches are append-only, so a state taken earlier stays valid and `set_streaming_state` of it
+    # rewinds the stream).
+    streaming_capacity = 2048   # positions a stream can hold (KV cache rows allocated at the first streaming forward)
+
+    @contextmanager
+    def streaming(self):
+        """Context manager to enter streaming mode; the streaming state is reset on exit (streaming.py:59-67)."""
+        self._is_streaming = True
+        try:
+            yield
+        finally:
+            self._is_streaming = False
+            self.reset_streaming()
+
+    def reset_streaming(self):
+        self._stream = None
+
+    def _stream_begin(self, B: int, condition_tensors: ConditionTensors):
+        dev = self.device
+        prepend, cross_src = self.fuser.fuse(condition_tensors)
+        P = 0 if prepend is None else prepend.shape[1]
+        Lc = 0 if cross_src is None else cross_src.shape[1]
+        cap = self.streaming_capacity
+        run = self._prepare_run(B, _C.CFG_NONE, P + cap + 1, Lc, cap + 1)
+        if prepend is not None:
+            prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
+        state = self._make_state(run, B, _C.CFG_NONE, P + cap + 1, Lc, cap + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
+        desc = self._packed['desc']
+        desc.pos_table = run['pos_table'].data_ptr()
+        run['gen_sequence'].fill_(-1)
+        run['seq_mask'].fill_(1)
+        run['pos'].zero_()
+        if cross_src is not None:
+            self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
+        self._prefill(desc, state, P)   # the fuser prepends on the first call only (conditioners.py:1722-1741)
+        self._stream = {'run': run, 'state': state, 'desc': desc, 'prepend': prepend, 'P': P, 'steps': 0, 'B': B}
+        return self._stream
+
+    def _streaming_forward(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
+        B, K, S = sequence.shape
+        st = getattr(self, '_stream', None)
+        if st is None:
+            st = self._stream_begin(B, condition_tensors)
+        assert st['B'] == B, "the batch size of a stream cannot change"
+        assert st['steps'] + S <= self.streaming_capacity, "stream longer than LMModel.streaming_capacity"
+        run, off = st['run'], st['steps']
+        run['gen_sequence'][:, :, off:off + S] = sequence.to(self.device)
+        outs = []
+        for _ in range(S):
+            _C.lm_step(st['desc'], st['state'], _C.STEP_DECODE)
+            outs.append(run['step_logits'].clone())
+        st['steps'] = off + S
+        return torch.stack(outs, dim=2)
+
+    def get_streaming_state(self) -> tp.Dict[str, torch.Tensor]:
+        """Key names of the reference (streaming.py:75-86): `transformer.offsets`,
+        `fuser.offsets`, `transformer.layers.{i}.self_attn.past_keys|past_values|offset`.  K / V: [B, H, t, hd] views."""
+        st = getattr(self, '_stream', None)
+        if st is None:
+            return {}
+        run, B = st['run'], st['B']
+        t = st['P'] + st['steps']
+        dev = self.device
+        state = {'transformer.offsets': torch.full((B,), t, dtype=torch.long, device=dev),
+                 'fuser.offsets': torch.full((B,), st['steps'], dtype=torch.long, device=dev)}
+        for li in range(self.num_layers):
+            pre = f'transformer.layers.{li}.self_attn.'
+            state[pre + 'past_keys'] = run['k'][li][:, :, :t]
+            state[pre + 'past_values'] = run['v'][li][:, :, :t]
+            state[pre + 'offset'] = torch.tensor(t, dtype=torch.long, device=dev)
+        return state
+
+    def set_streaming_state(self, state: tp.Dict[str, torch.Tensor]):
+        """Inverse of get_streaming_state (streaming.py:88-104): rewinds / restores the stream.  K / V tensors that are
+        not views of this model's own caches are copied in."""
+        st = getattr(self, '_stream', None)
+        if not state:
+            self._stream = None
+            return
+        assert st is not None, "set_streaming_state: no stream to restore into (run a streaming forward first)"
+        run = st['run']
+        t = int(state['transformer.offsets'][0])
+        assert st['P'] <= t <= st['P'] + self.streaming_capacity
+        known = {'transformer.offsets', 'fuser.offsets'}
+        for li in range(self.num_layers):
+            pre = f'transformer.layers.{li}.self_attn.'
+            for name, cache in (('past_keys', run['k'][li]), ('past_values', run['v'][li])):
+                src = state[pre + name]
+                assert src.shape[2] == t, (src.shape, t)
+                if src.data_ptr() != cache.data_ptr():
+                    cache[:, :, :t].copy_(src)
+                known.add(pre + name)
+            known.add(pre + 'offset')
+        assert set(state.keys()) <= known, sorted(set(state.keys()) - known)
+        st['steps'] = t - st['P']
+        run['pos'][:2] = torch.tensor([t, 0], dtype=torch.int32, device=run['pos'].device)
+        run['gen_sequence'][:, :, st['steps']:].fill_(-1)
+
     # ------------------------------------------------------------------------------------- teacher forcing
     @torch.no_grad()
     def forward_steps(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
@@ -545,10 +704,10 @@ class LMModel(nn.Module):
         prepend, cross_src = self.fuser.fuse(condition_tensors)
         P = 0 if prepend is None else prepend.shape[1]
         Lc = 0 if cross_src is None else cross_src.shape[1]
-        run = self._prepare_run(B, False, P + S + 1, Lc, S + 1)
+        run = self._prepare_run(B, _C.CFG_NONE, P + S + 1, Lc, S + 1)
         if prepend is not None:
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
-        state = self._make_state(run, B, False, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
+        state = self._make_state(run, B, _C.CFG_NONE, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
         desc = self._packed['desc']
         desc.pos_table = run['pos_table'].data_ptr()
         seq = torch.full((B, K, S + 1), -1, dtype=torch.long, device=dev)
@@ -578,6 +737,8 @@ class LMModel(nn.Module):
             condition_tensors = self.condition_provider(tokenized)
         else:
             assert not conditions, "Shouldn't pass both conditions and condition_tensors."
+        if getattr(self, '_is_streaming', False):
+            return self._streaming_forward(sequence, condition_tensors)
         return self.forward_steps(sequence, condition_tensors)
 
     @torch.no_grad()

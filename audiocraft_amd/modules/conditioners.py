@@ -113,6 +113,37 @@ class ClassifierFreeGuidanceDropout(nn.Module):
         return samples
 
 
+class AttributeDropout(nn.Module):
+    """Per-attribute dropout (reference conditioners.py:1380-1424); a fresh module is in training mode, which is how
+    the generation path uses it (p = 1.0 / 0.0: deterministic)."""
+
+    def __init__(self, p: tp.Dict[str, tp.Dict[str, float]], active_on_eval: bool = False, seed: int = 1234):
+        super().__init__()
+        self.active_on_eval = active_on_eval
+        self.rng = torch.Generator()
+        self.rng.manual_seed(seed)
+        self.p = {condition_type: defaultdict(lambda: 0, probs) for condition_type, probs in p.items()}
+
+    def forward(self, samples: tp.List[ConditioningAttributes]) -> tp.List[ConditioningAttributes]:
+        if not self.training and not self.active_on_eval:
+            return samples
+        samples = deepcopy(samples)
+        for condition_type, ps in self.p.items():
+            for condition, p in ps.items():
+                if torch.rand(1, generator=self.rng).item() < p:
+                    for sample in samples:
+                        dropout_condition(sample, condition_type, condition)
+        return samples
+
+
+def _drop_description_condition(conditions: tp.List[ConditioningAttributes]) -> tp.List[ConditioningAttributes]:
+    """Text dropped, wav kept: the middle row group of double CFG (reference conditioners.py:223-236)."""
+    for condition in conditions:
+        assert 'description' in condition.text.keys()
+        assert 'self_wav' in condition.wav.keys()
+    return AttributeDropout(p={'text': {'description': 1.0}, 'wav': {'self_wav': 0.0}})(conditions)
+
+
 # ------------------------------------------------------------------------------------------ conditioners
 
 class BaseConditioner(nn.Module):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 100 /* 0.1.0 */
+#define ACMI_VERSION 110 /* 0.1.1: CFG modes (double CFG, per-row cross-attention length), acmi_sample takes cfg_mode */
 
 #define ACMI_OK 0
 #define ACMI_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -167,9 +167,12 @@ typedef struct {
 } acmi_lm_model;
 
 typedef struct {
-    int Beff;               /* rows run through the transformer: 2B with CFG ([cond; uncond]), else B */
+    int Beff;               /* rows run through the transformer: B x (1 | 2 | 3) by use_cfg */
     int B;                  /* samples */
-    int use_cfg;
+    int use_cfg;            /* ACMI_CFG_NONE: rows = samples;  ACMI_CFG_PAIR: [cond; uncond] (lm.py:391-399; also the
+                               two_step_cfg mode of lm.py:377-387, whose two passes are the two row groups with their
+                               own cross-attention lengths, see cross_len_rows);  ACMI_CFG_DOUBLE: [text + wav; wav;
+                               null], MusicGen-Style double CFG (lm.py:362-376) */
     int Tmax;               /* KV cache capacity (positions) = rows of pos_table */
     int Lc;                 /* cross-attention source length (0 if none) */
     int n_prepend;          /* P: rows of `prepend` consumed as inputs before the first token step */
@@ -199,7 +202,16 @@ typedef struct {
     /* sampling (lm.py:402-418, utils/utils.py:88-122) */
     int use_sampling; float temp; int top_k; float top_p; float cfg_coef;
     uint64_t seed;
+    float cfg_coef_beta;    /* ACMI_CFG_DOUBLE: logits = u + cfg_coef * (w + cfg_coef_beta * (c - w) - u) */
+    const int* cross_len_rows; /* device int[Beff] or NULL: cross-attention source length of every row (<= Lc; the
+                               caches hold Lc positions per row, the tail of a shorter row is never read).  Lets the
+                               conditional and the unconditional pass of two_step_cfg keep their own padded lengths
+                               (the reference runs them as two forwards with separate streaming states) */
 } acmi_lm_state;
+
+#define ACMI_CFG_NONE 0
+#define ACMI_CFG_PAIR 1
+#define ACMI_CFG_DOUBLE 2
 
 #define ACMI_STEP_PREFILL 0 /* run the layers at position g (.. g + n_pos - 1), no head / sampling (prompt + prepend rows) */
 #define ACMI_STEP_DECODE 1  /* layers + out_norm + heads + CFG + sampling + pattern write-back */
@@ -318,6 +330,8 @@ typedef struct {
      * LayerNorm (norm_cross, transformer.py:559-565) of the cross-attention query. */
     const float* q_stats; int q_stats_np; int q_stats_cnt; float eps;
     const float* q_colsum; const float* q_bias;
+    const int* len_rows;    /* device int[cache_rows] or NULL: per-cache-row length (overrides len / len_dev; `len` must
+                               still be given: it sizes the launch and bounds every row's length) */
 } acmi_attn_desc;
 int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 
@@ -325,9 +339,12 @@ int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 int acmi_kv_store(const float* src, void* cache, int kvdtype, int Beff, int H, int hd, int Tcap,
                   int t0, int L, void* stream);
 
-/* CFG mix + sampling on logits [Beff, K*card] (lm.py:391-418): tokens_out [B, K] int64. */
+/* CFG mix + sampling on logits [Beff, K*card] (lm.py:362-418): tokens_out [B, K] int64.
+ * cfg_mode ACMI_CFG_NONE (Beff = B) | ACMI_CFG_PAIR (2B rows, u + (c - u) * cfg_coef) | ACMI_CFG_DOUBLE (3B rows,
+ * u + cfg_coef * (w + cfg_coef_beta * (c - w) - u)); every operation rounded on its own like the reference's
+ * tensor expression (no fma). */
 int acmi_sample(const float* logits, int64_t* tokens_out, float* mixed_out, int B, int K, int card,
-                int use_cfg, float cfg_coef, int use_sampling, float temp, int top_k, float top_p,
+                int cfg_mode, float cfg_coef, float cfg_coef_beta, int use_sampling, float temp, int top_k, float top_p,
                 uint64_t seed, uint64_t step, void* stream);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ class SynthTextRagged(TextConditioner):
 def make_two_step():
     cfg = dict(dim=32, num_heads=4, num_layers=2, hidden_scale=4, n_q=4, card=32, cross_attention=True,
                delays=[0, 1, 2, 3], cfg_coef=3.0, seed=3, cond_dim=8, Lc=5)
+    torch.manual_seed(1000 + cfg['seed'])   # the conditioners' output_proj is initialised HERE, before build_lm seeds
     lm = mg.build_lm(cfg, {'description': SynthTextRagged(cfg['cond_dim'], cfg['dim'], cfg['Lc'])},
                      {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []})
     conds = [ConditioningAttributes(text={'description': f'p{i}'}) for i in range(3)]
@@ -62,13 +63,15 @@ def make_two_step():
 def make_double_cfg():
     cfg = dict(dim=32, num_heads=4, num_layers=2, hidden_scale=4, n_q=4, card=32, cross_attention=False,
                delays=[0, 1, 2, 3], cfg_coef=3.0, seed=4, cond_dim=8, Lc=3, P=6, cfg_coef_beta=5.0)
+    torch.manual_seed(1000 + cfg['seed'])
     lm = mg.build_lm(cfg, {'description': mg.SynthText(cfg['cond_dim'], cfg['dim'], cfg['Lc']),
                            'self_wav': mg.SynthChroma(cfg['dim'], cfg['P'])},
                      {'cross': [], 'prepend': ['self_wav', 'description'], 'sum': [], 'input_interpolate': []})
     conds = []
+    gw = torch.Generator().manual_seed(77)
     for i in range(2):
         c = ConditioningAttributes(text={'description': f'm{i}'})
-        c.wav['self_wav'] = WavCondition(torch.randn(1, 1, 64), torch.tensor([64]), [1200], [None], [0.])
+        c.wav['self_wav'] = WavCondition(torch.randn(1, 1, 64, generator=gw), torch.tensor([64]), [1200], [None], [0.])
         conds.append(c)
     rec = []
     h = lm.register_forward_hook(lambda mod, inp, out: rec.append(out.detach().clone()))

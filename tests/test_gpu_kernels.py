@@ -497,3 +497,35 @@ def test_sample_top_p_support(C):
     for step in range(300):
         t, _ = C.sample(lg, 1, 1, card, False, 1.0, True, 1.0, 0, 0.7, 5, step)
         assert support[t.item()]
+
+
+def test_sample_double_cfg_mix_bit_exact(C):
+    """rows [cond; wav; uncond] -> u + coef * (w + beta * (c - w) - u), every operation rounded like the reference's
+    tensor expression (lm.py:372-376)."""
+    g = torch.Generator().manual_seed(3)
+    B, K, card = 2, 4, 2048
+    logits = torch.randn(3 * B, K * card, generator=g) * 4
+    toks, mixed = C.sample(logits.cuda(), B, K, card, C.CFG_DOUBLE, 3.0, False, 1.0, 0, 0.0, 0, 0, want_mixed=True,
+                           cfg_coef_beta=5.0)
+    ref = olm.double_cfg_mix(logits.view(3 * B, K, card), 3.0, 5.0)
+    assert torch.equal(mixed.cpu(), ref)
+    assert torch.equal(toks.cpu(), ref.argmax(-1))
+
+
+def test_attention_per_row_lengths(C):
+    """len_rows: every cache row attends over its own number of positions (two_step_cfg: the conditional and the
+    unconditional pass keep their own condition length inside one launch)."""
+    g = torch.Generator().manual_seed(4)
+    rows, H, hd, Tcap = 6, 4, 64, 16
+    q = torch.randn(rows, H * hd, generator=g)
+    k = torch.randn(rows, H, Tcap, hd, generator=g)
+    v = torch.randn(rows, H, Tcap, hd, generator=g)
+    lens = torch.tensor([5, 5, 5, 1, 16, 9], dtype=torch.int32)
+    out = torch.empty(rows, H * hd, device='cuda')
+    C.attn_decode(q.cuda(), k.cuda(), v.cuda(), out, Tcap, len_rows=lens.cuda())
+    for b in range(rows):
+        n = int(lens[b])
+        qq = q[b].view(H, 1, hd)
+        w = torch.softmax(qq @ k[b, :, :n].transpose(-1, -2) / math.sqrt(hd), dim=-1)
+        ref = (w @ v[b, :, :n]).reshape(-1)
+        assert torch.allclose(out[b].cpu(), ref, atol=2e-5, rtol=1e-4), (b, (out[b].cpu() - ref).abs().max())

@@ -281,3 +281,123 @@ def test_musicgen_small_architecture_greedy_parity():
     assert torch.equal(toks.cpu(), ref_t)
     r = rel(lg.cpu(), ref_l)
     assert r < 1e-4, f"logits rel-L2 {r}"
+
+
+# ------------------------------------------------------------------------------------------ CFG modes 2 and 3
+
+def test_lm_two_step_cfg_vs_reference_golden():
+    """two_step_cfg (reference lm.py:377-387, 498-505): conditional / unconditional passes with their own condition length
+    (5 vs 1) -- on the device the two row groups of one step with per-row cross-attention lengths; the mix uses the
+    MODEL's cfg_coef (the golden run passed cfg_coef=7 on purpose)."""
+    cfg, sd, a = load_golden('lm_two_step')
+    lm = build_lm(cfg, sd)
+    ct = {'description': (a['cross_src'].cuda(), torch.ones(a['cross_src'].shape[:2], dtype=torch.int64).cuda())}
+    nt = {'description': (a['null_cross_src'].cuda(), torch.ones(a['null_cross_src'].shape[:2], dtype=torch.int64).cuda())}
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=10, use_sampling=False, condition_tensors=(ct, nt),
+                           cfg_coef=7.0, return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
+    assert rel(lg.cpu(), ref) < 1e-4
+    # a longer null source than the conditional one is just as valid (lengths are per row, the buffer is the max)
+    nt2 = {'description': (torch.zeros(3, 8, cfg['dim']).cuda(), torch.ones(3, 8, dtype=torch.int64).cuda())}
+    toks2 = lm.generate(None, [], num_samples=3, max_gen_len=10, use_sampling=False, condition_tensors=(ct, nt2))
+    assert torch.equal(toks2.cpu(), a['greedy_tokens'])   # an all-zero source contributes exactly 0 at any length
+
+
+def test_lm_double_cfg_vs_reference_golden():
+    """cfg_coef_beta (MusicGen-Style double CFG, lm.py:362-376): 3B rows [text + wav; wav; null]."""
+    cfg, sd, a = load_golden('lm_double_cfg')
+    lm = build_lm(cfg, sd)
+    P, Lc = cfg['P'], cfg['Lc']
+    pre = a['prepend_src'].cuda()
+    ones = lambda n: torch.ones(pre.shape[0], n, dtype=torch.int64).cuda()  # noqa: E731
+    ct = {'description': (pre[:, P:], ones(Lc)), 'self_wav': (pre[:, :P], ones(P))}
+    toks, lg = lm.generate(None, [], num_samples=2, max_gen_len=9, use_sampling=False, condition_tensors=ct,
+                           cfg_coef_beta=cfg['cfg_coef_beta'], return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    assert rel(lg.cpu(), olm.double_cfg_mix(a['step_logits'], cfg['cfg_coef'], cfg['cfg_coef_beta'])) < 1e-4
+
+
+def test_cfg_modes_from_attributes_midsize():
+    """The three modes through `conditions` (attributes -> provider -> fuser) on a mid-size model vs the oracle."""
+    from audiocraft_amd.models import builders
+    from audiocraft_amd.modules.conditioners import ConditioningAttributes, WavCondition
+    torch.manual_seed(0)
+    cfg = dict(dim=128, num_heads=4, num_layers=3, n_q=4, card=512, hidden_scale=4, cfg_coef=2.5,
+               conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 32, 'length': 5},
+                             'self_wav': {'kind': 'chroma', 'embedder': 'synthetic', 'n_frames': 9}},
+               fuser={'prepend': ['self_wav', 'description']})
+    lm = builders.get_lm_model(cfg, 'cuda', torch.float32)
+    cw = lm.condition_provider.conditioners['self_wav']
+    cw.chroma_len = 9
+
+    def chroma_of(x):   # content dependent (the stock synthetic embedder draws by row index): same wav -> same frames
+        cls = (x.wav.reshape(x.wav.shape[0], -1)[:, :9 * 7:7].abs() * 1000).long() % 12
+        e = torch.nn.functional.one_hot(cls, 12).float()
+        return torch.where((x.length.cpu() == 0).view(-1, 1, 1), torch.zeros_like(e), e.cpu())
+    cw.embedder = chroma_of
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=128, num_heads=4, num_layers=3, n_q=4, card=512, cross_attention=False, cfg_coef=2.5)
+    conds = []
+    for i in range(2):
+        c = ConditioningAttributes(text={'description': f'x{i}'})
+        c.wav['self_wav'] = WavCondition(torch.randn(1, 1, 640), torch.tensor([640]), [32000], [None], [0.])
+        conds.append(c)
+    # double CFG: [text + wav; wav; null]
+    ct3 = lm._cfg_condition_tensors(conds, cfg_coef_beta=4.0)
+    pre3, _ = lm.fuser.fuse(ct3)
+    assert pre3.shape[0] == 6
+    toks = lm.generate(None, conds, max_gen_len=12, use_sampling=False, cfg_coef_beta=4.0, check=True)
+    ref = olm.generate(sd, oc, None, 2, None, pre3.float().cpu(), max_gen_len=12, use_sampling=False, cfg_coef_beta=4.0)
+    assert torch.equal(toks.cpu(), ref)
+    # the middle group really is "wav kept, text dropped"
+    d = ct3['description'][0]
+    assert (d[2:4] == 0).all() and (d[4:] == 0).all() and not (d[:2] == 0).all()
+    w = ct3['self_wav'][0]
+    assert torch.equal(w[:2], w[2:4]) and not torch.equal(w[:2], w[4:])
+    # two-step with equal prepend lengths == one-step (same rows, same conditions; the reference's two orders of
+    # evaluation differ only in batching)
+    t2 = lm.generate(None, conds, max_gen_len=12, use_sampling=False, two_step_cfg=True, check=True)
+    t1 = lm.generate(None, conds, max_gen_len=12, use_sampling=False, check=True)
+    assert torch.equal(t1, t2)
+
+
+# ------------------------------------------------------------------------------------------ streaming protocol (a10)
+
+def test_streaming_protocol_matches_batch_and_rewinds():
+    """StreamingModule protocol on LMModel (reference streaming.py:20-119, tests/modules/test_transformer.py:133-161):
+    chunked streaming forwards == one forward over the whole sequence; get / set_streaming_state rewinds a stream;
+    the key names are the reference's; leaving the context resets the state."""
+    cfg, sd, a = load_golden('lm_text')
+    lm = build_lm(cfg, sd)
+    ones = torch.ones(a['cross_src'].shape[:2], dtype=torch.int64)
+    ct = {'description': (a['cross_src'].cuda(), ones.cuda())}
+    seq = a['tf_sequence'].cuda()                       # [6, 4, 9]
+    full = lm(seq, [], ct)
+    assert rel(full.cpu(), a['tf_logits']) < 1e-4        # the reference's batch forward
+    assert lm.get_streaming_state() == {}
+    with lm.streaming():
+        parts = [lm(seq[..., 0:1], [], ct), lm(seq[..., 1:4], [], ct)]
+        state = lm.get_streaming_state()
+        keys = set(state.keys())
+        assert {'transformer.offsets', 'fuser.offsets', 'transformer.layers.0.self_attn.past_keys',
+                'transformer.layers.1.self_attn.past_values', 'transformer.layers.0.self_attn.offset'} <= keys
+        H, hd = cfg['num_heads'], cfg['dim'] // cfg['num_heads']
+        assert state['transformer.layers.0.self_attn.past_keys'].shape == (6, H, 4, hd)   # time_dim 2, like the torch backend
+        assert int(state['transformer.offsets'][0]) == 4 and state['transformer.offsets'].shape == (6,)
+        tail_a = lm(seq[..., 4:9], [], ct)
+        assert int(lm.get_streaming_state()['transformer.offsets'][0]) == 9
+        lm.set_streaming_state(state)                   # rewind to step 4 and replay the tail
+        tail_b = lm(seq[..., 4:9], [], ct)
+        assert torch.equal(tail_a, tail_b)
+        streamed = torch.cat(parts + [tail_a], dim=2)
+    assert torch.equal(streamed, full)                   # streaming == batch (same kernels, same order: bit exact)
+    assert lm.get_streaming_state() == {}                # reset on exit
+    # a state restored from COPIES (not views of the live caches) works too
+    with lm.streaming():
+        lm(seq[..., 0:4], [], ct)
+        saved = {k: v.clone() for k, v in lm.get_streaming_state().items()}
+        lm(seq[..., 4:6], [], ct)
+        lm.set_streaming_state(saved)
+        tail_c = lm(seq[..., 4:9], [], ct)
+    assert torch.equal(tail_c, tail_a)
