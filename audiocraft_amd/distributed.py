@@ -55,27 +55,63 @@ def shard_range(total: int, rk: int, world: int) -> tp.Tuple[int, int]:
     return start, start + base + (1 if rk < extra else 0)
 
 
+_MAX_CONDS, _NAME_BYTES = 8, 32   # header layout: per condition 4 int64 words of name + (rows, L, d)
+
+
+def _pack_header(ct: ConditionTensors) -> torch.Tensor:
+    assert len(ct) <= _MAX_CONDS, f"at most {_MAX_CONDS} conditions"
+    h = torch.zeros(_MAX_CONDS, _NAME_BYTES // 8 + 3, dtype=torch.int64)
+    for i, (name, (e, m)) in enumerate(ct.items()):
+        raw = name.encode()
+        assert 0 < len(raw) <= _NAME_BYTES, f"condition name '{name}' longer than {_NAME_BYTES} bytes"
+        h[i, :_NAME_BYTES // 8] = torch.frombuffer(bytearray(raw.ljust(_NAME_BYTES, b'\0')), dtype=torch.int64)
+        assert e.dim() == 3 and tuple(m.shape) == tuple(e.shape[:2]), (name, tuple(e.shape), tuple(m.shape))
+        h[i, _NAME_BYTES // 8:] = torch.tensor(e.shape, dtype=torch.int64)
+    return h
+
+
+def _unpack_header(h: torch.Tensor) -> tp.List[tp.Tuple[str, tp.Tuple[int, int, int]]]:
+    out = []
+    for row in h.cpu():
+        rows, L, d = (int(v) for v in row[_NAME_BYTES // 8:])
+        if rows == 0:
+            continue
+        name = row[:_NAME_BYTES // 8].contiguous().numpy().tobytes().rstrip(b'\0').decode()
+        out.append((name, (rows, L, d)))
+    return out
+
+
 def broadcast_condition_tensors(ct: tp.Optional[ConditionTensors], device, src: int = 0) -> ConditionTensors:
-    """Broadcast {name: (emb [2B, L, d] f32, mask [2B, L] int64)} from `src`; other ranks pass None."""
+    """Broadcast {name: (emb [rows, L, d] f32, mask [rows, L] int64)} from `src`; other ranks pass None.
+    TWO collectives whatever the number of conditions: a fixed-layout int64 header (names, shapes) and one f32 payload
+    (embeddings and masks back to back) -- no pickling (`broadcast_object_list`) on the path."""
     if world_size() == 1:
         assert ct is not None
         return ct
-    meta = [None]
     if rank() == src:
         assert ct is not None
-        meta = [[(k, tuple(e.shape), tuple(m.shape)) for k, (e, m) in ct.items()]]
-    dist.broadcast_object_list(meta, src=src)
+        header = _pack_header(ct).to(device)
+    else:
+        header = torch.zeros(_MAX_CONDS, _NAME_BYTES // 8 + 3, dtype=torch.int64, device=device)
+    dist.broadcast(header, src=src)
+    layout = _unpack_header(header)
+    total = sum(rows * L * d + rows * L for _, (rows, L, d) in layout)
+    if rank() == src:
+        payload = torch.cat([t for name, _ in layout for t in (
+            ct[name][0].to(device=device, dtype=torch.float32).reshape(-1),
+            ct[name][1].to(device=device, dtype=torch.float32).reshape(-1))])
+        assert payload.numel() == total
+    else:
+        payload = torch.empty(total, device=device, dtype=torch.float32)
+    dist.broadcast(payload, src=src)
     out: ConditionTensors = {}
-    for name, eshape, mshape in meta[0]:
-        if rank() == src:
-            e = ct[name][0].to(device=device, dtype=torch.float32).contiguous()
-            m = ct[name][1].to(device=device, dtype=torch.int64).contiguous()
-        else:
-            e = torch.empty(eshape, device=device, dtype=torch.float32)
-            m = torch.empty(mshape, device=device, dtype=torch.int64)
-        dist.broadcast(e, src=src)
-        dist.broadcast(m, src=src)
-        out[name] = (e, m)
+    off = 0
+    for name, (rows, L, d) in layout:
+        e = payload[off:off + rows * L * d].view(rows, L, d)
+        off += rows * L * d
+        m = payload[off:off + rows * L].view(rows, L).to(torch.int64)
+        off += rows * L
+        out[name] = (e.contiguous(), m.contiguous())
     return out
 
 
