@@ -101,7 +101,10 @@ _ln_tile_reduce = _sig('acmi_ln_tile_reduce', [vp, vp, i32, vp, i32, i32, i32, f
 _kv_store = _sig('acmi_kv_store', [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, f32, i32, f32, u64, u64, vp])
 
-EXPORTS = ['acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
+_chroma = _sig('acmi_chroma', [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp])
+_chroma_frames = _sig('acmi_chroma_frames', [i32, i32])
+
+EXPORTS = ['acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
@@ -331,3 +334,19 @@ def sample(logits, B, K, card, use_cfg, cfg_coef, use_sampling, temp, top_k, top
 
 def lm_step(model_desc: LMModelDesc, state: LMState, mode: int):
     check(_lm_step(C.byref(model_desc), C.byref(state), mode, stream()), 'acmi_lm_step')
+
+
+def chroma(wav: torch.Tensor, radix2_exp: int, twiddle: torch.Tensor, fbanks: torch.Tensor, argmax: bool,
+           want_raw: bool = False):
+    """wav [B, T] f32 -> chroma [B, frames, n_chroma] f32 (acmi_chroma); with want_raw also the un-normalised values."""
+    B, T = wav.shape
+    n_chroma = fbanks.shape[0]
+    assert fbanks.shape[1] == (1 << radix2_exp) // 2 + 1 and twiddle.shape == ((1 << radix2_exp) // 2, 2)
+    frames = _chroma_frames(T, radix2_exp)
+    if frames < 0:
+        raise AcmiError(f"acmi_chroma: unsupported radix2_exp {radix2_exp}")
+    out = torch.empty(B, frames, n_chroma, device=wav.device, dtype=torch.float32)
+    raw = torch.empty_like(out) if want_raw else None
+    check(_chroma(ptr(wav), B, T, wav.stride(0), radix2_exp, ptr(twiddle), ptr(fbanks), n_chroma, int(argmax), ptr(out),
+                  ptr(raw), stream()), 'acmi_chroma')
+    return (out, raw) if want_raw else out

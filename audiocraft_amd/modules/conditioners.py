@@ -243,29 +243,58 @@ class SyntheticTextEmbedder:
 
 
 class ChromaStemConditioner(WaveformConditioner):
-    """Melody conditioning (reference conditioners.py:571-759): chroma frames [B, n_frames, n_chroma]
-    -> output_proj.  Demucs stem separation + the chroma front-end are third-party; they are reached
-    through `embedder(WavCondition) -> chroma [B, n_frames, n_chroma]`.  As in `MusicGen.get_pretrained`
-    (musicgen.py:90-92) evaluation uses `match_len_on_eval=True` and no masking."""
+    """Melody conditioning (reference conditioners.py:571-759): wav -> [stems: vocals + other] -> chroma frames
+    [B, n_frames, n_chroma] (argmax one-hot) -> repeat / trim to the training length -> output_proj.
+
+    The chroma front-end runs on the device (`modules/chroma.py` -> `acmi_chroma`).  Demucs (`htdemucs`, the stem
+    separation in front of it) is a third-party model that is neither in the reference tree nor installable here: it
+    plugs in as `stem_separator(wav [B, 1, T], sample_rate) -> wav [B, 1, T]`; without one the chroma is taken from the
+    full mix.  `embedder(WavCondition) -> chroma` replaces the whole front-end (synthetic chroma for benchmarks).  As in
+    `MusicGen.get_pretrained` (musicgen.py:90-92) evaluation uses `match_len_on_eval=True` and no masking."""
 
     def __init__(self, output_dim: int, sample_rate: int, n_chroma: int, radix2_exp: int, duration: float,
-                 match_len_on_eval: bool = True, device=None, embedder=None, **kwargs):
+                 match_len_on_eval: bool = True, device=None, embedder=None, stem_separator=None, **kwargs):
         super().__init__(n_chroma, output_dim, device)
+        from .chroma import ChromaExtractor
         self.sample_rate = sample_rate
         self.match_len_on_eval = match_len_on_eval
-        self.winhop = (2 ** radix2_exp) >> 2
-        self.chroma_len = int(duration * sample_rate / self.winhop) + 1  # conditioners.py:642-646
+        self.duration = duration
+        # the reference builds it with argmax from the conditioner config (chroma_stem.argmax: true, chroma2music.yaml)
+        self.__dict__['chroma'] = ChromaExtractor(sample_rate=sample_rate, n_chroma=n_chroma, radix2_exp=radix2_exp,
+                                                   argmax=kwargs.get('argmax', True), device=device)
+        self.winhop = self.chroma.winhop
+        self.chroma_len = int(duration * sample_rate) // self.winhop + 1  # == _get_chroma_len(), conditioners.py:642-646
         self.embedder = embedder
+        self.stem_separator = stem_separator
         self._use_masking = not match_len_on_eval
+
+    def _downsampling_factor(self) -> int:
+        return self.winhop
 
     def tokenize(self, x: WavCondition) -> WavCondition:
         return x
 
-    def forward(self, x: WavCondition) -> ConditionType:
-        if self.embedder is None:
-            raise RuntimeError("ChromaStemConditioner needs an `embedder` (Demucs + chroma extraction are "
-                               "third-party models outside this package)")
-        chroma = self.embedder(x).float()
+    @torch.no_grad()
+    def _compute_wav_embedding(self, wav: torch.Tensor, sample_rate: int) -> torch.Tensor:
+        """conditioners.py:678-691: stems, then chroma; a nullified wav (1 sample) goes straight to the extractor,
+        which zero pads it (all-zero frames -> one-hot on class 0, like the reference's argmax)."""
+        extractor = self.__dict__['chroma']
+        if extractor.fbanks.device != self.output_proj.weight.device:
+            extractor.to(self.output_proj.weight.device)
+        if wav.shape[-1] == 1:
+            return extractor(wav)
+        if self.stem_separator is not None:
+            wav = self.stem_separator(wav, sample_rate)
+        elif sample_rate != self.sample_rate:
+            raise NotImplementedError(f"melody at {sample_rate} Hz: resample to {self.sample_rate} Hz before conditioning")
+        return extractor(wav)
+
+    def _get_wav_embedding(self, x: WavCondition) -> torch.Tensor:
+        if self.embedder is not None:
+            chroma = self.embedder(x).float()
+        else:
+            assert all(sr == x.sample_rate[0] for sr in x.sample_rate), "All sample rates in batch should be equal."
+            chroma = self._compute_wav_embedding(x.wav, x.sample_rate[0])
         B, T, _ = chroma.shape
         if self.match_len_on_eval:  # conditioners.py:737-748
             if T > self.chroma_len:
@@ -273,6 +302,10 @@ class ChromaStemConditioner(WaveformConditioner):
             elif T < self.chroma_len:
                 n_repeat = -(-self.chroma_len // T)
                 chroma = chroma.repeat(1, n_repeat, 1)[:, :self.chroma_len]
+        return chroma
+
+    def forward(self, x: WavCondition) -> ConditionType:
+        chroma = self._get_wav_embedding(x)
         if self._use_masking and x.length is not None:
             lengths = (x.length / self.winhop).to(chroma.device)
             mask = (torch.arange(chroma.shape[1], device=chroma.device)[None] < lengths[:, None]).int()

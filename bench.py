@@ -182,7 +182,7 @@ def pmc_traffic_per_launch():
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
 
 
-def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 40, late_steps: int = 8,
+def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 30, late_steps: int = 4,
                  late_context: int = 1400):
     """The oracle (kind "port": restatement of the reference CPU algorithm, incl. its torch.cat KV cache) on the host
     cores, on a bounded sample of the same workload, as SURVEY.md section 8(d) specifies: `early_steps` decode positions

@@ -347,6 +347,23 @@ int acmi_sample(const float* logits, int64_t* tokens_out, float* mixed_out, int 
                 int cfg_mode, float cfg_coef, float cfg_coef_beta, int use_sampling, float temp, int top_k, float top_p,
                 uint64_t seed, uint64_t step, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Melody front-end (MusicGen-melody, BASELINE.json config #5)
+ * ------------------------------------------------------------------------------------------ */
+
+/* ChromaExtractor.forward (audiocraft/modules/chroma.py:46-66): wav [B, T] f32 (row stride wav_stride) ->
+ * power spectrogram (n_fft = win = 2^radix2_exp, hop n_fft / 4, periodic Hann, centre reflect padding, frames divided by
+ * sqrt(sum w^2): torchaudio Spectrogram(power=2, center=True, normalized=True)) -> fbanks [n_chroma, n_fft/2 + 1] f32
+ * (librosa.filters.chroma, a constant table built by the host) -> x / max(|x|_inf, 1e-6) over the chroma axis ->
+ * with `argmax`, the one-hot of the largest class (first index on ties) -> out [B, frames, n_chroma] f32.
+ * A row shorter than n_fft is zero padded to n_fft, (n_fft - T) / 2 samples in front (chroma.py:50-54).
+ * twiddle: [n_fft / 2] pairs (cos, -sin)(2 pi k / n_fft) f32, computed by the host in double precision.
+ * raw_out (or NULL): the un-normalised chroma, same shape (parity tests: near-tie margins of the argmax).
+ * frames = acmi_chroma_frames(T, radix2_exp) = 1 + max(T, n_fft) / (n_fft / 4). */
+int acmi_chroma_frames(int T, int radix2_exp);
+int acmi_chroma(const float* wav, int B, int T, int wav_stride, int radix2_exp, const float* twiddle,
+                const float* fbanks, int n_chroma, int argmax, float* out, float* raw_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,112 @@
+"""-m gpu: the melody front-end on the device (acmi_chroma: framed power spectrum -> chroma filterbank -> inf-norm ->
+argmax one-hot) against oracle/chroma.py, through the C ABI; and the ChromaStemConditioner path of config #5.
+
+Gate (like the RVQ indices): the argmax class of every frame is identical to the oracle's, except
+where the oracle itself has a near-tie (two classes within 1e-4 relative), which is reported, not hidden."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import chroma as och  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def C():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from audiocraft_amd import _C
+    return _C
+
+
+def _signals(sr, T, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) / sr
+    rows = [np.sin(2 * np.pi * 440.0 * t),                                            # A
+            np.sin(2 * np.pi * 261.63 * t) + 0.5 * np.sin(2 * np.pi * 392.0 * t),      # C + G
+            0.3 * rng.standard_normal(T),                                             # noise: many near-flat frames
+            np.sin(2 * np.pi * (200 + 300 * t) * t) + 0.05 * rng.standard_normal(T),  # chirp
+            np.where(t < 0.5 * T / sr, np.sin(2 * np.pi * 329.63 * t), np.sin(2 * np.pi * 493.88 * t))]  # E then B
+    return np.stack(rows).astype(np.float32)
+
+
+@pytest.mark.parametrize('sr,exp,T', [(32000, 14, 3 * 32000 + 123), (32000, 14, 960000), (16000, 12, 40001), (8000, 10, 9000)])
+def test_chroma_kernel_vs_oracle(C, sr, exp, T):
+    from audiocraft_amd.modules.chroma import ChromaExtractor
+    wav = _signals(sr, T, 0)
+    ext = ChromaExtractor(sr, 12, exp, argmax=True, device='cuda')
+    onehot, raw = ext(torch.from_numpy(wav).cuda(), return_raw=True)
+    ref_onehot, ref_raw = och.chroma_extract(wav, sr, 12, exp, argmax=True, return_raw=True)
+    onehot, raw = onehot.cpu().numpy(), raw.cpu().numpy()
+    assert onehot.shape == ref_onehot.shape == (5, 1 + T // (2 ** exp // 4), 12)
+    scale = np.abs(ref_raw).max(axis=-1, keepdims=True) + 1e-30
+    assert np.abs(raw - ref_raw).max() / np.abs(ref_raw).max() < 2e-5, "un-normalised chroma"
+    assert (np.abs(raw - ref_raw) / scale).max() < 1e-3, "per-frame relative error of the chroma vector"
+    got_idx, ref_idx = onehot.argmax(-1), ref_onehot.argmax(-1)
+    assert (onehot.sum(-1) == 1).all()
+    bad = np.argwhere(got_idx != ref_idx)
+    top2 = np.sort(ref_raw, axis=-1)[..., -2:]
+    margin = (top2[..., 1] - top2[..., 0]) / (top2[..., 1] + 1e-30)
+    for b, f in bad:
+        assert margin[b, f] < 1e-4, f"row {b} frame {f}: class {got_idx[b, f]} vs {ref_idx[b, f]}, margin {margin[b, f]:.2e}"
+    print(f"[parity] chroma sr={sr} n_fft=2^{exp} T={T}: {got_idx.size - len(bad)}/{got_idx.size} frames identical "
+          f"({len(bad)} near-ties), raw rel err {np.abs(raw - ref_raw).max() / np.abs(ref_raw).max():.1e}")
+    # soft (non-argmax) output: x / max(|x|_inf, eps)
+    soft = ChromaExtractor(sr, 12, exp, argmax=False, device='cuda')(torch.from_numpy(wav).cuda()).cpu().numpy()
+    assert np.abs(soft - och.chroma_extract(wav, sr, 12, exp, argmax=False)).max() < 1e-3
+
+
+def test_chroma_short_and_null_wav(C):
+    """T < n_fft: centred zero padding to n_fft (chroma.py:50-54); the nullified wav of the CFG null condition (one zero
+    sample) gives 5 all-zero frames whose argmax is class 0."""
+    from audiocraft_amd.modules.chroma import ChromaExtractor
+    ext = ChromaExtractor(32000, 12, 14, argmax=True, device='cuda')
+    null = ext(torch.zeros(3, 1, 1).cuda()).cpu().numpy()
+    assert null.shape == (3, 5, 12) and (null[..., 0] == 1).all() and null.sum() == 15
+    for T in (5001, 16383, 1000):
+        wav = _signals(32000, T, 1)[:3]
+        got = ext(torch.from_numpy(wav).cuda()).cpu().numpy()
+        ref = och.chroma_extract(wav, 32000, 12, 14, argmax=True)
+        assert got.shape == ref.shape == (3, 5, 12)
+        assert (got.argmax(-1) == ref.argmax(-1)).mean() > 0.9     # noise row: near-ties are possible
+        assert (got[:2].argmax(-1) == ref[:2].argmax(-1)).all()      # tonal rows: exact
+
+
+def test_chroma_conditioner_end_to_end(C):
+    """ChromaStemConditioner with the device front-end as its default embedder (config #5 minus Demucs): attributes ->
+    collate -> chroma -> repeat to 235 frames -> output_proj, vs the oracle chroma + an f32 matmul; null conditions are
+    one-hot on class 0 (NOT zeros), as the reference's argmax gives."""
+    from audiocraft_amd.models import builders
+    from audiocraft_amd.modules.conditioners import ConditioningAttributes, WavCondition
+    torch.manual_seed(0)
+    cfg = dict(dim=64, num_heads=4, num_layers=1, n_q=4, card=64, hidden_scale=4, cfg_coef=3.0,
+               conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 16, 'length': 4},
+                             'self_wav': {'kind': 'chroma', 'embedder': None, 'n_chroma': 12, 'radix2_exp': 14,
+                                          'duration': 30., 'sample_rate': 32000}},
+               fuser={'prepend': ['self_wav', 'description']})
+    lm = builders.get_lm_model(cfg, 'cuda', torch.float32)
+    cw = lm.condition_provider.conditioners['self_wav']
+    assert cw.chroma_len == 235 and cw.embedder is None
+    sig = _signals(32000, 5 * 32000, 2)
+    conds = []
+    for i in range(2):
+        c = ConditioningAttributes(text={'description': f'm{i}'})
+        w = torch.from_numpy(sig[i + 3])[None, None]
+        c.wav['self_wav'] = WavCondition(w, torch.tensor([w.shape[-1]]), [32000], [None], [0.])
+        conds.append(c)
+    ct = lm._cfg_condition_tensors(conds)
+    emb, mask = ct['self_wav']
+    assert emb.shape == (4, 235, 64) and mask.shape == (4, 235) and (mask == 1).all()
+    W = cw.output_proj.weight.detach().float().cpu().numpy()
+    bvec = cw.output_proj.bias.detach().float().cpu().numpy()
+    ch = och.match_length(och.chroma_extract(sig[3:5], 32000, 12, 14, argmax=True), 235)   # 40 frames tiled to 235
+    ref = ch @ W.T + bvec
+    got = emb.cpu().numpy()
+    same = (np.abs(got[:2] - ref).max(axis=-1) < 1e-5)
+    assert same.mean() > 0.98, same.mean()      # a differing frame = a near-tie of the argmax (checked in the kernel test)
+    # null rows: 5 frames of class 0 tiled to 235 -> every position is W[:, 0] + bias
+    assert np.abs(got[2:] - (W[:, 0] + bvec)).max() < 1e-5
+    # and the melody path runs end to end from attributes
+    toks = lm.generate(None, conds, max_gen_len=6, use_sampling=False, check=True)
+    assert toks.shape == (2, 4, 6)

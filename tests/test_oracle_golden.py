@@ -125,3 +125,49 @@ def test_lm_oracle_double_cfg_matches_reference():
     assert torch.equal(toks, a['greedy_tokens'])
     assert torch.allclose(logits, olm.double_cfg_mix(a['step_logits'], cfg['cfg_coef'], cfg['cfg_coef_beta']),
                           atol=5e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ chroma front-end (a20 / f3)
+
+def test_chroma_oracle_stft_matches_scipy():
+    """The Spectrogram restatement (periodic Hann, reflect centre padding, "window" normalisation, power 2) against an
+    independent implementation of the same STFT definition (scipy.signal.stft, another code path)."""
+    import numpy as np
+    import scipy.signal
+    from oracle import chroma as och
+    rng = np.random.default_rng(0)
+    n_fft, hop, T = 1024, 256, 5000
+    wav = rng.standard_normal((2, T)).astype(np.float32)
+    got = och.power_spectrogram(wav, n_fft, hop)
+    assert got.shape == (2, n_fft // 2 + 1, 1 + T // hop)
+    w = scipy.signal.get_window('hann', n_fft, fftbins=True)
+    x = np.pad(wav.astype(np.float64), ((0, 0), (n_fft // 2, n_fft // 2)), mode='reflect')
+    _, _, Z = scipy.signal.stft(x, window=w, nperseg=n_fft, noverlap=n_fft - hop, boundary=None, padded=False)
+    ref = np.abs(Z * w.sum()) ** 2 / np.sum(w ** 2)      # scipy scales by 1 / sum(w); torchaudio by 1 / sqrt(sum w^2)
+    assert ref.shape == got.shape
+    assert np.allclose(got, ref, rtol=2e-4, atol=1e-5 * ref.max())
+
+
+def test_chroma_oracle_known_answers():
+    import numpy as np
+    from oracle import chroma as och
+    sr, exp = 32000, 14
+    fb = och.chroma_filterbank(sr, 2 ** exp)
+    assert fb.shape == (12, 2 ** exp // 2 + 1) and fb.dtype == np.float32 and (fb >= 0).all()
+    # the FFT bin nearest to a pitch has its largest weight on that pitch class (row 0 = C with base_c)
+    for hz, cls in ((440.0, 9), (261.63, 0), (329.63, 4), (1046.5, 0), (196.0, 7)):
+        assert int(fb[:, int(round(hz * 2 ** exp / sr))].argmax()) == cls
+    t = np.arange(3 * sr) / sr
+    tones = np.stack([np.sin(2 * np.pi * 440.0 * t), np.sin(2 * np.pi * 329.63 * t) + 0.2 * np.sin(2 * np.pi * 440.0 * t)])
+    ch = och.chroma_extract(tones.astype(np.float32), sr, 12, exp, argmax=True)
+    assert ch.shape == (2, 1 + 3 * sr // 4096, 12)
+    assert (ch.sum(-1) == 1).all() and (ch[0].argmax(-1) == 9).all() and (ch[1].argmax(-1) == 4).all()
+    soft = och.chroma_extract(tones.astype(np.float32), sr, 12, exp, argmax=False)
+    assert np.allclose(soft.max(-1), 1.0)                              # inf-norm over the chroma axis
+    # a nullified wav (1 zero sample, conditioners.py:165-181) is zero padded to n_fft: every frame all-zero, and argmax
+    # of an all-zero frame is class 0 -- that is what the reference feeds the LM for the null condition
+    null = och.chroma_extract(np.zeros((1, 1), np.float32), sr, 12, exp, argmax=True)
+    assert null.shape == (1, 5, 12) and (null[..., 0] == 1).all() and null.sum() == 5
+    assert och.match_length(null, 235).shape == (1, 235, 12) and och.match_length(ch, 10).shape == (2, 10, 12)
+    # 30 s at 32 kHz -> 235 frames (the prefix length of config #5)
+    assert 1 + (30 * sr) // 4096 == 235
