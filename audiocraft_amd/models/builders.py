@@ -84,7 +84,8 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
                                         dim=c.get('dim'))
         elif kind == 'chroma':
             cc = ChromaStemConditioner(dim, c.get('sample_rate', 32000), c.get('n_chroma', 12),
-                                       c.get('radix2_exp', 14), c.get('duration', 30.), device=device)
+                                       c.get('radix2_exp', 14), c.get('duration', 30.), device=device,
+                                       argmax=c.get('argmax', True))
             embedder = c.get('embedder')
             if embedder == 'synthetic':
                 embedder = SyntheticChromaEmbedder(c.get('n_frames', cc.chroma_len), c.get('n_chroma', 12),

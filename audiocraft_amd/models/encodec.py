@@ -59,6 +59,19 @@ class CompressionModel(ABC, nn.Module):
     @abstractmethod
     def set_num_codebooks(self, n: int): ...
 
+    @staticmethod
+    def get_pretrained(name: str, device='cuda') -> 'CompressionModel':
+        """reference encodec.py:88-122.  `debug_compression_model`, a path (file / directory holding a
+        `compression_state_dict.bin` written by `audiocraft.utils.export`), or a released name resolved on disk under
+        $AUDIOCRAFT_CACHE_DIR (there is no network here; the DAC / HuggingFace-EnCodec wrappers are third-party codecs
+        outside the path and raise)."""
+        from . import builders, loaders
+        if name in ('dac_44khz', 'dac_24khz'):
+            raise NotImplementedError("DAC codecs are third-party models outside the MusicGen path")
+        if name == 'debug_compression_model':
+            return builders.get_debug_compression_model(device).eval()
+        return loaders.load_compression_model(name, device=device).eval()
+
 
 class EncodecModel(CompressionModel):
     """SEANet encoder -> residual vector quantizer -> SEANet decoder on the waveform (reference

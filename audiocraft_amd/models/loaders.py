@@ -92,7 +92,10 @@ def lm_cfg_from_xp(cfg: dict) -> dict:
             conds[name] = {'kind': 't5', 'name': c['t5']['name']}
         elif model == 'chroma_stem':
             cs = c['chroma_stem']
+            # cache_path / eval_wavs are training-time conveniences (the reference deletes cache_path on load,
+            # loaders.py:117); the front-end parameters are what matters here
             conds[name] = {'kind': 'chroma', 'n_chroma': cs['n_chroma'], 'radix2_exp': cs['radix2_exp'],
+                           'argmax': cs.get('argmax', False), 'match_len_on_eval': True,
                            'sample_rate': cfg.get('sample_rate', 32000),
                            'duration': cfg.get('dataset', {}).get('segment_duration', 30.)}
         else:
@@ -109,11 +112,29 @@ def load_lm_model(file_or_id: str, device='cuda', weight_dtype=None):
     cfg = parse_cfg(pkg['xp.cfg'])
     if weight_dtype is None:
         weight_dtype = torch.bfloat16
-    lm = builders.get_lm_model(lm_cfg_from_xp(cfg), device, weight_dtype)
-    state = _drop_third_party_buffers(pkg['best_state'])
+    state = _drop_third_party_buffers(_remap_mha_keys(pkg['best_state']))
+    lm_cfg = lm_cfg_from_xp(cfg)
+    for name, c in lm_cfg['conditioners'].items():   # the checkpoint is the truth for a conditioner's input width
+        w = state.get(f'condition_provider.conditioners.{name}.output_proj.weight')
+        if w is not None and c['kind'] == 't5':
+            c['dim'] = int(w.shape[1])
+    lm = builders.get_lm_model(lm_cfg, device, weight_dtype)
     lm.load_state_dict(state)
     lm.cfg = cfg
     return lm
+
+
+def _remap_mha_keys(state: dict) -> dict:
+    """Checkpoints of models built with custom=False, memory_efficient=False hold their attention inside an
+    nn.MultiheadAttention (`...self_attn.mha.in_proj_weight`, transformer.py:211-214); the reference renames between
+    the two layouts on load (transformer.py:224-231).  Same tensors, same layout: strip the `mha.` level."""
+    out = {}
+    for k, v in state.items():
+        for att in ('.self_attn.mha.', '.cross_attention.mha.'):
+            if att in k:
+                k = k.replace(att, att[:-4])
+        out[k] = v
+    return out
 
 
 def _drop_third_party_buffers(state: dict) -> dict:
@@ -145,8 +166,9 @@ def load_compression_model(file_or_id: str, device='cuda'):
     """reference loaders.py:78-91.  `{'pretrained': name}` stubs redirect to the named codec
     (only the 32 kHz MusicGen codec, whose weights must also be on disk)."""
     pkg = _get_state_dict(file_or_id, 'compression_state_dict.bin')
-    if 'pretrained' in pkg:
-        return load_compression_model(pkg['pretrained'], device)
+    if 'pretrained' in pkg:   # written by export_pretrained_compression_model (utils/export.py:37-55)
+        from .encodec import CompressionModel
+        return CompressionModel.get_pretrained(pkg['pretrained'], device)
     cfg = parse_cfg(pkg['xp.cfg'])
     model = builders.get_compression_model(compression_cfg_from_xp(cfg), device)
     model.load_state_dict(pkg['best_state'])

@@ -83,6 +83,13 @@ def install():
             lazy(n)
     sys.modules['omegaconf'].DictConfig = type('DictConfig', (), {})
 
+    class _OmegaConf:   # utils/export.py only needs the YAML dump of an (already plain) config mapping
+        @staticmethod
+        def to_yaml(cfg):
+            import yaml
+            return yaml.safe_dump(cfg, sort_keys=False)
+    sys.modules['omegaconf'].OmegaConf = _OmegaConf
+
     class _Tok:
         def __init__(s, t):
             s.text = t

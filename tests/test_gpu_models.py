@@ -401,3 +401,39 @@ def test_streaming_protocol_matches_batch_and_rewinds():
         lm.set_streaming_state(saved)
         tail_c = lm(seq[..., 4:9], [], ct)
     assert torch.equal(tail_c, tail_a)
+
+
+# ------------------------------------------------------------------------------------------ reference-written checkpoints (f1)
+
+def test_models_loaded_from_reference_written_checkpoints():
+    """loaders.load_lm_model / load_compression_model on files written by the reference's own utils/export.py
+    (tests/golden/ckpt_ref, make_ckpt_golden.py) -> greedy tokens / waveform identical to the reference's."""
+    import os
+    import numpy as np
+    from audiocraft_amd.models import loaders
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ckpt_ref')
+    # text LM (xp.cfg with conditioners.args) + its codec
+    cfg, _, a = load_golden('lm_text')
+    lm = loaders.load_lm_model(os.path.join(root, 'text'), device='cuda', weight_dtype=torch.float32)
+    ct = {'description': (a['cross_src'].cuda(), torch.ones(a['cross_src'].shape[:2], dtype=torch.int64).cuda())}
+    toks = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    codec = loaders.load_compression_model(os.path.join(root, 'text'), device='cuda')
+    _, _, c = load_golden('codec_noncausal')
+    assert (codec.decode(c['codes'].cuda()).cpu() - c['decoded']).abs().max().item() < 1e-4
+    # melody LM (chroma2music conditioners, third-party buffer in the checkpoint)
+    cfg, _, a = load_golden('lm_melody')
+    lm = loaders.load_lm_model(os.path.join(root, 'melody'), device='cuda', weight_dtype=torch.float32)
+    P, Lc = cfg['P'], cfg['Lc']
+    pre = a['prepend_src'].cuda()
+    ct = {'description': (pre[:, P:], torch.ones(pre.shape[0], Lc, dtype=torch.int64).cuda()),
+          'self_wav': (pre[:, :P], torch.ones(pre.shape[0], P, dtype=torch.int64).cuda())}
+    toks = lm.generate(None, [], num_samples=2, max_gen_len=9, use_sampling=False, condition_tensors=ct, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    # nn.MultiheadAttention key layout
+    exp = np.load(os.path.join(root, 'mha', 'expected.npz'))
+    lm = loaders.load_lm_model(os.path.join(root, 'mha'), device='cuda', weight_dtype=torch.float32)
+    cs = torch.from_numpy(exp['cross_src']).cuda()
+    ct = {'description': (cs, torch.ones(cs.shape[:2], dtype=torch.int64).cuda())}
+    toks = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct, check=True)
+    assert torch.equal(toks.cpu(), torch.from_numpy(exp['greedy_tokens']))

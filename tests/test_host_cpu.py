@@ -376,3 +376,63 @@ def test_streamable_conv_geometry_and_constructor_checks():
         StreamableConvTranspose1d(2, 1, kernel_size=4, causal=True, trim_right_ratio=2, device='cpu')
     enc = SEANetEncoder(channels=1, dimension=16, n_filters=4, ratios=[8, 5, 4, 4], device='cpu')
     assert enc.hop_length == 640
+
+
+# ------------------------------------------------------------------------------------------ reference-written checkpoints
+
+CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ckpt_ref')
+
+
+def test_loader_reads_reference_written_lm_checkpoints():
+    """Files produced by the reference's own audiocraft/utils/export.py (tests/golden/make_ckpt_golden.py): xp.cfg composed
+    from the reference's YAML files incl. `conditioners.args`, `attribute_dropout.args`, `chroma_stem.cache_path`; a
+    third-party buffer under the chroma conditioner; and the nn.MultiheadAttention key layout."""
+    from audiocraft_amd.models import loaders
+    from conftest import load_golden
+    for sub, golden in (('text', 'lm_text'), ('melody', 'lm_melody')):
+        lm = loaders.load_lm_model(os.path.join(CKPT, sub), device='cpu', weight_dtype=torch.float32)
+        cfg, sd, _ = load_golden(golden)
+        got = lm.state_dict()
+        assert set(got.keys()) == set(sd.keys())
+        for k in sd:
+            assert torch.equal(got[k], sd[k]), k
+        assert lm.dim == cfg['dim'] and lm.num_layers == cfg['num_layers'] and lm.cfg_coef == cfg['cfg_coef']
+        assert lm.has_cross_attention == cfg['cross_attention']
+        assert lm.pattern_provider.delays == cfg['delays']
+    assert list(lm.fuser.fuse2cond['prepend']) == ['self_wav', 'description']     # melody: prepend order of chroma2music.yaml
+    cw = lm.condition_provider.conditioners['self_wav']
+    assert cw.chroma_len == 235 and cw.chroma.argmax and cw.chroma.nfft == 16384
+    assert lm.cfg['conditioners']['self_wav']['chroma_stem']['cache_path'].startswith('/checkpoint')   # cfg kept verbatim
+    # nn.MultiheadAttention layout: `self_attn.mha.in_proj_weight` -> `self_attn.in_proj_weight`
+    lm = loaders.load_lm_model(os.path.join(CKPT, 'mha'), device='cpu', weight_dtype=torch.float32)
+    raw = torch.load(os.path.join(CKPT, 'mha', 'state_dict.bin'), map_location='cpu', weights_only=False)['best_state']
+    assert any('.mha.' in k for k in raw)
+    assert torch.equal(lm.state_dict()['transformer.layers.1.cross_attention.in_proj_weight'],
+                       raw['transformer.layers.1.cross_attention.mha.in_proj_weight'])
+
+
+def test_loader_reads_reference_written_codec_checkpoints(monkeypatch, tmp_path):
+    from audiocraft_amd.models import loaders
+    from audiocraft_amd.models.encodec import CompressionModel
+    from conftest import load_golden
+    m = loaders.load_compression_model(os.path.join(CKPT, 'text'), device='cpu')
+    cfg, sd, _ = load_golden('codec_noncausal')
+    got = m.state_dict()
+    assert set(got.keys()) == set(sd.keys())
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert m.sample_rate == cfg['sample_rate'] and m.frame_rate == cfg['frame_rate'] and m.num_codebooks == cfg['n_q']
+    # {'pretrained': 'facebook/encodec_32khz'}: resolved through CompressionModel.get_pretrained -> the cache directory
+    stub = torch.load(os.path.join(CKPT, 'stub', 'compression_state_dict.bin'), map_location='cpu', weights_only=False)
+    assert stub['pretrained'] == 'facebook/encodec_32khz'
+    cache = tmp_path / 'facebook--encodec_32khz'
+    cache.mkdir()
+    import shutil
+    shutil.copy(os.path.join(CKPT, 'text', 'compression_state_dict.bin'), cache / 'compression_state_dict.bin')
+    monkeypatch.setenv('AUDIOCRAFT_CACHE_DIR', str(tmp_path))
+    m2 = loaders.load_compression_model(os.path.join(CKPT, 'stub'), device='cpu')
+    assert torch.equal(m2.state_dict()['quantizer.vq.layers.0._codebook.embed'], sd['quantizer.vq.layers.0._codebook.embed'])
+    m3 = CompressionModel.get_pretrained(os.path.join(CKPT, 'text'), device='cpu')
+    assert not m3.training and m3.cardinality == cfg['bins']
+    with pytest.raises(NotImplementedError):
+        CompressionModel.get_pretrained('dac_44khz')
