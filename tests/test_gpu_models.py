@@ -437,3 +437,40 @@ def test_models_loaded_from_reference_written_checkpoints():
     ct = {'description': (cs, torch.ones(cs.shape[:2], dtype=torch.int64).cuda())}
     toks = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct, check=True)
     assert torch.equal(toks.cpu(), torch.from_numpy(exp['greedy_tokens']))
+
+
+def test_t5_conditioner_real_huggingface_path(tmp_path):
+    """T5Conditioner with `embedder=None`: the HuggingFace tokenizer + T5EncoderModel path (reference conditioners.py:
+    422-515), exercised for real on a tiny random-init T5 saved to disk (no released weights exist offline): batch
+    padding to the longest prompt, attention mask, empty strings -> zero mask -> exactly zero rows after output_proj."""
+    import sentencepiece as spm
+    from transformers import T5Config, T5EncoderModel, T5Tokenizer
+    from audiocraft_amd.modules.conditioners import ConditioningAttributes, ConditioningProvider, T5Conditioner
+    corpus = tmp_path / 'corpus.txt'
+    corpus.write_text('\n'.join(['happy rock with electric guitar', 'sad slow piano ballad', 'energetic drum and bass',
+                                 'lofi hip hop beat to relax', 'orchestral epic trailer music'] * 20))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / 'spiece'), vocab_size=40,
+                                   pad_id=0, eos_id=1, unk_id=2, bos_id=-1, hard_vocab_limit=False)
+    sp = spm.SentencePieceProcessor(model_file=str(tmp_path / 'spiece.model'))
+    t5dir = tmp_path / 't5-tiny'
+    tok = T5Tokenizer([(sp.id_to_piece(i), sp.get_score(i)) for i in range(sp.get_piece_size())], extra_ids=0)
+    tok.save_pretrained(str(t5dir))
+    torch.manual_seed(0)
+    enc = T5EncoderModel(T5Config(vocab_size=64, d_model=32, d_kv=8, d_ff=64, num_layers=2, num_heads=4)).eval()
+    enc.save_pretrained(str(t5dir))
+    cond = T5Conditioner(str(t5dir), output_dim=48, device='cuda', dim=32)
+    provider = ConditioningProvider({'description': cond}, device='cuda')
+    texts = ['sad slow piano ballad', 'rock', None]
+    attrs = [ConditioningAttributes(text={'description': t}) for t in texts]
+    emb, mask = provider(provider.tokenize(attrs))['description']
+    # reference semantics, computed directly with HuggingFace + torch
+    ins = tok(['sad slow piano ballad', 'rock', ''], return_tensors='pt', padding=True)
+    ref_mask = ins['attention_mask'].clone()
+    ref_mask[2] = 0
+    with torch.no_grad():
+        hid = enc(**ins).last_hidden_state
+    W, bvec = cond.output_proj.weight.detach().cpu(), cond.output_proj.bias.detach().cpu()
+    ref = (hid @ W.T + bvec) * ref_mask.unsqueeze(-1)
+    assert torch.equal(mask.cpu(), ref_mask) and mask.shape[1] == ins['input_ids'].shape[1]
+    assert torch.allclose(emb.cpu(), ref, atol=2e-5, rtol=1e-4), (emb.cpu() - ref).abs().max()
+    assert (emb[2] == 0).all() and (emb[1, int(ref_mask[1].sum()):] == 0).all()   # null prompt and padding: exact zeros
