@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libacmi.so')
+LIB_PATH = os.environ.get('ACMI_LIB') or os.path.join(_HERE, 'csrc', 'libacmi.so')   # ACMI_LIB: A/B builds (dev)
 
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_REFLECT = 0, 1

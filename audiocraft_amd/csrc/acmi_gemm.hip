@@ -323,13 +323,15 @@ struct TlExtras {
     int tpos;                 // QKV: the position the new K / V rows are stored at
 };
 
-template <typename WT, int MT, int LN, int NT, int C>
-__device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, const u32x4* __restrict__ at,
-                                         const u32x4* __restrict__ al, int mts, int mtl, int mtv, int kc0, int ks,
-                                         const float* __restrict__ st_ptr, int np,
-                                         const float* __restrict__ pb, const float* __restrict__ pc,
-                                         const float* __restrict__ pr, const int* __restrict__ ppos,
-                                         f32x4 (&acc)[NT * MT], TlExtras& ex) {
+// everything a chunk needs besides the weight stream; evaluated AFTER the weight requests are out (see tl_chunk)
+struct TlLate {
+    const u32x4* at; const u32x4* al; int mts, mtl, mtv;
+    const float* st_ptr; const float* pb; const float* pc; const float* pr; const int* ppos;
+};
+
+template <typename WT, int MT, int LN, int NT, int C, typename LateFn>
+__device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, int kc0, int ks, int np,
+                                         const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex) {
     constexpr bool HL = LN == 2 || LN == 3;
     const int lane = threadIdx.x & 63;
     const int wts = p.NKC * 64;  // fragment lanes between the NT adjacent n-tiles of this workgroup
@@ -345,7 +347,19 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
         }
+        // The weight requests need four kernel arguments and ~20 instructions of address arithmetic; the ~100
+        // instructions (and two more scalar-load round trips) that set up the activation, statistics and epilogue
+        // operand addresses used to sit in FRONT of them: ~0.5 us before the first HBM request of every launch.
+        __builtin_amdgcn_sched_barrier(0);
     }
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    const TlLate L = late_fn(opaque0);
+    const u32x4* __restrict__ at = L.at;
+    const u32x4* __restrict__ al = L.al;
+    const int mts = L.mts, mtl = L.mtl, mtv = L.mtv;
+    const float* st_ptr = L.st_ptr; const float* pb = L.pb; const float* pc = L.pc; const float* pr = L.pr;
+    const int* ppos = L.ppos;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         const int ko = (kc0 + i * ks) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
@@ -362,10 +376,6 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
                 lv[u][i] = (al + (ub * mtl + min(kc0 + i * ks, p.lo_split - 1) * 64))[lane];
         }
     }
-    // (the asm keeps these loop-invariant loads here, behind the weight stream, instead of in front of the K loop)
-    int opaque0 = 0;
-    asm volatile("" : "+s"(opaque0));
-    st_ptr += opaque0; pb += opaque0; pc += opaque0; pr += opaque0; ppos += opaque0;
     if (LN == 1 || LN == 2) {
         const int jj = (int)(threadIdx.x & 15);
 #pragma unroll
@@ -409,7 +419,6 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     float* rowstat = red + (size_t)NT * MT * nw * 256;  // [16 MT][2] mean, rstd
     const int n0 = ntile * 16, NKC = p.NKC;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
-    const int mts = p.a_rbs * 64, mtl = p.alo_rbs * 64;  // fragment lanes between consecutive 16-row blocks (a, a_lo)
     const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
     const float* own = reinterpret_cast<const float*>(wt + (size_t)(kbeg + min(wave, kcs - 1)) * 64 + lane);
 
@@ -421,20 +430,29 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         f32x4 accs[NT * MT];
 #pragma unroll
         for (int u = 0; u < NT * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const u32x4* at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mg >> 4) * mts);
-        const u32x4* al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mg >> 4) * mtl) : nullptr;
-        // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
-        const int ngroups = 4 * mtv;
-        const float* st_ptr = own;
-        if (FOLD) st_ptr = p.a_stats + min(mg + min(wave, ngroups - 1) * 4 + (lane >> 4), p.M - 1) * p.a_np * 2;
-        // this thread's first epilogue element
-        const int e0 = (int)threadIdx.x, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
-        const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
-        const int egn = min(n0 + 16 * et + enn, p.N - 1), egm = min(mg + 16 * eu + emm, p.M - 1);
-        const float* pb = p.bias != nullptr ? p.bias + egn : own;
-        const float* pc = p.colsum != nullptr ? p.colsum + egn : own;
-        const float* pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
-        const int* ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+        const int ngroups = 4 * mtv;   // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
+        // addresses of everything but the weights: evaluated by tl_chunk once its weight requests are out
+        // (`z` is an opaque zero produced behind the weight requests: added to every index these addresses derive from,
+        // it keeps loop-invariant code motion from hoisting the arithmetic back in front of them)
+        auto late = [&](const int z) -> TlLate {
+            TlLate L;
+            const int mgz = mg + z, lz = lane + z, wz = wave + z, n0z = n0 + z;
+            L.mts = p.a_rbs * 64; L.mtl = p.alo_rbs * 64;   // fragment lanes between consecutive 16-row blocks (a, a_lo)
+            L.mtv = mtv;
+            L.at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mgz >> 4) * L.mts);
+            L.al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mgz >> 4) * L.mtl) : nullptr;
+            L.st_ptr = own;
+            if (FOLD) L.st_ptr = p.a_stats + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), p.M - 1) * p.a_np * 2;
+            // this thread's first epilogue element
+            const int e0 = (int)threadIdx.x + z, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
+            const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
+            const int egn = min(n0z + 16 * et + enn, p.N - 1), egm = min(mgz + 16 * eu + emm, p.M - 1);
+            L.pb = p.bias != nullptr ? p.bias + egn : own;
+            L.pc = p.colsum != nullptr ? p.colsum + egn : own;
+            L.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
+            L.ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+            return L;
+        };
         TlExtras ex;
 
         // wave w owns the CONTIGUOUS run of K fragments [w fpw, (w + 1) fpw) (+ a ragged tail): its requests walk
@@ -443,7 +461,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         int kc = kbeg + wave * p.fpw, rem = p.fpw;
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            tl_chunk<WT, MT, LN, NT, Cn>(p, wt, at, al, mts, mtl, mtv, kc, ks, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex); \
+            tl_chunk<WT, MT, LN, NT, Cn>(p, wt, kc, ks, p.a_np, late, accs, ex); \
             kc += Cn * ks; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -457,7 +475,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
 #undef ACMI_TL_RUN
         kc = kbeg + nw * p.fpw + wave;
         if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
-            tl_chunk<WT, MT, LN, NT, 1>(p, wt, at, al, mts, mtl, mtv, kc, ks, st_ptr, p.a_np, pb, pc, pr, ppos, accs, ex);
+            tl_chunk<WT, MT, LN, NT, 1>(p, wt, kc, ks, p.a_np, late, accs, ex);
 
         // ---- deterministic cross-wave reduction through LDS
 #pragma unroll
