@@ -110,7 +110,7 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
 
 
 def musicgen_lm_cfg(scale: str = 'small', melody: bool = False, synthetic: bool = True, text_len: int = 16,
-                    stereo: bool = False) -> dict:
+                    stereo: bool = False, synthetic_chroma: bool = False) -> dict:
     """Architecture of facebook/musicgen-{small,medium,large,melody}[ -stereo ].  Stereo:
     8 codebooks = left / right interleaved per RVQ level, each pair sharing its delay."""
     cfg = dict(LM_SCALES[scale], n_q=8 if stereo else 4, card=2048, hidden_scale=4, cfg_coef=3.0)
@@ -119,7 +119,9 @@ def musicgen_lm_cfg(scale: str = 'small', melody: bool = False, synthetic: bool 
     emb = 'synthetic' if synthetic else None
     cfg['conditioners'] = {'description': {'kind': 't5', 'name': 't5-base', 'embedder': emb, 'length': text_len}}
     if melody:  # config/conditioner/chroma2music.yaml: prepend [self_wav, description], no cross-attention
-        cfg['conditioners']['self_wav'] = {'kind': 'chroma', 'embedder': emb, 'n_chroma': 12, 'radix2_exp': 14,
+        # the chroma front-end runs on the device (acmi_chroma) unless a synthetic one is asked for; Demucs is pluggable
+        cfg['conditioners']['self_wav'] = {'kind': 'chroma', 'embedder': 'synthetic' if synthetic_chroma else None,
+                                           'n_chroma': 12, 'radix2_exp': 14,
                                            'duration': 30., 'sample_rate': 32000}
         cfg['fuser'] = {'prepend': ['self_wav', 'description']}
     else:       # config/conditioner/text2music.yaml
