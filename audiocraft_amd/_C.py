@@ -104,7 +104,9 @@ _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, f3
 _chroma = _sig('acmi_chroma', [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp])
 _chroma_frames = _sig('acmi_chroma_frames', [i32, i32])
 
-EXPORTS = ['acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
+_resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp])
+
+EXPORTS = ['acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
@@ -350,3 +352,12 @@ def chroma(wav: torch.Tensor, radix2_exp: int, twiddle: torch.Tensor, fbanks: to
     check(_chroma(ptr(wav), B, T, wav.stride(0), radix2_exp, ptr(twiddle), ptr(fbanks), n_chroma, int(argmax), ptr(out),
                   ptr(raw), stream()), 'acmi_chroma')
     return (out, raw) if want_raw else out
+
+
+def resample_frac(x: torch.Tensor, kernel: torch.Tensor, old_sr: int, new_sr: int, width: int, out_len: int):
+    """x [rows, T] f32 -> y [rows, out_len] (acmi_resample_frac); kernel [new_sr, 2 * width + old_sr]."""
+    rows, T = x.shape
+    assert kernel.shape == (new_sr, 2 * width + old_sr)
+    y = torch.empty(rows, out_len, device=x.device, dtype=torch.float32)
+    check(_resample(ptr(x), ptr(y), ptr(kernel), rows, T, out_len, old_sr, new_sr, width, stream()), 'acmi_resample_frac')
+    return y

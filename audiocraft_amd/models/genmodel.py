@@ -18,25 +18,7 @@ from .lm import LMModel
 ProgressFn = tp.Callable[[int, int], None]
 
 
-def convert_audio(wav: torch.Tensor, from_rate: float, to_rate: float, to_channels: int) -> torch.Tensor:
-    """Channel handling of `audiocraft.data.audio_utils.convert_audio` (reference
-    audiocraft/data/audio_utils.py:18-59): down-mix to mono, replicate mono, or keep the first channels.
-    Resampling is `julius.resample_frac` in the reference -- a third-party routine that is not part of
-    this package -- so the two rates must already agree."""
-    have = wav.shape[-2]
-    if have != to_channels:
-        if to_channels == 1:
-            wav = wav.mean(dim=-2, keepdim=True)
-        elif have == 1:
-            wav = wav.expand(*wav.shape[:-2], to_channels, wav.shape[-1])
-        elif have > to_channels:
-            wav = wav[..., :to_channels, :]
-        else:
-            raise ValueError('The audio file has less channels than requested but is not mono.')
-    if int(from_rate) != int(to_rate):
-        raise NotImplementedError(f"resample {from_rate} -> {to_rate} Hz before calling: sample-rate conversion "
-                                  "(julius in the reference) is outside this package")
-    return wav
+from ..data_audio_utils import convert_audio  # noqa: E402,F401  (re-exported: MusicGen imports it from here)
 
 
 def get_wrapped_compression_model(compression_model: CompressionModel, cfg: dict) -> CompressionModel:

@@ -364,6 +364,13 @@ int acmi_chroma_frames(int T, int radix2_exp);
 int acmi_chroma(const float* wav, int B, int T, int wav_stride, int radix2_exp, const float* twiddle,
                 const float* fbanks, int n_chroma, int argmax, float* out, float* raw_out, void* stream);
 
+/* julius.resample_frac (called by audiocraft/data/audio_utils.py:54-59 `convert_audio`): polyphase windowed-sinc FIR.
+ * The rates are already divided by their gcd; kernel [new_sr, 2 * width + old_sr] f32 holds the filter of every output
+ * phase (built by the host: sinc(t) * cos^2(t / zeros / 2), zeros = 24, cut-off 0.945 * min(old, new), each row normalised
+ * to sum 1); x [rows, T] -> y [rows, Tout], Tout <= ceil(T * new_sr / old_sr), the input replicate-padded at both ends. */
+int acmi_resample_frac(const float* x, float* y, const float* kernel, int rows, int T, int Tout, int old_sr, int new_sr,
+                       int width, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

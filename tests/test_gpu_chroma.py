@@ -110,3 +110,21 @@ def test_chroma_conditioner_end_to_end(C):
     # and the melody path runs end to end from attributes
     toks = lm.generate(None, conds, max_gen_len=6, use_sampling=False, check=True)
     assert toks.shape == (2, 4, 6)
+
+
+def test_resample_kernel_vs_oracle(C):
+    """acmi_resample_frac (convert_audio's julius.resample_frac) vs oracle/resample.py, incl. the replicate-padded edges."""
+    from oracle import resample as ors
+    from audiocraft_amd.data_audio_utils import convert_audio, resample_frac
+    rng = np.random.default_rng(0)
+    for old, new, T in ((44100, 32000, 30011), (16000, 32000, 5000), (48000, 32000, 12345), (32000, 16000, 7777)):
+        x = rng.standard_normal((2, 2, T)).astype(np.float32)
+        got = resample_frac(torch.from_numpy(x).cuda(), old, new).cpu().numpy()
+        ref = ors.resample_frac(x, old, new)
+        assert got.shape == ref.shape == (2, 2, int(np.floor(T * new / old)))
+        assert np.abs(got - ref).max() < 2e-5, (old, new, np.abs(got - ref).max())
+    w = torch.from_numpy(rng.standard_normal((3, 2, 4410)).astype(np.float32)).cuda()
+    out = convert_audio(w, 44100, 32000, 1)            # resample, then down-mix (audio_utils.py:54-59)
+    assert out.shape == (3, 1, 3200)
+    assert torch.allclose(out, resample_frac(w, 44100, 32000).mean(dim=-2, keepdim=True))
+    assert convert_audio(w, 32000, 32000, 2) is w
