@@ -204,7 +204,7 @@ class StreamableLSTM(nn.Module):
                 bias = (getattr(p, f'bias_ih_l{layer}').detach().float()
                         + getattr(p, f'bias_hh_l{layer}').detach().float()).contiguous()
                 self._prep.append((w_ih, w_hh, bias))
-        work = torch.empty(_C.lstm_work_floats(B, H), device=x.device, dtype=torch.float32)
+        work = torch.zeros(_C.lstm_work_floats(B, H), device=x.device, dtype=torch.float32)
         d = _C.ConvDesc()
         d.B, d.Cin, d.Tin, d.Cout, d.Tout = B, H, T, 4 * H, T
         d.ksize, d.stride, d.dilation, d.pad_left = 1, 1, 1, 0
@@ -217,6 +217,11 @@ class StreamableLSTM(nn.Module):
             last = layer == self.num_layers - 1
             _C.lstm_layer(gates, w_hh, x if (self.skip and last) else None, out, work, B, H, T)
             y = out
+        # the persistent recurrence kernel counts bounded-spin give-ups of its all-gather in the last words of `work`
+        # (never seen on an otherwise idle device; a non-zero count means the result is not to be trusted)
+        if int(work[5 * B * H:].view(torch.int32)[0]) != 0:
+            raise RuntimeError("acmi_lstm_layer: the persistent LSTM kernel gave up waiting for a workgroup "
+                               "(set ACMI_LSTM_PERSISTENT=0 to use the per-step kernel)")
         return y
 
 
