@@ -436,3 +436,41 @@ def test_loader_reads_reference_written_codec_checkpoints(monkeypatch, tmp_path)
     assert not m3.training and m3.cardinality == cfg['bins']
     with pytest.raises(NotImplementedError):
         CompressionModel.get_pretrained('dac_44khz')
+
+
+# ------------------------------------------------------------------------------------------ output stage (f4)
+
+def test_audio_write_and_normalisation(tmp_path):
+    """audio_write / normalize_audio (reference data/audio.py:159-231, data/audio_utils.py:62-152)."""
+    import math
+    import wave
+    import numpy as np
+    from audiocraft_amd.data_audio import audio_write, loudness, normalize_audio
+    sr = 32000
+    t = torch.arange(2 * sr) / sr
+    tone = torch.sin(2 * math.pi * 997.0 * t)[None]
+    # ITU-R BS.1770: a 997 Hz sine of amplitude a in one channel reads -3.01 + 20 log10(a) LKFS
+    assert abs(loudness(0.5 * tone, sr) - (-9.03)) < 0.05
+    assert abs(loudness(0.1 * tone, sr) - (-23.01)) < 0.05
+    assert abs(loudness(torch.cat([0.5 * tone, 0.5 * tone]), sr) - (-6.02)) < 0.06    # two channels: +3.01 dB
+    # (torchaudio's biquads clamp their output to [-1, 1]: a full-scale tone, boosted by the K-weighting shelf, reads lower)
+    assert loudness(tone, sr) < -3.01
+    wav = 0.05 * tone
+    peak = normalize_audio(wav, strategy='peak')
+    assert abs(peak.abs().max().item() - 10 ** (-1 / 20)) < 1e-6
+    assert normalize_audio(3 * tone, strategy='clip').abs().max().item() <= 10 ** (-1 / 20) + 1e-6
+    rms = normalize_audio(wav.clone(), strategy='rms')
+    assert abs(rms.pow(2).mean().sqrt().item() - 10 ** (-18 / 20)) < 1e-4
+    loud = normalize_audio(wav.clone(), strategy='loudness', sample_rate=sr)
+    assert abs(loudness(loud, sr) - (-14.0)) < 0.05
+    assert normalize_audio(1e-4 * tone, strategy='loudness', sample_rate=sr).abs().max() < 2e-4    # below the energy floor
+    p = audio_write(tmp_path / 'sub' / 'clip', torch.cat([wav, -wav]), sr, strategy='peak')
+    assert p.name == 'clip.wav' and p.exists()
+    with wave.open(str(p)) as f:
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (2, 2, sr, 2 * sr)
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype='<i2').reshape(-1, 2)
+    assert abs(int(np.abs(pcm).max()) - round(10 ** (-1 / 20) * 32768)) <= 1 and (pcm[:, 0] == -pcm[:, 1]).all()
+    with pytest.raises(RuntimeError):
+        audio_write(tmp_path / 'x', wav, sr, format='aiff')
+    with pytest.raises(ValueError):
+        audio_write(tmp_path / 'x', torch.zeros(1, 1, 10), sr)
