@@ -239,21 +239,43 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
         __syncthreads();
         float thr = 0.f;
         if (p.top_p > 0.f) {
-            // keep i unless the probability mass sorted strictly before it exceeds top_p (utils.py:125-141)
-            float keepflag[ACMI_MAX_CARD / 256];
+            // utils.sample_top_p (utils.py:125-141): in descending order, keep i unless the mass sorted strictly before it
+            // exceeds top_p.  The kept set is {p_i >= x*} with x* the smallest value whose strictly-greater mass
+            // f(x) = sum_{p_j > x} p_j is <= top_p; f is a non-increasing step function, so x* is found by bisection on
+            // the float bit pattern (non-negative floats order like their bits): 31 block reductions instead of the
+            // card^2 comparisons of a direct evaluation.  Only the group of values equal to x* can be kept partially
+            // (ties are ordered by index, like a stable sort).
+            auto mass_above = [&](float x) {
+                float m = 0.f;
+                for (int i = threadIdx.x; i < card; i += blockDim.x) m += vals[i] > x ? vals[i] : 0.f;
+                return block_sum(m, sval);
+            };
+            unsigned lo = 0u, hi = 0x3f800000u;   // f(1.0) = 0 <= top_p always
+            while (lo < hi) {                       // block-uniform: every thread sees the same reductions
+                const unsigned mid = lo + ((hi - lo) >> 1);
+                if (mass_above(__uint_as_float(mid)) <= p.top_p) hi = mid; else lo = mid + 1;
+            }
+            const float xs = __uint_as_float(lo);
+            const float fstar = mass_above(xs);
+            float ties = 0.f;
+            for (int i = threadIdx.x; i < card; i += blockDim.x) ties += vals[i] == xs ? 1.f : 0.f;
+            ties = block_sum(ties, sval);
+            unsigned dropmask = 0u;   // card <= 4096 -> <= 16 elements per thread
             int cnt = 0;
             for (int i = threadIdx.x; i < card; i += blockDim.x, ++cnt) {
                 const float pi = vals[i];
-                float before = 0.f;
-                for (int j = 0; j < card; ++j) {
-                    const float pj = vals[j];
-                    before += (pj > pi || (pj == pi && j < i)) ? pj : 0.f;
+                bool keep = pi >= xs;
+                if (keep && pi == xs && ties > 1.5f) {   // rank of this element inside its tie group (rare path)
+                    int r = 0;
+                    for (int j = 0; j < i; ++j) r += vals[j] == xs ? 1 : 0;
+                    keep = fstar + (float)r * xs <= p.top_p;
                 }
-                keepflag[cnt] = before > p.top_p ? 0.f : 1.f;
+                if (!keep) dropmask |= 1u << cnt;
             }
-            __syncthreads();
+            __syncthreads();   // every thread has read what it needs of the un-filtered probabilities
             cnt = 0;
-            for (int i = threadIdx.x; i < card; i += blockDim.x, ++cnt) vals[i] *= keepflag[cnt];
+            for (int i = threadIdx.x; i < card; i += blockDim.x, ++cnt)
+                if (dropmask & (1u << cnt)) vals[i] = 0.f;
             __syncthreads();
         } else if (p.top_k > 0 && p.top_k < card) {
             // k-th largest probability by 4-pass radix select on the (non-negative) float bit patterns

@@ -718,11 +718,15 @@ class LMModel(nn.Module):
         if cross_src is not None:
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
         self._prefill(desc, state, P)
-        outs = []
+        outs = torch.empty(B, K, S, self.card, device=dev, dtype=torch.float32)
+        graph = self._capture(desc, state) if S > 2 else None   # one captured position, replayed S times
         for i in range(S):
-            _C.lm_step(desc, state, _C.STEP_DECODE)
-            outs.append(run['step_logits'].clone())  # the sampler only writes slots still at -1
-        return torch.stack(outs, dim=2)
+            if graph is not None:
+                graph.replay()
+            else:
+                _C.lm_step(desc, state, _C.STEP_DECODE)
+            outs[:, :, i].copy_(run['step_logits'])  # the sampler only writes slots still at -1
+        return outs
 
     # ------------------------------------------------------------------------------------- reference forward API
     @torch.no_grad()

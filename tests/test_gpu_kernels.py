@@ -529,3 +529,29 @@ def test_attention_per_row_lengths(C):
         w = torch.softmax(qq @ k[b, :, :n].transpose(-1, -2) / math.sqrt(hd), dim=-1)
         ref = (w @ v[b, :, :n]).reshape(-1)
         assert torch.allclose(out[b].cpu(), ref, atol=2e-5, rtol=1e-4), (b, (out[b].cpu() - ref).abs().max())
+
+
+def test_sample_top_p_full_card_and_ties(C):
+    """top-p at the real cardinality (2048) incl. a tie group straddling the threshold: every draw lies in the
+    reference's support (utils.sample_top_p, utils.py:125-141) and the high-probability classes are all reached."""
+    g = torch.Generator().manual_seed(7)
+    card = 2048
+    logits = torch.randn(1, card, generator=g) * 2.5
+    # a tie group that straddles the threshold: five equal logits in the middle of the kept mass
+    srt = torch.sort(logits[0], descending=True)[0]
+    logits[0, 100:105] = srt[40]
+    probs = torch.softmax(logits.view(1, 1, card), -1)
+    for top_p in (0.3, 0.9):
+        ps, pi = olm.top_p_filter(probs, top_p)
+        support = torch.zeros(card, dtype=torch.bool)
+        support[pi[0, 0][ps[0, 0] > 0]] = True
+        seen = torch.zeros(card, dtype=torch.bool)
+        lg = logits.cuda()
+        for step in range(1500):
+            t, _ = C.sample(lg, 1, 1, card, False, 1.0, True, 1.0, 0, top_p, 11, step)
+            assert support[t.item()], (top_p, t.item())
+            seen[t.item()] = True
+        top = probs[0, 0].clone()
+        top[~support] = 0
+        heavy = top > 0.01
+        assert seen[heavy].all()
