@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 // =====================================================================================================
 // embedding sum + sinusoidal position
@@ -28,6 +29,10 @@ struct EmbedArgs {
     void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
 };
 
+// BF16: element type of the tables; KQ >= n_q: codebook tables read per row (compile time, so that every load of a phase
+// is an unconditional, branch-free request: with `if (k < K)` / `bf16 ? .. : ..` around them hipcc put each load in its own
+// basic block followed by its own s_waitcnt vmcnt(0) -- 24 serialised memory round trips, 17 us of an 18.7 us kernel)
+template <bool BF16, int KQ>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     __shared__ float sred[4];
     const int m = blockIdx.x;              // row = position-of-the-call * Beff + CFG row
@@ -37,54 +42,46 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     float loc[8];  // d <= 2048
     float sum = 0.f;
     int cnt = 0;
-    // the K tokens of this step, read once (inside the channel loop the stores to x would force a reload and
-    // serialise token -> embedding-row round trips: 17 -> 7 us)
-    int toks[16];
+    // Three dependent memory round trips in all: position -> tokens -> embedding rows.
+    const int sidx = max(g - p.P, 0);      // (rows of the prepended condition never read their tokens)
+    int64_t tok64[KQ];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        int64_t tok = (g >= p.P && k < p.K) ? p.gen_sequence[((size_t)b * p.K + k) * p.S + (g - p.P)] : 0;
+    for (int k = 0; k < KQ; ++k) tok64[k] = p.gen_sequence[((size_t)b * p.K + min(k, p.K - 1)) * p.S + sidx];
+    int toks[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+        int64_t tok = tok64[k];
         if (tok < 0 || tok > p.card) tok = p.card;  // never happens for a well-formed sequence
         toks[k] = (int)tok;
     }
-    // Three dependent memory round trips in all (position -> tokens -> embedding rows): every load of a phase is
-    // requested before the first wait.  With the loads inside the per-channel loop (behind the stores to x, which the
-    // compiler must assume alias) each of the d / 256 iterations was a round trip of its own: 20 -> ~7 us per position.
     constexpr int CPT = 8;   // channels per thread, d <= 2048
-    float ev[CPT][16], pv[CPT];
+    typedef typename std::conditional<BF16, bf16_t, float>::type ET;
+    ET ev[CPT][KQ];
+    float pv[CPT], pre[CPT];
+    const bool is_prepend = g < p.P;       // block uniform
+    const float* prow = p.prepend != nullptr ? p.prepend + ((size_t)m0 * p.P + min(g, max(p.P - 1, 0))) * p.d : p.pos_table;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int cch = min((int)threadIdx.x + i * 256, p.d - 1);
         pv[i] = p.pos_table[(size_t)g * p.d + cch];
-        if (g < p.P) {
-            ev[i][0] = p.prepend[((size_t)m0 * p.P + g) * p.d + cch];
-        } else {
+        pre[i] = prow[cch];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < p.K) {
-                    const size_t ei = (size_t)toks[k] * p.d + cch;
-                    ev[i][k] = p.w_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(p.emb[k])[ei])
-                                        : reinterpret_cast<const float*>(p.emb[k])[ei];
-                }
-            }
-        }
+        for (int k = 0; k < KQ; ++k)
+            ev[i][k] = reinterpret_cast<const ET*>(p.emb[min(k, p.K - 1)])[(size_t)toks[k] * p.d + cch];
     }
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int cch = (int)threadIdx.x + i * 256;
         if (cch >= p.d) break;
-        float v;
-        if (g < p.P) {
-            v = ev[i][0];
-        } else {
-            v = 0.f;
+        float v = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < p.K) v += ev[i][k];   // same order as the reference's sum over codebooks (lm.py:241)
-        }
+        for (int k = 0; k < KQ; ++k)       // same order as the reference's sum over codebooks (lm.py:241)
+            if (k < p.K) v += ld_f32<ET>(&ev[i][k]);
+        if (is_prepend) v = pre[i];
         v += p.pos_scale * pv[i];
         p.x[(size_t)m * p.d + cch] = v;
         if (p.xt_hi != nullptr) {
-            if (p.w_bf16) {
+            if (BF16) {
                 const size_t ti = tiled_index<bf16_t>(m, cch, p.xt_nkc);
                 const bf16_t hi = f32_to_bf16(v);
                 reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
@@ -94,13 +91,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
                 reinterpret_cast<float*>(p.xt_hi)[tiled_index<float>(m, cch, p.xt_nkc)] = v;
             }
         }
-        loc[cnt++] = v;
+        loc[i] = v;
+        cnt = i + 1;
         sum += v;
     }
     // two-pass (mean, M2) of the row for the first LayerNorm
     const float mean = block_sum(sum, sred) / (float)p.d;
     float q = 0.f;
-    for (int i = 0; i < cnt; ++i) q += (loc[i] - mean) * (loc[i] - mean);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < cnt) q += (loc[i] - mean) * (loc[i] - mean);
     q = block_sum(q, sred);
     if (threadIdx.x == 0) { p.stats[(size_t)m * 2] = mean; p.stats[(size_t)m * 2 + 1] = q; }
 }
@@ -203,17 +203,29 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
     const int k = blockIdx.x, b = blockIdx.y;
     const int card = p.card;
     const float* cond = p.logits + ((size_t)b * p.K + k) * card;
-    // row groups: PAIR [cond; uncond], DOUBLE [cond (text + wav); wav; uncond]
-    const float* second = p.logits + ((size_t)(p.B + b) * p.K + k) * card;
-    const float* third = p.logits + ((size_t)(2 * p.B + b) * p.K + k) * card;
+    // row groups: PAIR [cond; uncond], DOUBLE [cond (text + wav); wav; uncond]; a group the mode does not have aliases
+    // `cond`, so that the loads below are unconditional (a branch around a load costs a memory round trip of its own:
+    // the loads of one phase must be requested back to back)
+    const float* second = p.use_cfg != ACMI_CFG_NONE ? p.logits + ((size_t)(p.B + b) * p.K + k) * card : cond;
+    const float* third = p.use_cfg == ACMI_CFG_DOUBLE ? p.logits + ((size_t)(2 * p.B + b) * p.K + k) * card : cond;
     const int gpos = p.pos ? p.pos[0] : 0;
-    for (int i = threadIdx.x; i < card; i += blockDim.x) {
-        float v = cond[i];
+    constexpr int EPT = ACMI_MAX_CARD / 256;   // elements per thread
+    float lc[EPT], l2[EPT], l3[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = min((int)threadIdx.x + e * 256, card - 1);
+        lc[e] = cond[i]; l2[e] = second[i]; l3[e] = third[i];
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = (int)threadIdx.x + e * 256;
+        if (i >= card) break;
+        float v = lc[e];
         if (p.use_cfg == ACMI_CFG_PAIR) {  // uncond + (cond - uncond) * coef, rounded after every op like the reference (no fma)
-            const float u = second[i];
+            const float u = l2[e];
             v = __fadd_rn(u, __fmul_rn(__fsub_rn(v, u), p.cfg_coef));
         } else if (p.use_cfg == ACMI_CFG_DOUBLE) {  // uncond + coef * (wav + beta * (cond - wav) - uncond), lm.py:372-376
-            const float w = second[i], u = third[i];
+            const float w = l2[e], u = l3[e];
             const float inner = __fsub_rn(__fadd_rn(w, __fmul_rn(p.cfg_beta, __fsub_rn(v, w))), u);
             v = __fadd_rn(u, __fmul_rn(p.cfg_coef, inner));
         }
@@ -480,7 +492,13 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
     if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = wbf ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
-    hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, st, e);
+#define ACMI_EMBED_CASE(KQv)                                                                        \
+    if (m->n_q <= KQv) {                                                                           \
+        if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
+        else hipLaunchKernelGGL((embed_kernel<false, KQv>), dim3(M), dim3(256), 0, st, e);         \
+    } else
+    ACMI_EMBED_CASE(4) ACMI_EMBED_CASE(8) ACMI_EMBED_CASE(16) {}
+#undef ACMI_EMBED_CASE
     if ((rc = acmi_check_launch("embed_kernel"))) return rc;
 
     for (int li = 0; li < m->num_layers; ++li) {
