@@ -10,6 +10,16 @@
 // single-query attention over a KV cache
 // =====================================================================================================
 
+// (dpp_f32<CTRL>: acmi_common.h -- cross-lane exchange through the DPP path of the VALU instead of ds_bpermute)
+template <int LPP>   // sum over groups of LPP consecutive lanes (LPP = 1, 2, 4, 8, 16), result in every lane of the group
+__device__ __forceinline__ float group_sum(float v) {
+    if (LPP >= 2) v += dpp_f32<0xB1>(v);
+    if (LPP >= 4) v += dpp_f32<0x4E>(v);
+    if (LPP >= 8) v += dpp_f32<0x141>(v);
+    if (LPP >= 16) v += dpp_f32<0x140>(v);
+    return v;
+}
+
 __device__ __forceinline__ float raw_to_f32(bf16_t v) { return bf16_to_f32(v); }
 __device__ __forceinline__ float raw_to_f32(float v) { return v; }
 
@@ -100,15 +110,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             float part = 0.f;
 #pragma unroll
             for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kr[i][e]), part);
-#pragma unroll
-            for (int off = 1; off < LPP; off <<= 1) part += __shfl_xor(part, off, 64);
+            part = group_sum<LPP>(part);
             s[i] = (t < len) ? part * scale : -INFINITY;
         }
         float cmax = s[0];
 #pragma unroll
         for (int i = 1; i < NI; ++i) cmax = fmaxf(cmax, s[i]);
 #pragma unroll
-        for (int off = LPP; off < 64; off <<= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, off, 64));
+        for (int off = LPP; off < 64; off <<= 1)   // across the position groups of the wave (xor 8 = row_ror:8, DPP)
+            cmax = fmaxf(cmax, (LPP == 8 && off == 8) ? dpp_f32<0x128>(cmax) : __shfl_xor(cmax, off, 64));
         const float m_new = fmaxf(m, cmax);  // finite: every processed chunk has >= 1 valid position
         const float alpha = expf(m - m_new);
         l *= alpha;
@@ -127,9 +137,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     }
 #pragma unroll
     for (int off = LPP; off < 64; off <<= 1) {
-        l += __shfl_xor(l, off, 64);
+        const bool dpp8 = LPP == 8 && off == 8;
+        l += dpp8 ? dpp_f32<0x128>(l) : __shfl_xor(l, off, 64);
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) o[e] += __shfl_xor(o[e], off, 64);
+        for (int e = 0; e < DPL; ++e) o[e] += dpp8 ? dpp_f32<0x128>(o[e]) : __shfl_xor(o[e], off, 64);   // same dims, other position group
     }
     __shared__ float sm_o[4][HD];
     __shared__ float sm_m[4], sm_l[4];

@@ -70,13 +70,37 @@ template <int N, typename T> __device__ __forceinline__ void ldn(const T* p, flo
 }
 
 // ---------------------------------------------------------------- wave / block reductions
+// Cross-lane exchange through the DPP path of the VALU wherever the partner lies in the same row of 16 lanes: __shfl_xor
+// compiles to ds_bpermute_b32, a round trip through the LDS crossbar (~60 cycles of dependent latency per step).
+//   0xB1 = quad_perm [1,0,3,2] (xor 1)   0x4E = quad_perm [2,3,0,1] (xor 2)   0x128 = row_ror:8 (xor 8)
+//   0x141 = row_half_mirror (i <-> 7 - i): once the quad steps are done every lane of a quad holds the same bits, so
+//   the mirror partner is bit-for-bit the xor-4 partner.  The four steps below therefore equal the xor butterfly exactly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 consecutive lanes of a row, in every lane
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x128>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x128>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }

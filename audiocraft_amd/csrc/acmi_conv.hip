@@ -197,9 +197,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
             for (int bb = 0; bb < LSTM_BB; ++bb) acc[bb] = fmaf(wv, hs[bb * H + k], acc[bb]);
         }
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1)
-#pragma unroll
-            for (int bb = 0; bb < LSTM_BB; ++bb) acc[bb] += __shfl_xor(acc[bb], off, 64);
+        for (int bb = 0; bb < LSTM_BB; ++bb) acc[bb] = row16_sum(acc[bb]);
         if (ksl == 0) {
 #pragma unroll
             for (int bb = 0; bb < LSTM_BB; ++bb) gs[r * LSTM_BB + bb] = acc[bb];
@@ -341,9 +339,7 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
                 if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads from being hoisted en bloc
             }
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1)
-#pragma unroll
-                for (int q = 0; q < LSTM_BB; ++q) acc[q] += __shfl_xor(acc[q], off, 64);
+            for (int q = 0; q < LSTM_BB; ++q) acc[q] = row16_sum(acc[q]);
             if (ksl == 0) {
 #pragma unroll
                 for (int q = 0; q < LSTM_BB; ++q) gs[r * LSTM_BB + q] = acc[q];

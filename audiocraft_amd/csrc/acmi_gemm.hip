@@ -190,8 +190,7 @@ __device__ __forceinline__ void rowstat_finish(const float (&pm)[8], const float
     float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) sm += (jj + 16 * i < np) ? pm[i] : 0.f;
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+    sm = row16_sum(sm);
     const float mean = sm / (float)np;
     float q2 = 0.f;
 #pragma unroll
@@ -199,8 +198,7 @@ __device__ __forceinline__ void rowstat_finish(const float (&pm)[8], const float
         const float dlt = pm[i] - mean;
         q2 += (jj + 16 * i < np) ? pq[i] + (float)cnt * dlt * dlt : 0.f;
     }
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) q2 += __shfl_xor(q2, off, 64);
+    q2 = row16_sum(q2);
     if (jj == 0) {
         dst[(lane >> 4) * 2] = mean;
         dst[(lane >> 4) * 2 + 1] = 1.0f / sqrtf(q2 / (float)K + eps);
@@ -523,12 +521,10 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             if (p.stats_out != nullptr) {
                 // (mean, M2) of this workgroup's 16 output features per row, for the LayerNorm of the consumer
                 float sm = valid ? v : 0.f;
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) sm += __shfl_xor(sm, off, 64);
+                sm = row16_sum(sm);
                 const float mb = sm * (1.0f / 16.0f);
                 float dq = valid ? (v - mb) * (v - mb) : 0.f;
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) dq += __shfl_xor(dq, off, 64);
+                dq = row16_sum(dq);
                 if (nn == 0 && gm < p.M)
                     *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> 4) + ntile + t) * 2) = make_float2(mb, dq);
             }

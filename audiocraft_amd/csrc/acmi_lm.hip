@@ -156,12 +156,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 
 // block-wide argmax with first-index tie break; all threads get the result
 __device__ __forceinline__ int block_argmax(float v, int idx, float* sval, int* sidx) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(idx, off, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    // (value, index) butterflies: partners inside a row of 16 lanes through DPP (acmi_common.h), then xor 16 / 32
+#define ACMI_ARGMAX_STEP(OV, OI) { const float ov = (OV); const int oi = (OI); if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; } }
+    ACMI_ARGMAX_STEP(dpp_f32<0xB1>(v), dpp_i32<0xB1>(idx))
+    ACMI_ARGMAX_STEP(dpp_f32<0x4E>(v), dpp_i32<0x4E>(idx))
+    ACMI_ARGMAX_STEP(dpp_f32<0x141>(v), dpp_i32<0x141>(idx))
+    ACMI_ARGMAX_STEP(dpp_f32<0x128>(v), dpp_i32<0x128>(idx))
+    ACMI_ARGMAX_STEP(__shfl_xor(v, 16, 64), __shfl_xor(idx, 16, 64))
+    ACMI_ARGMAX_STEP(__shfl_xor(v, 32, 64), __shfl_xor(idx, 32, 64))
+#undef ACMI_ARGMAX_STEP
     const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) { sval[wave] = v; sidx[wave] = idx; }
     __syncthreads();
