@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 110 /* 0.1.1: CFG modes (double CFG, per-row cross-attention length), acmi_sample takes cfg_mode */
+#define ACMI_VERSION 120 /* 0.1.2: cross-attention query split between the QKV launch (x0 part) and the out-projection launch */
 
 #define ACMI_OK 0
 #define ACMI_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -133,9 +133,8 @@ typedef struct {
     const void* w_out;      /* self_attn.out_proj.weight  [d, d] */
     const void* w_cq;       /* cross_attention.in_proj_weight[:d]  [d, d]  (NULL if no cross-attn) */
     const void* w_cout;     /* cross_attention.out_proj.weight     [d, d] */
-    const void* w_xcq;      /* [d, 2 d_pad] = [w_cq | w_cq W_out] (d_pad = d rounded up to the K tile; both blocks
-                               computed in f32 from the folded w_cq, then rounded): lets the cross-attention query
-                               ride in the out-projection launch (acmi_linear_pair); NULL = separate launch */
+    const void* w_xcq;      /* legacy ([w_cq | w_cq W_out], one launch with a concatenated activation); unused by acmi_lm_step
+                               since 0.1.2, kept for acmi_linear_pair tests */
     const void* w_ff1;      /* linear1.weight [ffn, d] */
     const void* w_ff2;      /* linear2.weight [d, ffn] */
     const float* b_qkv;     /* [3d]  norm1      folded */
@@ -152,6 +151,15 @@ typedef struct {
     void* v_cache;          /* [Beff, H, Tmax, hd] */
     const void* ck_cache;   /* cross-attention keys   [Beff, H, Lc, hd] in `kvdtype`, projected once */
     const void* cv_cache;   /* cross-attention values [Beff, H, Lc, hd] */
+    /* Cross-attention query without a launch of its own, and without a dependency edge: with x1 = x0 + att W_out^T,
+     *     x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T.
+     * The first term needs only x0, the INPUT of the QKV launch, so it rides there as a fourth block of output features
+     * (w_qkvx = [w_qkv ; w_cq'], [4d, d]; the block is stored raw, without the LayerNorm epilogue, into state->r); the
+     * second term rides in the out-projection launch (acmi_linear_pair: w_out and w_mq = w_cq' W_out on the same
+     * activation `att`, accumulating onto r).  norm_cross is applied to r by the attention kernel (acmi_attn_desc).
+     * All NULL = separate q projection.  b_qkvx / cs_qkvx: [4d], zeros in the last block. */
+    const void* w_qkvx; const float* b_qkvx; const float* cs_qkvx;
+    const void* w_mq;       /* [d, d] = w_cq' W_out, computed in f32, then rounded */
 } acmi_lm_layer;
 
 typedef struct {

@@ -39,8 +39,7 @@ class ConvDesc(C.Structure):
 class LMLayer(C.Structure):
     _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_xcq', vp), ('w_ff1', vp), ('w_ff2', vp),
                 ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
-                ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp),
-                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp)]
+                ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp)]
 
 
 class LMModelDesc(C.Structure):

@@ -1,0 +1,273 @@
+// Single-query attention over the KV cache (self and cross) and the KV scatter, gfx950 (CDNA4, wave64).
+// Reference semantics: audiocraft/modules/transformer.py:266-298 (_complete_kv), :412-414 (SDPA for one new
+// step), :559-565 (norm_cross, as the optional LayerNorm hook on the query).
+#include "acmi_lm_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+// =====================================================================================================
+// single-query attention over a KV cache
+// =====================================================================================================
+
+// (dpp_f32<CTRL>: acmi_common.h -- cross-lane exchange through the DPP path of the VALU instead of ds_bpermute)
+template <int LPP>   // sum over groups of LPP consecutive lanes (LPP = 1, 2, 4, 8, 16), result in every lane of the group
+__device__ __forceinline__ float group_sum(float v) {
+    if (LPP >= 2) v += dpp_f32<0xB1>(v);
+    if (LPP >= 4) v += dpp_f32<0x4E>(v);
+    if (LPP >= 8) v += dpp_f32<0x141>(v);
+    if (LPP >= 16) v += dpp_f32<0x140>(v);
+    return v;
+}
+
+__device__ __forceinline__ float raw_to_f32(bf16_t v) { return bf16_to_f32(v); }
+__device__ __forceinline__ float raw_to_f32(float v) { return v; }
+
+struct AttnArgs {
+    const float* q; const void* kc; const void* vc; void* out;
+    int out_tiled, out_bf16, out_rbs, out_col0;  // tiled output: K tiles per 16-row block, first column
+    int H, Tcap, len; const int* len_dev; int len_bias; float scale;
+    const int* len_rows;  // per-cache-row length (two_step_cfg: the two passes keep their own condition length), or NULL
+    int rpp;      // rows per position: query row b belongs to cache row b % rpp; with len_dev its length grows by b / rpp
+    // optional LayerNorm hook on q (the cross-attention query arrives as x W'^T, see acmi_linear_pair):
+    //   q <- rstd[b] (q - mean[b] colsum) + bias, mean / rstd of row b from the (mean, M2) partials of x
+    const float* q_stats; int q_np, q_cnt, q_K; float q_eps; const float* q_colsum; const float* q_bias;
+};
+
+template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
+__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
+    const float* __restrict__ q = p.q;
+    const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.kc);
+    const KT* __restrict__ vc = reinterpret_cast<const KT*>(p.vc);
+    const int H = p.H, Tcap = p.Tcap;
+    const float scale = p.scale;
+    constexpr int DPL = HD >= 8 ? 8 : HD;  // dims per lane
+    constexpr int LPP = HD / DPL;          // lanes per position
+    constexpr int PPI = 64 / LPP;          // positions covered by one load instruction of a wave
+    constexpr int NI = sizeof(KT) == 2 ? 8 : 4;  // positions per lane per chunk (K and V loads in flight: 2 * NI)
+    typedef KT rawv __attribute__((ext_vector_type(DPL)));
+    constexpr int CH = NI * PPI;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane % LPP, pp = lane / LPP;
+    const int b0 = b % p.rpp, pidx = b / p.rpp;   // several positions per call (prefill): cache row, position index
+    const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len)) : (p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len);
+
+    float qv[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * DPL + e];
+    // LayerNorm hook: everything it needs is requested here, consumed after the first K / V chunk is in flight
+    float qcs[DPL], qb[DPL], spm[2], spq[2];
+    if (QN) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            qcs[e] = p.q_colsum[h * HD + c * DPL + e];
+            qb[e] = p.q_bias[h * HD + c * DPL + e];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // np <= 128 equal-count partials of row b, contiguous
+            const float2 t = *reinterpret_cast<const float2*>(p.q_stats + ((size_t)b * p.q_np + min(lane + 64 * i, p.q_np - 1)) * 2);
+            spm[i] = t.x; spq[i] = t.y;
+        }
+    }
+    const KT* kb = kc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
+    const KT* vb = vc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
+
+    float m = -INFINITY, l = 0.f, o[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+
+    const int nwv = blockDim.x >> 6;  // 1, 2 or 4 waves share the positions of this (row, head)
+    // K and V of a whole chunk are requested together (2 * NI wide loads in flight per lane); the first chunk
+    // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x)
+    rawv kr[NI], vr[NI];
+    auto load_kv = [&](int t0) {
+        // branch free: lanes past the end re-read the last position (their scores are masked below); a per-lane
+        // zero fill would write the registers of loads still in flight and make every load wait for the previous
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int t = min(t0 + i * PPI + pp, len - 1);
+            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
+            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
+    };
+    load_kv(wave * CH);
+    if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
+        const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
+        const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
+        const float d0 = spm[0] - mean, d1 = spm[1] - mean;
+        const float q2 = (v0 ? spq[0] + (float)p.q_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.q_cnt * d1 * d1 : 0.f);
+        const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.q_K + p.q_eps);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - mean * qcs[e]) + qb[e];
+    }
+    for (int t0 = wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
+        float s[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + i * PPI + pp;
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kr[i][e]), part);
+            part = group_sum<LPP>(part);
+            s[i] = (t < len) ? part * scale : -INFINITY;
+        }
+        float cmax = s[0];
+#pragma unroll
+        for (int i = 1; i < NI; ++i) cmax = fmaxf(cmax, s[i]);
+#pragma unroll
+        for (int off = LPP; off < 64; off <<= 1)   // across the position groups of the wave (xor 8 = row_ror:8, DPP)
+            cmax = fmaxf(cmax, (LPP == 8 && off == 8) ? dpp_f32<0x128>(cmax) : __shfl_xor(cmax, off, 64));
+        const float m_new = fmaxf(m, cmax);  // finite: every processed chunk has >= 1 valid position
+        const float alpha = expf(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int t = t0 + i * PPI + pp;
+            const float pr = (t < len) ? expf(s[i] - m_new) : 0.f;
+            l += pr;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vr[i][e]), o[e]);
+        }
+        m = m_new;
+        if (t0 + nwv * CH < len) load_kv(t0 + nwv * CH);
+    }
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) {
+        const bool dpp8 = LPP == 8 && off == 8;
+        l += dpp8 ? dpp_f32<0x128>(l) : __shfl_xor(l, off, 64);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] += dpp8 ? dpp_f32<0x128>(o[e]) : __shfl_xor(o[e], off, 64);   // same dims, other position group
+    }
+    __shared__ float sm_o[4][HD];
+    __shared__ float sm_m[4], sm_l[4];
+    if (lane < LPP) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) sm_o[wave][c * DPL + e] = o[e];
+    }
+    if (lane == 0) { sm_m[wave] = m; sm_l[wave] = l; }
+    __syncthreads();
+    if (threadIdx.x < HD) {
+        float M = sm_m[0];
+        for (int w = 1; w < nwv; ++w) M = fmaxf(M, sm_m[w]);
+        float num = 0.f, den = 0.f;
+        for (int w = 0; w < nwv; ++w) {
+            const float f = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - M);
+            num += f * sm_o[w][threadIdx.x];
+            den += f * sm_l[w];
+        }
+        const float r = num / den;
+        const int f = h * HD + threadIdx.x;
+        if (!p.out_tiled) {
+            reinterpret_cast<float*>(p.out)[(size_t)b * H * HD + f] = r;
+        } else if (p.out_bf16) {  // A-fragment order for the out-projection GEMM (include/acmi.h)
+            reinterpret_cast<bf16_t*>(p.out)[tiled_index<bf16_t>(b, p.out_col0 + f, p.out_rbs)] = f32_to_bf16(r);
+        } else {
+            reinterpret_cast<float*>(p.out)[tiled_index<float>(b, p.out_col0 + f, p.out_rbs)] = r;
+        }
+    }
+}
+
+template <typename KT>
+static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
+    static int attn_nw = -1;
+    if (attn_nw < 0) { const char* e = getenv("ACMI_ATTN_NW"); attn_nw = e ? atoi(e) : 4; if (attn_nw != 1 && attn_nw != 2) attn_nw = 4; }
+    // waves per (row, head): 4 by default; a host-known short length (cross-attention) needs no more waves than
+    // it has 64-position chunks (bf16 cache, hd 64) -- idle waves still cost dispatch time
+    int nwv = attn_nw;
+    if (a.len_dev == nullptr) {
+        const int dpl = hd >= 8 ? 8 : hd, chunk = (sizeof(KT) == 2 ? 8 : 4) * (64 / (hd / dpl));
+        const int need = (a.len + chunk - 1) / chunk;
+        while (nwv > 1 && nwv / 2 >= need) nwv /= 2;
+    }
+    dim3 grid(a.H, Beff), block(64 * nwv);
+#define ACMI_ATTN_CASE(HD)                                                                              \
+    case HD:                                                                                            \
+        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false>), grid, block, 0, st, a);            \
+        break;
+    switch (hd) {
+        ACMI_ATTN_CASE(4)
+        ACMI_ATTN_CASE(8)
+        ACMI_ATTN_CASE(16)
+        ACMI_ATTN_CASE(32)
+        ACMI_ATTN_CASE(64)
+        ACMI_ATTN_CASE(128)
+        default:
+            acmi_set_error("acmi_attn_decode: head dim %d unsupported (4,8,16,32,64,128)", hd);
+            return ACMI_EINVAL;
+    }
+#undef ACMI_ATTN_CASE
+    return acmi_check_launch("attn_decode_kernel");
+}
+
+extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
+    ACMI_REQUIRE(dsc != nullptr, "acmi_attn_decode_ex: null descriptor");
+    const acmi_attn_desc& c = *dsc;
+    ACMI_REQUIRE(c.out_mode == ACMI_OUT_TILED || c.out_mode == ACMI_OUT_F32, "acmi_attn_decode: bad out_mode %d", c.out_mode);
+    ACMI_REQUIRE(c.Beff > 0 && c.H > 0 && c.Tcap > 0 && c.hd > 0, "acmi_attn_decode: bad shape");
+    ACMI_REQUIRE(c.len_dev != nullptr || (c.len > 0 && c.len <= c.Tcap), "acmi_attn_decode: len=%d out of (0, %d]", c.len, c.Tcap);
+    const int kt = c.out_dtype == ACMI_BF16 ? 32 : 16, nkc = (c.H * c.hd + kt - 1) / kt;
+    AttnArgs a = {};
+    a.q = c.q; a.kc = c.k_cache; a.vc = c.v_cache; a.out = c.out;
+    a.out_tiled = c.out_mode == ACMI_OUT_TILED; a.out_bf16 = c.out_dtype == ACMI_BF16;
+    a.out_rbs = c.out_rbs > 0 ? c.out_rbs : nkc; a.out_col0 = c.out_col0;
+    ACMI_REQUIRE(c.out_col0 >= 0 && c.out_col0 % kt == 0 && a.out_rbs * kt >= c.out_col0 + c.H * c.hd,
+                 "acmi_attn_decode: tiled output placement col0=%d rbs=%d does not hold %d columns", c.out_col0, a.out_rbs, c.H * c.hd);
+    a.H = c.H; a.Tcap = c.Tcap; a.len = c.len; a.len_dev = c.len_dev; a.len_bias = c.len_bias; a.len_rows = c.len_rows;
+    ACMI_REQUIRE(c.len_rows == nullptr || (c.len_dev == nullptr && c.len > 0), "acmi_attn_decode: len_rows needs a host `len` bound");
+    a.rpp = c.cache_rows > 0 ? c.cache_rows : c.Beff;
+    ACMI_REQUIRE(c.Beff % a.rpp == 0, "acmi_attn_decode: %d query rows are not a multiple of %d cache rows", c.Beff, a.rpp);
+    a.scale = 1.0f / sqrtf((float)c.hd);
+    if (c.q_colsum != nullptr) {
+        ACMI_REQUIRE(c.q_stats != nullptr && c.q_stats_np >= 1 && c.q_stats_np <= 128 && c.q_stats_np * c.q_stats_cnt > 0,
+                     "acmi_attn_decode: q LayerNorm hook needs 1..128 statistics partials");
+        a.q_stats = c.q_stats; a.q_np = c.q_stats_np; a.q_cnt = c.q_stats_cnt; a.q_K = c.q_stats_np * c.q_stats_cnt;
+        a.q_eps = c.eps; a.q_colsum = c.q_colsum;
+        a.q_bias = c.q_bias != nullptr ? c.q_bias : nullptr;
+        ACMI_REQUIRE(c.q_bias != nullptr, "acmi_attn_decode: q_bias is required with q_colsum (pass zeros for none)");
+    }
+    return c.kvdtype == ACMI_BF16 ? launch_attn_t<bf16_t>(a, c.Beff, c.hd, (hipStream_t)stream)
+                                  : launch_attn_t<float>(a, c.Beff, c.hd, (hipStream_t)stream);
+}
+
+extern "C" int acmi_attn_decode(const float* q, const void* k_cache, const void* v_cache, int kvdtype, void* out,
+                                int out_mode, int out_dtype, int Beff, int H, int hd, int Tcap, int len,
+                                const int* len_dev, int len_bias, void* stream) {
+    acmi_attn_desc c = {};
+    c.q = q; c.k_cache = k_cache; c.v_cache = v_cache; c.kvdtype = kvdtype; c.out = out; c.out_mode = out_mode;
+    c.out_dtype = out_dtype; c.Beff = Beff; c.H = H; c.hd = hd; c.Tcap = Tcap; c.len = len; c.len_dev = len_dev;
+    c.len_bias = len_bias;
+    return acmi_attn_decode_ex(&c, stream);
+}
+
+// scatter [Beff, L, H*hd] f32 rows into a [Beff, H, Tcap, hd] cache
+template <typename KT>
+__global__ void kv_store_kernel(const float* __restrict__ src, KT* __restrict__ cache, int H, int hd, int Tcap, int t0,
+                                int L, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int dd = i % hd;
+        size_t r = i / hd;
+        const int h = r % H; r /= H;
+        const int t = r % L;
+        const int b = r / L;
+        st_f32(cache + (((size_t)b * H + h) * Tcap + t0 + t) * hd + dd, src[i]);
+    }
+}
+
+extern "C" int acmi_kv_store(const float* src, void* cache, int kvdtype, int Beff, int H, int hd, int Tcap, int t0,
+                             int L, void* stream) {
+    ACMI_REQUIRE(t0 >= 0 && L > 0 && t0 + L <= Tcap, "acmi_kv_store: range [%d, %d) outside cache %d", t0, t0 + L, Tcap);
+    const size_t total = (size_t)Beff * L * H * hd;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (kvdtype == ACMI_BF16)
+        hipLaunchKernelGGL(kv_store_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           reinterpret_cast<bf16_t*>(cache), H, hd, Tcap, t0, L, total);
+    else
+        hipLaunchKernelGGL(kv_store_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           reinterpret_cast<float*>(cache), H, hd, Tcap, t0, L, total);
+    return acmi_check_launch("kv_store_kernel");
+}

@@ -1,0 +1,420 @@
+// SEANet convolution kernels for gfx950: implicit-GEMM Conv1d / ConvTranspose1d in exact f32 on the
+// matrix cores (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain), plus the LSTM recurrence.
+//
+// conv_mfma_kernel: GEMM rows = output channels (for transposed convs: (channel, phase) pairs of the
+// polyphase decomposition), GEMM cols = output time steps, K = Cin * ksize.  A 64 x 64 output tile per
+// 256-thread workgroup (4 waves, 2 x 2 of 32 x 32); per K chunk the weight tile and the input span
+// (with halo) are staged through LDS with coalesced reads; padding (zero / reflect, asymmetric,
+// "extra" right padding), the ELU that precedes every SEANet conv, bias, the resnet skip add and the
+// transposed-conv trim + phase interleave are all folded into the load / store index math.
+// The input span is stored de-interleaved by stride phase so that the MFMA B-operand reads of a
+// strided conv hit 32 consecutive LDS banks.
+// Reference: audiocraft/modules/conv.py:47-88,185-243; audiocraft/modules/seanet.py:16-60.
+#include "acmi_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+struct ConvArgs {
+    acmi_conv_desc d;
+    const float* x; const float* w; const float* bias; const float* res; float* y;
+    int Tq;    // GEMM columns per batch item
+    int CIC;   // input channels per K chunk
+    int KCE;   // CIC * ksize rounded up to even
+    int KCP;   // LDS row pitch of the weight tile (odd)
+    int LP;    // LDS row pitch of one (channel, phase) input row
+};
+
+__device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow, int pos) {
+    const acmi_conv_desc& d = a.d;
+    int src = pos;
+    if (d.pad_mode == ACMI_PAD_REFLECT) {
+        if (src < 0) src = -src;
+        if (src >= d.reflect_len) src = 2 * (d.reflect_len - 1) - src;
+    }
+    if (src < 0 || src >= d.Tin) return 0.f;
+    float v = xrow[src];
+    if (d.elu_in) v = v > 0.f ? v : d.elu_alpha * expm1f(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const acmi_conv_desc& d = a.d;
+    const int s = d.stride, ks = d.ksize;
+    float* Ws = smem;                                   // [64][KCP]
+    float* Xs = Ws + 64 * a.KCP;                        // [CIC][s][LP]
+    int* koff = reinterpret_cast<int*>(Xs + a.CIC * s * a.LP);  // [KCE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, kk = lane >> 5;
+    const int q0 = blockIdx.x * 64, m0 = blockIdx.y * 64, b = blockIdx.z;
+    const int span = 63 * s + (ks - 1) * d.dilation + 1;
+    const int base_in = q0 * s - d.pad_left;
+    const int KC = a.CIC * ks;
+
+    for (int kl = tid; kl < a.KCE; kl += 256) {
+        int off = 0;
+        if (kl < KC) {
+            const int ci = kl / ks, j = kl - ci * ks;
+            const int jd = j * d.dilation;
+            off = (ci * s + jd % s) * a.LP + jd / s;
+        }
+        koff[kl] = off;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const size_t wpitch = (size_t)d.Cin * ks;
+    for (int ci0 = 0; ci0 < d.Cin; ci0 += a.CIC) {
+        const int cic = min(a.CIC, d.Cin - ci0);
+        const int kvalid = cic * ks;
+        __syncthreads();
+        // ---- weight tile: 16 rows per wave, 64 consecutive k per pass
+        for (int r = wave; r < 64; r += 4) {
+            const int mrow = m0 + r;
+            const float* wsrc = a.w + (size_t)mrow * wpitch + (size_t)ci0 * ks;
+            for (int kl = lane; kl < a.KCE; kl += 64)
+                Ws[r * a.KCP + kl] = (mrow < d.Cout && kl < kvalid) ? wsrc[kl] : 0.f;
+        }
+        // ---- input span, phase de-interleaved
+        for (int ci = wave; ci < a.CIC; ci += 4) {
+            const float* xrow = a.x + ((size_t)b * d.Cin + ci0 + ci) * d.Tin;
+            float* dst = Xs + (size_t)ci * s * a.LP;
+            if (s == 1) {
+                for (int rel = lane; rel < span; rel += 64)
+                    dst[rel] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+            } else {
+                for (int rel = lane; rel < span; rel += 64) {
+                    const int qq = rel / s, ph = rel - qq * s;
+                    dst[ph * a.LP + qq] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        const float* wp = Ws + (wr * 32 + li) * a.KCP + kk;
+        const float* xp = Xs + wc * 32 + li;
+        for (int k2 = 0; k2 < a.KCE; k2 += 2) {
+            const float av = wp[k2];
+            const float bv = xp[koff[k2 + kk]];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue
+    const int q = q0 + wc * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int mrow = m0 + wr * 32 + row;
+        if (mrow >= d.Cout) continue;
+        float v = acc[r];
+        if (d.shuffle <= 1) {
+            if (q < d.Tout) {
+                const size_t oi = ((size_t)b * d.Cout + mrow) * d.Tout + q;
+                if (a.bias) v += a.bias[mrow];
+                if (a.res) v += a.res[oi];
+                a.y[oi] = v;
+            }
+        } else {
+            const int co = mrow / d.shuffle, ph = mrow - co * d.shuffle;
+            const long long o = (long long)q * d.shuffle + ph - d.trim_left;
+            if (o >= 0 && o < d.Tout && q < a.Tq) {
+                const size_t oi = ((size_t)b * (d.Cout / d.shuffle) + co) * d.Tout + (size_t)o;
+                if (a.bias) v += a.bias[co];
+                if (a.res) v += a.res[oi];
+                a.y[oi] = v;
+            }
+        }
+    }
+}
+
+extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float* w, const float* bias,
+                           const float* residual, float* y, void* stream) {
+    ACMI_REQUIRE(dp != nullptr, "acmi_conv1d: null descriptor");
+    const acmi_conv_desc& d = *dp;
+    ACMI_REQUIRE(d.B >= 0 && d.Cin > 0 && d.Cout > 0 && d.ksize > 0 && d.stride > 0 && d.dilation > 0,
+                 "acmi_conv1d: bad shape");
+    ACMI_REQUIRE(d.ksize <= 128, "acmi_conv1d: ksize=%d unsupported (max 128)", d.ksize);
+    ACMI_REQUIRE(d.shuffle >= 1 && d.Cout % d.shuffle == 0, "acmi_conv1d: Cout=%d not divisible by shuffle=%d", d.Cout,
+                 d.shuffle);
+    ACMI_REQUIRE(d.shuffle == 1 || (d.stride == 1 && d.dilation == 1), "acmi_conv1d: shuffle needs stride=dilation=1");
+    ACMI_REQUIRE(d.pad_mode == ACMI_PAD_ZERO || d.reflect_len >= d.Tin, "acmi_conv1d: reflect_len < Tin");
+    if (d.B == 0 || d.Tout <= 0) return ACMI_OK;
+    ConvArgs a;
+    a.d = d; a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    a.Tq = d.shuffle > 1 ? (int)(((long long)d.Tout + d.trim_left + d.shuffle - 1) / d.shuffle) : d.Tout;
+    int cic = 128 / d.ksize;
+    if (cic < 1) cic = 1;
+    if (cic > d.Cin) cic = d.Cin;
+    // keep the staged input span within the LDS budget
+    const int lp = 64 + ((d.ksize - 1) * d.dilation) / d.stride + 2;
+    while (cic > 1 && (size_t)cic * d.stride * lp * 4 > 24 * 1024) cic >>= 1;
+    a.CIC = cic;
+    a.KCE = (cic * d.ksize + 1) & ~1;
+    a.KCP = a.KCE | 1;
+    a.LP = lp;
+    const size_t lds = ((size_t)64 * a.KCP + (size_t)a.CIC * d.stride * a.LP + a.KCE) * sizeof(float);
+    ACMI_REQUIRE(lds <= 64 * 1024, "acmi_conv1d: LDS budget exceeded (%zu B)", lds);
+    dim3 grid((a.Tq + 63) / 64, (d.Cout + 63) / 64, d.B), block(256);
+    hipLaunchKernelGGL(conv_mfma_kernel, grid, block, lds, (hipStream_t)stream, a);
+    return acmi_check_launch("conv_mfma_kernel");
+}
+
+// =====================================================================================================
+// LSTM recurrence (audiocraft/modules/lstm.py:19-25 -> nn.LSTM, gate order i, f, g, o)
+// =====================================================================================================
+
+#define LSTM_BB 8  // batch rows per pass
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ gates_in,
+                                                        const float* __restrict__ w_hh,
+                                                        const float* __restrict__ h_prev, float* __restrict__ h_next,
+                                                        float* __restrict__ cst, const float* __restrict__ skip,
+                                                        float* __restrict__ y, int B, int H, int T, int t) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    float* hs = sh;                 // [LSTM_BB][H]
+    float* gs = sh + LSTM_BB * H;   // [16][LSTM_BB]
+    const int tid = threadIdx.x;
+    const int r = tid >> 4, ksl = tid & 15;
+    const int gate = r >> 2, u = r & 3;
+    const int j0 = blockIdx.x * 4;
+    const bool jvalid = j0 + u < H;
+    const float* wrow = w_hh + ((size_t)gate * H + (jvalid ? j0 + u : 0)) * H;
+    for (int b0 = 0; b0 < B; b0 += LSTM_BB) {
+        const int nb = min(LSTM_BB, B - b0);
+        for (int idx = tid; idx < LSTM_BB * H; idx += 256) hs[idx] = idx < nb * H ? h_prev[(size_t)b0 * H + idx] : 0.f;
+        __syncthreads();
+        float acc[LSTM_BB];
+#pragma unroll
+        for (int bb = 0; bb < LSTM_BB; ++bb) acc[bb] = 0.f;
+        for (int k = ksl; k < H; k += 16) {
+            const float wv = wrow[k];
+#pragma unroll
+            for (int bb = 0; bb < LSTM_BB; ++bb) acc[bb] = fmaf(wv, hs[bb * H + k], acc[bb]);
+        }
+#pragma unroll
+        for (int bb = 0; bb < LSTM_BB; ++bb) acc[bb] = row16_sum(acc[bb]);
+        if (ksl == 0) {
+#pragma unroll
+            for (int bb = 0; bb < LSTM_BB; ++bb) gs[r * LSTM_BB + bb] = acc[bb];
+        }
+        __syncthreads();
+        if (tid < 4 * LSTM_BB) {
+            const int uu = tid & 3, bb = tid >> 2;
+            const int j = j0 + uu, bidx = b0 + bb;
+            if (bb < nb && j < H) {
+                const size_t gbase = ((size_t)bidx * 4 * H + j) * T + t;
+                const float gi = gs[(0 * 4 + uu) * LSTM_BB + bb] + gates_in[gbase];
+                const float gf = gs[(1 * 4 + uu) * LSTM_BB + bb] + gates_in[gbase + (size_t)H * T];
+                const float gg = gs[(2 * 4 + uu) * LSTM_BB + bb] + gates_in[gbase + (size_t)2 * H * T];
+                const float go = gs[(3 * 4 + uu) * LSTM_BB + bb] + gates_in[gbase + (size_t)3 * H * T];
+                const float ig = 1.f / (1.f + expf(-gi));
+                const float fg = 1.f / (1.f + expf(-gf));
+                const float og = 1.f / (1.f + expf(-go));
+                const size_t si = (size_t)bidx * H + j;
+                const float cn = fg * cst[si] + ig * tanhf(gg);
+                const float hn = og * tanhf(cn);
+                cst[si] = cn;
+                h_next[si] = hn;
+                const size_t yi = ((size_t)bidx * H + j) * T + t;
+                y[yi] = skip ? hn + skip[yi] : hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Persistent form: ONE launch per LSTM layer.  Workgroup g owns hidden units 4g .. 4g+3 (16 gate rows of W_hh) for all T
+// steps and keeps its 16 x H slice of W_hh in REGISTERS (64 floats per thread at H = 1024; the step kernel above
+// re-streams all 16.8 MB of W_hh from L2 at every step).  What remains per step is the all-gather of h_{t-1}: 32 KB per
+// workgroup at B = 8.  The data is its own flag (MI355X guide, Guideline 16 form R2, here with a sentinel instead of a
+// tag): hidden values are never NaN, so a slot holding the quiet-NaN pattern LSTM_EMPTY means "not written yet".
+//   * three [B, H] f32 buffers rotate by step (t mod 3); all slots start EMPTY;
+//   * the owner of a slot writes h_t with a write-through (agent-scope) store; readers sweep the previous step's buffer
+//     with agent-scope 16-byte loads (the 4 units of one owner and one batch row) until no value is EMPTY;
+//   * right after its own gather of step t - 1 a workgroup re-arms its slots in the buffer of step t + 1 (it holds step
+//     t - 2, which every workgroup finished reading before it published step t - 1 -- and all of those have just been
+//     seen); the publish of step t + 1 into that buffer is one full step (and an s_waitcnt vmcnt(0)) later.
+// Spins are bounded (err[0] counts give-ups; the host checks it).
+// -----------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#define LSTM_EMPTY 0x7fc00001u
+
+template <int KI>   // KI = ceil(H / 16) <= 64: W_hh values per thread
+__global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __restrict__ gates_in,
+                                                              const float* __restrict__ w_hh, float* __restrict__ cst,
+                                                              const float* __restrict__ skip, float* __restrict__ y,
+                                                              unsigned* hbuf, unsigned* err, int B, int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    // h_{t-1} in LDS, k-major: hs[k][q], pitch 12 floats (two conflict-free ds_read_b128 fetch the 8 batch values of a k)
+    constexpr int HP = 12;
+    float* hs = sh;                    // [H][HP]
+    float* gs = sh + (size_t)H * HP;   // [16][LSTM_BB]
+    const int tid = threadIdx.x;
+    const int r = tid >> 4, ksl = tid & 15;
+    const int gate = r >> 2, u = r & 3;
+    const int j0 = blockIdx.x * 4;
+    const bool jvalid = j0 + u < H;
+    const float* wrow = w_hh + ((size_t)gate * H + (jvalid ? j0 + u : 0)) * H;
+    float wv[KI];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) wv[i] = (ksl + 16 * i < H) ? wrow[ksl + 16 * i] : 0.f;
+    const size_t BH = (size_t)B * H;
+    const int H4 = H >> 2;                       // 16-byte groups per row (H % 4 == 0 is required by the launcher)
+    const bool one_pass = B <= LSTM_BB;
+    float c_reg = 0.f;                           // cell state of this thread's (unit, row) when B fits one pass
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hbuf, 0, (int)(3 * BH * 4), 0x00020000);
+
+    for (int t = 0; t < T; ++t) {
+        const unsigned prev_off = (unsigned)(((t + 2) % 3) * BH);   // buffer of step t - 1
+        unsigned* hnext = hbuf + (size_t)(t % 3) * BH;              // buffer of step t
+        unsigned* hrearm = hbuf + (size_t)((t + 1) % 3) * BH;       // buffer of step t + 1 (still holds step t - 2)
+        for (int b0 = 0; b0 < B; b0 += LSTM_BB) {
+            const int nb = min(LSTM_BB, B - b0);
+            // this thread's gate inputs of the step: requested before the sweep (they do not depend on h)
+            float gin[4] = {0.f, 0.f, 0.f, 0.f};
+            const int uu = tid & 3, bb = tid >> 2, j = j0 + uu, bidx = b0 + bb;
+            const bool owner = tid < 4 * LSTM_BB && bb < nb && j < H;
+            if (owner) {
+                const size_t gbase = ((size_t)bidx * 4 * H + j) * T + t;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) gin[g4] = gates_in[gbase + (size_t)g4 * H * T];
+            }
+            // ---- all-gather of h_{t-1}[b0 .. b0 + nb): 16-byte groups (row q, units 4 k4 .. 4 k4 + 3), 8 per thread in flight
+            if (t == 0) {
+                for (int idx = tid; idx < H * HP; idx += 256) hs[idx] = 0.f;
+            } else {
+                const int ngr = nb * H4;
+                for (int base = 0; base < LSTM_BB * H4; base += 256 * 8) {
+                    u32x4_t v[8];
+                    unsigned pending = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (base + i * 256 + tid < ngr) pending |= 1u << i;
+                    unsigned spins = 0;
+                    while (pending) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (pending & (1u << i)) {
+                                const int idx = base + i * 256 + tid;    // = q * H4 + k4
+                                v[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs, (prev_off + (unsigned)(b0 * H) + (unsigned)idx * 4u) * 4u, 0, 16 /* sc1 */);
+                            }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if ((pending & (1u << i)) && v[i][0] != LSTM_EMPTY && v[i][1] != LSTM_EMPTY &&
+                                v[i][2] != LSTM_EMPTY && v[i][3] != LSTM_EMPTY) {
+                                const int idx = base + i * 256 + tid, q = idx / H4, k = (idx - q * H4) * 4;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) hs[(k + e) * HP + q] = __uint_as_float(v[i][e]);
+                                pending &= ~(1u << i);
+                            }
+                        if (pending && ++spins > 1000000u) { atomicAdd(err, 1u); break; }
+                    }
+                }
+                for (int idx = tid; idx < (LSTM_BB - nb) * H; idx += 256)   // rows past nb of this pass: zeros
+                    hs[(idx % H) * HP + nb + idx / H] = 0.f;
+            }
+            __syncthreads();
+            // the WHOLE gather is complete (barrier above): re-arm this workgroup's slots of step t + 1 (header comment)
+            if (owner) __hip_atomic_store(hrearm + (size_t)bidx * H + j, LSTM_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- 16 rows x H against nb hidden vectors: W from registers, h from LDS
+            float acc[LSTM_BB];
+#pragma unroll
+            for (int q = 0; q < LSTM_BB; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int k = min(ksl + 16 * i, H - 1);
+                const float4 h0 = *reinterpret_cast<const float4*>(hs + k * HP);
+                const float4 h1 = *reinterpret_cast<const float4*>(hs + k * HP + 4);
+                acc[0] = fmaf(wv[i], h0.x, acc[0]); acc[1] = fmaf(wv[i], h0.y, acc[1]);
+                acc[2] = fmaf(wv[i], h0.z, acc[2]); acc[3] = fmaf(wv[i], h0.w, acc[3]);
+                acc[4] = fmaf(wv[i], h1.x, acc[4]); acc[5] = fmaf(wv[i], h1.y, acc[5]);
+                acc[6] = fmaf(wv[i], h1.z, acc[6]); acc[7] = fmaf(wv[i], h1.w, acc[7]);
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads from being hoisted en bloc
+            }
+#pragma unroll
+            for (int q = 0; q < LSTM_BB; ++q) acc[q] = row16_sum(acc[q]);
+            if (ksl == 0) {
+#pragma unroll
+                for (int q = 0; q < LSTM_BB; ++q) gs[r * LSTM_BB + q] = acc[q];
+            }
+            __syncthreads();
+            if (owner) {
+                const float gi = gs[(0 * 4 + uu) * LSTM_BB + bb] + gin[0];
+                const float gf = gs[(1 * 4 + uu) * LSTM_BB + bb] + gin[1];
+                const float gg = gs[(2 * 4 + uu) * LSTM_BB + bb] + gin[2];
+                const float go = gs[(3 * 4 + uu) * LSTM_BB + bb] + gin[3];
+                const float ig = 1.f / (1.f + expf(-gi));
+                const float fg = 1.f / (1.f + expf(-gf));
+                const float og = 1.f / (1.f + expf(-go));
+                const size_t si = (size_t)bidx * H + j;
+                const float cp = t == 0 ? 0.f : (one_pass ? c_reg : cst[si]);
+                const float cn = fg * cp + ig * tanhf(gg);
+                const float hn = og * tanhf(cn);
+                c_reg = cn;
+                if (!one_pass) cst[si] = cn;   // private to this workgroup
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm store of the previous step has landed
+                __hip_atomic_store(hnext + si, __float_as_uint(hn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const size_t yi = ((size_t)bidx * H + j) * T + t;
+                y[yi] = skip ? hn + skip[yi] : hn;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// work: 3 * B * H floats for the step form (h double buffer + c); the persistent form needs c (B * H floats), three
+// hidden-state buffers (3 * B * H floats) and an error word: 5 * B * H + 4 floats cover both
+extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H + 4; }
+
+static int lstm_persistent_ok(int B, int H) {
+    static int want = -1;
+    if (want < 0) { const char* e = getenv("ACMI_LSTM_PERSISTENT"); want = (e && e[0] == '0') ? 0 : 1; }
+    // every workgroup must be resident for the all-gather to complete: 256-thread workgroups of ~110 VGPRs and 33 KB of
+    // LDS fit 4 per CU, far more than the (H + 3) / 4 <= 256 this admits
+    return want && H <= 1024 && H % 4 == 0 && H / 4 <= 256 && B >= 1;
+}
+
+
+
+extern "C" int acmi_lstm_layer(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, int B,
+                               int H, int T, void* stream) {
+    ACMI_REQUIRE(B > 0 && H > 0 && T >= 0, "acmi_lstm_layer: bad shape");
+    ACMI_REQUIRE((size_t)(LSTM_BB * H + 16 * LSTM_BB) * 4 <= 64 * 1024, "acmi_lstm_layer: H=%d too large", H);
+    hipStream_t st = (hipStream_t)stream;
+    float* h0 = work;
+    float* h1 = work + (size_t)B * H;
+    float* c = work + (size_t)2 * B * H;
+    if (hipMemsetAsync(work, 0, sizeof(float) * 3 * B * H, st) != hipSuccess) {
+        acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
+        return ACMI_ELAUNCH;
+    }
+    const size_t lds = (size_t)(LSTM_BB * H + 16 * LSTM_BB) * sizeof(float);
+    dim3 grid((H + 3) / 4), block(256);
+    if (T > 0 && lstm_persistent_ok(B, H)) {
+        const size_t lds_p = (size_t)(12 * H + 16 * LSTM_BB) * sizeof(float);
+        // layout of `work` for this form: [c: B H floats][h buffers: 3 B H words, all EMPTY][...][err: 1 word]
+        unsigned* hbuf = reinterpret_cast<unsigned*>(work + (size_t)B * H);
+        unsigned* err = reinterpret_cast<unsigned*>(work + (size_t)5 * B * H);
+        if (hipMemsetAsync(work, 0, sizeof(float) * ((size_t)5 * B * H + 4), st) != hipSuccess ||
+            hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, (size_t)3 * B * H, st) != hipSuccess) {
+            acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
+            return ACMI_ELAUNCH;
+        }
+        const int ki = (H + 15) / 16;
+#define ACMI_LSTM_CASE(KIv) if (ki <= KIv) { hipLaunchKernelGGL(lstm_persistent_kernel<KIv>, grid, block, lds_p, st, gates_in, w_hh, work, skip, y, hbuf, err, B, H, T); return acmi_check_launch("lstm_persistent_kernel"); }
+        ACMI_LSTM_CASE(8) ACMI_LSTM_CASE(16) ACMI_LSTM_CASE(32) ACMI_LSTM_CASE(64)
+#undef ACMI_LSTM_CASE
+    }
+    for (int t = 0; t < T; ++t) {
+        hipLaunchKernelGGL(lstm_step_kernel, grid, block, lds, st, gates_in, w_hh, (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, c,
+                           skip, y, B, H, T, t);
+    }
+    return acmi_check_launch("lstm_step_kernel");
+}

@@ -506,10 +506,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
                 continue;
             }
             size_t oi = 0;
-            // QKV launch carrying the x0 part of the cross-attention query: features >= 3d are stored raw
-            const bool rawcol = p.qkv && gn >= 3 * p.d;
             if (valid) {
-                if (FOLD && !rawcol) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
+                if (FOLD) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
                     const float* rs = rowstat + (u * 16 + mm) * 2;
                     v = rs[1] * (v - rs[0] * (first ? ex.colsum : p.colsum[gn]));
                 }
@@ -546,8 +544,6 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
                 const int part = gn / p.d, f = gn - part * p.d;
                 if (part == 0) {
                     p.q_out[(size_t)gm * p.d + f] = v;
-                } else if (part == 3) {
-                    p.r_out[(size_t)gm * p.d + f] = v;
                 } else {
                     const int h = f / p.hd, dd = f - h * p.hd;
                     const int pidx = gm / p.rpp, brow = gm - pidx * p.rpp;  // several positions per call (prefill)

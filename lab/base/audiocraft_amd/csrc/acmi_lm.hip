@@ -483,9 +483,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     // Cross-attention query without a launch of its own (include/acmi.h, acmi_linear_pair): needs the folded
     // LayerNorm, the [W_cq' | W_cq' W_out] matrices, xh buffers wide enough for [x | att] and a second pair.
     static const bool pair_enabled = !(getenv("ACMI_CROSS_FUSED") != nullptr && getenv("ACMI_CROSS_FUSED")[0] == '0');
-    const bool pair = pair_enabled && m->cross_attention && c.lnm == LN_FOLD && m->layers[0].w_qkvx != nullptr &&
-                      m->layers[0].w_mq != nullptr && s->xn2 != nullptr && (!wbf || s->xlo2 != nullptr) && s->r != nullptr &&
-                      c.rbs >= 2 * c.nkc_d;
+    const bool pair = pair_enabled && m->cross_attention && c.lnm == LN_FOLD && m->layers[0].w_xcq != nullptr &&
+                      s->xn2 != nullptr && (!wbf || s->xlo2 != nullptr) && s->r != nullptr && c.rbs >= 2 * c.nkc_d;
     void* const xh2[2] = {s->xn, s->xn2};
     void* const xl2[2] = {s->xlo, s->xlo2};
     int cur = 0;
@@ -512,10 +511,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             LinArgs a = {};
             a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
             a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
-            if (pair) {   // + the x0 part of the cross-attention query as a fourth, raw block of features -> r
-                a.r_out = s->r;
-                if ((rc = gemm_ln_x(c, a, L.w_qkvx, L.b_qkvx, L.cs_qkvx, 4 * d))) return rc;
-            } else if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
+            if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
         }
         // self attention over positions [0, g]; output in A-fragment order for the out projection: into `att`,
         // or next to x ([x | att], columns d_pad ..) when the out projection is paired with the cross query
@@ -536,13 +532,14 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.Beff = M; ca.H = H; ca.hd = hd; ca.Tcap = s->Lc;
             ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows;
             if (pair) {
-                // ONE launch: x1 = x0 + att W_out^T (fragments of x1 into the other buffer pair) and
-                // r += att (W_cq' W_out)^T, which completes r = x1 W_cq'^T (its x0 part came out of the QKV launch)
+                // ONE launch: x1 = x0 + att W_out^T (fragments of x1 into the other buffer pair: this launch
+                // still reads x0's) and r = [x0 | att] [W_cq' | W_cq' W_out]^T = x1 W_cq'^T
                 LinArgs p0 = {}, p1 = {};
                 const void* att_half = reinterpret_cast<const unsigned char*>(c.xh) + (size_t)c.nkc_d * 1024;  // K tile nkc_d
                 gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1]);
-                p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs;
-                p1.w = L.w_mq; p1.residual = s->r; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = d;
+                p1.a = c.xh; p1.a_tiled = 1; p1.a_rbs = c.rbs; p1.a_lo = wbf ? c.xl : nullptr; p1.alo_rbs = c.nkc_d;
+                p1.lo_split = wbf ? c.nkc_d : 0;
+                p1.w = L.w_xcq; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = 2 * c.nkc_d * c.kt;
                 if ((rc = acmi_launch_pair(p0, p1, m->wdtype, st))) return rc;
                 cur ^= 1; c.xh = xh2[cur]; c.xl = xl2[cur]; c.np = d / 16; c.cnt = 16;
                 // the cross-attention kernel applies norm_cross to r from the statistics of x1

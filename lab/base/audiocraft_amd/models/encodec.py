@@ -1,0 +1,229 @@
+"""EnCodec compression model on MI355X.
+
+API mirror of `audiocraft.models.encodec.CompressionModel` / `EncodecModel`
+(reference audiocraft/models/encodec.py:28-259): encode / decode / decode_latent / forward and the
+channels / frame_rate / sample_rate / cardinality / num_codebooks / total_codebooks properties.
+The HF / DAC / stereo-interleave wrappers of the reference are outside this path.
+"""
+import math
+import typing as tp
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from ..modules.seanet import invalidate_prepared
+from ..quantization.vq import BaseQuantizer
+
+
+@dataclass
+class QuantizedResult:
+    x: torch.Tensor
+    codes: torch.Tensor
+    bandwidth: torch.Tensor          # kb/s
+    penalty: tp.Optional[torch.Tensor] = None
+
+
+def _abstract_property(name: str, doc: str):
+    def getter(self):
+        raise NotImplementedError(f"{type(self).__name__} must define `{name}`")
+    getter.__isabstractmethod__ = True
+    return property(getter, doc=doc)
+
+
+class CompressionModel(ABC, nn.Module):
+    """Audio tokenizer interface (reference `CompressionModel`, encodec.py:28-85): `encode(x[B, C, T]) ->
+    (codes[B, K, T'], scale | None)`, `decode(codes, scale) -> wav[B, C, T]`, `decode_latent(codes)`,
+    `forward(x) -> QuantizedResult`, `set_num_codebooks(n)` and the read-only properties below."""
+
+    channels = _abstract_property('channels', "audio channels")
+    frame_rate = _abstract_property('frame_rate', "token frames per second")
+    sample_rate = _abstract_property('sample_rate', "audio sample rate")
+    cardinality = _abstract_property('cardinality', "entries per codebook")
+    num_codebooks = _abstract_property('num_codebooks', "codebooks in use")
+    total_codebooks = _abstract_property('total_codebooks', "codebooks available")
+
+    @abstractmethod
+    def forward(self, x: torch.Tensor) -> QuantizedResult: ...
+
+    @abstractmethod
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]: ...
+
+    @abstractmethod
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None): ...
+
+    @abstractmethod
+    def decode_latent(self, codes: torch.Tensor): ...
+
+    @abstractmethod
+    def set_num_codebooks(self, n: int): ...
+
+    @staticmethod
+    def get_pretrained(name: str, device='cuda') -> 'CompressionModel':
+        """reference encodec.py:88-122.  `debug_compression_model`, a path (file / directory holding a
+        `compression_state_dict.bin` written by `audiocraft.utils.export`), or a released name resolved on disk under
+        $AUDIOCRAFT_CACHE_DIR (there is no network here; the DAC / HuggingFace-EnCodec wrappers are third-party codecs
+        outside the path and raise)."""
+        from . import builders, loaders
+        if name in ('dac_44khz', 'dac_24khz'):
+            raise NotImplementedError("DAC codecs are third-party models outside the MusicGen path")
+        if name == 'debug_compression_model':
+            return builders.get_debug_compression_model(device).eval()
+        return loaders.load_compression_model(name, device=device).eval()
+
+
+class EncodecModel(CompressionModel):
+    """SEANet encoder -> residual vector quantizer -> SEANet decoder on the waveform (reference
+    `EncodecModel`, encodec.py:125-259).  `renormalize=True` (divide by the mono RMS before encoding,
+    multiply back after decoding; encodec.py:186-204) is kept for completeness -- no MusicGen codec uses
+    it -- and runs as three elementwise torch ops."""
+    frame_rate: float = 0
+    sample_rate: int = 0
+    channels: int = 0
+
+    def __init__(self, encoder: nn.Module, decoder: nn.Module, quantizer: BaseQuantizer, frame_rate: int,
+                 sample_rate: int, channels: int, causal: bool = False, renormalize: bool = False):
+        super().__init__()
+        assert not (causal and renormalize), 'Causal model does not support renormalize'
+        self.encoder, self.decoder, self.quantizer = encoder, decoder, quantizer
+        self.frame_rate, self.sample_rate, self.channels = frame_rate, sample_rate, channels
+        self.causal, self.renormalize = causal, renormalize
+        self.eval()
+
+    # folded weights are cached inside the conv / quantizer modules: drop them whenever parameters change
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        result = super().load_state_dict(state_dict, strict=strict, **kw)
+        invalidate_prepared(self)
+        return result
+
+    def _apply(self, fn, *args, **kw):
+        result = super()._apply(fn, *args, **kw)
+        invalidate_prepared(self)
+        return result
+
+    total_codebooks = property(lambda self: self.quantizer.total_codebooks)
+    num_codebooks = property(lambda self: self.quantizer.num_codebooks)
+    cardinality = property(lambda self: self.quantizer.bins)
+
+    def set_num_codebooks(self, n: int):
+        self.quantizer.set_num_codebooks(n)
+
+    def preprocess(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        if not self.renormalize:
+            return x, None
+        rms = x.mean(dim=1, keepdim=True).pow(2).mean(dim=2, keepdim=True).sqrt()
+        scale = 1e-8 + rms
+        return x / scale, scale.view(-1, 1)
+
+    def postprocess(self, x: torch.Tensor, scale: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        if scale is None:
+            return x
+        assert self.renormalize
+        return x * scale.view(-1, 1, 1)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        assert x.dim() == 3
+        x, scale = self.preprocess(x)
+        return self.quantizer.encode(self.encoder(x)), scale
+
+    @torch.no_grad()
+    def decode_latent(self, codes: torch.Tensor):
+        return self.quantizer.decode(codes)
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        # the result keeps the encoder's extra right padding; callers trim to the length they expect
+        return self.postprocess(self.decoder(self.decode_latent(codes)), scale)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        assert x.dim() == 3
+        codes, scale = self.encode(x)
+        out = self.decode(codes, scale)
+        assert out.shape[-1] >= x.shape[-1], (out.shape[-1], x.shape[-1])
+        kbps = codes.shape[1] * math.log2(self.cardinality) * self.frame_rate / 1000
+        return QuantizedResult(out[..., :x.shape[-1]], codes, torch.tensor(kbps).to(out))
+
+
+class InterleaveStereoCompressionModel(CompressionModel):
+    """Stereo on top of a mono codec (reference audiocraft/models/encodec.py:397-506): left / right are
+    encoded independently and their codebooks interleaved ([B, K, T] x 2 -> [B, 2K, T], left first per level);
+    `per_timestep=True` interleaves along time instead.  Pure host logic over `EncodecModel`."""
+
+    def __init__(self, model: CompressionModel, per_timestep: bool = False):
+        super().__init__()
+        self.model = model
+        self.per_timestep = per_timestep
+        assert self.model.channels == 1, "Wrapped model is expected to be for monophonic audio"
+
+    @property
+    def total_codebooks(self):
+        return self.model.total_codebooks
+
+    @property
+    def num_codebooks(self):
+        """With K the virtual number of codebooks: the wrapped model runs K // 2 per channel."""
+        return self.model.num_codebooks if self.per_timestep else self.model.num_codebooks * 2
+
+    def set_num_codebooks(self, n: int):
+        if not self.per_timestep:
+            assert n % 2 == 0
+            n //= 2
+        self.model.set_num_codebooks(n)
+
+    @property
+    def num_virtual_steps(self) -> float:
+        return 2 if self.per_timestep else 1
+
+    @property
+    def frame_rate(self) -> float:
+        return self.model.frame_rate * self.num_virtual_steps
+
+    @property
+    def sample_rate(self) -> int:
+        return self.model.sample_rate
+
+    @property
+    def channels(self) -> int:
+        return 2
+
+    @property
+    def cardinality(self):
+        return self.model.cardinality
+
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        raise NotImplementedError("Not supported, use encode and decode.")
+
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        B, C, T = x.shape
+        assert C == self.channels, f"Expecting stereo audio but audio num channels is {C}"
+        codes, scale = self.model.encode(x.reshape(B * C, 1, T))          # [(B C), K, T']
+        K, Tp = codes.shape[1], codes.shape[2]
+        codes = codes.view(B, C, K, Tp)
+        if self.per_timestep:
+            codes = codes.permute(0, 2, 3, 1).reshape(B, K, Tp * C)       # b k (t c)
+        else:
+            codes = codes.permute(0, 2, 1, 3).reshape(B, K * C, Tp)       # b (k c) t
+        return codes.contiguous(), None if scale is None else scale.view(B, C)
+
+    def get_left_right_codes(self, codes: torch.Tensor) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        B = codes.shape[0]
+        if self.per_timestep:
+            c = codes.view(B, codes.shape[1], -1, 2).permute(0, 3, 1, 2)  # b k (t c) -> b c k t
+        else:
+            c = codes.view(B, -1, 2, codes.shape[2]).permute(0, 2, 1, 3)  # b (k c) t -> b c k t
+        return c[:, 0].contiguous(), c[:, 1].contiguous()
+
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        B, K, T = codes.shape
+        assert T % self.num_virtual_steps == 0 and K == self.num_codebooks
+        left, right = self.get_left_right_codes(codes)
+        both = torch.cat([left, right], dim=0)
+        sc = None if scale is None else torch.cat([scale[:, 0], scale[:, 1]], dim=0).reshape(-1, 1)
+        out = self.model.decode(both, sc)                                 # [2B, 1, T']
+        return torch.cat([out[:B], out[B:]], dim=1)
+
+    def decode_latent(self, codes: torch.Tensor):
+        raise NotImplementedError("Not supported by interleaved stereo wrapped models.")

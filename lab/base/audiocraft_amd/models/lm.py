@@ -243,21 +243,21 @@ class LMModel(nn.Module):
                     raise NotImplementedError("cross-attention in_proj_bias is not wired into acmi_lm_step")
                 ipw = ca.in_proj_weight
                 ent['w_cq'], ent['b_cq'], ent['cs_cq'] = folded(ipw[:d], layer.norm_cross)
-                # x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T: the x0 part is a fourth block of
-                # output features of the QKV launch (raw, no LayerNorm epilogue), the att part rides in the out-projection
-                # launch (include/acmi.h, acmi_lm_layer.w_qkvx / w_mq)
+                # [W_cq' | W_cq' W_out]: x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T, so
+                # the cross-attention query rides in the out-projection launch (include/acmi.h, acmi_linear_pair);
+                # each block starts on a K-tile boundary of the [x | att] activation
+                kt = _C._tile_params(wd)[1]
+                dp = -(-d // kt) * kt
                 g_c = layer.norm_cross.weight.detach().to(device=dev, dtype=torch.float32)
                 wq = ipw[:d].detach().to(device=dev, dtype=torch.float32) * g_c[None, :]
-                g_1 = layer.norm1.weight.detach().to(device=dev, dtype=torch.float32)
-                wqkv = layer.self_attn.in_proj_weight.detach().to(device=dev, dtype=torch.float32) * g_1[None, :]
-                ent['w_qkvx'] = W(torch.cat([wqkv, wq], dim=0))
-                ent['b_qkvx'] = Fp(torch.cat([ent['b_qkv'], torch.zeros(d, device=dev)]))
-                ent['cs_qkvx'] = Fp(torch.cat([ent['cs_qkv'], torch.zeros(d, device=dev)]))
-                ent['w_mq'] = W(wq @ layer.self_attn.out_proj.weight.detach().to(device=dev, dtype=torch.float32))
+                xcq = torch.zeros(d, 2 * dp, device=dev, dtype=torch.float32)
+                xcq[:, :d] = wq
+                xcq[:, dp:dp + d] = wq @ layer.self_attn.out_proj.weight.detach().to(device=dev, dtype=torch.float32)
+                ent['w_xcq'] = W(xcq)
                 ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]), 'w_cout': W(ca.out_proj.weight)})
             L = layers[li]
             for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
-                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq'):
+                      'cs_cq', 'cs_ff1'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]

@@ -76,7 +76,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     stats = torch.zeros(B_eff, np_, 2, device=dev)
     stats[..., 1] = 16.0
     q = torch.empty(B_eff, d, device=dev)
-    qkv = torch.empty(B_eff, 4 * d, device=dev)
+    qkv = torch.empty(B_eff, 3 * d, device=dev)
     h = _C.tiled_activation_buffer(B_eff, ffn, wd, dev)
     logits = torch.empty(B_eff, lm.n_q * lm.card, device=dev)
     launches = 0
@@ -109,22 +109,21 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
         # the same GEMM launches acmi_lm_step issues for one position (same shapes, operand layouts, weights)
         nonlocal launches, nbytes, cur
         for ent in pk['per_layer']:
-            if 'w_qkvx' in ent:
-                # QKV + the x0 part of the cross-attention query (a fourth block of features), then the out projection
-                # and the att part of that query in one launch (acmi_linear_pair); acmi_lm_layer.w_qkvx / w_mq
-                consume(ent['w_qkvx'], qkv, _C.OUT_F32, ent['cs_qkvx'], ent['b_qkvx'])
+            consume(ent['w_qkv'], qkv, _C.OUT_F32, ent['cs_qkv'], ent['b_qkv'])
+            if 'w_xcq' in ent:
+                # out projection + cross-attention query in one launch (acmi_linear_pair)
                 att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
                 p0 = produce_desc(att_half, ent['w_out'], rbs, cur ^ 1)
-                p1 = _C.linear_desc(att_half, ent['w_mq'], q, B_eff, _C.A_TILED, _C.OUT_F32, residual=q, a_rbs=rbs)
+                p1 = _C.linear_desc(xh[cur], ent['w_xcq'], q, B_eff, _C.A_TILED, _C.OUT_F32, a_lo=xl[cur], a_rbs=rbs,
+                                    lo_K=dp if wd == torch.bfloat16 else 0)
                 _C.linear_pair(p0, p1)
                 launches += 1
-                # consume() counted w_qkvx = W_qkv + W_cq, as SURVEY.md section 8(d) does; w_mq (= W_cq' W_out, +d^2
-                # elements per layer) is extra traffic of this formulation and shows up in the PMC bytes instead
-                nbytes += wbytes(ent['w_out'])
+                # algorithmic bytes: W_out + W_cq as in SURVEY.md section 8(d); the launch really streams W_cq twice
+                # over ([W_cq' | W_cq' W_out], +d^2 elements per layer), which shows up in the PMC traffic instead
+                nbytes += wbytes(ent['w_out']) + wbytes(ent['w_cq'])
                 cur ^= 1
                 produce(catt, ent['w_cout'])
             else:
-                consume(ent['w_qkv'], qkv, _C.OUT_F32, ent['cs_qkv'], ent['b_qkv'])
                 att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
                 _C.linear_launch(produce_desc(att_half, ent['w_out'], rbs, cur))
                 launches += 1

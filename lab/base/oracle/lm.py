@@ -1,0 +1,273 @@
+"""Oracle (TEST INFRASTRUCTURE) -- MusicGen LMModel: streaming transformer forward + generate loop.
+
+Functional fp32 restatement over a reference-format state dict (keys as dumped from
+`audiocraft.models.lm.LMModel.state_dict()`).  The KV cache grows by `torch.cat` exactly like the
+reference (audiocraft/modules/transformer.py:266-298) so the timed CPU baseline pays the same
+O(T^2) copies the reference pays.
+"""
+import math
+import typing as tp
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+from . import patterns
+
+
+@dataclass
+class LMConfig:
+    """LMModel / StreamingTransformer constructor arguments used by MusicGen
+    (config/model/lm/musicgen_lm.yaml, config/model/lm/default.yaml)."""
+    dim: int = 1024
+    num_heads: int = 16
+    num_layers: int = 24
+    hidden_scale: int = 4
+    n_q: int = 4
+    card: int = 2048
+    cross_attention: bool = True
+    delays: tp.List[int] = field(default_factory=lambda: [0, 1, 2, 3])
+    max_period: float = 10000.
+    positional_scale: float = 1.0
+    cfg_coef: float = 3.0
+    eps: float = 1e-5
+
+
+def create_sin_embedding(positions: torch.Tensor, dim: int, max_period: float = 10000.) -> torch.Tensor:
+    """audiocraft/modules/transformer.py:70-89: cos first, then sin; divisor half_dim - 1."""
+    half = dim // 2
+    positions = positions.to(torch.float32)
+    adim = torch.arange(half, dtype=torch.float32).view(1, 1, -1)
+    phase = positions / (torch.full([], max_period) ** (adim / (half - 1)))
+    return torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1)
+
+
+def _ln(x, sd, prefix, eps):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + '.weight'], sd[prefix + '.bias'], eps)
+
+
+def _attention(q, k, v, causal: bool):
+    """F.scaled_dot_product_attention semantics (transformer.py:412-414): scale 1/sqrt(hd),
+    lower-triangular mask aligned top-left when `causal` (only used when #q == #k)."""
+    scale = 1.0 / math.sqrt(q.shape[-1])
+    w = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        Tq, Tk = w.shape[-2:]
+        m = torch.ones(Tq, Tk, dtype=torch.bool).tril()
+        w = w.masked_fill(~m, float('-inf'))
+    return torch.softmax(w, dim=-1) @ v
+
+
+class LMState:
+    """Streaming state (audiocraft/modules/streaming.py:20-119): per-layer past K/V + offsets."""
+    def __init__(self, num_layers: int):
+        self.past_k: tp.List[tp.Optional[torch.Tensor]] = [None] * num_layers
+        self.past_v: tp.List[tp.Optional[torch.Tensor]] = [None] * num_layers
+        self.offset = 0          # transformer.offsets (same for every row)
+        self.first_step = True   # fuser: 'offsets' not yet in state (conditioners.py:1722-1727)
+
+
+def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.Optional[torch.Tensor],
+                        state: tp.Optional[LMState]) -> torch.Tensor:
+    """StreamingTransformer.forward (transformer.py:693-713) + StreamingTransformerLayer.forward
+    (:550-574, norm_first) + StreamingMultiheadAttention.forward (:315-451, custom / memory-efficient
+    torch-SDPA branch, layout "b h t d").  x: [B, T, C]."""
+    B, T, C = x.shape
+    H = cfg.num_heads
+    hd = C // H
+    offset = state.offset if state is not None else 0
+    pos = torch.arange(T).view(1, -1, 1) + offset
+    x = x + cfg.positional_scale * create_sin_embedding(pos, C, cfg.max_period)
+    for li in range(cfg.num_layers):
+        p = f'transformer.layers.{li}'
+        # --- self attention (pre-norm)
+        h = _ln(x, sd, p + '.norm1', cfg.eps)
+        proj = F.linear(h, sd[p + '.self_attn.in_proj_weight'], sd.get(p + '.self_attn.in_proj_bias'))
+        packed = proj.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)  # "b t (p h d) -> p b h t d"
+        q, k, v = packed[0], packed[1], packed[2]
+        # _get_mask (transformer.py:233-247): no mask for one step; lower-triangular for T>1, which
+        # the reference only supports when there is no past (raises otherwise).
+        causal = T > 1
+        if state is not None:
+            if state.past_k[li] is not None:
+                assert T == 1, "reference raises 'Not supported at the moment' here"
+                k = torch.cat([state.past_k[li], k], dim=2)   # _complete_kv, transformer.py:274-281
+                v = torch.cat([state.past_v[li], v], dim=2)
+            state.past_k[li], state.past_v[li] = k, v
+        a = _attention(q, k, v, causal)
+        a = a.permute(0, 2, 1, 3).reshape(B, T, C)
+        x = x + F.linear(a, sd[p + '.self_attn.out_proj.weight'], sd.get(p + '.self_attn.out_proj.bias'))
+        # --- cross attention: q/k/v projections with the three slices of in_proj_weight, k/v
+        # re-projected at every call, no key-padding mask (transformer.py:344-361, 542-548)
+        if cfg.cross_attention:
+            assert cross_src is not None
+            h = _ln(x, sd, p + '.norm_cross', cfg.eps)
+            w = sd[p + '.cross_attention.in_proj_weight']
+            bq = bk = bv = None
+            if p + '.cross_attention.in_proj_bias' in sd:
+                bq, bk, bv = sd[p + '.cross_attention.in_proj_bias'].chunk(3)
+            qc = F.linear(h, w[:C], bq).view(B, T, H, hd).transpose(1, 2)
+            kc = F.linear(cross_src, w[C:2 * C], bk).view(B, -1, H, hd).transpose(1, 2)
+            vc = F.linear(cross_src, w[2 * C:], bv).view(B, -1, H, hd).transpose(1, 2)
+            a = _attention(qc, kc, vc, False).transpose(1, 2).reshape(B, T, C)
+            x = x + F.linear(a, sd[p + '.cross_attention.out_proj.weight'],
+                             sd.get(p + '.cross_attention.out_proj.bias'))
+        # --- feed forward, exact (erf) GELU
+        h = _ln(x, sd, p + '.norm2', cfg.eps)
+        h = F.gelu(F.linear(h, sd[p + '.linear1.weight'], sd.get(p + '.linear1.bias')))
+        x = x + F.linear(h, sd[p + '.linear2.weight'], sd.get(p + '.linear2.bias'))
+    if state is not None:
+        state.offset = offset + T
+    return x
+
+
+def lm_forward(sd: dict, cfg: LMConfig, sequence: torch.Tensor, cross_src: tp.Optional[torch.Tensor],
+               prepend_src: tp.Optional[torch.Tensor] = None,
+               state: tp.Optional[LMState] = None) -> torch.Tensor:
+    """LMModel.forward (audiocraft/models/lm.py:221-268) with precomputed condition tensors.
+    sequence [B, K, S] int64 -> logits [B, K, S, card].  `prepend_src` [B, P, C] is concatenated
+    before the tokens on the first (or non-streaming) call only (ConditionFuser.forward,
+    conditioners.py:1739-1741) and the logits are cropped back to the last S steps (lm.py:265-266)."""
+    B, K, S = sequence.shape
+    x = sum(F.embedding(sequence[:, k], sd[f'emb.{k}.weight']) for k in range(K))
+    first = state.first_step if state is not None else True
+    if prepend_src is not None and first:
+        x = torch.cat([prepend_src, x], dim=1)
+    if state is not None:
+        state.first_step = False
+    out = transformer_forward(sd, cfg, x, cross_src, state)
+    out = _ln(out, sd, 'out_norm', cfg.eps)
+    logits = torch.stack([F.linear(out, sd[f'linears.{k}.weight'], sd.get(f'linears.{k}.bias'))
+                          for k in range(K)], dim=1)
+    return logits[:, :, -S:]
+
+
+# ----------------------------------------------------------------------------- sampling
+
+def multinomial(probs: torch.Tensor, generator=None) -> torch.Tensor:
+    """utils.multinomial (audiocraft/utils/utils.py:88-105), num_samples=1."""
+    flat = probs.reshape(-1, probs.shape[-1])
+    out = torch.multinomial(flat, num_samples=1, generator=generator)
+    return out.reshape(*probs.shape[:-1], 1)
+
+
+def top_k_filter(probs: torch.Tensor, k: int) -> torch.Tensor:
+    """The deterministic half of utils.sample_top_k (utils.py:108-122): keep every prob >= the
+    k-th largest (ties included), renormalise."""
+    kth = torch.topk(probs, k, dim=-1)[0][..., [-1]]
+    probs = probs * (probs >= kth).float()
+    return probs / probs.sum(dim=-1, keepdim=True)
+
+
+def top_p_filter(probs: torch.Tensor, p: float):
+    """Deterministic half of utils.sample_top_p (utils.py:125-141) -> (sorted probs, sort index)."""
+    ps, pi = torch.sort(probs, dim=-1, descending=True)
+    cum = torch.cumsum(ps, dim=-1)
+    ps = ps * (~(cum - ps > p)).float()
+    return ps / ps.sum(dim=-1, keepdim=True), pi
+
+
+def cfg_mix(all_logits: torch.Tensor, cfg_coef: float) -> torch.Tensor:
+    """lm.py:391-399: rows [cond; uncond] -> uncond + (cond - uncond) * coef."""
+    B = all_logits.shape[0] // 2
+    cond, uncond = all_logits.split(B, dim=0)
+    return uncond + (cond - uncond) * cfg_coef
+
+
+def double_cfg_mix(all_logits: torch.Tensor, cfg_coef: float, cfg_coef_beta: float) -> torch.Tensor:
+    """lm.py:372-376 (MusicGen-Style double CFG): rows [text + wav; wav only; null] ->
+    uncond + coef * (wav + beta * (cond - wav) - uncond)."""
+    B = all_logits.shape[0] // 3
+    cond, wav, uncond = all_logits.split(B, dim=0)
+    return uncond + cfg_coef * (wav + cfg_coef_beta * (cond - wav) - uncond)
+
+
+def sample_next_token(logits: torch.Tensor, use_sampling: bool, temp: float, top_k: int, top_p: float,
+                      generator=None) -> torch.Tensor:
+    """lm.py:402-418 on logits [B, K, card] (last step) -> [B, K, 1]."""
+    if use_sampling and temp > 0.0:
+        probs = torch.softmax(logits / temp, dim=-1)
+        if top_p > 0.0:
+            ps, pi = top_p_filter(probs, top_p)
+            return torch.gather(pi, -1, multinomial(ps, generator))
+        if top_k > 0:
+            return multinomial(top_k_filter(probs, top_k), generator)
+        return multinomial(probs, generator)
+    return torch.argmax(logits, dim=-1, keepdim=True)
+
+
+# ----------------------------------------------------------------------------- generate
+
+@torch.no_grad()
+def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_samples: int,
+             cross_src: tp.Optional[torch.Tensor], prepend_src: tp.Optional[torch.Tensor] = None,
+             max_gen_len: int = 256, use_sampling: bool = True, temp: float = 1.0, top_k: int = 250,
+             top_p: float = 0.0, cfg_coef: tp.Optional[float] = None, remove_prompts: bool = False,
+             generator=None, callback=None, return_logits: bool = False, max_steps: tp.Optional[int] = None,
+             cfg_coef_beta: tp.Optional[float] = None, null_cross_src: tp.Optional[torch.Tensor] = None,
+             null_prepend_src: tp.Optional[torch.Tensor] = None):
+    """LMModel.generate (audiocraft/models/lm.py:420-587).
+
+    Default one-forward CFG mode: `cross_src` / `prepend_src` hold the already-batched `[cond; uncond]` condition
+    tensors ([2B, L, C]); pass both as None for unconditional generation (no CFG).
+    `cfg_coef_beta` (double CFG, lm.py:362-376): the condition tensors hold `[text + wav; wav only; null]` (3B rows).
+    `null_cross_src` / `null_prepend_src` (two_step_cfg, lm.py:377-386): the conditional tensors hold B rows and
+    the unconditional pass runs separately on these, with its own condition length and streaming state; the mix
+    then uses the model's `cfg.cfg_coef` -- the reference ignores the `cfg_coef` argument on that branch.
+    """
+    coef = cfg.cfg_coef if cfg_coef is None else cfg_coef
+    use_cfg = cross_src is not None or prepend_src is not None
+    two_step = null_cross_src is not None or null_prepend_src is not None
+    assert not (two_step and cfg_coef_beta is not None)
+    null_state = LMState(cfg.num_layers) if two_step else None
+    K, special, unknown = cfg.n_q, cfg.card, -1
+    if prompt is None:
+        prompt = torch.zeros((num_samples, K, 0), dtype=torch.long)
+    B, _, T0 = prompt.shape
+    assert T0 < max_gen_len
+    gen_codes = torch.full((B, K, max_gen_len), unknown, dtype=torch.long)
+    gen_codes[..., :T0] = prompt
+    gen_sequence, mask = patterns.build_pattern_sequence(gen_codes, special, cfg.delays)
+    start = patterns.first_step_with_timestep(K, max_gen_len, T0, cfg.delays)
+    assert start is not None
+    state = LMState(cfg.num_layers)
+    S = gen_sequence.shape[-1]
+    prev = 0
+    all_logits = []
+    for offset in range(start, S):
+        if max_steps is not None and offset - start >= max_steps:
+            break
+        curr = gen_sequence[..., prev:offset]
+        if two_step:
+            cond = lm_forward(sd, cfg, curr, cross_src, prepend_src, state)
+            uncond = lm_forward(sd, cfg, curr, null_cross_src, null_prepend_src, null_state)
+            logits = uncond + (cond - uncond) * cfg.cfg_coef
+        elif cfg_coef_beta is not None:
+            logits = lm_forward(sd, cfg, torch.cat([curr, curr, curr], dim=0), cross_src, prepend_src, state)
+            logits = double_cfg_mix(logits, coef, cfg_coef_beta)
+        else:
+            seq = torch.cat([curr, curr], dim=0) if use_cfg else curr
+            logits = lm_forward(sd, cfg, seq, cross_src, prepend_src, state)
+            if use_cfg:
+                logits = cfg_mix(logits, coef)
+        logits = logits[:, :, -1]  # [B, K, card]
+        if return_logits:
+            all_logits.append(logits)
+        nxt = sample_next_token(logits, use_sampling, temp, top_k, top_p, generator)
+        valid = mask[..., offset:offset + 1].expand(B, -1, -1)
+        nxt[~valid] = special
+        cur = gen_sequence[..., offset:offset + 1]
+        gen_sequence[..., offset:offset + 1] = torch.where(cur == unknown, nxt, cur)
+        prev = offset
+        if callback is not None:
+            callback(1 + offset - start, S - start)
+    if max_steps is not None:
+        return gen_sequence, (torch.stack(all_logits, dim=2) if return_logits else None)
+    assert not (gen_sequence == unknown).any()
+    out_codes, out_mask = patterns.revert_pattern_sequence(gen_sequence, unknown, max_gen_len, cfg.delays)
+    assert (out_codes != unknown).all() and out_mask.all()
+    out = out_codes[..., (T0 if remove_prompts else 0):max_gen_len]
+    assert (out >= 0).all() and (out <= cfg.card).all()
+    if return_logits:
+        return out, torch.stack(all_logits, dim=2)  # [B, K, steps, card]
+    return out

@@ -1,0 +1,211 @@
+"""TEST INFRASTRUCTURE ONLY -- re-check the oracle against the UNMODIFIED reference at sizes larger than the committed
+golden fixtures.  Runs in the build container only (needs /root/reference; nothing here travels to the GPU box):
+
+    python -m oracle.validate_against_reference            # all checks, ~1 min on 8 cores
+    python -m oracle.validate_against_reference lm codec   # a subset
+
+Checks (each prints a line and the script exits non-zero on the first failure):
+  lm       mid-size LMModel (d 256, 4 layers, 8 heads, cross-attention, card 2048, seeded random weights with perturbed
+           LayerNorm parameters): reference `LMModel.forward` (batch) and `LMModel.generate` (greedy, CFG; plain, two_step_cfg)
+           vs oracle.lm.lm_forward / generate  -> logits rel-L2 <= 1e-5, tokens identical
+  melody   prepend-conditioned LMModel (no cross-attention) incl. double CFG (cfg_coef_beta)
+  stereo   8 codebooks with delays [0,0,1,1,2,2,3,3]
+  codec    EncodecModel at the 32 kHz geometry with n_filters 16 (all layers, LSTM, RVQ 4 x 2048) on 0.7 s of audio:
+           latents, codes (bit exact on the reference's own latents), decoded waveform
+  chroma   oracle.chroma against the reference ChromaExtractor arithmetic is NOT possible here: torchaudio / librosa are
+           third-party and absent -- see oracle/chroma.py for how that row is pinned instead.
+"""
+import sys
+
+import torch
+
+from . import refstubs  # noqa: F401  (installs the import stubs; afterwards the reference imports)
+
+if not refstubs.available():   # pragma: no cover
+    print("validate_against_reference: /root/reference not present, nothing to do")
+    sys.exit(0)
+
+from audiocraft.models.encodec import EncodecModel  # noqa: E402
+from audiocraft.models.lm import LMModel  # noqa: E402
+from audiocraft.modules.codebooks_patterns import DelayedPatternProvider  # noqa: E402
+from audiocraft.modules.conditioners import (  # noqa: E402
+    ClassifierFreeGuidanceDropout, ConditionFuser, ConditioningAttributes, ConditioningProvider, TextConditioner,
+    WaveformConditioner, WavCondition)
+from audiocraft.modules.seanet import SEANetDecoder, SEANetEncoder  # noqa: E402
+from audiocraft.quantization.vq import ResidualVectorQuantizer  # noqa: E402
+
+from . import codec as ocodec  # noqa: E402
+from . import lm as olm  # noqa: E402
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+class _Text(TextConditioner):
+    """Seeded stand-in for the T5 encoder output (third party), then the real output_proj + mask multiply; an all-null
+    batch is one position long (what T5 gives for empty strings)."""
+    def __init__(self, dim, output_dim, L):
+        super().__init__(dim, output_dim)
+        self.L = L
+
+    def tokenize(self, x):
+        return x
+
+    def forward(self, x):
+        g = torch.Generator().manual_seed(99)
+        L = 1 if all(xi is None for xi in x) else self.L
+        mask = torch.tensor([[1] * L if xi is not None else [0] * L for xi in x])
+        e = torch.randn(len(x), L, self.dim, generator=g)
+        return self.output_proj(e) * mask.unsqueeze(-1), mask
+
+
+class _Chroma(WaveformConditioner):
+    def __init__(self, output_dim, P):
+        super().__init__(12, output_dim, 'cpu')
+        self.P = P
+        self._use_masking = False
+
+    def _downsampling_factor(self):
+        return 1
+
+    def _get_wav_embedding(self, x):
+        g = torch.Generator().manual_seed(98)
+        cls = torch.randint(0, 12, (x.wav.shape[0], self.P), generator=g)
+        e = torch.nn.functional.one_hot(cls, 12).float()
+        return torch.where((x.length == 0).view(-1, 1, 1), torch.zeros_like(e), e)
+
+
+def _build_lm(dim, heads, layers, n_q, card, delays, conditioners, fuse, seed):
+    torch.manual_seed(seed)
+    lm = LMModel(DelayedPatternProvider(n_q, delays=delays), ConditioningProvider(conditioners), ConditionFuser(fuse),
+                 n_q=n_q, card=card, dim=dim, num_heads=heads, hidden_scale=4, norm='layer_norm', norm_first=True,
+                 bias_proj=False, weight_init='gaussian', depthwise_init='current', zero_bias_init=True, cfg_coef=3.0,
+                 num_layers=layers, dropout=0., activation='gelu', bias_ff=False, bias_attn=False, causal=True,
+                 custom=False, memory_efficient=True, attention_as_float32=False,
+                 cross_attention=bool(fuse['cross']), positional_embedding='sin').eval()
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            if '.norm' in k or k.startswith('out_norm'):
+                p.add_(0.1 * torch.randn_like(p))
+    return lm
+
+
+def _record(lm, fn):
+    rec = []
+    h = lm.register_forward_hook(lambda mod, inp, out: rec.append(out.detach().clone()))
+    out = fn()
+    h.remove()
+    return out, rec
+
+
+def check_lm():
+    torch.manual_seed(1)
+    fuse = {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []}
+    lm = _build_lm(256, 8, 4, 4, 2048, [0, 1, 2, 3], {'description': _Text(64, 256, 7)}, fuse, seed=11)
+    sd = {k: v.detach() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True)
+    conds = [ConditioningAttributes(text={'description': f't{i}'}) for i in range(3)]
+    null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+    ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+    seq = torch.randint(0, 2049, (6, 4, 40), generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = lm(seq, [], ct)
+    got = olm.lm_forward(sd, oc, seq, ct['description'][0])
+    r = rel(got, ref)
+    assert r < 1e-5, r
+    toks, rec = _record(lm, lambda: lm.generate(None, conds, max_gen_len=24, use_sampling=False))
+    otoks, ologits = olm.generate(sd, oc, None, 3, ct['description'][0], max_gen_len=24, use_sampling=False,
+                                  return_logits=True)
+    assert torch.equal(toks, otoks)
+    r2 = rel(ologits, olm.cfg_mix(torch.stack([x[:, :, -1] for x in rec], dim=2), 3.0))
+    assert r2 < 1e-5, r2
+    # two_step_cfg: separate passes, own condition lengths (7 vs 1), model's cfg_coef
+    c1 = lm.condition_provider(lm.condition_provider.tokenize(conds))
+    n1 = lm.condition_provider(lm.condition_provider.tokenize(null))
+    toks2 = lm.generate(None, conds, max_gen_len=16, use_sampling=False, two_step_cfg=True, cfg_coef=9.0)
+    otoks2 = olm.generate(sd, oc, None, 3, c1['description'][0], max_gen_len=16, use_sampling=False, cfg_coef=9.0,
+                          null_cross_src=n1['description'][0])
+    assert torch.equal(toks2, otoks2)
+    print(f"lm      ok: batch forward rel-L2 {r:.1e}, greedy tokens identical (plain + two_step_cfg), step logits rel-L2 {r2:.1e}")
+
+
+def check_melody():
+    fuse = {'cross': [], 'prepend': ['self_wav', 'description'], 'sum': [], 'input_interpolate': []}
+    torch.manual_seed(3)
+    lm = _build_lm(128, 4, 3, 4, 512, [0, 1, 2, 3], {'description': _Text(32, 128, 5), 'self_wav': _Chroma(128, 20)},
+                   fuse, seed=12)
+    sd = {k: v.detach() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=128, num_heads=4, num_layers=3, n_q=4, card=512, cross_attention=False)
+    conds = []
+    for i in range(2):
+        c = ConditioningAttributes(text={'description': f'm{i}'})
+        c.wav['self_wav'] = WavCondition(torch.randn(1, 1, 64), torch.tensor([64]), [1200], [None], [0.])
+        conds.append(c)
+    null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+    ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+    prepend = torch.cat([ct['self_wav'][0], ct['description'][0]], dim=1)
+    toks = lm.generate(None, conds, max_gen_len=14, use_sampling=False)
+    otoks = olm.generate(sd, oc, None, 2, None, prepend, max_gen_len=14, use_sampling=False)
+    assert torch.equal(toks, otoks)
+    from audiocraft.models.lm import _drop_description_condition
+    ct3 = lm.condition_provider(lm.condition_provider.tokenize(conds + _drop_description_condition(conds) + null))
+    prepend3 = torch.cat([ct3['self_wav'][0], ct3['description'][0]], dim=1)
+    toks3 = lm.generate(None, conds, max_gen_len=14, use_sampling=False, cfg_coef_beta=4.0)
+    otoks3 = olm.generate(sd, oc, None, 2, None, prepend3, max_gen_len=14, use_sampling=False, cfg_coef_beta=4.0)
+    assert torch.equal(toks3, otoks3)
+    print("melody  ok: greedy tokens identical (prepend path; double CFG)")
+
+
+def check_stereo():
+    fuse = {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []}
+    delays = [0, 0, 1, 1, 2, 2, 3, 3]
+    torch.manual_seed(4)
+    lm = _build_lm(128, 4, 2, 8, 256, delays, {'description': _Text(32, 128, 4)}, fuse, seed=13)
+    sd = {k: v.detach() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=128, num_heads=4, num_layers=2, n_q=8, card=256, cross_attention=True, delays=delays)
+    conds = [ConditioningAttributes(text={'description': f's{i}'}) for i in range(2)]
+    null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+    ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+    prompt = torch.randint(0, 256, (2, 8, 4), generator=torch.Generator().manual_seed(5))
+    for pr in (None, prompt):
+        toks = lm.generate(pr, conds, max_gen_len=15, use_sampling=False)
+        otoks = olm.generate(sd, oc, pr, 2, ct['description'][0], max_gen_len=15, use_sampling=False)
+        assert torch.equal(toks, otoks)
+    print("stereo  ok: greedy tokens identical with delays [0,0,1,1,2,2,3,3] (no prompt, 4-step prompt)")
+
+
+def check_codec():
+    torch.manual_seed(6)
+    kw = dict(channels=1, dimension=128, n_filters=16, n_residual_layers=1, ratios=[8, 5, 4, 4], activation='ELU',
+              activation_params={'alpha': 1.}, norm='weight_norm', norm_params={}, kernel_size=7, residual_kernel_size=3,
+              last_kernel_size=7, dilation_base=2, causal=False, pad_mode='constant', true_skip=True, compress=2, lstm=2,
+              disable_norm_outer_blocks=0)
+    m = EncodecModel(SEANetEncoder(**kw), SEANetDecoder(**kw, trim_right_ratio=1.0),
+                     ResidualVectorQuantizer(dimension=128, n_q=4, bins=2048, kmeans_init=False),
+                     frame_rate=50, sample_rate=32000, channels=1).eval()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    c = ocodec.CodecConfig(channels=1, dimension=128, n_filters=16, n_residual_layers=1, ratios=[8, 5, 4, 4],
+                           causal=False, pad_mode='constant', lstm=2, norm='weight_norm', n_q=4, bins=2048,
+                           sample_rate=32000, frame_rate=50)
+    wav = 0.3 * torch.randn(2, 1, 22400)
+    with torch.no_grad():
+        lat = m.encoder(wav)
+        codes, _ = m.encode(wav)
+        dec = m.decode(codes)
+    olat = ocodec.seanet_encoder(sd, c, wav)
+    assert rel(olat, lat) < 1e-5
+    assert torch.equal(ocodec.rvq_encode(lat, ocodec.codebooks_from_state(sd, 4)), codes)
+    odec = ocodec.encodec_decode(sd, c, codes)
+    assert (odec - dec).abs().max().item() < 2e-5
+    print(f"codec   ok: latents rel-L2 {rel(olat, lat):.1e}, codes bit exact, waveform max abs {(odec - dec).abs().max().item():.1e}")
+
+
+CHECKS = {'lm': check_lm, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    names = sys.argv[1:] or list(CHECKS)
+    for n in names:
+        CHECKS[n]()
+    print("all checks passed")
