@@ -40,7 +40,7 @@ class LMLayer(C.Structure):
     _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_xcq', vp), ('w_ff1', vp), ('w_ff2', vp),
                 ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp),
-                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp)]
+                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp)]
 
 
 class LMModelDesc(C.Structure):
@@ -85,7 +85,7 @@ class LinearDesc(C.Structure):
                 ('a_stats_np', i32), ('a_stats_cnt', i32), ('w', vp), ('wdtype', i32), ('bias', vp), ('residual', vp),
                 ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('ksplit', i32), ('M', i32), ('N', i32), ('K', i32),
                 ('a_lo', vp), ('colsum', vp), ('xt_hi', vp), ('xt_lo', vp), ('a_rbs', i32), ('a_lo_rbs', i32),
-                ('xt_rbs', i32), ('xt_lo_rbs', i32), ('lo_K', i32)]
+                ('xt_rbs', i32), ('xt_lo_rbs', i32), ('lo_K', i32), ('w_half', i32)]
 
 
 class AttnDesc(C.Structure):
@@ -208,13 +208,23 @@ def untile_matrix(t: torch.Tensor, R: int, K: int) -> torch.Tensor:
     return t.permute(0, 3, 1, 2, 4).reshape(rt * 16, nkc * 4 * epl)[:R, :K]
 
 
-class TiledWeight:
-    """nn.Linear weight [N, K] in tiled (B-fragment) order + its logical shape."""
+def tile_matrix_half(m: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[N, K] -> half-tile order (include/acmi.h, acmi_linear_desc.w_half): T[j][u][lane = kg*16 + s*8 + f][e] =
+    m[j*8 + f][u*2KT + s*KT + kg*epl + e]; N a multiple of 8, K a multiple of 2 KT."""
+    epl, kt = _tile_params(dtype)
+    N, K = m.shape
+    assert N % 8 == 0 and K % (2 * kt) == 0, (N, K)
+    return m.to(dtype).view(N // 8, 8, K // (2 * kt), 2, 4, epl).permute(0, 2, 4, 3, 1, 5).contiguous()
 
-    def __init__(self, w: torch.Tensor, dtype: torch.dtype):
+
+class TiledWeight:
+    """nn.Linear weight [N, K] in tiled (B-fragment) order + its logical shape.  half=True: half-tile order."""
+
+    def __init__(self, w: torch.Tensor, dtype: torch.dtype, half: bool = False):
         self.N, self.K = w.shape
         self.dtype = dtype
-        self.data = tile_matrix(w.detach(), dtype)
+        self.half = half
+        self.data = tile_matrix_half(w.detach(), dtype) if half else tile_matrix(w.detach(), dtype)
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -259,6 +269,7 @@ def linear_desc(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0
     d.M, d.N, d.K = M, w.N, (w.K if K is None else K)
     d.a_lo, d.colsum, d.xt_hi, d.xt_lo = ptr(a_lo), ptr(colsum), ptr(xt_hi), ptr(xt_lo)
     d.a_rbs, d.a_lo_rbs, d.xt_rbs, d.xt_lo_rbs, d.lo_K = a_rbs, a_lo_rbs, xt_rbs, xt_lo_rbs, lo_K
+    d.w_half = 1 if getattr(w, 'half', False) else 0
     return d
 
 

@@ -89,6 +89,12 @@ __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 conse
     v += dpp_f32<0x128>(v);
     return v;
 }
+__device__ __forceinline__ float row8_sum(float v) {    // sum over the 8 consecutive lanes of a half row, in every lane
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
     v += __shfl_xor(v, 16, 64);

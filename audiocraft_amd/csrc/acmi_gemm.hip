@@ -171,30 +171,33 @@ extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K,
     return acmi_launch_ln_tile(const_cast<float*>(x), out, wdtype, M, K, eps, nullptr, 0, (hipStream_t)stream);
 }
 
-// Folded LayerNorm, row statistics: a "group" is 4 rows (16 lanes each); every lane fetches up to 8 of the
-// producer's equal-count (mean, M2) partials of its row (np <= 128), combined later with Chan's formula.
+// Folded LayerNorm, row statistics: a "group" is 4 rows (16 lanes each); every lane fetches up to NS (8, or 16 when the
+// producer ran with 8-feature workgroups) of the producer's equal-count (mean, M2) partials of its row (np <= 16 NS),
+// combined later with Chan's formula.
 // Layout stats[row][np][2]: the partials of a row are contiguous, so a wave's load touches 4 lines, not 64
 // (with [np][row][2] the gather cost ~2 us per consuming launch).
+template <int NS>
 __device__ __forceinline__ void rowstat_load(const float* __restrict__ stats, int np, int M, int row0, int lane,
-                                             float (&pm)[8], float (&pq)[8]) {
+                                             float (&pm)[16], float (&pq)[16]) {
     const int row = min(row0 + (lane >> 4), M - 1), jj = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {  // 16 consecutive partials of one row per 16 lanes: one 128-B line
+    for (int i = 0; i < NS; ++i) {  // 16 consecutive partials of one row per 16 lanes: one 128-B line
         const float2 t = *reinterpret_cast<const float2*>(stats + ((size_t)row * np + min(jj + 16 * i, np - 1)) * 2);
         pm[i] = t.x; pq[i] = t.y;
     }
 }
-__device__ __forceinline__ void rowstat_finish(const float (&pm)[8], const float (&pq)[8], int np, int cnt, int K, float eps,
+template <int NS>
+__device__ __forceinline__ void rowstat_finish(const float (&pm)[16], const float (&pq)[16], int np, int cnt, int K, float eps,
                                                int lane, float* __restrict__ dst /* [4][2] */) {
     const int jj = lane & 15;
     float sm = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm += (jj + 16 * i < np) ? pm[i] : 0.f;
+    for (int i = 0; i < NS; ++i) sm += (jj + 16 * i < np) ? pm[i] : 0.f;
     sm = row16_sum(sm);
     const float mean = sm / (float)np;
     float q2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NS; ++i) {
         const float dlt = pm[i] - mean;
         q2 += (jj + 16 * i < np) ? pq[i] + (float)cnt * dlt * dlt : 0.f;
     }
@@ -316,7 +319,7 @@ static int launch_rowmajor(LinArgs& a, hipStream_t st) {
 #define ACMI_TL_WFIRST(LN) true
 #endif
 struct TlExtras {
-    float pm[8], pq[8];     // LN > 0: (mean, M2) partials of this lane's statistics row
+    float pm[16], pq[16];   // LN > 0: (mean, M2) partials of this lane's statistics row (the first NS of them)
     float bias, colsum, res;  // epilogue operands of this thread's first output element
     int tpos;                 // QKV: the position the new K / V rows are stored at
 };
@@ -327,7 +330,7 @@ struct TlLate {
     const float* st_ptr; const float* pb; const float* pc; const float* pr; const int* ppos;
 };
 
-template <typename WT, int MT, int LN, int NT, int C, typename LateFn>
+template <typename WT, int MT, int LN, int NT, int NS, int C, typename LateFn>
 __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, int kc0, int ks, int np,
                                          const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex) {
     constexpr bool HL = LN == 2 || LN == 3;
@@ -377,7 +380,7 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
     if (LN == 1 || LN == 2) {
         const int jj = (int)(threadIdx.x & 15);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NS; ++i) {
             const float2 t = *reinterpret_cast<const float2*>(st_ptr + min(jj + 16 * i, np - 1) * 2);
             ex.pm[i] = t.x; ex.pq[i] = t.y;
         }
@@ -397,25 +400,64 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
         }
 }
 
+// Half-tile workgroups (HT): 8 output features per workgroup, for the narrow GEMM with the long K (FFN2: N = d gives
+// only d / 16 = 96 workgroups of 16 features, each pulling 196 KB of weights through one CU's TA while 160 CUs idle).
+// The weight comes in the "half-tile" order (include/acmi.h, acmi_linear_desc.w_half): a 1 KB unit holds 8 features x
+// 2 KT columns, lane (kg, c) = feature c & 7, K fragment c >> 3 of the unit, so a unit is ONE full-width load and is the
+// B operand of TWO MFMAs: with the A fragment 2u the accumulator columns 0-7 are feature sums, with A fragment 2u + 1
+// the columns 8-15 are (the other columns hold products of mismatched K ranges and are dropped).  Two accumulators per
+// row block, merged at the end by a rotation of 8 lanes.  No LayerNorm variants: the producers of x are plain GEMMs.
+template <typename WT, int MT, int C, typename LateFn>
+__device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __restrict__ wt, int ku0, const LateFn& late_fn,
+                                            f32x4 (&acc)[2 * MT], TlExtras& ex) {
+    const int lane = threadIdx.x & 63;
+    u32x4 bv[C], av[MT][2 * C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
+    __builtin_amdgcn_sched_barrier(0);
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    const TlLate L = late_fn(opaque0);
+    const u32x4* __restrict__ at = L.at;
+    const int mts = L.mts, mtv = L.mtv;
+    const float* pb = L.pb; const float* pr = L.pr;
+#pragma unroll
+    for (int i = 0; i < 2 * C; ++i) {
+        const int ko = (2 * ku0 + i) * 64;
+#pragma unroll
+        for (int u = 0; u < MT; ++u) av[u][i] = (at + (min(u, mtv - 1) * mts + ko))[lane];
+    }
+    ex.bias = *pb; ex.res = *pr;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            mma_frag(av[u][2 * i], bv[i], acc[2 * u], WT());
+            mma_frag(av[u][2 * i + 1], bv[i], acc[2 * u + 1], WT());
+        }
+}
+
 // NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
 // the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs.
-template <typename WT, int MT, int LN, int NT = 1>
+template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false>
 __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, const int kslice, const int ksp) {
     static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
-    const int ntile = wgtile * NT;   // first n-tile of this workgroup
+    static_assert(!HT || (NT == 1 && LN == 0), "half-tile workgroups: plain GEMM, one (half) n-tile");
+    const int ntile = wgtile * NT;   // first n-tile of this workgroup (HT: the half-tile index)
     constexpr int D = (LN == 2 || LN == 3) ? 2 : 1;
     constexpr bool FOLD = LN == 1 || LN == 2;
     // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
     // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
     // VGPRs of a 2-waves-per-SIMD launch
-    constexpr int CQ = (LN > 0 ? 44 : 52) / (NT + MT * D);
+    constexpr int CQ = HT ? 52 / (1 + 2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (NT + MT * D));
     constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
     float* red = reinterpret_cast<float*>(smem);        // [NT MT][nw][256] partial accumulators
     float* rowstat = red + (size_t)NT * MT * nw * 256;  // [16 MT][2] mean, rstd
-    const int n0 = ntile * 16, NKC = p.NKC;
+    const int n0 = ntile * (HT ? 8 : 16), NKC = HT ? p.NKC >> 1 : p.NKC;   // HT: K counted in 1 KB weight units
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
     const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
     const float* own = reinterpret_cast<const float*>(wt + (size_t)(kbeg + min(wave, kcs - 1)) * 64 + lane);
@@ -425,9 +467,9 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     {
         const int mg = (int)blockIdx.z * 16 * MT;
         const int mtv = min(MT, (p.M - mg + 15) >> 4);
-        f32x4 accs[NT * MT];
+        f32x4 accs[(HT ? 2 : NT) * MT];
 #pragma unroll
-        for (int u = 0; u < NT * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < (HT ? 2 : NT) * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int ngroups = 4 * mtv;   // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
         // addresses of everything but the weights: evaluated by tl_chunk once its weight requests are out
         // (`z` is an opaque zero produced behind the weight requests: added to every index these addresses derive from,
@@ -444,7 +486,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             // this thread's first epilogue element
             const int e0 = (int)threadIdx.x + z, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
             const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
-            const int egn = min(n0z + 16 * et + enn, p.N - 1), egm = min(mgz + 16 * eu + emm, p.M - 1);
+            const int egn = min(n0z + (HT ? (enn & 7) : 16 * et + enn), p.N - 1), egm = min(mgz + 16 * eu + emm, p.M - 1);
             L.pb = p.bias != nullptr ? p.bias + egn : own;
             L.pc = p.colsum != nullptr ? p.colsum + egn : own;
             L.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
@@ -459,7 +501,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         int kc = kbeg + wave * p.fpw, rem = p.fpw;
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            tl_chunk<WT, MT, LN, NT, Cn>(p, wt, kc, ks, p.a_np, late, accs, ex); \
+            if constexpr (HT) tl_chunk_ht<WT, MT, Cn>(p, wt, kc, late, accs, ex);                                       \
+            else tl_chunk<WT, MT, LN, NT, NS, Cn>(p, wt, kc, ks, p.a_np, late, accs, ex);                               \
             kc += Cn * ks; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -472,8 +515,16 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         ACMI_TL_RUN(1)
 #undef ACMI_TL_RUN
         kc = kbeg + nw * p.fpw + wave;
-        if (kc < kbeg + kcs)  // ragged tail: the first kcs % nw waves own one more fragment
-            tl_chunk<WT, MT, LN, NT, 1>(p, wt, kc, ks, p.a_np, late, accs, ex);
+        if (kc < kbeg + kcs) {  // ragged tail: the first kcs % nw waves own one more fragment
+            if constexpr (HT) tl_chunk_ht<WT, MT, 1>(p, wt, kc, late, accs, ex);
+            else tl_chunk<WT, MT, LN, NT, NS, 1>(p, wt, kc, ks, p.a_np, late, accs, ex);
+        }
+        if constexpr (HT) {  // columns 0-7 of the even accumulators + columns 8-15 of the odd ones, rotated onto 0-7
+#pragma unroll
+            for (int u = 0; u < MT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accs[u][r] = accs[2 * u][r] + dpp_f32<0x128>(accs[2 * u + 1][r]);
+        }
 
         // ---- deterministic cross-wave reduction through LDS
 #pragma unroll
@@ -483,11 +534,11 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         if (FOLD) {
             // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
-            if (wave < ngroups) rowstat_finish(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8);
+            for (int i = 0; i < NS; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
+            if (wave < ngroups) rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8);
             for (int g = wave + nw; g < ngroups; g += nw) {
-                rowstat_load(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
-                rowstat_finish(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8);
+                rowstat_load<NS>(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
+                rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8);
             }
         }
         __syncthreads();
@@ -500,7 +551,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             float v = 0.f;
             for (int w = 0; w < nw; ++w) v += red[((size_t)(t * MT + u) * nw + w) * 256 + idx];
             const int gm = mg + 16 * u + mm, gn = n0 + 16 * t + nn;
-            const bool valid = gm < p.M && gn < p.N;
+            const bool valid = gm < p.M && gn < p.N && (!HT || nn < 8);
             if (ksp > 1) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
                 if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
                 continue;
@@ -522,13 +573,14 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             }
             if (p.stats_out != nullptr) {
                 // (mean, M2) of this workgroup's 16 output features per row, for the LayerNorm of the consumer
+                // (HT: of its 8 features; lanes 8-15 of a row hold nothing and stay out of lanes 0-7's sums)
                 float sm = valid ? v : 0.f;
-                sm = row16_sum(sm);
-                const float mb = sm * (1.0f / 16.0f);
+                sm = HT ? row8_sum(sm) : row16_sum(sm);
+                const float mb = sm * (HT ? 0.125f : 0.0625f);
                 float dq = valid ? (v - mb) * (v - mb) : 0.f;
-                dq = row16_sum(dq);
+                dq = HT ? row8_sum(dq) : row16_sum(dq);
                 if (nn == 0 && gm < p.M)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> 4) + ntile + t) * 2) = make_float2(mb, dq);
+                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> (HT ? 3 : 4)) + ntile + t) * 2) = make_float2(mb, dq);
             }
             if (!valid) continue;
             if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
@@ -567,9 +619,9 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     }
 }
 
-template <typename WT, int MT, int LN, int NT>
+template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false>
 __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
-    tl_body<WT, MT, LN, NT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+    tl_body<WT, MT, LN, NT, NS, HT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
@@ -605,22 +657,24 @@ static int tiled_prepare(LinArgs& a) {
     if (a.a_rbs <= 0) a.a_rbs = a.NKC;
     if (a.alo_rbs <= 0) a.alo_rbs = a.lo_split > 0 ? a.lo_split : a.NKC;  // a lo buffer holds only the columns that have one
     ACMI_REQUIRE(a.a_rbs >= a.NKC, "acmi_linear: a_rbs=%d < K tiles %d", a.a_rbs, a.NKC);
-    ACMI_REQUIRE(a.stats_out == nullptr || a.N % 16 == 0, "acmi_linear: stats_out needs N %% 16 == 0 (N=%d)", a.N);
+    ACMI_REQUIRE(a.stats_out == nullptr || a.N % (a.w_half ? 8 : 16) == 0, "acmi_linear: stats_out needs N %% %d == 0 (N=%d)",
+                 a.w_half ? 8 : 16, a.N);
     ACMI_REQUIRE(a.ksplit == 1 || (!a.qkv && a.stats_out == nullptr && a.xt_hi == nullptr),
                  "acmi_linear: split-K is incompatible with QKV scatter / stats_out / xt_hi");
     return ACMI_OK;
 }
 
-template <typename WT, int MT, int LN, int NT>
+template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false>
 static int launch_tiled_t(LinArgs& a, hipStream_t st) {
-    const int wgs = ((a.N + 15) / 16 / NT) * a.ksplit, frags = a.NKC / a.ksplit;
+    const int gx = HT ? a.N / 8 : (a.N + 15) / 16 / NT;
+    const int wgs = gx * a.ksplit, frags = (HT ? a.NKC / 2 : a.NKC) / a.ksplit;
     const int nw = tiled_waves(wgs, frags * NT);
     a.kcs = frags; a.fpw = frags / nw;
     const size_t lds = (size_t)NT * MT * nw * 1024 + (size_t)MT * 128;
     if (lds > 64 * 1024) {  // 2 n-tiles x 4 row blocks x 8 waves: just above the default dynamic LDS limit
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
                 return ACMI_ELAUNCH;
@@ -628,7 +682,7 @@ static int launch_tiled_t(LinArgs& a, hipStream_t st) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT>), dim3((a.N + 15) / 16 / NT, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
+    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
                        dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_tiled_kernel");
 }
@@ -643,6 +697,27 @@ static int launch_tiled(LinArgs& a, hipStream_t st) {
     // the activation fragments, re-read by every workgroup, are then shared by two n-tiles
     static const bool wide_ok = !(getenv("ACMI_LIN_WIDE") != nullptr && getenv("ACMI_LIN_WIDE")[0] == '0');
     const int tiles = (a.N + 15) / 16;
+    if (a.w_half) {   // 8-feature workgroups over a weight in half-tile order
+        ACMI_REQUIRE(ln == 0 && a.ksplit == 1 && !a.qkv && a.NKC % 2 == 0 && a.N % 8 == 0 && mt <= 2,
+                     "acmi_linear: w_half needs a plain GEMM (no LayerNorm / split-K / QKV scatter), N %% 8 == 0 (N=%d), "
+                     "an even number of K tiles (%d) and M <= 32 (M=%d)", a.N, a.NKC, a.M);
+        if (mt == 1) return launch_tiled_t<WT, 1, 0, 1, 8, true>(a, st);
+        return launch_tiled_t<WT, 2, 0, 1, 8, true>(a, st);
+    }
+    if (a.colsum != nullptr && a.a_np > 128) {   // statistics of a half-tile producer: up to 256 partials per row
+        ACMI_REQUIRE(a.a_np <= 256 && mt <= 2, "acmi_linear: %d statistics partials per row unsupported (<= 256, and <= 128 "
+                     "for M > 32; M=%d)", a.a_np, a.M);
+        const bool wide = wide_ok && a.ksplit == 1 && tiles > 256 && tiles % 2 == 0 && a.N % 16 == 0 &&
+                          a.stats_out == nullptr && a.xt_hi == nullptr;
+#define ACMI_TLS_CASE(MTv, LNv)                                                          \
+        if (mt == MTv && ln == LNv) {                                                     \
+            if (wide) return launch_tiled_t<WT, MTv, LNv, 2, 16>(a, st);                  \
+            return launch_tiled_t<WT, MTv, LNv, 1, 16>(a, st);                            \
+        }
+        ACMI_TLS_CASE(1, 1) ACMI_TLS_CASE(1, 2) ACMI_TLS_CASE(2, 1) ACMI_TLS_CASE(2, 2)
+#undef ACMI_TLS_CASE
+        return ACMI_EINVAL;
+    }
     if (wide_ok && ln != 3 && a.ksplit == 1 && tiles > 256 && tiles % 2 == 0 && a.N % 16 == 0 &&
         a.stats_out == nullptr && a.xt_hi == nullptr) {
 #define ACMI_TLW_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv, 2>(a, st);
@@ -690,7 +765,7 @@ int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     if (a.ksplit < 1) a.ksplit = 1;
     if (a.rpp <= 0) a.rpp = a.M;
     ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
-    ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 128 && a.a_np * a.a_cnt == a.K),
+    ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 256 && a.a_np * a.a_cnt == a.K),
                  "acmi_linear: folded LayerNorm needs a tiled activation and row statistics (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
     ACMI_REQUIRE(a.colsum == nullptr || a.ksplit == 1, "acmi_linear: folded LayerNorm cannot be combined with split-K");
     if (a.a_tiled) return wdtype == ACMI_BF16 ? launch_tiled<bf16_t>(a, st) : launch_tiled<float>(a, st);
@@ -738,7 +813,7 @@ static int desc_to_args(const acmi_linear_desc& c, LinArgs& p) {
         ACMI_REQUIRE(p.xt_nkc >= (c.N + kt - 1) / kt && p.xt_lo_nkc >= (c.N + kt - 1) / kt,
                      "acmi_linear: xt_rbs=%d / xt_lo_rbs=%d too small for N=%d", c.xt_rbs, c.xt_lo_rbs, c.N);
     }
-    p.stats_out = c.stats_out; p.ksplit = c.ksplit;
+    p.stats_out = c.stats_out; p.ksplit = c.ksplit; p.w_half = c.w_half;
     p.w = c.w; p.bias = c.bias; p.residual = c.residual; p.out = c.out; p.out_mode = c.out_mode; p.act = c.act;
     p.M = c.M; p.N = c.N; p.K = c.K;
     return ACMI_OK;

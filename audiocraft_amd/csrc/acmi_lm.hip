@@ -450,11 +450,12 @@ static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs
         p.xt_hi = xh; p.xt_lo = m->wdtype == ACMI_BF16 ? xl : nullptr; p.xt_nkc = c.rbs; p.xt_lo_nkc = c.nkc_d;
     }
 }
-static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K) {
+static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool w_half = false) {
     LinArgs p = {};
     gemm_produce_x_args(c, p, a, 0, w, K, c.xh, c.xl);
+    p.w_half = w_half;
     int rc = acmi_launch_lin(p, c.m->wdtype, c.st);
-    c.np = c.m->dim / 16; c.cnt = 16;
+    c.cnt = w_half ? 8 : 16; c.np = c.m->dim / c.cnt;   // 8-feature workgroups leave 8-element partials
     return rc;
 }
 
@@ -562,7 +563,12 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             LinArgs a = {};
             a.out = s->hidden; a.out_mode = ACMI_OUT_TILED; a.act = 1;
             if ((rc = gemm_ln_x(c, a, L.w_ff1, L.b_ff1, L.cs_ff1, F))) return rc;
-            if ((rc = gemm_produce_x(c, s->hidden, L.w_ff2, F))) return rc;
+            // FFN2: N = d is narrow and K = 4d long: 8-feature workgroups put it on twice the CUs (small calls only:
+            // their consumers hold d / 8 statistics partials per row in registers)
+            static const bool half_ok = !(getenv("ACMI_FFN2_HALF") != nullptr && getenv("ACMI_FFN2_HALF")[0] == '0');
+            const bool half = half_ok && L.w_ff2h != nullptr && c.lnm == LN_FOLD && M <= 32 && d % 8 == 0 && d / 8 <= 256 &&
+                              F % (2 * c.kt) == 0;
+            if ((rc = gemm_produce_x(c, s->hidden, half ? L.w_ff2h : L.w_ff2, F, half))) return rc;
         }
     }
     if (mode == ACMI_STEP_DECODE) {

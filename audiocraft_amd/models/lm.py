@@ -197,8 +197,8 @@ class LMModel(nn.Module):
         wd = self.weight_dtype
         keep: tp.List[torch.Tensor] = []
 
-        def W(t):  # nn.Linear weight [N, K] -> MFMA B-fragment order ("tiled weight", include/acmi.h)
-            tw = _C.TiledWeight(t.detach().to(dev), wd)
+        def W(t, half=False):  # nn.Linear weight [N, K] -> MFMA B-fragment order ("tiled weight", include/acmi.h)
+            tw = _C.TiledWeight(t.detach().to(dev), wd, half=half)
             keep.append(tw)
             return tw
 
@@ -235,6 +235,10 @@ class LMModel(nn.Module):
                     raise NotImplementedError("out_proj / linear2 biases are not wired into acmi_lm_step; "
                                               "MusicGen checkpoints have none (bias_attn = bias_ff = false)")
             ent = {'w_out': W(layer.self_attn.out_proj.weight), 'w_ff2': W(layer.linear2.weight)}
+            kt2 = 64 if wd == torch.bfloat16 else 32
+            if d % 8 == 0 and d // 8 <= 256 and self.ffn_dim % kt2 == 0:
+                # 8-feature workgroups for FFN2 in calls of <= 32 rows (acmi_lm_layer.w_ff2h): a second copy of the weight
+                ent['w_ff2h'] = W(layer.linear2.weight, half=True)
             ent['w_qkv'], ent['b_qkv'], ent['cs_qkv'] = folded(layer.self_attn.in_proj_weight, layer.norm1, layer.self_attn.in_proj_bias)
             ent['w_ff1'], ent['b_ff1'], ent['cs_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
             if layer.cross_attention is not None:
@@ -257,7 +261,7 @@ class LMModel(nn.Module):
                 ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]), 'w_cout': W(ca.out_proj.weight)})
             L = layers[li]
             for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
-                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq'):
+                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]
@@ -318,7 +322,7 @@ class LMModel(nn.Module):
         run['x'] = torch.zeros(rows, d, **f32)
         run['q'] = torch.zeros(rows, d, **f32)
         # activations that feed a GEMM directly live in A-fragment order, zero padded
-        run['stats'] = torch.zeros(rows, max(1, d // 16), 2, **f32)
+        run['stats'] = torch.zeros(rows, max(1, d // 8), 2, **f32)
         # x as raw fragments: two (hi, lo) pairs, the hi buffers twice as wide so that the self-attention output
         # sits next to x ([x | att], the operand of the paired out-projection / cross-query launch)
         kt = _C._tile_params(self.weight_dtype)[1]

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 120 /* 0.1.2: cross-attention query split between the QKV launch (x0 part) and the out-projection launch */
+#define ACMI_VERSION 120 /* 0.1.2: cross-attention query split between the QKV launch (x0 part) and the out-projection
+                            launch; half-tile (8-feature) workgroups for FFN2 */
 
 #define ACMI_OK 0
 #define ACMI_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -160,6 +161,8 @@ typedef struct {
      * All NULL = separate q projection.  b_qkvx / cs_qkvx: [4d], zeros in the last block. */
     const void* w_qkvx; const float* b_qkvx; const float* cs_qkvx;
     const void* w_mq;       /* [d, d] = w_cq' W_out, computed in f32, then rounded */
+    const void* w_ff2h;     /* w_ff2 in half-tile order (acmi_linear_desc.w_half), used for calls of <= 32 rows when d / 8 <= 256
+                               and the FFN width is a multiple of 2 KT; NULL = always the 16-feature form */
 } acmi_lm_layer;
 
 typedef struct {
@@ -198,7 +201,7 @@ typedef struct {
                                pos[1] = scratch ticket counter (must be 0 between steps) */
     float* x;               /* [Beff, d] f32 residual stream */
     float* q;               /* [Beff, d] f32 */
-    float* stats;           /* [Beff][max(1, d/16)][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
+    float* stats;           /* [Beff][max(1, d/8)][2] f32: LayerNorm statistics partials of x (see acmi_linear_desc) */
     void* xn;               /* tiled activation [ceil(Beff/16)*16, d_pad] in wdtype, zero-initialised: standardised x
                                (separate LayerNorm kernel) or the raw x / its bf16 high part (folded LayerNorm) */
     void* xlo;              /* bf16 weights + folded LayerNorm: tiled [., d_pad], low part x - bf16(x); else NULL */
@@ -304,6 +307,14 @@ typedef struct {
     /* a_lo WITHOUT colsum: hi + lo activation and no LayerNorm; only the first lo_K columns (a multiple of
      * KT) have a lo term -- the [x | att] operand of acmi_linear_pair. */
     int lo_K;
+    /* w_half != 0: `w` is in HALF-TILE order and the GEMM runs with 8 output features per workgroup (twice the
+     * workgroups of the 16-feature form: for a narrow N with a long K, e.g. FFN2, whose N / 16 workgroups would leave
+     * most of the 256 CUs idle).  Unit u of half-tile j (8 features j*8 .. j*8+7, K columns u*2KT .. (u+1)*2KT - 1) is
+     * 64 lanes x 16 B at ((j * (K / 2KT) + u) * 64 + lane) * 16 B; lane = kg * 16 + s * 8 + f holds
+     * w[j*8 + f][u*2KT + s*KT + kg*e .. + e - 1] (e = elements per 16 B, KT = 4 e).  Requires a plain GEMM (no colsum /
+     * a_lo / ksplit), N % 8 == 0, K % (2 KT) == 0 and M <= 32.  With stats_out the partials are of 8 elements:
+     * stats_out[(m * (N / 8) + j) * 2 ..], and the consumer passes a_stats_np = N / 8 (<= 256), a_stats_cnt = 8. */
+    int w_half;
 } acmi_linear_desc;
 int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
 

@@ -306,6 +306,46 @@ def test_linear_folded_layernorm(C, M, d, N2, dt):
         assert rel(out3.cpu(), ref) < 6e-3
 
 
+@pytest.mark.parametrize('M,d,K1,N2', [(16, 1536, 6144, 6144), (16, 1536, 6144, 512), (5, 2048, 8192, 8192), (32, 1024, 4096, 4096),
+                                       (17, 1536, 448, 256), (3, 72, 192, 96)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_linear_half_tile_producer_and_consumer(C, M, d, K1, N2, dt):
+    """8-feature workgroups (acmi_linear_desc.w_half; FFN2 of acmi_lm_step): the producer x1 = x0 + A W1^T over a
+    weight in half-tile order must equal the 16-feature form up to the accumulation order, and leaves d / 8 statistics
+    partials of 8 elements per row, which the LayerNorm-consuming GEMM combines (up to 256 partials per row)."""
+    g = torch.Generator().manual_seed(M + d + K1)
+    a = torch.randn(M, K1, generator=g)
+    w1 = torch.randn(d, K1, generator=g) / math.sqrt(K1)
+    x0 = torch.randn(M, d, generator=g) * 2 + 0.5
+    w2 = torch.randn(N2, d, generator=g) / math.sqrt(d)
+    b2 = 0.1 * torch.randn(N2, generator=g)
+    x1_ref = x0 + a.to(dt).float() @ w1.to(dt).float().t()
+    ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t() + b2
+    at = C.tile_matrix(a.cuda(), dt)
+    w1h = C.TiledWeight(w1.cuda(), dt, half=True)
+    x = x0.cuda().clone()
+    stats = torch.full((M, d // 8, 2), float('nan'), device='cuda')
+    hi = C.tiled_activation_buffer(M, d, dt, 'cuda')
+    lo = C.tiled_activation_buffer(M, d, dt, 'cuda') if dt == torch.bfloat16 else None
+    C.linear_ex(at, w1h, x, M, C.A_TILED, C.OUT_F32, stats_out=stats, residual=x, xt_hi=hi, xt_lo=lo)
+    assert rel(x.cpu(), x1_ref) < (2e-6 if dt == torch.float32 else 1e-5)
+    x16 = x0.cuda().clone()   # the 16-feature form on the same operands
+    C.linear_ex(at, C.TiledWeight(w1.cuda(), dt), x16, M, C.A_TILED, C.OUT_F32, residual=x16)
+    assert (x - x16).abs().max() <= 4e-6 * x16.abs().max()
+    xh = C.untile_matrix(hi, M, d).float()
+    assert torch.equal(xh, x.to(dt).float())
+    if dt == torch.bfloat16:
+        assert torch.equal(C.untile_matrix(lo, M, d).float(), (x - xh).to(dt).float())
+    blocks = x.view(M, d // 8, 8)
+    assert torch.allclose(stats[..., 0], blocks.mean(-1), atol=2e-6)
+    assert torch.allclose(stats[..., 1], ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-6)
+    out = torch.empty(M, N2, device='cuda')
+    C.linear_ex(hi, C.TiledWeight(w2.cuda(), dt), out, M, C.A_TILED, C.OUT_F32, a_stats=stats, np_=d // 8, cnt=8, bias=b2.cuda(),
+                a_lo=lo, colsum=w2.to(dt).double().sum(1).float().cuda())
+    r = rel(out.cpu(), ref)
+    assert r < (3e-6 if dt == torch.float32 else 2e-4), f"rel-L2 {r}"
+
+
 @pytest.mark.parametrize('M,d', [(16, 1536), (5, 512), (33, 1024), (16, 48), (64, 256)])
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_linear_pair_out_proj_and_cross_query(C, M, d, dt):
