@@ -72,8 +72,8 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     cat[:, :d], cat[:, dp:dp + d] = rnd(d), rnd(d)
     xh = [_C.tile_matrix(cat, wd), _C.tile_matrix(cat, wd)]
     xl = [_C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if wd == torch.bfloat16 else None for _ in range(2)]
-    np_ = max(1, d // 16)
-    stats = torch.zeros(B_eff, np_, 2, device=dev)
+    np_ = max(1, d // 16)                                     # statistics partials of the current x (cnt elements each)
+    stats = torch.zeros(B_eff, max(1, d // 8), 2, device=dev)
     stats[..., 1] = 16.0
     q = torch.empty(B_eff, d, device=dev)
     qkv = torch.empty(B_eff, 4 * d, device=dev)
@@ -99,15 +99,17 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                               xt_lo=xl[dst], a_rbs=a_rbs, xt_rbs=rbs)
 
     def produce(a, w):
-        # x = x0 + a @ W^T, also written as raw fragments and statistics partials
-        nonlocal launches, nbytes
+        # x = x0 + a @ W^T, also written as raw fragments and statistics partials (of 16 elements; of 8 when the weight
+        # is in half-tile order: FFN2 on 8-feature workgroups)
+        nonlocal launches, nbytes, np_
         _C.linear_launch(produce_desc(a, w, 0, cur))
+        np_ = d // (8 if w.half else 16)
         launches += 1
         nbytes += wbytes(w)
 
     def one_position():
         # the same GEMM launches acmi_lm_step issues for one position (same shapes, operand layouts, weights)
-        nonlocal launches, nbytes, cur
+        nonlocal launches, nbytes, cur, np_
         for ent in pk['per_layer']:
             if 'w_qkvx' in ent:
                 # QKV + the x0 part of the cross-attention query (a fourth block of features), then the out projection
@@ -121,6 +123,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                 # consume() counted w_qkvx = W_qkv + W_cq, as SURVEY.md section 8(d) does; w_mq (= W_cq' W_out, +d^2
                 # elements per layer) is extra traffic of this formulation and shows up in the PMC bytes instead
                 nbytes += wbytes(ent['w_out'])
+                np_ = d // 16
                 cur ^= 1
                 produce(catt, ent['w_cout'])
             else:
@@ -129,8 +132,9 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                 _C.linear_launch(produce_desc(att_half, ent['w_out'], rbs, cur))
                 launches += 1
                 nbytes += wbytes(ent['w_out'])
+                np_ = d // 16
             consume(ent['w_ff1'], h, _C.OUT_TILED, ent['cs_ff1'], ent['b_ff1'], act=1)
-            produce(hid, ent['w_ff2'])
+            produce(hid, ent['w_ff2h'] if 'w_ff2h' in ent and B_eff <= 32 else ent['w_ff2'])
         consume(pk['w_head'], logits, _C.OUT_F32, pk['cs_head'], pk['b_head'])
 
     one_position()  # warm
