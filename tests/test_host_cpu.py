@@ -77,6 +77,24 @@ def test_tiling_roundtrip():
         assert t[1, 1, 3, 5, 1] == w.to(dt)[16 + 5, 1 * 4 * e + 3 * e + 1]
 
 
+def test_half_tile_order_matches_the_header():
+    """acmi_linear_desc.w_half (include/acmi.h): unit u of half-tile j is 64 lanes x 16 B; lane = kg*16 + s*8 + f holds
+    w[j*8 + f][u*2KT + s*KT + kg*e .. + e - 1]."""
+    from audiocraft_amd import _C
+    for dt, e in ((torch.float32, 4), (torch.bfloat16, 8)):
+        kt = 4 * e
+        w = torch.randn(24, 6 * kt)
+        t = _C.tile_matrix_half(w, dt).reshape(3, 3, 64, e)     # [half-tile j][unit u][lane][element]
+        wd = w.to(dt)
+        for j, u, kg, s_, f in ((0, 0, 0, 0, 0), (2, 1, 3, 1, 7), (1, 2, 2, 0, 5), (2, 2, 1, 1, 0)):
+            lane = kg * 16 + s_ * 8 + f
+            k0 = u * 2 * kt + s_ * kt + kg * e
+            assert torch.equal(t[j, u, lane], wd[j * 8 + f, k0:k0 + e])
+        assert _C.TiledWeight(w, dt, half=True).half and not _C.TiledWeight(w, dt).half
+    with pytest.raises(AssertionError):
+        _C.tile_matrix_half(torch.randn(20, 64), torch.bfloat16)     # N % 8
+
+
 # ------------------------------------------------------------------------------------------ patterns
 
 @pytest.mark.parametrize('T,delays', [(7, None), (1, None), (12, [0, 1, 2, 3]), (9, [0, 0, 1, 3]), (5, [0, 0, 0, 0])])
