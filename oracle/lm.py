@@ -31,6 +31,11 @@ class LMConfig:
     positional_scale: float = 1.0
     cfg_coef: float = 3.0
     eps: float = 1e-5
+    # options of StreamingTransformer no MusicGen release uses (config/model/lm/default.yaml:25-33), part of the
+    # decode step all the same: rotary positions, xPos decay, a bounded receptive field
+    positional_embedding: str = 'sin'      # 'sin' | 'rope' | 'sin_rope' (transformer.py:632-637, 701-704)
+    xpos: bool = False
+    past_context: tp.Optional[int] = None
 
 
 def create_sin_embedding(positions: torch.Tensor, dim: int, max_period: float = 10000.) -> torch.Tensor:
@@ -42,18 +47,45 @@ def create_sin_embedding(positions: torch.Tensor, dim: int, max_period: float = 
     return torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1)
 
 
+def rope_rotate(x: torch.Tensor, start: int, max_period: float, scale: float, xpos: bool, invert_decay: bool) -> torch.Tensor:
+    """RotaryEmbedding.rotate (audiocraft/modules/rope.py:75-96) on x [B, H, T, hd] (time_dim = 2): pairs (2i, 2i+1) of the
+    head dimension are complex numbers, multiplied by  (e^{i pos f_i} * decay_i(pos)) * scale + (1 - scale)  with
+    f_i = max_period^(-2i / hd) (:59-61) and the xPos decay ((i / (hd/2) + 0.4) / 1.4)^(pos / 512) (rope.py:26-44), inverted
+    for keys (:111-114)."""
+    hd, T = x.shape[-1], x.shape[2]
+    adim = torch.arange(0, hd, 2, dtype=torch.float32)[: hd // 2]
+    freqs = 1.0 / (max_period ** (adim / hd))
+    idx = torch.arange(start + T, dtype=torch.float32)
+    angles = torch.outer(idx, freqs)
+    rotation = torch.polar(torch.ones_like(angles), angles)[start:start + T].view(1, 1, T, -1)
+    decay: tp.Union[float, torch.Tensor] = 1.0
+    if xpos:
+        half = hd // 2
+        rates = (torch.arange(half, dtype=torch.float32) / half + 0.4) / 1.4
+        sc = rates ** (idx / 512).unsqueeze(-1)
+        decay = torch.polar(sc, torch.zeros_like(sc))[start:start + T].view(1, 1, T, -1)
+        if invert_decay:
+            decay = decay ** -1
+    xc = torch.view_as_complex(x.to(torch.float32).reshape(*x.shape[:-1], -1, 2))
+    out = torch.view_as_real(xc * ((rotation * decay) * scale + (1.0 - scale))).view_as(x)
+    return out.type_as(x)
+
+
 def _ln(x, sd, prefix, eps):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + '.weight'], sd[prefix + '.bias'], eps)
 
 
-def _attention(q, k, v, causal: bool):
+def _attention(q, k, v, causal: bool, past_context: tp.Optional[int] = None):
     """F.scaled_dot_product_attention semantics (transformer.py:412-414): scale 1/sqrt(hd),
-    lower-triangular mask aligned top-left when `causal` (only used when #q == #k)."""
+    lower-triangular mask aligned top-left when `causal` (only used when #q == #k).  past_context: the custom
+    attention's mask (_get_mask, transformer.py:249-264): a query at position p sees keys p - past_context .. p."""
     scale = 1.0 / math.sqrt(q.shape[-1])
     w = (q @ k.transpose(-1, -2)) * scale
     if causal:
         Tq, Tk = w.shape[-2:]
         m = torch.ones(Tq, Tk, dtype=torch.bool).tril()
+        if past_context is not None:
+            m &= torch.ones(Tq, Tk, dtype=torch.bool).triu(-past_context)
         w = w.masked_fill(~m, float('-inf'))
     return torch.softmax(w, dim=-1) @ v
 
@@ -63,6 +95,7 @@ class LMState:
     def __init__(self, num_layers: int):
         self.past_k: tp.List[tp.Optional[torch.Tensor]] = [None] * num_layers
         self.past_v: tp.List[tp.Optional[torch.Tensor]] = [None] * num_layers
+        self.ctx_offset: tp.List[tp.Optional[int]] = [None] * num_layers   # attention 'offset': keys dropped by past_context
         self.offset = 0          # transformer.offsets (same for every row)
         self.first_step = True   # fuser: 'offsets' not yet in state (conditioners.py:1722-1727)
 
@@ -77,7 +110,12 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
     hd = C // H
     offset = state.offset if state is not None else 0
     pos = torch.arange(T).view(1, -1, 1) + offset
-    x = x + cfg.positional_scale * create_sin_embedding(pos, C, cfg.max_period)
+    if cfg.positional_embedding in ('sin', 'sin_rope'):
+        x = x + cfg.positional_scale * create_sin_embedding(pos, C, cfg.max_period)
+    use_rope = cfg.positional_embedding in ('rope', 'sin_rope')
+
+    def ls(name):   # LayerScale (transformer.py:92-110, 526-538): a per-channel gain on the residual branch, or identity
+        return sd.get(f'{name}.scale', 1.0)
     for li in range(cfg.num_layers):
         p = f'transformer.layers.{li}'
         # --- self attention (pre-norm)
@@ -88,15 +126,28 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
         # _get_mask (transformer.py:233-247): no mask for one step; lower-triangular for T>1, which
         # the reference only supports when there is no past (raises otherwise).
         causal = T > 1
+        if use_rope:
+            # _apply_rope (transformer.py:300-313, 394-395): the new q / k are rotated BEFORE they join the cache, at
+            # start = (keys dropped so far) + (keys cached).  That is the absolute position -- except after a FIRST
+            # streaming call longer than past_context: _complete_kv (:286-297) drops the surplus keys but initialises
+            # the dropped-keys counter to 0, so every later position lags by (first length - past_context).  Restated
+            # as is (tests/golden/lm_rope.npz: a 9-step prompt against past_context 6).
+            start = 0
+            if state is not None and state.past_k[li] is not None:
+                start = (state.ctx_offset[li] or 0) + state.past_k[li].shape[2]
+            q = rope_rotate(q, start, cfg.max_period, cfg.positional_scale, cfg.xpos, False)
+            k = rope_rotate(k, start, cfg.max_period, cfg.positional_scale, cfg.xpos, True)
         if state is not None:
             if state.past_k[li] is not None:
                 assert T == 1, "reference raises 'Not supported at the moment' here"
                 k = torch.cat([state.past_k[li], k], dim=2)   # _complete_kv, transformer.py:274-281
                 v = torch.cat([state.past_v[li], v], dim=2)
-            state.past_k[li], state.past_v[li] = k, v
-        a = _attention(q, k, v, causal)
+            keep = 0 if cfg.past_context is None else max(0, k.shape[2] - cfg.past_context)   # :286-293
+            state.past_k[li], state.past_v[li] = k[:, :, keep:], v[:, :, keep:]
+            state.ctx_offset[li] = 0 if state.ctx_offset[li] is None else state.ctx_offset[li] + keep
+        a = _attention(q, k, v, causal, cfg.past_context)
         a = a.permute(0, 2, 1, 3).reshape(B, T, C)
-        x = x + F.linear(a, sd[p + '.self_attn.out_proj.weight'], sd.get(p + '.self_attn.out_proj.bias'))
+        x = x + ls(p + '.layer_scale_1') * F.linear(a, sd[p + '.self_attn.out_proj.weight'], sd.get(p + '.self_attn.out_proj.bias'))
         # --- cross attention: q/k/v projections with the three slices of in_proj_weight, k/v
         # re-projected at every call, no key-padding mask (transformer.py:344-361, 542-548)
         if cfg.cross_attention:
@@ -110,12 +161,12 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
             kc = F.linear(cross_src, w[C:2 * C], bk).view(B, -1, H, hd).transpose(1, 2)
             vc = F.linear(cross_src, w[2 * C:], bv).view(B, -1, H, hd).transpose(1, 2)
             a = _attention(qc, kc, vc, False).transpose(1, 2).reshape(B, T, C)
-            x = x + F.linear(a, sd[p + '.cross_attention.out_proj.weight'],
-                             sd.get(p + '.cross_attention.out_proj.bias'))
+            x = x + ls(p + '.layer_scale_cross') * F.linear(a, sd[p + '.cross_attention.out_proj.weight'],
+                                                            sd.get(p + '.cross_attention.out_proj.bias'))
         # --- feed forward, exact (erf) GELU
         h = _ln(x, sd, p + '.norm2', cfg.eps)
         h = F.gelu(F.linear(h, sd[p + '.linear1.weight'], sd.get(p + '.linear1.bias')))
-        x = x + F.linear(h, sd[p + '.linear2.weight'], sd.get(p + '.linear2.bias'))
+        x = x + ls(p + '.layer_scale_2') * F.linear(h, sd[p + '.linear2.weight'], sd.get(p + '.linear2.bias'))
     if state is not None:
         state.offset = offset + T
     return x

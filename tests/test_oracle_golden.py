@@ -19,8 +19,11 @@ def codec_cfg(cfg):
     return ocodec.CodecConfig(**{k: cfg[k] for k in CODEC_KEYS})
 
 
+LM_OPT_KEYS = ['positional_embedding', 'xpos', 'past_context', 'positional_scale']
+
+
 def lm_cfg(cfg):
-    return olm.LMConfig(**{k: cfg[k] for k in LM_KEYS})
+    return olm.LMConfig(**{k: cfg[k] for k in LM_KEYS}, **{k: cfg[k] for k in LM_OPT_KEYS if k in cfg})
 
 
 @pytest.mark.parametrize('name', ['codec_noncausal', 'codec_causal', 'codec_renorm'])
@@ -74,6 +77,29 @@ def test_lm_text_oracle_matches_reference():
                         remove_prompts=True)
     assert torch.equal(toks, a['cont_tokens_removed'])
     assert torch.allclose(olm.top_k_filter(a['probs'], 5), a['probs_top5'], atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['lm_rope', 'lm_sin_rope'])
+def test_lm_rope_oracle_matches_reference(name):
+    """Rotary positions (rope.py:75-114), xPos decay, past_context (transformer.py:249-264, 286-293) and LayerScale
+    (:92-110): goldens from the reference's custom attention, whose streaming path equals its full forward
+    (tests/modules/test_rope.py:66-121) -- see tests/golden/make_rope_golden.py for why not the memory-efficient one."""
+    cfg, sd, a = load_golden(name)
+    c = lm_cfg(cfg)
+    assert c.positional_embedding == cfg['positional_embedding'] and ('layer_scale' in cfg) == any('layer_scale' in k for k in sd)
+    logits = olm.lm_forward(sd, c, a['tf_sequence'], a['cross_src'])
+    assert torch.allclose(logits, a['tf_logits'], atol=2e-5, rtol=1e-4)
+    st = olm.LMState(c.num_layers)   # streaming == full forward, the window included
+    steps = [olm.lm_forward(sd, c, a['tf_sequence'][..., i:i + 1], a['cross_src'], None, st)
+             for i in range(a['tf_sequence'].shape[-1])]
+    assert torch.allclose(torch.cat(steps, dim=2), a['tf_logits'], atol=3e-5, rtol=1e-4)
+    if c.past_context is not None:
+        assert st.past_k[0].shape[2] == c.past_context
+    toks, lg = olm.generate(sd, c, None, 3, a['cross_src'], max_gen_len=14, use_sampling=False, return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    assert torch.allclose(lg, olm.cfg_mix(a['greedy_step_logits'], c.cfg_coef), atol=1e-4, rtol=1e-4)
+    toks = olm.generate(sd, c, a['prompt'], 3, a['cross_src'], max_gen_len=14, use_sampling=False)
+    assert torch.equal(toks, a['cont_tokens'])
 
 
 def test_lm_melody_oracle_matches_reference():
