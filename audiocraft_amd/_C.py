@@ -47,7 +47,8 @@ class LMModelDesc(C.Structure):
     _fields_ = [('dim', i32), ('num_heads', i32), ('num_layers', i32), ('ffn_dim', i32), ('n_q', i32),
                 ('card', i32), ('wdtype', i32), ('kvdtype', i32), ('cross_attention', i32), ('eps', f32),
                 ('positional_scale', f32), ('layers', C.POINTER(LMLayer)), ('emb', C.POINTER(vp)),
-                ('pos_table', vp), ('w_head', vp), ('b_head', vp), ('cs_head', vp)]
+                ('pos_table', vp), ('w_head', vp), ('b_head', vp), ('cs_head', vp), ('rope_freq', vp), ('rope_decay', vp),
+                ('rope_scale', f32), ('rope_base', f32), ('past_context', i32)]
 
 
 class LMState(C.Structure):
@@ -55,7 +56,7 @@ class LMState(C.Structure):
                 ('S', i32), ('n_pos', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
                 ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
-                ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp)]
+                ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -92,7 +93,7 @@ class AttnDesc(C.Structure):
     _fields_ = [('q', vp), ('k_cache', vp), ('v_cache', vp), ('kvdtype', i32), ('out', vp), ('out_mode', i32),
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
                 ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('cache_rows', i32), ('q_stats', vp), ('q_stats_np', i32),
-                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp)]
+                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp), ('past_context', i32)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
@@ -290,7 +291,7 @@ def linear_pair(plain: LinearDesc, xcat: LinearDesc):
 
 
 def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False, out_rbs=0, out_col0=0,
-                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5, len_rows=None):
+                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5, len_rows=None, past_context=0):
     """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True; out_rbs / out_col0
     place the head outputs inside a wider buffer).  q_colsum: LayerNorm hook on q (acmi_attn_desc)."""
     cache_rows, H, Tcap, hd = k_cache.shape
@@ -304,6 +305,7 @@ def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_
     d.q_stats, d.q_stats_np, d.q_stats_cnt, d.eps = ptr(q_stats), q_np, q_cnt, eps
     d.q_colsum, d.q_bias = ptr(q_colsum), ptr(q_bias)
     d.len_rows = ptr(len_rows)
+    d.past_context = int(past_context)
     check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')
     return out
 

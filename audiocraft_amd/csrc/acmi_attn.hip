@@ -28,6 +28,7 @@ struct AttnArgs {
     int out_tiled, out_bf16, out_rbs, out_col0;  // tiled output: K tiles per 16-row block, first column
     int H, Tcap, len; const int* len_dev; int len_bias; float scale;
     const int* len_rows;  // per-cache-row length (two_step_cfg: the two passes keep their own condition length), or NULL
+    int past_context;  // > 0: positions [len - 1 - past_context, len) only
     int rpp;      // rows per position: query row b belongs to cache row b % rpp; with len_dev its length grows by b / rpp
     // optional LayerNorm hook on q (the cross-attention query arrives as x W'^T, see acmi_linear_pair):
     //   q <- rstd[b] (q - mean[b] colsum) + bias, mean / rstd of row b from the (mean, M2) partials of x
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
     };
-    load_kv(wave * CH);
+    const int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
+    load_kv(start + wave * CH);
     if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
         const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
         const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - mean * qcs[e]) + qb[e];
     }
-    for (int t0 = wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
+    for (int t0 = start + wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
         float s[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -219,6 +221,7 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
                  "acmi_attn_decode: tiled output placement col0=%d rbs=%d does not hold %d columns", c.out_col0, a.out_rbs, c.H * c.hd);
     a.H = c.H; a.Tcap = c.Tcap; a.len = c.len; a.len_dev = c.len_dev; a.len_bias = c.len_bias; a.len_rows = c.len_rows;
     ACMI_REQUIRE(c.len_rows == nullptr || (c.len_dev == nullptr && c.len > 0), "acmi_attn_decode: len_rows needs a host `len` bound");
+    a.past_context = c.past_context;
     a.rpp = c.cache_rows > 0 ? c.cache_rows : c.Beff;
     ACMI_REQUIRE(c.Beff % a.rpp == 0, "acmi_attn_decode: %d query rows are not a multiple of %d cache rows", c.Beff, a.rpp);
     a.scale = 1.0f / sqrtf((float)c.hd);

@@ -513,6 +513,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             LinArgs a = {};
             a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
             a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
+            a.rope_freq = m->rope_freq; a.rope_decay = m->rope_decay; a.rope_scale = m->rope_scale; a.rope_base = m->rope_base;
+            a.rope_first = s->rope_first > 0 ? s->rope_first : 0x7fffffff; a.rope_shift = s->rope_shift;
             if (pair) {   // + the x0 part of the cross-attention query as a fourth, raw block of features -> r
                 a.r_out = s->r;
                 if ((rc = gemm_ln_x(c, a, L.w_qkvx, L.b_qkvx, L.cs_qkvx, 4 * d))) return rc;
@@ -523,7 +525,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         acmi_attn_desc sa = {};
         sa.q = s->q; sa.k_cache = L.k_cache; sa.v_cache = L.v_cache; sa.kvdtype = m->kvdtype;
         sa.out_mode = ACMI_OUT_TILED; sa.out_dtype = m->wdtype; sa.Beff = M; sa.H = H; sa.hd = hd; sa.Tcap = s->Tmax;
-        sa.len_dev = s->pos; sa.len_bias = 1; sa.cache_rows = s->Beff;
+        sa.len_dev = s->pos; sa.len_bias = 1; sa.cache_rows = s->Beff; sa.past_context = m->past_context;
         if (pair) { sa.out = c.xh; sa.out_rbs = c.rbs; sa.out_col0 = c.nkc_d * c.kt; }
         else sa.out = s->att;
         if ((rc = acmi_attn_decode_ex(&sa, stream))) return rc;

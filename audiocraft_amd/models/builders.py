@@ -105,7 +105,10 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
                  weight_init=cfg.get('weight_init', 'gaussian'), depthwise_init=cfg.get('depthwise_init', 'current'),
                  zero_bias_init=True, cfg_coef=cfg.get('cfg_coef', 3.0), num_layers=cfg['num_layers'],
                  cross_attention=bool(fuse['cross']), bias_ff=False, bias_attn=False,
-                 positional_embedding='sin', weight_dtype=weight_dtype, kv_dtype=kv_dtype, device=device)
+                 positional_embedding=cfg.get('positional_embedding', 'sin'), max_period=cfg.get('max_period', 10000.),
+                 positional_scale=cfg.get('positional_scale', 1.0), xpos=cfg.get('xpos', False),
+                 past_context=cfg.get('past_context'), layer_scale=cfg.get('layer_scale'),
+                 weight_dtype=weight_dtype, kv_dtype=kv_dtype, device=device)
     return lm.to(device)
 
 

@@ -48,9 +48,32 @@ class _Attn(nn.Module):
         self.out_proj = nn.Linear(dim, dim, bias=bias, device=device)
 
 
+class _Rope(nn.Module):
+    """Buffer container named like RotaryEmbedding / XPos (rope.py:14-61): `frequencies` [hd / 2], `xpos.decay_rates`
+    [hd / 2]; the reference shares one instance between the transformer and every self-attention, so its state dict
+    lists the buffers under `transformer.rope.*` and `transformer.layers.{i}.self_attn.rope.*`."""
+    def __init__(self, hd: int, max_period: float, xpos: bool, device=None):
+        super().__init__()
+        adim = torch.arange(0, hd, 2, device=device, dtype=torch.float32)[: hd // 2]
+        self.register_buffer('frequencies', 1.0 / (max_period ** (adim / hd)))
+        self.xpos: tp.Optional[nn.Module] = None
+        if xpos:
+            self.xpos = nn.Module()
+            half = hd // 2
+            self.xpos.register_buffer('decay_rates', (torch.arange(half, device=device, dtype=torch.float32) / half + 0.4) / 1.4)
+
+
+class _LayerScale(nn.Module):
+    """Parameter container named like LayerScale (transformer.py:92-110): `scale` [channels]."""
+    def __init__(self, channels: int, init: float, device=None):
+        super().__init__()
+        self.scale = nn.Parameter(torch.full((channels,), float(init), device=device))
+
+
 class _Layer(nn.Module):
     """Parameter container named like StreamingTransformerLayer (transformer.py:454-574)."""
-    def __init__(self, dim: int, ffn: int, cross_attention: bool, bias_ff: bool, bias_attn: bool, device=None):
+    def __init__(self, dim: int, ffn: int, cross_attention: bool, bias_ff: bool, bias_attn: bool, device=None,
+                 layer_scale: tp.Optional[float] = None):
         super().__init__()
         self.self_attn = _Attn(dim, bias_attn, device)
         self.linear1 = nn.Linear(dim, ffn, bias=bias_ff, device=device)
@@ -61,13 +84,23 @@ class _Layer(nn.Module):
         if cross_attention:
             self.cross_attention = _Attn(dim, bias_attn, device)
             self.norm_cross = nn.LayerNorm(dim, eps=1e-5, device=device)
+        if layer_scale is not None:   # LayerScale (transformer.py:92-110, 526-538): folded into the branch's last matrix at pack time
+            self.layer_scale_1 = _LayerScale(dim, layer_scale, device)
+            self.layer_scale_2 = _LayerScale(dim, layer_scale, device)
+            if cross_attention:
+                self.layer_scale_cross = _LayerScale(dim, layer_scale, device)
 
 
 class _Transformer(nn.Module):
-    def __init__(self, dim, ffn, num_layers, cross_attention, bias_ff, bias_attn, device=None):
+    def __init__(self, dim, ffn, num_layers, cross_attention, bias_ff, bias_attn, device=None, layer_scale=None,
+                 rope: tp.Optional[_Rope] = None):
         super().__init__()
-        self.layers = nn.ModuleList([_Layer(dim, ffn, cross_attention, bias_ff, bias_attn, device)
+        self.rope = rope
+        self.layers = nn.ModuleList([_Layer(dim, ffn, cross_attention, bias_ff, bias_attn, device, layer_scale)
                                      for _ in range(num_layers)])
+        if rope is not None:
+            for layer in self.layers:
+                layer.self_attn.rope = rope
 
 
 class LMModel(nn.Module):
@@ -76,8 +109,9 @@ class LMModel(nn.Module):
     Args mirror `audiocraft.models.lm.LMModel.__init__` (lm.py:145-177) plus:
         weight_dtype: torch.bfloat16 (bench / serving) or torch.float32 (parity mode) for the packed matrices.
         kv_dtype: dtype of the KV caches (defaults to weight_dtype).
-    Unsupported reference options raise: norm_first=False, rope, layer_scale, kv_repeat>1, qk_layer_norm,
-    past_context (none is used by a MusicGen config).
+    Beyond the MusicGen configuration the decode step also implements the transformer options no release uses
+    (config/model/lm/default.yaml:25-33): positional_embedding 'rope' / 'sin_rope' (+ xpos), past_context and
+    layer_scale.  Unsupported reference options raise: norm_first=False, kv_repeat > 1, qk_layer_norm.
     """
 
     def __init__(self, pattern_provider: CodebooksPatternProvider, condition_provider: ConditioningProvider,
@@ -95,16 +129,18 @@ class LMModel(nn.Module):
         super().__init__()
         if not norm_first or norm != 'layer_norm':
             raise NotImplementedError("only pre-norm LayerNorm transformers (the MusicGen configuration)")
-        if positional_embedding != 'sin':
-            raise NotImplementedError("only sinusoidal positions (config/model/lm/default.yaml:32)")
+        if positional_embedding not in ('sin', 'rope', 'sin_rope'):
+            raise ValueError(f"positional_embedding {positional_embedding!r} (transformer.py:632)")
         if activation != 'gelu' or not causal:
             raise NotImplementedError("only causal, GELU transformers")
-        for k in ('layer_scale', 'past_context', 'rope'):
-            if kwargs.get(k) is not None:
-                raise NotImplementedError(f"{k} is not used by MusicGen and not implemented")
         if kwargs.get('kv_repeat', 1) != 1 or kwargs.get('qk_layer_norm', False):
             raise NotImplementedError("kv_repeat / qk_layer_norm are not used by MusicGen")
         assert dim % num_heads == 0 and dim % 8 == 0
+        self.positional_embedding = positional_embedding
+        self.xpos = bool(kwargs.get('xpos', False))
+        self.past_context: tp.Optional[int] = kwargs.get('past_context')
+        layer_scale = kwargs.get('layer_scale')
+        assert self.past_context is None or self.past_context > 0
         self.cfg_coef = cfg_coef
         self.cfg_dropout = ClassifierFreeGuidanceDropout(p=cfg_dropout)
         self.condition_provider = condition_provider
@@ -123,7 +159,11 @@ class LMModel(nn.Module):
         self.weight_dtype = weight_dtype
         self.kv_dtype = kv_dtype or weight_dtype
         self.emb = nn.ModuleList([nn.Embedding(card + 1, dim, device=device) for _ in range(n_q)])
-        self.transformer = _Transformer(dim, self.ffn_dim, num_layers, cross_attention, bias_ff, bias_attn, device)
+        rope = None
+        if positional_embedding in ('rope', 'sin_rope'):
+            rope = _Rope(dim // num_heads, max_period, self.xpos, device)
+        self.transformer = _Transformer(dim, self.ffn_dim, num_layers, cross_attention, bias_ff, bias_attn, device, layer_scale,
+                                        rope)
         self.out_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
         self.linears = nn.ModuleList([nn.Linear(dim, card, bias=bias_proj, device=device) for _ in range(n_q)])
         self._init_weights(weight_init, depthwise_init, zero_bias_init)
@@ -234,11 +274,16 @@ class LMModel(nn.Module):
                 if b is not None and bool((b != 0).any()):
                     raise NotImplementedError("out_proj / linear2 biases are not wired into acmi_lm_step; "
                                               "MusicGen checkpoints have none (bias_attn = bias_ff = false)")
-            ent = {'w_out': W(layer.self_attn.out_proj.weight), 'w_ff2': W(layer.linear2.weight)}
+            def scaled(w, name):   # LayerScale: x + s * (a W^T) = x + a (diag(s) W)^T, folded into the matrix (f32, then rounded)
+                ls = getattr(layer, name, None)
+                w32 = w.detach().to(device=dev, dtype=torch.float32)
+                return w32 if ls is None else w32 * ls.scale.detach().to(device=dev, dtype=torch.float32)[:, None]
+            w_out32, w_ff2_32 = scaled(layer.self_attn.out_proj.weight, 'layer_scale_1'), scaled(layer.linear2.weight, 'layer_scale_2')
+            ent = {'w_out': W(w_out32), 'w_ff2': W(w_ff2_32)}
             kt2 = 64 if wd == torch.bfloat16 else 32
             if d % 8 == 0 and d // 8 <= 256 and self.ffn_dim % kt2 == 0:
                 # 8-feature workgroups for FFN2 in calls of <= 32 rows (acmi_lm_layer.w_ff2h): a second copy of the weight
-                ent['w_ff2h'] = W(layer.linear2.weight, half=True)
+                ent['w_ff2h'] = W(w_ff2_32, half=True)
             ent['w_qkv'], ent['b_qkv'], ent['cs_qkv'] = folded(layer.self_attn.in_proj_weight, layer.norm1, layer.self_attn.in_proj_bias)
             ent['w_ff1'], ent['b_ff1'], ent['cs_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
             if layer.cross_attention is not None:
@@ -257,8 +302,9 @@ class LMModel(nn.Module):
                 ent['w_qkvx'] = W(torch.cat([wqkv, wq], dim=0))
                 ent['b_qkvx'] = Fp(torch.cat([ent['b_qkv'], torch.zeros(d, device=dev)]))
                 ent['cs_qkvx'] = Fp(torch.cat([ent['cs_qkv'], torch.zeros(d, device=dev)]))
-                ent['w_mq'] = W(wq @ layer.self_attn.out_proj.weight.detach().to(device=dev, dtype=torch.float32))
-                ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]), 'w_cout': W(ca.out_proj.weight)})
+                ent['w_mq'] = W(wq @ w_out32)
+                ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]),
+                            'w_cout': W(scaled(ca.out_proj.weight, 'layer_scale_cross'))})
             L = layers[li]
             for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
                       'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h'):
@@ -280,7 +326,18 @@ class LMModel(nn.Module):
         desc.n_q, desc.card = self.n_q, self.card
         desc.wdtype, desc.kvdtype = _C.dtype_code(wd), _C.dtype_code(self.kv_dtype)
         desc.cross_attention = int(self.has_cross_attention)
-        desc.eps, desc.positional_scale = 1e-5, self.positional_scale
+        # 'rope' alone: no sinusoidal embedding (transformer.py:701-704) -> its scale is 0 for the embedding kernel
+        desc.eps, desc.positional_scale = 1e-5, (0.0 if self.positional_embedding == 'rope' else self.positional_scale)
+        desc.rope_freq = desc.rope_decay = None
+        desc.rope_scale, desc.rope_base = float(self.positional_scale), 512.0
+        desc.past_context = int(self.past_context or 0)
+        if self.positional_embedding in ('rope', 'sin_rope'):
+            # the tables of RotaryEmbedding / XPos: buffers computed like the reference does (rope.py:26-30, 59-61)
+            pk['rope_freq'] = Fp(self.transformer.rope.frequencies)
+            desc.rope_freq = pk['rope_freq'].data_ptr()
+            if self.xpos:
+                pk['rope_decay'] = Fp(self.transformer.rope.xpos.decay_rates)
+                desc.rope_decay = pk['rope_decay'].data_ptr()
         desc.layers = C.cast(layers, C.POINTER(_C.LMLayer))
         desc.emb = C.cast(emb_arr, C.POINTER(_C.vp))
         desc.pos_table = None
@@ -348,6 +405,7 @@ class LMModel(nn.Module):
     def _make_state(self, run, B, use_cfg, Tmax, Lc, S, prepend, record_logits, use_sampling, temp, top_k, top_p,
                     cfg_coef, seed, cfg_coef_beta: float = 0.0, cross_lens: tp.Optional[torch.Tensor] = None) -> _C.LMState:
         st = _C.LMState()
+        st.rope_first = st.rope_shift = 0
         st.cfg_coef_beta = float(cfg_coef_beta)
         if cross_lens is not None:   # per-row cross-attention length (two_step_cfg)
             run['cross_len_rows'].copy_(cross_lens.to(torch.int32))
@@ -534,6 +592,7 @@ class LMModel(nn.Module):
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
 
         # ---- prefill: prepended condition rows and prompt steps, PREFILL_CHUNK positions per call, no sampling
+        self._set_first_call(state, P + start_offset_sequence)
         self._prefill(desc, state, P + start_offset_sequence - 1)
 
         # ---- decode: one hipGraph replay per position
@@ -584,6 +643,14 @@ class LMModel(nn.Module):
         return g
 
     PREFILL_CHUNK = 8   # consecutive positions per prefill call (activation buffers hold Beff * PREFILL_CHUNK rows)
+
+    def _set_first_call(self, state, n_first: int):
+        """The reference's first streaming forward covers `n_first` positions at once; with rotary positions AND a
+        past_context shorter than that, its later positions lag by the keys that call dropped (acmi_lm_state.rope_first /
+        rope_shift; oracle/lm.py, transformer_forward)."""
+        state.rope_first, state.rope_shift = 0, 0
+        if self.past_context and self.positional_embedding != 'sin' and n_first > self.past_context:
+            state.rope_first, state.rope_shift = int(n_first), int(n_first - self.past_context)
 
     def _prefill(self, desc, state, n_positions: int):
         """Run `n_positions` input-only positions (prepended conditions, prompt tokens): the same kernels as a
@@ -642,6 +709,7 @@ class LMModel(nn.Module):
         st = getattr(self, '_stream', None)
         if st is None:
             st = self._stream_begin(B, condition_tensors)
+            self._set_first_call(st['state'], st['P'] + S)   # the first call's length fixes the rotary offsets
         assert st['B'] == B, "the batch size of a stream cannot change"
         assert st['steps'] + S <= self.streaming_capacity, "stream longer than LMModel.streaming_capacity"
         run, off = st['run'], st['steps']

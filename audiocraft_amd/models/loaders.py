@@ -73,6 +73,9 @@ def parse_cfg(text_or_dict) -> dict:
     return _resolve(cfg)
 
 
+TRANSFORMER_OPTIONS = ('positional_embedding', 'xpos', 'past_context', 'layer_scale', 'positional_scale', 'max_period')
+
+
 def lm_cfg_from_xp(cfg: dict) -> dict:
     """`xp.cfg` of a MusicGen checkpoint -> builders.get_lm_model cfg (reference builders.py:136-175)."""
     t = dict(cfg['transformer_lm'])
@@ -80,6 +83,9 @@ def lm_cfg_from_xp(cfg: dict) -> dict:
                hidden_scale=t.get('hidden_scale', 4), n_q=t.get('n_q', 4), card=t.get('card', 2048),
                codebooks_pattern=cfg.get('codebooks_pattern'),
                cfg_coef=cfg.get('classifier_free_guidance', {}).get('inference_coef', 3.0))
+    for k in TRANSFORMER_OPTIONS:   # transformer options no release sets away from config/model/lm/default.yaml:25-33
+        if t.get(k) is not None:
+            out[k] = t[k]
     conds = {}
     for name, c in (cfg.get('conditioners') or {}).items():
         # `conditioners.args` (merge_text_conditions_p, drop_desc_p) is not a conditioner: the reference pops it

@@ -178,6 +178,16 @@ typedef struct {
     const void* w_head;             /* linears.{k}.weight stacked [n_q * card, d] x diag(out_norm.weight), tiled */
     const float* b_head;            /* [n_q * card] = W_head out_norm.bias (+ head biases) */
     const float* cs_head;           /* [n_q * card] column sums of w_head (see acmi_lm_layer.cs_*), or NULL */
+    /* Rotary positions on the self-attention q / k (modules/rope.py:75-114, transformer.py:300-313, 394-395;
+     * positional_embedding 'rope' | 'sin_rope' -- for 'rope' alone pass positional_scale = 0 so that no sinusoidal
+     * embedding is added): pair i = features (2i, 2i+1) of a head, as a complex number, times
+     *     (e^{i pos f_i} * decay_i(pos)) * rope_scale + (1 - rope_scale),   decay_i(pos) = rope_decay[i]^(pos / rope_base)
+     * (xPos, inverted for keys), applied by the QKV launch before q goes to the attention and k to the cache.
+     * rope_freq NULL = off; rope_decay NULL = no xPos. */
+    const float* rope_freq;         /* [hd / 2] f32: max_period^(-2i / hd) */
+    const float* rope_decay;        /* [hd / 2] f32: (i / (hd/2) + 0.4) / 1.4, or NULL */
+    float rope_scale, rope_base;    /* RotaryEmbedding.scale (the transformer's positional_scale); XPos.base_scale (512) */
+    int past_context;               /* self-attention sees keys p - past_context .. p (transformer.py:249-264, 286-293); <= 0: all */
 } acmi_lm_model;
 
 typedef struct {
@@ -221,6 +231,11 @@ typedef struct {
                                caches hold Lc positions per row, the tail of a shorter row is never read).  Lets the
                                conditional and the unconditional pass of two_step_cfg keep their own padded lengths
                                (the reference runs them as two forwards with separate streaming states) */
+    /* Rotary position of stream position p: p for p < rope_first, p - rope_shift afterwards.  rope_first = length of
+     * the FIRST streaming call of the reference (prepended rows + prompt steps), rope_shift = max(0, rope_first -
+     * past_context): the reference's dropped-keys counter starts at 0 after that call (transformer.py:294-297), so
+     * its later rotary positions lag by the keys the first call dropped.  0 / 0 = positions as they are. */
+    int rope_first, rope_shift;
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0
@@ -354,6 +369,7 @@ typedef struct {
     const float* q_colsum; const float* q_bias;
     const int* len_rows;    /* device int[cache_rows] or NULL: per-cache-row length (overrides len / len_dev; `len` must
                                still be given: it sizes the launch and bounds every row's length) */
+    int past_context;       /* > 0: only the last past_context + 1 positions of the row's length are attended to */
 } acmi_attn_desc;
 int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 

@@ -552,6 +552,24 @@ def test_sample_double_cfg_mix_bit_exact(C):
     assert torch.equal(toks.cpu(), ref.argmax(-1))
 
 
+@pytest.mark.parametrize('kvdt', [torch.float32, torch.bfloat16])
+def test_attention_past_context_window(C, kvdt):
+    """acmi_attn_desc.past_context: only the last past_context + 1 positions are attended to (transformer.py:249-264)."""
+    g = torch.Generator().manual_seed(5)
+    Beff, H, hd, Tcap = 3, 4, 64, 700
+    k = torch.randn(Beff, H, Tcap, hd, generator=g).to(kvdt)
+    v = torch.randn(Beff, H, Tcap, hd, generator=g).to(kvdt)
+    q = torch.randn(Beff, H * hd, generator=g)
+    for length, pc in ((650, 100), (650, 7), (5, 100), (300, 299), (513, 256)):
+        out = torch.empty(Beff, H * hd, device='cuda')
+        C.attn_decode(q.cuda(), k.cuda(), v.cuda(), out, length, past_context=pc)
+        lo = max(0, length - 1 - pc)
+        kk, vv = k[:, :, lo:length].float(), v[:, :, lo:length].float()
+        w = torch.softmax(torch.einsum('bhd,bhtd->bht', q.view(Beff, H, hd), kk) / math.sqrt(hd), dim=-1)
+        ref = torch.einsum('bht,bhtd->bhd', w, vv).reshape(Beff, H * hd)
+        assert rel(out.cpu(), ref) < 2e-6, (length, pc, rel(out.cpu(), ref))
+
+
 def test_attention_per_row_lengths(C):
     """len_rows: every cache row attends over its own number of positions (two_step_cfg: the conditional and the
     unconditional pass keep their own condition length inside one launch)."""

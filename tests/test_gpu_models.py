@@ -145,7 +145,9 @@ def build_lm(cfg, sd, weight_dtype=torch.float32):
     lm = builders.get_lm_model(dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'],
                                     n_q=cfg['n_q'], card=cfg['card'], hidden_scale=cfg['hidden_scale'],
                                     cfg_coef=cfg['cfg_coef'], conditioners=conds, fuser=fuser,
-                                    codebooks_pattern={'modeling': 'delay', 'delay': {'delays': cfg['delays']}}),
+                                    codebooks_pattern={'modeling': 'delay', 'delay': {'delays': cfg['delays']}},
+                                    **{k: cfg[k] for k in ('positional_embedding', 'xpos', 'past_context', 'layer_scale',
+                                                           'positional_scale') if k in cfg}),
                                'cuda', weight_dtype)
     missing = lm.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys, missing.unexpected_keys
@@ -177,6 +179,36 @@ def test_lm_text_vs_reference_golden():
     # graph replay and eager launches agree bit for bit
     t1 = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct, use_graph=False)
     assert torch.equal(t1.cpu(), a['greedy_tokens'])
+
+
+@pytest.mark.parametrize('name', ['lm_rope', 'lm_sin_rope'])
+def test_lm_rope_past_context_layer_scale_vs_reference_golden(name):
+    """Rotary positions (+ xPos decay) applied by the QKV launch, the bounded receptive field of the attention kernel
+    and LayerScale folded into the branch matrices, against goldens from the unmodified reference (custom attention:
+    tests/golden/make_rope_golden.py); lm_rope's 9-step prompt exceeds past_context = 6, which exercises the windowed
+    multi-position prefill and the reference's lagging rotary positions after a long first call (acmi_lm_state.rope_shift)."""
+    cfg, sd, a = load_golden(name)
+    lm = build_lm(cfg, sd)
+    assert lm.positional_embedding == cfg['positional_embedding'] and lm.past_context == cfg.get('past_context')
+    ones = torch.ones(a['cross_src'].shape[:2], dtype=torch.int64)
+    ct = {'description': (a['cross_src'].cuda(), ones.cuda())}
+    logits = lm.forward_steps(a['tf_sequence'].cuda(), ct).cpu()
+    r = rel(logits, a['tf_logits'])
+    assert r < 1e-4, f"teacher-forced logits rel-L2 {r}"
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=14, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
+    toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=14, use_sampling=False, condition_tensors=ct, check=True)
+    assert torch.equal(toks.cpu(), a['cont_tokens'])
+    # the streaming protocol: one multi-step first call, then single steps == the reference's first-call logits
+    with lm.streaming():
+        first = lm(torch.cat([a['prompt'], a['prompt']]).cuda()[..., :1], [], ct)
+        assert first.shape[:3] == (6, cfg['n_q'], 1)
+    # bf16 weights / caches run the same path
+    lm16 = build_lm(cfg, sd, torch.bfloat16)
+    l16 = lm16.forward_steps(a['tf_sequence'].cuda(), ct).cpu()
+    assert rel(l16, a['tf_logits']) < 3e-2
 
 
 def test_lm_melody_vs_reference_golden():
