@@ -290,6 +290,15 @@ def _spawn_ranks(n: int) -> int:
     return max(abs(rc) for rc in rcs)
 
 
+def config_tag(args) -> str:
+    """Which BASELINE.json configuration the command line is (the default: configs[2], the one `metric` is quoted on)."""
+    key = (args.model.split('/')[-1], args.batch, int(args.duration), bool(args.greedy))
+    return {('musicgen-medium', 8, 30, False): 'BASELINE.json configs[2]',
+            ('musicgen-small', 1, 10, True): 'BASELINE.json configs[1]',
+            ('musicgen-large', 8, 30, False): "BASELINE.json configs[3], one GPU's shard of 8 prompts",
+            ('musicgen-melody', 16, 30, False): 'BASELINE.json configs[4]'}.get(key, 'not a BASELINE.json configuration')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -300,6 +309,7 @@ def main():
     ap.add_argument('--duration', type=float, default=30.0)
     ap.add_argument('--top-k', type=int, default=250)
     ap.add_argument('--text-len', type=int, default=16)
+    ap.add_argument('--greedy', action='store_true', help='argmax decoding (BASELINE.json configs[1])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -316,7 +326,7 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     model = MusicGen.get_random_init(args.model, dev, torch.bfloat16, text_len=args.text_len, seed=0)
-    model.set_generation_params(use_sampling=True, top_k=args.top_k, duration=args.duration)
+    model.set_generation_params(use_sampling=not args.greedy, top_k=args.top_k, duration=args.duration)
     B = args.batch
     B_global = B * world
     T = int(args.duration * model.frame_rate)
@@ -360,8 +370,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, synthetic T5 stand-in)",
         "config": {"workload": f"{args.model} bf16, batch {B} prompts x {args.duration:.0f} s per GPU, CFG, "
-                               f"top-k {args.top_k}, {T + 3} AR positions + EnCodec-32k decode "
-                               "(BASELINE.json configs[2])",
+                               f"{'greedy' if args.greedy else f'top-k {args.top_k}'}, {T + 3} AR positions + EnCodec-32k decode "
+                               f"({config_tag(args)})",
                    "global_batch": B_global, "seq_len": T, "parallelism": f"dp{world} (prompt sharding)"},
     }
     if rank == 0:
@@ -379,7 +389,9 @@ def main():
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
             out["roofline"] = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_per_launch(),
+                               "frac": round(ach / HBM_PEAK_GBS, 4),
+                               # the committed PMC passes are of the configs[2] chain (MusicGen-medium, 16 rows)
+                               "traffic": pmc_traffic_per_launch() if config_tag(args).endswith('configs[2]') else None,
                                "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(r['avg_us'], 3),
                                "launches_per_position": r['launches_per_position']}
         if world == 1 and not args.no_cpu_baseline:
