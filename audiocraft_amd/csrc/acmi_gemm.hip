@@ -571,25 +571,6 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
                     if (p.residual) v += first ? ex.res : p.residual[oi];
                 }
             }
-            if (p.qkv && p.rope_freq != nullptr) {
-                // rotary positions (include/acmi.h, acmi_lm_model.rope_freq): features (2i, 2i+1) of a head are one complex
-                // number; the partner sits in the neighbouring lane (DPP, executed by every lane)
-                const float pv = dpp_f32<0xB1>(v);
-                const int rpart = gn / p.d, rf = gn - rpart * p.d, rdd = rf - (rf / p.hd) * p.hd, ri = rdd >> 1;
-                if (valid && rpart < 2) {
-                    int pos = ex.tpos + gm / p.rpp;
-                    if (pos >= p.rope_first) pos -= p.rope_shift;
-                    float sn, cs;
-                    sincosf((float)pos * p.rope_freq[ri], &sn, &cs);
-                    float dc = 1.0f;
-                    if (p.rope_decay != nullptr) {
-                        dc = powf(p.rope_decay[ri], (float)pos / p.rope_base);
-                        if (rpart == 1) dc = 1.0f / dc;        // keys: inverted decay
-                    }
-                    const float re = cs * dc * p.rope_scale + (1.0f - p.rope_scale), im = sn * dc * p.rope_scale;
-                    v = (rdd & 1) ? pv * im + v * re : v * re - pv * im;
-                }
-            }
             if (p.stats_out != nullptr) {
                 // (mean, M2) of this workgroup's 16 output features per row, for the LayerNorm of the consumer
                 // (HT: of its 8 features; lanes 8-15 of a row hold nothing and stay out of lanes 0-7's sums)

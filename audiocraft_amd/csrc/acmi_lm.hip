@@ -415,6 +415,53 @@ static bool fold_uses_lo() {  // experiment switch: ACMI_LN_LO=0 drops the low p
 }
 
 // ---- the step's GEMM chain ---------------------------------------------------------------------------
+// Rotary positions (include/acmi.h, acmi_lm_model.rope_freq; rope.py:75-114) as a launch of their own after the QKV GEMM:
+// one thread per complex pair (features 2i, 2i+1 of a head) rotates q in place and the k row the GEMM has just appended
+// to the cache.  Inside the GEMM's epilogue the same code cost EVERY variant of the kernel ~20 spilled SGPRs (six more
+// kernel arguments, the sincosf / powf bodies) and the non-rotary decode step 3.4 % -- no released model uses rotary
+// positions, so they pay for themselves here (one more launch per layer).  With a bf16 cache k is rounded twice (by the
+// GEMM's store and by this one); exact in f32 parity mode.
+struct RopeArgs {
+    float* q; void* kc; int kv_bf16; int H, hd, Tcap, d, rpp; const int* pos;
+    const float* freq; const float* decay; float scale, base; int first, shift;
+};
+
+__global__ __launch_bounds__(1024) void rope_qk_kernel(const RopeArgs p) {
+    const int gm = blockIdx.x, pi = threadIdx.x, half = p.hd >> 1;
+    const int h = pi / half, i = pi - h * half;
+    const int pidx = gm / p.rpp, brow = gm - pidx * p.rpp;      // several positions per call (prefill)
+    const int tpos = *p.pos + pidx;
+    const int rp = tpos >= p.first ? tpos - p.shift : tpos;     // rotary position (acmi_lm_state.rope_first / rope_shift)
+    float sn, cs;
+    sincosf((float)rp * p.freq[i], &sn, &cs);
+    float dq = 1.0f, dk = 1.0f;
+    if (p.decay != nullptr) {
+        dq = powf(p.decay[i], (float)rp / p.base);
+        dk = 1.0f / dq;                                         // keys: inverted decay (rope.py:111-114)
+    }
+    const float one_m = 1.0f - p.scale;
+    {   // q
+        float* qp = p.q + (size_t)gm * p.d + h * p.hd + 2 * i;
+        const float re = cs * dq * p.scale + one_m, im = sn * dq * p.scale;
+        const float a = qp[0], b = qp[1];
+        qp[0] = a * re - b * im;
+        qp[1] = a * im + b * re;
+    }
+    const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + tpos) * p.hd + 2 * i;
+    const float re = cs * dk * p.scale + one_m, im = sn * dk * p.scale;
+    if (p.kv_bf16) {
+        bf16_t* kp = reinterpret_cast<bf16_t*>(p.kc) + ci;
+        const float a = bf16_to_f32(kp[0]), b = bf16_to_f32(kp[1]);
+        kp[0] = f32_to_bf16(a * re - b * im);
+        kp[1] = f32_to_bf16(a * im + b * re);
+    } else {
+        float* kp = reinterpret_cast<float*>(p.kc) + ci;
+        const float a = kp[0], b = kp[1];
+        kp[0] = a * re - b * im;
+        kp[1] = a * im + b * re;
+    }
+}
+
 // The residual stream x lives in four forms (include/acmi.h, acmi_lm_state): f32 row-major `x`, raw fragments
 // xh / xl (hi / lo) and the statistics partials.  StepCtx tracks which fragment buffers currently hold x.
 struct StepCtx {
@@ -513,12 +560,18 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             LinArgs a = {};
             a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
             a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
-            a.rope_freq = m->rope_freq; a.rope_decay = m->rope_decay; a.rope_scale = m->rope_scale; a.rope_base = m->rope_base;
-            a.rope_first = s->rope_first > 0 ? s->rope_first : 0x7fffffff; a.rope_shift = s->rope_shift;
             if (pair) {   // + the x0 part of the cross-attention query as a fourth, raw block of features -> r
                 a.r_out = s->r;
                 if ((rc = gemm_ln_x(c, a, L.w_qkvx, L.b_qkvx, L.cs_qkvx, 4 * d))) return rc;
             } else if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
+            if (m->rope_freq != nullptr) {   // rotary positions on the new q / k rows (rotary models only)
+                RopeArgs ra = {};
+                ra.q = s->q; ra.kc = L.k_cache; ra.kv_bf16 = kvbf; ra.H = H; ra.hd = hd; ra.Tcap = s->Tmax; ra.d = d; ra.rpp = s->Beff;
+                ra.pos = s->pos; ra.freq = m->rope_freq; ra.decay = m->rope_decay; ra.scale = m->rope_scale; ra.base = m->rope_base;
+                ra.first = s->rope_first > 0 ? s->rope_first : 0x7fffffff; ra.shift = s->rope_shift;
+                hipLaunchKernelGGL(rope_qk_kernel, dim3(M), dim3(d / 2), 0, st, ra);
+                if ((rc = acmi_check_launch("rope_qk_kernel"))) return rc;
+            }
         }
         // self attention over positions [0, g]; output in A-fragment order for the out projection: into `att`,
         // or next to x ([x | att], columns d_pad ..) when the out projection is paired with the cross query

@@ -32,7 +32,6 @@ struct LinArgs {
     int kcs, fpw; // tiled path: K tiles per split-K slice, fragments every wave owns (kcs / waves), set by the launcher
     int qkv;      // QKV scatter epilogue
     float* q_out; void* k_cache; void* v_cache; int kv_bf16; int H, hd, Tcap, d; const int* pos;
-    const float* rope_freq; const float* rope_decay; float rope_scale, rope_base; int rope_first, rope_shift;  // QKV: rotary q / k
     int w_half;   // the weight is in half-tile order (8 features x 2 K tiles per 1 KB unit): 8-feature workgroups
     float* r_out; // QKV scatter with N = 4d: the fourth block of features is stored raw (no LayerNorm epilogue) to r_out [M, d]
     int rpp;      // QKV scatter: rows per position (row gm = position gm / rpp of the call, cache row gm % rpp)

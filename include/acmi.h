@@ -182,7 +182,8 @@ typedef struct {
      * positional_embedding 'rope' | 'sin_rope' -- for 'rope' alone pass positional_scale = 0 so that no sinusoidal
      * embedding is added): pair i = features (2i, 2i+1) of a head, as a complex number, times
      *     (e^{i pos f_i} * decay_i(pos)) * rope_scale + (1 - rope_scale),   decay_i(pos) = rope_decay[i]^(pos / rope_base)
-     * (xPos, inverted for keys), applied by the QKV launch before q goes to the attention and k to the cache.
+     * (xPos, inverted for keys), applied to the q rows and the freshly appended k rows by a launch of its own right after
+     * the QKV GEMM (with a bf16 cache k is therefore rounded twice; exact with an f32 cache).
      * rope_freq NULL = off; rope_decay NULL = no xPos. */
     const float* rope_freq;         /* [hd / 2] f32: max_period^(-2i / hd) */
     const float* rope_decay;        /* [hd / 2] f32: (i / (hd/2) + 0.4) / 1.4, or NULL */
