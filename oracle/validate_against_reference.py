@@ -76,14 +76,16 @@ class _Chroma(WaveformConditioner):
         return torch.where((x.length == 0).view(-1, 1, 1), torch.zeros_like(e), e)
 
 
-def _build_lm(dim, heads, layers, n_q, card, delays, conditioners, fuse, seed):
+def _build_lm(dim, heads, layers, n_q, card, delays, conditioners, fuse, seed, **extra):
     torch.manual_seed(seed)
+    if extra:   # rotary positions / past_context: the custom attention (see tests/golden/make_rope_golden.py for why)
+        extra = dict(dict(custom=True, memory_efficient=False), **extra)
     lm = LMModel(DelayedPatternProvider(n_q, delays=delays), ConditioningProvider(conditioners), ConditionFuser(fuse),
                  n_q=n_q, card=card, dim=dim, num_heads=heads, hidden_scale=4, norm='layer_norm', norm_first=True,
                  bias_proj=False, weight_init='gaussian', depthwise_init='current', zero_bias_init=True, cfg_coef=3.0,
                  num_layers=layers, dropout=0., activation='gelu', bias_ff=False, bias_attn=False, causal=True,
-                 custom=False, memory_efficient=True, attention_as_float32=False,
-                 cross_attention=bool(fuse['cross']), positional_embedding='sin').eval()
+                 attention_as_float32=False, cross_attention=bool(fuse['cross']),
+                 **dict(dict(custom=False, memory_efficient=True, positional_embedding='sin'), **extra)).eval()
     with torch.no_grad():
         for k, p in lm.named_parameters():
             if '.norm' in k or k.startswith('out_norm'):
@@ -128,6 +130,33 @@ def check_lm():
                           null_cross_src=n1['description'][0])
     assert torch.equal(toks2, otoks2)
     print(f"lm      ok: batch forward rel-L2 {r:.1e}, greedy tokens identical (plain + two_step_cfg), step logits rel-L2 {r2:.1e}")
+
+
+def check_rope():
+    """Rotary positions + xPos + past_context + LayerScale at d 256 / 8 heads / 4 layers, window 20 against 60 positions
+    and a 30-step prompt (longer than the window: the reference's lagging rotary positions after a long first call)."""
+    fuse = {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []}
+    for extra in (dict(positional_embedding='rope', xpos=True, past_context=20, layer_scale=0.2, positional_scale=0.9),
+                  dict(positional_embedding='sin_rope', past_context=33),
+                  dict(positional_embedding='rope')):
+        lm = _build_lm(256, 8, 4, 4, 2048, [0, 1, 2, 3], {'description': _Text(64, 256, 7)}, fuse, seed=21, **extra)
+        sd = {k: v.detach() for k, v in lm.state_dict().items()}
+        oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True,
+                          **{k: v for k, v in extra.items() if k != 'layer_scale'})
+        conds = [ConditioningAttributes(text={'description': f't{i}'}) for i in range(2)]
+        null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+        ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+        seq = torch.randint(0, 2049, (4, 4, 60), generator=torch.Generator().manual_seed(3))
+        with torch.no_grad():
+            ref = lm(seq, [], ct)
+        r = rel(olm.lm_forward(sd, oc, seq, ct['description'][0]), ref)
+        assert r < 1e-5, (extra, r)
+        toks = lm.generate(None, conds, max_gen_len=40, use_sampling=False)
+        assert torch.equal(toks, olm.generate(sd, oc, None, 2, ct['description'][0], max_gen_len=40, use_sampling=False))
+        prompt = torch.randint(0, 2048, (2, 4, 30), generator=torch.Generator().manual_seed(4))
+        toks = lm.generate(prompt, conds, max_gen_len=44, use_sampling=False)
+        assert torch.equal(toks, olm.generate(sd, oc, prompt, 2, ct['description'][0], max_gen_len=44, use_sampling=False)), extra
+    print(f"rope    ok: full forward rel-L2 {r:.1e}, greedy + continuation tokens identical (rope+xpos+window+LayerScale, sin_rope+window, rope)")
 
 
 def check_melody():
@@ -201,7 +230,7 @@ def check_codec():
     print(f"codec   ok: latents rel-L2 {rel(olat, lat):.1e}, codes bit exact, waveform max abs {(odec - dec).abs().max().item():.1e}")
 
 
-CHECKS = {'lm': check_lm, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
+CHECKS = {'lm': check_lm, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
