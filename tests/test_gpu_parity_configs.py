@@ -103,6 +103,37 @@ def test_medium_bf16_cfg16_teacher_forced():
     assert worst < 2 * BF16_TOL, f"worst row rel-L2 {worst}"
 
 
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 1e-4), (torch.bfloat16, BF16_TOL)])
+def test_rotary_window_small_geometry_vs_oracle(wdt, tol):
+    """Rotary positions + xPos, past_context and LayerScale at the MusicGen-small geometry (d 1024 / 16 heads of 64; 6
+    layers keep the oracle cheap): 96 teacher-forced positions against a window of 40 -- the attention kernel's start
+    offset crosses several of its 64-position chunks --, rows of 5, f32 and bf16 (bf16 cache: k is rounded twice, by the
+    GEMM's store and by the rotary launch)."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(0)
+    cfg = dict(builders.musicgen_lm_cfg('small', text_len=12), num_layers=6, positional_embedding='rope', xpos=True,
+               past_context=40, layer_scale=0.25, positional_scale=0.9)
+    lm = builders.get_lm_model(cfg, 'cuda', wdt)
+    _perturb_norms(lm)
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            if 'layer_scale' in k:
+                p.mul_(1.0 + 0.5 * torch.rand_like(p))
+    sd = _oracle_sd(lm, wdt == torch.bfloat16)
+    assert any('layer_scale_cross' in k for k in sd) and 'transformer.rope.frequencies' in sd
+    oc = olm.LMConfig(dim=1024, num_heads=16, num_layers=6, n_q=4, card=2048, cross_attention=True,
+                      positional_embedding='rope', xpos=True, past_context=40, positional_scale=0.9)
+    Beff, S = 5, 96
+    cross = torch.randn(Beff, 12, 1024, generator=torch.Generator().manual_seed(21))
+    ct = {'description': (cross.cuda(), torch.ones(Beff, 12, dtype=torch.int64).cuda())}
+    seq = torch.randint(0, 2049, (Beff, 4, S), generator=torch.Generator().manual_seed(22))
+    got = lm.forward_steps(seq.cuda(), ct).cpu()
+    ref = olm.lm_forward(sd, oc, seq, cross)
+    r, r_last = rel(got, ref), rel(got[:, :, -8:], ref[:, :, -8:])
+    print(f"[parity] rotary + window, small geometry, {wdt}: logits rel-L2 {r:.3e} (last 8 positions {r_last:.3e})")
+    assert r < tol and r_last < tol, (r, r_last)
+
+
 def test_medium_bf16_late_context_prefill_then_decode():
     """1400-token prompt for 8 samples (16 CFG rows) through the 8-positions-per-call prefill (128 rows per GEMM
     launch: 4 row blocks x 2 row groups, per-row positions in the QKV scatter and the attention), then 11 decode
