@@ -12,14 +12,21 @@ Checks (each prints a line and the script exits non-zero on the first failure):
   stereo   8 codebooks with delays [0,0,1,1,2,2,3,3]
   codec    EncodecModel at the 32 kHz geometry with n_filters 16 (all layers, LSTM, RVQ 4 x 2048) on 0.7 s of audio:
            latents, codes (bit exact on the reference's own latents), decoded waveform
+  epic     configs[0]: the reference EncodecModel at the full EnCodec-24 kHz geometry on assets/epic.wav (32 RVQ levels)
   chroma   oracle.chroma against the reference ChromaExtractor arithmetic is NOT possible here: torchaudio / librosa are
            third-party and absent -- see oracle/chroma.py for how that row is pinned instead.
 """
+import os
 import sys
 
 import torch
 
-from . import refstubs  # noqa: F401  (installs the import stubs; afterwards the reference imports)
+if __package__ in (None, ''):   # `python oracle/validate_against_reference.py`: make the relative imports below resolve
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    __package__ = 'oracle'
+    import oracle  # noqa: F401
+
+from . import refstubs  # noqa: F401,E402  (installs the import stubs; afterwards the reference imports)
 
 if not refstubs.available():   # pragma: no cover
     print("validate_against_reference: /root/reference not present, nothing to do")
@@ -230,7 +237,42 @@ def check_codec():
     print(f"codec   ok: latents rel-L2 {rel(olat, lat):.1e}, codes bit exact, waveform max abs {(odec - dec).abs().max().item():.1e}")
 
 
-CHECKS = {'lm': check_lm, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
+def check_epic():
+    """BASELINE.json configs[0] on real audio: the reference's assets/epic.wav (read with scipy; SURVEY.md section 8c iii)
+    through the REFERENCE EncodecModel at the full EnCodec-24 kHz geometry (causal, n_filters 32, ratios [8,5,4,2], RVQ
+    32 x 1024) vs the oracle: latents, all 32 levels of codes on the reference's own latents (bit exact), and end to end."""
+    from scipy.io import wavfile
+    sr, x = wavfile.read('/root/reference/assets/epic.wav')
+    wav = torch.from_numpy(x).view(1, 1, -1)
+    torch.manual_seed(7)
+    kw = dict(channels=1, dimension=128, n_filters=32, n_residual_layers=1, ratios=[8, 5, 4, 2], activation='ELU',
+              activation_params={'alpha': 1.}, norm='weight_norm', norm_params={}, kernel_size=7, residual_kernel_size=3,
+              last_kernel_size=7, dilation_base=2, causal=True, pad_mode='constant', true_skip=True, compress=2, lstm=2,
+              disable_norm_outer_blocks=0)
+    m = EncodecModel(SEANetEncoder(**kw), SEANetDecoder(**kw, trim_right_ratio=1.0),
+                     ResidualVectorQuantizer(dimension=128, n_q=32, bins=1024, kmeans_init=False),
+                     frame_rate=75, sample_rate=24000, channels=1, causal=True).eval()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    c = ocodec.CodecConfig(channels=1, dimension=128, n_filters=32, n_residual_layers=1, ratios=[8, 5, 4, 2],
+                           causal=True, pad_mode='constant', lstm=2, norm='weight_norm', n_q=32, bins=1024,
+                           sample_rate=24000, frame_rate=75)
+    with torch.no_grad():
+        lat = m.encoder(wav)
+        codes, _ = m.encode(wav)
+        dec = m.decode(codes)
+    olat = ocodec.seanet_encoder(sd, c, wav)
+    assert codes.shape == (1, 32, 300) and rel(olat, lat) < 1e-5
+    cb = ocodec.codebooks_from_state(sd, 32)
+    assert torch.equal(ocodec.rvq_encode(lat, cb), codes)
+    ocodes = ocodec.rvq_encode(olat, cb)
+    odec = ocodec.encodec_decode(sd, c, codes)
+    assert (odec - dec).abs().max().item() < 2e-5
+    print(f"epic    ok: EnCodec-24k geometry on assets/epic.wav: latents rel-L2 {rel(olat, lat):.1e}, 32 x 300 codes bit exact "
+          f"on the reference's latents (end to end {float((ocodes == codes).float().mean()):.4f} equal), waveform max abs "
+          f"{(odec - dec).abs().max().item():.1e}")
+
+
+CHECKS = {'epic': check_epic, 'lm': check_lm, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 from conftest import load_golden  # noqa: E402
 from oracle import codec as ocodec  # noqa: E402
 from oracle import lm as olm  # noqa: E402
+from parity_utils import assert_codes_near_tie  # noqa: E402
 from test_oracle_golden import codec_cfg, lm_cfg  # noqa: E402
 
 
@@ -53,10 +54,11 @@ def test_encodec_vs_reference_golden(name):
     # hard gate: RVQ on the reference's own latents is bit exact
     codes = m.quantizer.encode(a['latents'].cuda()).cpu()
     assert torch.equal(codes, a['codes'])
-    # end to end encode: report agreement (a flip needs a near-tie in the oracle)
+    # end to end encode: every index that differs from the reference's must be a near tie that the fp32 round-off of the
+    # latents can flip, per RVQ level (parity_utils.assert_codes_near_tie)
     codes2, scale = m.encode(wav)
-    agree = (codes2.cpu() == a['codes']).float().mean().item()
-    assert agree > 0.97, f"end-to-end code agreement {agree}"
+    assert_codes_near_tie(codes2, a['codes'], lat, a['latents'], ocodec.codebooks_from_state(sd, cfg['n_q']),
+                          what=f'golden {name}')
     assert torch.equal(m.decode_latent(a['codes'].cuda()).cpu(), a['quantized_latents'])
     dec = m.decode(a['codes'].cuda(), None if 'scale' not in a else a['scale'].cuda()).cpu()
     assert dec.shape == a['decoded'].shape
@@ -83,7 +85,7 @@ def test_encodec_32khz_geometry_vs_oracle():
     codes_ref = ocodec.rvq_encode(lat_ref, ocodec.codebooks_from_state(sd, 4))
     assert torch.equal(m.quantizer.encode(lat_ref.cuda()).cpu(), codes_ref)   # identical latents: bit exact
     codes, _ = m.encode(wav.cuda())
-    assert (codes.cpu() == codes_ref).float().mean() > 0.97
+    assert_codes_near_tie(codes, codes_ref, lat, lat_ref, ocodec.codebooks_from_state(sd, 4), what='EnCodec-32k geometry')
     dec_ref = ocodec.encodec_decode(sd, c, codes_ref, fast_lstm=True)
     dec = m.decode(codes_ref.cuda()).cpu()
     assert dec.shape == dec_ref.shape
@@ -112,10 +114,42 @@ def test_encodec_24khz_geometry_config1():
     assert torch.equal(m.quantizer.encode(lat_ref.cuda()).cpu(), codes_ref)   # identical latents: bit exact
     codes, scale = m.encode(wav.cuda())
     assert scale is None and codes.shape == (1, 32, 750)
-    assert (codes[:, 0].cpu() == codes_ref[:, 0]).float().mean() > 0.97   # latents differ by fp32 round-off only
+    # all 32 levels: a differing index must be a near tie of the oracle's decision (latents differ by fp32 round-off only)
+    assert_codes_near_tie(codes, codes_ref, lat, lat_ref, ocodec.codebooks_from_state(sd, 32), what='configs[0] randn input')
     dec_ref = ocodec.encodec_decode(sd, c, codes_ref, fast_lstm=True)
     dec = m.decode(codes_ref.cuda()).cpu()
     assert dec.shape == dec_ref.shape == (1, 1, 240000)
+    assert (dec - dec_ref).abs().max().item() < 1e-4
+
+
+def test_encodec_24khz_geometry_on_reference_asset():
+    """configs[0] on real audio (SURVEY.md section 8c iii): the 3 s of the reference's assets/epic.wav (32 kHz mono f32,
+    committed as tests/golden/epic_wav.npz by make_epic_fixture.py; taken as raw samples at the model rate -- content, not
+    pitch, matters for a codes gate) through the EnCodec-24 kHz geometry.  Codes [1, 32, 300]: bit exact on identical
+    latents, and end to end every differing index is a near tie (per RVQ level); waveform <= 1e-4."""
+    import os
+    import numpy as np
+    from audiocraft_amd.models import builders
+    from conftest import GOLDEN
+    wav = torch.from_numpy(np.load(os.path.join(GOLDEN, 'epic_wav.npz'))['wav']).view(1, 1, -1)
+    assert wav.shape[-1] == 96000 and 0.5 < float(wav.abs().max()) < 1.0
+    torch.manual_seed(0)
+    m = builders.get_compression_model(builders.ENCODEC_24KHZ, 'cuda')
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    c = ocodec.CodecConfig(channels=1, dimension=128, n_filters=32, n_residual_layers=1, ratios=[8, 5, 4, 2],
+                           causal=True, pad_mode='constant', lstm=2, norm='weight_norm', n_q=32, bins=1024,
+                           sample_rate=24000, frame_rate=75)
+    lat_ref = ocodec.seanet_encoder(sd, c, wav, fast_lstm=True)
+    lat = m.encoder(wav.cuda()).cpu()
+    assert lat.shape == lat_ref.shape == (1, 128, 300)
+    assert rel(lat, lat_ref) < 2e-5
+    cb = ocodec.codebooks_from_state(sd, 32)
+    codes_ref = ocodec.rvq_encode(lat_ref, cb)
+    assert torch.equal(m.quantizer.encode(lat_ref.cuda()).cpu(), codes_ref)   # identical latents: bit exact, 32 levels
+    codes, _ = m.encode(wav.cuda())
+    assert_codes_near_tie(codes, codes_ref, lat, lat_ref, cb, what='configs[0] epic.wav')
+    dec_ref = ocodec.encodec_decode(sd, c, codes_ref, fast_lstm=True)
+    dec = m.decode(codes_ref.cuda()).cpu()
     assert (dec - dec_ref).abs().max().item() < 1e-4
 
 
@@ -295,9 +329,19 @@ def test_compute_predictions_matches_oracle():
 
 
 def test_musicgen_small_architecture_greedy_parity():
-    """BASELINE.json configs[1] at reduced length: MusicGen-small architecture (d=1024, 24 layers, 16 heads,
-    cross-attention), 1 prompt, greedy, fp32 mode -> tokens identical to the oracle, logits rel-L2 <= 1e-4."""
+    """BASELINE.json configs[1] exactly as SURVEY.md section 8(d) states it: MusicGen-small architecture (d = 1024, 24
+    layers, 16 heads, cross-attention), 1 prompt x 10 s => T = 500, **503 autoregressive steps**, greedy, cfg_coef 3,
+    synthetic text condition of 12 rows, fp32 mode.  Gates: tokens identical to `oracle.lm.generate` (free running),
+    CFG-mixed logits of all 503 steps rel-L2 <= 1e-4.
+
+    A free-running greedy comparison over 2012 arg-max decisions is only well posed where no decision is a near tie, so the
+    test is two-stage: (1) the oracle, teacher-forced with the DEVICE's tokens (one batch forward: batch == streaming),
+    gives logits for every step -- rel-L2 gate, and every device token must be the oracle's arg-max unless the oracle's
+    top-2 gap at that decision is below twice the measured logit error of that step (a near tie, reported); (2) the
+    oracle's own free-running generate must give identical tokens up to the first such near tie (all 500 frames when
+    there is none)."""
     from audiocraft_amd.models import builders
+    from oracle import patterns as opat
     torch.manual_seed(0)
     lm = builders.get_lm_model(builders.musicgen_lm_cfg('small', text_len=12), 'cuda', torch.float32)
     sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
@@ -306,13 +350,39 @@ def test_musicgen_small_architecture_greedy_parity():
     cross = torch.randn(2, 12, 1024, generator=g)
     cross[1:] = 0
     ct = {'description': (cross.cuda(), torch.ones(2, 12, dtype=torch.int64).cuda())}
-    T = 24
+    T = 500
     toks, lg = lm.generate(None, [], num_samples=1, max_gen_len=T, use_sampling=False, condition_tensors=ct,
                            return_logits=True, check=True)
-    ref_t, ref_l = olm.generate(sd, oc, None, 1, cross, max_gen_len=T, use_sampling=False, return_logits=True)
-    assert torch.equal(toks.cpu(), ref_t)
-    r = rel(lg.cpu(), ref_l)
+    toks, lg = toks.cpu(), lg.cpu()                     # [1, 4, 500], [1, 4, 503, 2048]
+    assert lg.shape[2] == T + 3
+    # (1) teacher-forced oracle on the device's tokens
+    seq, mask = opat.build_pattern_sequence(toks, 2048)                # [1, 4, 504]; step s is predicted by output s - 1
+    S = seq.shape[-1]
+    pair = torch.cat([seq, seq], dim=0)[..., :S - 1]
+    ref = olm.cfg_mix(olm.lm_forward(sd, oc, pair, cross), 3.0)        # [1, 4, 503, 2048]
+    r = rel(lg, ref)
+    print(f"[parity] configs[1] small fp32, 503 steps: CFG logits rel-L2 {r:.3e}")
     assert r < 1e-4, f"logits rel-L2 {r}"
+    err = (lg - ref).abs().amax(dim=-1)[0]                               # [4, 503] max abs error per decision
+    top2 = ref[0].topk(2, dim=-1).values                                 # [4, 503, 2]
+    gap = top2[..., 0] - top2[..., 1]
+    dev_arg = lg[0].argmax(dim=-1)
+    ref_arg = ref[0].argmax(dim=-1)
+    valid = mask[:, 1:S]                                                 # decisions that are written back (not special)
+    differ = (dev_arg != ref_arg) & valid
+    near = gap <= 2.0 * err
+    assert not (differ & ~near).any(), "a device token is not the oracle's arg-max and the decision is not a near tie"
+    nv = (near & valid).any(dim=0)                                       # [503]
+    first_tie = int(nv.float().argmax()) if bool(nv.any()) else None
+    print(f"[parity] configs[1]: {int(valid.sum())} arg-max decisions, {int(differ.sum())} differ (all near ties), "
+          f"min top-2 gap {float(gap[valid].min()):.3e}, max logit err {float(err.max()):.3e}, first near tie at step {first_tie}")
+    # (2) free-running oracle
+    ref_t = olm.generate(sd, oc, None, 1, cross, max_gen_len=T, use_sampling=False)
+    if first_tie is None:
+        assert torch.equal(toks, ref_t), "greedy tokens differ from the oracle's free-running generate"
+    else:
+        upto = max(first_tie - 3, 0)          # frames fully decided before the near-tie step (max delay 3)
+        assert torch.equal(toks[..., :upto], ref_t[..., :upto])
 
 
 # ------------------------------------------------------------------------------------------ CFG modes 2 and 3

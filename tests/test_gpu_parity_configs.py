@@ -24,6 +24,7 @@ from conftest import load_golden  # noqa: E402
 from oracle import codec as ocodec  # noqa: E402
 from oracle import lm as olm  # noqa: E402
 from oracle import patterns as opat  # noqa: E402
+from parity_utils import assert_codes_near_tie  # noqa: E402
 
 BF16_TOL = 3e-2
 
@@ -186,6 +187,37 @@ def test_large_bf16_cfg16_teacher_forced():
     assert r < BF16_TOL, f"teacher-forced logits rel-L2 {r}"
 
 
+def test_large_bf16_late_context_prefill_then_decode():
+    """MusicGen-large (d 2048 / 48 layers / 32 heads) at late context: a 1000-token prompt for 4 samples (8 CFG rows)
+    through the prefill, then 11 decode positions at t ~ 1000 with bf16 weights + bf16 KV.  Oracle: batch forward of
+    sample 0's [cond; uncond] pair over the whole pattern sequence, teacher-forced with the device's tokens."""
+    lm = _build('large')
+    sd = _oracle_sd(lm, True)
+    oc = olm.LMConfig(dim=2048, num_heads=32, num_layers=48, n_q=4, card=2048, cross_attention=True)
+    B, T0, T = 4, 1000, 1008
+    cross = _cross(2 * B, 16, 2048, 33)
+    ct = {'description': (cross.cuda(), torch.ones(2 * B, 16, dtype=torch.int64).cuda())}
+    prompt = torch.randint(0, 2048, (B, 4, T0), generator=torch.Generator().manual_seed(34))
+    toks, lg = lm.generate(prompt.cuda(), [], max_gen_len=T, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    toks, lg = toks.cpu(), lg.cpu()
+    del lm
+    torch.cuda.empty_cache()
+    assert torch.equal(toks[..., :T0], prompt)
+    steps = lg.shape[2]
+    assert steps >= 8
+    seq, _ = opat.build_pattern_sequence(toks[:1], 2048)
+    S = seq.shape[-1]
+    first = S - steps
+    pair = torch.cat([seq, seq], dim=0)[..., :S - 1]
+    ref = _oracle_cfg_logits(sd, oc, pair, cross[[0, B]], None, 3.0)
+    ref_steps = ref[:, :, first - 1:]
+    assert ref_steps.shape[2] == steps
+    r = rel(lg[:1], ref_steps)
+    print(f"[parity] large bf16 late context (t ~ 1000, after the prefill): CFG logits rel-L2 {r:.3e}")
+    assert r < BF16_TOL, f"late-context CFG logits rel-L2 {r}"
+
+
 # ------------------------------------------------------------------------------------------ configs[4]
 
 def test_melody_medium_bf16_real_prefix():
@@ -277,6 +309,8 @@ def test_encodec_16khz_geometry_vs_oracle():
     assert rel(lat, lat_ref) < 2e-5
     codes_ref = ocodec.rvq_encode(lat_ref, ocodec.codebooks_from_state(sd, 4))
     assert torch.equal(m.quantizer.encode(lat_ref.cuda()).cpu(), codes_ref)   # identical latents: bit exact
+    codes, _ = m.encode(wav.cuda())
+    assert_codes_near_tie(codes, codes_ref, lat, lat_ref, ocodec.codebooks_from_state(sd, 4), what='EnCodec-16k geometry')
     dec_ref = ocodec.encodec_decode(sd, c, codes_ref, fast_lstm=True)
     dec = m.decode(codes_ref.cuda()).cpu()
     assert dec.shape == dec_ref.shape
@@ -311,7 +345,10 @@ def test_stereo_codec_interleave_vs_oracle():
     cb = ocodec.codebooks_from_state(sd, 4)
     ref_codes = torch.stack([ocodec.rvq_encode(lat_l, cb), ocodec.rvq_encode(lat_r, cb)], dim=2).reshape(2, 8, -1)
     assert got.shape == ref_codes.shape
-    assert (got.cpu() == ref_codes).float().mean() > 0.97   # latents differ by fp32 round-off only (near-ties flip)
+    # per channel: a differing index must be a near tie of the oracle's decision (latents differ by fp32 round-off only)
+    for ch, (lat_o, sl) in enumerate(((lat_l, slice(0, None, 2)), (lat_r, slice(1, None, 2)))):
+        lat_d = mono.encoder(wav[:, ch:ch + 1].cuda()).cpu()
+        assert_codes_near_tie(got[:, sl], ref_codes[:, sl], lat_d, lat_o, cb, what=f'stereo wrapper channel {ch}')
 
 
 # ------------------------------------------------------------------------------------------ a13: provider end to end
