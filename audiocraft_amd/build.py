@@ -25,25 +25,49 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC=...)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(OUT):
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', '-ffp-contract=off']
+OBJDIR = os.path.join(CSRC, 'build')
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def needs_build() -> bool:
+    return _stale(OUT, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = True, out: str = OUT, defines=()) -> str:
+    """One object per translation unit (compiled in parallel, rebuilt only when the source or a header changed), then one
+    link.  `out` / `defines`: A/B library variants for same-box timing (ACMI_LIB selects the .so at import)."""
+    if not force and out == OUT and not needs_build():
         return OUT
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-pass-failed', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-o', OUT + '.tmp']
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+    tag = '' if not defines else '_' + '_'.join(d.replace('=', '-') for d in defines)
+    os.makedirs(OBJDIR, exist_ok=True)
+    inc = ['-I' + os.path.join(ROOT, 'include'), '-I' + CSRC] + ['-D' + d for d in defines]
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + tag + '.o')
+        path = os.path.join(CSRC, src)
+        if force or _stale(obj, [path] + HEADERS):
+            cmd = [_hipcc()] + FLAGS + inc + ['-c', path, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out + '.tmp'] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(OUT + '.tmp', OUT)
-    return OUT
+    os.replace(out + '.tmp', out)
+    return out
 
 
 if __name__ == '__main__':

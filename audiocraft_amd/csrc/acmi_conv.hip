@@ -255,7 +255,14 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
     constexpr int HP = 12;
     float* hs = sh;                    // [H][HP]
     float* gs = sh + (size_t)H * HP;   // [16][LSTM_BB]
+    int* s_abort = reinterpret_cast<int*>(gs + 16 * LSTM_BB);   // workgroup-wide "give up" flag (below)
     const int tid = threadIdx.x;
+    // A workgroup that starts only after another one has given up (it was not resident while the others spun) leaves at
+    // once, and so does every workgroup that sees the error word set while it waits: a residency failure costs ONE bounded
+    // spin, not one per remaining step.
+    if (tid == 0) *s_abort = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    __syncthreads();
+    if (*s_abort) return;
     const int r = tid >> 4, ksl = tid & 15;
     const int gate = r >> 2, u = r & 3;
     const int j0 = blockIdx.x * 4;
@@ -314,13 +321,17 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
                                 for (int e = 0; e < 4; ++e) hs[(k + e) * HP + q] = __uint_as_float(v[i][e]);
                                 pending &= ~(1u << i);
                             }
-                        if (pending && ++spins > 1000000u) { atomicAdd(err, 1u); break; }
+                        if (pending && (++spins & 0x3ffu) == 0u) {   // every 1024 polls: bounded wait, global abort flag
+                            if (spins > 1000000u) { atomicAdd(err, 1u); *s_abort = 1; break; }
+                            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *s_abort = 1; break; }
+                        }
                     }
                 }
                 for (int idx = tid; idx < (LSTM_BB - nb) * H; idx += 256)   // rows past nb of this pass: zeros
                     hs[(idx % H) * HP + nb + idx / H] = 0.f;
             }
             __syncthreads();
+            if (*s_abort) return;   // workgroup-uniform (written before the barrier): the host finds err != 0 and raises
             // the WHOLE gather is complete (barrier above): re-arm this workgroup's slots of step t + 1 (header comment)
             if (owner) __hip_atomic_store(hrearm + (size_t)bidx * H + j, LSTM_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // ---- 16 rows x H against nb hidden vectors: W from registers, h from LDS
@@ -373,12 +384,27 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
 // hidden-state buffers (3 * B * H floats) and an error word: 5 * B * H + 4 floats cover both
 extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H + 4; }
 
+// Every workgroup of the persistent form must be RESIDENT for its all-gather to complete.  The grid ((H + 3) / 4
+// workgroups) is checked against what the device this call runs on can hold: CUs (hipDeviceProp_t.multiProcessorCount:
+// 256 on a whole MI355X, fewer on a partitioned one) x the occupancy the runtime reports for this kernel with its LDS,
+// minus one workgroup per CU of margin when more than one fits (the API answers one too many at some SGPR counts,
+// MI355X_MICROARCH.md "Residency and cooperative launch").  Anything that does not fit runs the per-step kernel.
+// Residency can still be lost to OTHER work on the device (another stream or process): the kernel's spins are bounded,
+// the first give-up raises a device-wide abort flag (the err word) that every workgroup polls, and the host raises.
+template <typename KernelT>
+static bool lstm_grid_resident(KernelT kernel, int grid, size_t lds_bytes) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu <= 0) return false;
+    if (per_cu > 1) per_cu -= 1;
+    return (long)grid <= (long)cus * per_cu;
+}
+
 static int lstm_persistent_ok(int B, int H) {
     static int want = -1;
     if (want < 0) { const char* e = getenv("ACMI_LSTM_PERSISTENT"); want = (e && e[0] == '0') ? 0 : 1; }
-    // every workgroup must be resident for the all-gather to complete: 256-thread workgroups of ~110 VGPRs and 33 KB of
-    // LDS fit 4 per CU, far more than the (H + 3) / 4 <= 256 this admits
-    return want && H <= 1024 && H % 4 == 0 && H / 4 <= 256 && B >= 1;
+    return want && H <= 1024 && H % 4 == 0 && B >= 1;
 }
 
 
@@ -391,6 +417,8 @@ extern "C" int acmi_lstm_layer(const float* gates_in, const float* w_hh, const f
     float* h0 = work;
     float* h1 = work + (size_t)B * H;
     float* c = work + (size_t)2 * B * H;
+    // (the err word at work[5 B H] is NOT cleared here: it accumulates over the layers of a stack and the caller, who
+    // zeroed it, reads it once at the end -- a give-up in layer 0 must not be erased by layer 1's call)
     if (hipMemsetAsync(work, 0, sizeof(float) * 3 * B * H, st) != hipSuccess) {
         acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
         return ACMI_ELAUNCH;
@@ -398,18 +426,25 @@ extern "C" int acmi_lstm_layer(const float* gates_in, const float* w_hh, const f
     const size_t lds = (size_t)(LSTM_BB * H + 16 * LSTM_BB) * sizeof(float);
     dim3 grid((H + 3) / 4), block(256);
     if (T > 0 && lstm_persistent_ok(B, H)) {
-        const size_t lds_p = (size_t)(12 * H + 16 * LSTM_BB) * sizeof(float);
+        const size_t lds_p = (size_t)(12 * H + 16 * LSTM_BB) * sizeof(float) + 16;   // + the abort flag
         // layout of `work` for this form: [c: B H floats][h buffers: 3 B H words, all EMPTY][...][err: 1 word]
         unsigned* hbuf = reinterpret_cast<unsigned*>(work + (size_t)B * H);
         unsigned* err = reinterpret_cast<unsigned*>(work + (size_t)5 * B * H);
-        if (hipMemsetAsync(work, 0, sizeof(float) * ((size_t)5 * B * H + 4), st) != hipSuccess ||
-            hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, (size_t)3 * B * H, st) != hipSuccess) {
-            acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
-            return ACMI_ELAUNCH;
-        }
         const int ki = (H + 15) / 16;
-#define ACMI_LSTM_CASE(KIv) if (ki <= KIv) { hipLaunchKernelGGL(lstm_persistent_kernel<KIv>, grid, block, lds_p, st, gates_in, w_hh, work, skip, y, hbuf, err, B, H, T); return acmi_check_launch("lstm_persistent_kernel"); }
-        ACMI_LSTM_CASE(8) ACMI_LSTM_CASE(16) ACMI_LSTM_CASE(32) ACMI_LSTM_CASE(64)
+#define ACMI_LSTM_CASE(KIv)                                                                                                  \
+        if (ki <= KIv) {                                                                                                     \
+            if (lstm_grid_resident(lstm_persistent_kernel<KIv>, (int)grid.x, lds_p)) {                                       \
+                if (hipMemsetAsync(work, 0, sizeof(float) * (size_t)5 * B * H, st) != hipSuccess ||                          \
+                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, (size_t)3 * B * H, st) != hipSuccess) { \
+                    acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");                                                \
+                    return ACMI_ELAUNCH;                                                                                     \
+                }                                                                                                            \
+                hipLaunchKernelGGL(lstm_persistent_kernel<KIv>, grid, block, lds_p, st, gates_in, w_hh, work, skip, y, hbuf, \
+                                   err, B, H, T);                                                                            \
+                return acmi_check_launch("lstm_persistent_kernel");                                                          \
+            }                                                                                                                \
+        } else
+        ACMI_LSTM_CASE(8) ACMI_LSTM_CASE(16) ACMI_LSTM_CASE(32) ACMI_LSTM_CASE(64) {}
 #undef ACMI_LSTM_CASE
     }
     for (int t = 0; t < T; ++t) {

@@ -41,14 +41,20 @@ def resample_frac(x: torch.Tensor, old_sr: int, new_sr: int) -> torch.Tensor:
         return x
     g = math.gcd(old_sr, new_sr)
     o, n = old_sr // g, new_sr // g
+    # The filter runs on the MI355X only (acmi_resample_frac; there is no CPU implementation in the product).  Melodies and
+    # prompts are usually loaded on the host (MusicGen.generate_with_chroma calls convert_audio on them): such an input
+    # makes the round trip through the accelerator and comes back on its own device, like the reference's call would.
+    src_dev = x.device
     if not x.is_cuda:
-        raise RuntimeError("resample_frac runs on the MI355X (acmi_resample_frac); move the waveform to 'cuda'")
+        if not torch.cuda.is_available():
+            raise RuntimeError("resample_frac runs on the MI355X (acmi_resample_frac): no accelerator is visible")
+        x = x.cuda()
     kernel, width = _resample_kernel(o, n, x.device)
     shape = x.shape
     flat = x.reshape(-1, shape[-1]).float().contiguous()
     out_len = int(math.floor(n * shape[-1] / o))
     y = _C.resample_frac(flat, kernel, o, n, width, out_len)
-    return y.reshape(*shape[:-1], out_len)
+    return y.reshape(*shape[:-1], out_len).to(src_dev)
 
 
 def convert_audio_channels(wav: torch.Tensor, channels: int = 2) -> torch.Tensor:

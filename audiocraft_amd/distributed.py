@@ -33,6 +33,10 @@ def init_from_env(backend: tp.Optional[str] = None) -> tp.Tuple[int, int, int]:
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
+            n_dev = torch.cuda.device_count()
+            if local_rank >= n_dev:   # one process per GPU: LOCAL_RANK r drives HIP device r of this node
+                raise RuntimeError(f"rank {rank}: LOCAL_RANK={local_rank} but this node shows {n_dev} device(s) "
+                                   f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})")
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:

@@ -710,6 +710,7 @@ class LMModel(nn.Module):
         if st is None:
             st = self._stream_begin(B, condition_tensors)
             self._set_first_call(st['state'], st['P'] + S)   # the first call's length fixes the rotary offsets
+            st['first_len'] = st['P'] + S
         assert st['B'] == B, "the batch size of a stream cannot change"
         assert st['steps'] + S <= self.streaming_capacity, "stream longer than LMModel.streaming_capacity"
         run, off = st['run'], st['steps']
@@ -732,11 +733,17 @@ class LMModel(nn.Module):
         dev = self.device
         state = {'transformer.offsets': torch.full((B,), t, dtype=torch.long, device=dev),
                  'fuser.offsets': torch.full((B,), st['steps'], dtype=torch.long, device=dev)}
+        # `offset` of the reference = keys dropped by past_context SINCE the first call (transformer.py:289-297: the entry is
+        # created as tensor(0) by the first call, whatever that call dropped, and incremented by every later trim); the
+        # rotary position of the next step is offset + stored keys (transformer.py:300-313).  The caches here are never
+        # trimmed (the window is applied by the attention kernel), so K / V are returned at full length.
+        pc = self.past_context
+        dropped = 0 if not pc else max(0, t - pc) - max(0, st.get('first_len', t) - pc)
         for li in range(self.num_layers):
             pre = f'transformer.layers.{li}.self_attn.'
             state[pre + 'past_keys'] = run['k'][li][:, :, :t]
             state[pre + 'past_values'] = run['v'][li][:, :, :t]
-            state[pre + 'offset'] = torch.tensor(t, dtype=torch.long, device=dev)
+            state[pre + 'offset'] = torch.tensor(dropped, dtype=torch.long, device=dev)
         return state
 
     def set_streaming_state(self, state: tp.Dict[str, torch.Tensor]):
@@ -751,16 +758,29 @@ class LMModel(nn.Module):
         t = int(state['transformer.offsets'][0])
         assert st['P'] <= t <= st['P'] + self.streaming_capacity
         known = {'transformer.offsets', 'fuser.offsets'}
+        pc = self.past_context
         for li in range(self.num_layers):
             pre = f'transformer.layers.{li}.self_attn.'
             for name, cache in (('past_keys', run['k'][li]), ('past_values', run['v'][li])):
                 src = state[pre + name]
-                assert src.shape[2] == t, (src.shape, t)
+                # full length (this class's own states) or trimmed to the last past_context keys (a reference-format state)
+                n = src.shape[2]
+                assert n == t or (pc and n == min(t, pc)), (src.shape, t, pc)
                 if src.data_ptr() != cache.data_ptr():
-                    cache[:, :, :t].copy_(src)
+                    cache[:, :, t - n:t].copy_(src)
                 known.add(pre + name)
             known.add(pre + 'offset')
         assert set(state.keys()) <= known, sorted(set(state.keys()) - known)
+        # rotary lag: the reference's next rotary position is offset + stored keys (stored = min(t, past_context))
+        off_key = 'transformer.layers.0.self_attn.offset'
+        if pc and self.positional_embedding != 'sin' and off_key in state:
+            lag = t - (int(state[off_key]) + min(t, pc))
+            cst = st['state']
+            if lag > 0:
+                cst.rope_first, cst.rope_shift = (cst.rope_first if 0 < cst.rope_first <= t else t), lag
+            else:
+                cst.rope_first, cst.rope_shift = 0, 0
+            st['first_len'] = lag + pc if lag > 0 else min(st.get('first_len', t), pc)
         st['steps'] = t - st['P']
         run['pos'][:2] = torch.tensor([t, 0], dtype=torch.int32, device=run['pos'].device)
         run['gen_sequence'][:, :, st['steps']:].fill_(-1)

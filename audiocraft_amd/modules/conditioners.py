@@ -282,11 +282,15 @@ class ChromaStemConditioner(WaveformConditioner):
         if extractor.fbanks.device != self.output_proj.weight.device:
             extractor.to(self.output_proj.weight.device)
         if wav.shape[-1] == 1:
-            return extractor(wav)
+            return extractor(wav[:, :1])
+        dev = self.output_proj.weight.device
         if self.stem_separator is not None:
             wav = self.stem_separator(wav, sample_rate)
-        elif sample_rate != self.sample_rate:
-            raise NotImplementedError(f"melody at {sample_rate} Hz: resample to {self.sample_rate} Hz before conditioning")
+        # what the reference's `_get_stemmed_wav` ends with (conditioners.py:675: demucs.audio.convert_audio of the merged
+        # stems to the conditioner's rate, one channel): resample on the device (acmi_resample_frac), mean over channels.
+        # Without a separator the full mix takes the same route (a 2-channel melody for a stereo model, any sample rate).
+        from ..data_audio_utils import convert_audio
+        wav = convert_audio(wav.to(dev), sample_rate, self.sample_rate, 1)
         return extractor(wav)
 
     def _get_wav_embedding(self, x: WavCondition) -> torch.Tensor:

@@ -18,8 +18,9 @@ Extra objects on the JSON line:
                weight bytes of one decode position / number of its launches, divided by the
                average launch duration measured here with HIP events over one decode position's worth
                of launches (all layers, real shapes) on the launch stream.
-  cpu_baseline the oracle (a port of the reference's CPU algorithm, incl. its torch.cat KV cache)
-               timed on this box's host cores on a bounded sample of the same workload.
+  cpu_baseline the reference's CPU path timed on this box's host cores on a bounded sample of the same workload:
+               the imported reference itself where /root/reference exists (kind "reference"), else the oracle, a
+               port of the same algorithm incl. its torch.cat KV cache (kind "port": the GPU box).
 """
 import argparse
 import json
@@ -187,16 +188,20 @@ def pmc_traffic_per_launch():
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
 
 
-def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 30, late_steps: int = 4,
+def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 16, late_steps: int = 14,
                  late_context: int = 1400):
-    """The oracle (kind "port": restatement of the reference CPU algorithm, incl. its torch.cat KV cache) on the host
-    cores, on a bounded sample of the same workload, as SURVEY.md section 8(d) specifies: `early_steps` decode positions
-    at the start of the stream AND `late_steps` positions at context `late_context` (KV state of that length: the cost
-    of a position depends on the shapes only), both at the full batch; the per-position cost is taken as linear in the
-    context between the two measurements and integrated over all positions; plus the EnCodec decode of 1 s of audio at
-    the full batch, scaled to the duration."""
+    """The reference's CPU path on the host cores, on a bounded sample of the same workload, as SURVEY.md section 8(d)
+    specifies: `early_steps` decode positions at the start of the stream AND `late_steps` positions at context
+    `late_context` (KV state of that length: the cost of a position depends on the shapes only), both at the full batch;
+    the per-position cost is taken as linear in the context between the two measurements and integrated over all
+    positions; plus the EnCodec decode of 1 s of audio at the full batch, scaled to the duration.
+    kind "reference": the UNMODIFIED reference imported from /root/reference (oracle/ref_baseline.py) -- where that tree
+    exists (the build container); kind "port": the oracle, a restatement of the same algorithm incl. its torch.cat KV
+    cache -- on the GPU box, where the reference does not travel."""
     from oracle import codec as ocodec
     from oracle import lm as olm
+    from oracle import ref_baseline
+    use_ref = ref_baseline.available() and os.environ.get('ACMI_BENCH_CPU_KIND', 'reference') != 'port'
     log = lambda msg: print(f"[cpu_baseline {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)  # noqa: E731
     default_threads = torch.get_num_threads()
     log(f"copying weights to the host (torch default: {default_threads} threads)")
@@ -210,7 +215,15 @@ def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_step
     T = int(duration * model.frame_rate)
     n_pos = T + 3
 
+    ref_lm = None
+    if use_ref:
+        log("building the imported reference LMModel (kind: reference)")
+        ref_lm = ref_baseline.build_reference_lm(sd, lm.dim, lm.num_heads, lm.num_layers, lm.n_q, lm.card,
+                                                 lm.has_cross_attention)
+
     def run(steps):
+        if ref_lm is not None:
+            return ref_baseline.time_reference_positions(ref_lm, B, cross, top_k, steps, 1, 8)[0]
         t0 = time.perf_counter()
         olm.generate(sd, oc, None, B, cross, max_gen_len=T, top_k=top_k, max_steps=steps)
         return (time.perf_counter() - t0) / steps
@@ -227,27 +240,30 @@ def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_step
         if best_t is None or t < best_t:
             best_t, cores = t, nthr
     torch.set_num_threads(cores)
-    log(f"timing {early_steps} early-context positions with {cores} threads")
-    t_early = run(early_steps)
-    ctx_early = (early_steps - 1) / 2.0
-    # late context: a streaming state that already holds `late_context` positions per layer
-    log(f"{t_early * 1e3:.0f} ms/position; timing {late_steps} positions at context {late_context}")
-    H, hd = lm.num_heads, lm.dim // lm.num_heads
-    st = olm.LMState(lm.num_layers)
-    for li in range(lm.num_layers):
-        st.past_k[li] = torch.randn(2 * B, H, late_context, hd, generator=g)
-        st.past_v[li] = torch.randn(2 * B, H, late_context, hd, generator=g)
-    st.offset, st.first_step = late_context, False
-    tok = torch.randint(0, lm.card, (2 * B, lm.n_q, 1), generator=g)
-    with torch.no_grad():
-        olm.lm_forward(sd, oc, tok, cross, None, st)   # untimed first call
-        t0 = time.perf_counter()
-        for _ in range(late_steps):
-            logits = olm.lm_forward(sd, oc, tok, cross, None, st)
-            olm.sample_next_token(olm.cfg_mix(logits, 3.0)[:, :, -1], True, 1.0, top_k, 0.0)
-        t_late = (time.perf_counter() - t0) / late_steps
+    log(f"timing {early_steps} early-context and {late_steps} late-context ({late_context}) positions with {cores} threads")
+    ctx_early = (early_steps - 1) / 2.0 + 1
+    if ref_lm is not None:
+        t_early, t_late = ref_baseline.time_reference_positions(ref_lm, B, cross, top_k, early_steps, late_steps, late_context)
+        del ref_lm
+    else:
+        t_early = run(early_steps)
+        # late context: a streaming state that already holds `late_context` positions per layer
+        H, hd = lm.num_heads, lm.dim // lm.num_heads
+        st = olm.LMState(lm.num_layers)
+        for li in range(lm.num_layers):
+            st.past_k[li] = torch.randn(2 * B, H, late_context, hd, generator=g)
+            st.past_v[li] = torch.randn(2 * B, H, late_context, hd, generator=g)
+        st.offset, st.first_step = late_context, False
+        tok = torch.randint(0, lm.card, (2 * B, lm.n_q, 1), generator=g)
+        with torch.no_grad():
+            olm.lm_forward(sd, oc, tok, cross, None, st)   # untimed first call
+            t0 = time.perf_counter()
+            for _ in range(late_steps):
+                logits = olm.lm_forward(sd, oc, tok, cross, None, st)
+                olm.sample_next_token(olm.cfg_mix(logits, 3.0)[:, :, -1], True, 1.0, top_k, 0.0)
+            t_late = (time.perf_counter() - t0) / late_steps
+        del st
     ctx_late = late_context + 1 + (late_steps - 1) / 2.0
-    del st
     slope = (t_late - t_early) / (ctx_late - ctx_early)
     t_lm = sum(t_early + slope * (t - ctx_early) for t in range(n_pos))
     log(f"{t_late * 1e3:.0f} ms/position at context {late_context}; EnCodec decode sample")
@@ -256,12 +272,15 @@ def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_step
     cc = ocodec.CodecConfig(channels=1, dimension=128, n_filters=64, n_residual_layers=1, ratios=[8, 5, 4, 4],
                             causal=False, pad_mode='constant', lstm=2, norm='weight_norm', n_q=4, bins=2048,
                             sample_rate=32000, frame_rate=50)
-    codes = torch.randint(0, 2048, (B, 4, 50), generator=g)
-    t0 = time.perf_counter()
-    ocodec.encodec_decode(csd, cc, codes, fast_lstm=True)
-    t_codec_1s = time.perf_counter() - t0
+    if use_ref:
+        t_codec_1s = ref_baseline.time_reference_codec_decode(csd, B, 50, g)
+    else:
+        codes = torch.randint(0, 2048, (B, 4, 50), generator=g)
+        t0 = time.perf_counter()
+        ocodec.encodec_decode(csd, cc, codes, fast_lstm=True)
+        t_codec_1s = time.perf_counter() - t0
     wall = t_lm + t_codec_1s * duration
-    return dict(value=round(B * duration / wall, 4), unit='audio-s / wall-s', cores=cores, kind='port',
+    return dict(value=round(B * duration / wall, 4), unit='audio-s / wall-s', cores=cores, kind='reference' if use_ref else 'port',
                 sample=f"{early_steps} decode positions at context <= {early_steps} ({t_early * 1e3:.0f} ms/position) and "
                        f"{late_steps} positions at context {late_context} ({t_late * 1e3:.0f} ms/position), batch {B} "
                        f"(CFG rows {2 * B}); per-position cost linear in the context between the two, integrated over "
@@ -273,6 +292,11 @@ def _spawn_ranks(n: int) -> int:
     xGMI through torch.distributed, rendezvous on 127.0.0.1) and relay rank 0's JSON line."""
     import socket
     import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible MI355X devices, this node shows {have} "
+              f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}); nothing was run", file=sys.stderr)
+        return 2
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -320,9 +344,15 @@ def main():
     from audiocraft_amd import distributed as adist
     from audiocraft_amd.models.musicgen import MusicGen
     rank, world, local_rank = adist.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback)"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (there is no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():   # one process per GPU: LOCAL_RANK r drives HIP device r
+        sys.exit(f"bench.py: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} device(s) are visible to this rank; "
+                 f"--gpus {args.gpus} needs {args.gpus} MI355X on this node")
     torch.cuda.set_device(local_rank)
+    assert torch.cuda.current_device() == local_rank
     dev = torch.device('cuda', local_rank)
 
     model = MusicGen.get_random_init(args.model, dev, torch.bfloat16, text_len=args.text_len, seed=0)

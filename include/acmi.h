@@ -98,10 +98,15 @@ int acmi_conv1d(const acmi_conv_desc* d, const float* x, const float* w, const f
  * gates_in [B, 4H, T] f32 (= W_ih x + b_ih + b_hh, computed with acmi_conv1d, ksize 1) is given;
  * runs T sequential steps  gates = gates_in[:, :, t] + W_hh h;  i,f,g,o;  c,h update, zero initial
  * state, and writes y [B, H, T] (+ skip [B, H, T] if not NULL).  w_hh [4H, H] f32.
- * One persistent launch for all T steps when H % 4 == 0 and H <= 1024 (W_hh slice register resident, hidden state
- * all-gathered between workgroups at every step; needs the device to itself: every workgroup must be resident), else
- * one launch per step.  work: acmi_lstm_work_floats(B, H) floats = 5 * B * H + 4 (cell state, three hidden-state
- * buffers, and -- last 4 words -- an unsigned count of bounded-spin give-ups the caller should find at zero). */
+ * One persistent launch for all T steps when H % 4 == 0, H <= 1024 and the (H + 3) / 4 workgroups of that launch are
+ * all RESIDENT on the current device -- checked per call: multiProcessorCount x the runtime's occupancy answer for the
+ * kernel (minus one workgroup per CU of margin) must cover the grid; a partitioned or smaller device takes the fallback --
+ * (W_hh slice register resident, hidden state all-gathered between workgroups at every step), else one launch per step.
+ * Residency can still be lost to other work sharing the device: every spin is bounded, the first give-up sets the error
+ * word, every workgroup polls it and leaves, so the cost is one bounded spin (not one per step) and y is then garbage.
+ * work: acmi_lstm_work_floats(B, H) floats = 5 * B * H + 4 (cell state, three hidden-state buffers, and -- word
+ * 5 * B * H -- an unsigned count of give-ups).  The CALLER zeroes that word before the first layer of a stack and reads
+ * it once after the last: this function never clears it (a give-up in layer 0 must survive layer 1's call). */
 int acmi_lstm_layer(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work,
                     int B, int H, int T, void* stream);
 size_t acmi_lstm_work_floats(int B, int H);

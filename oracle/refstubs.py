@@ -1,10 +1,10 @@
 """TEST INFRASTRUCTURE ONLY -- import-stub harness that lets the *unmodified* reference
 sources under /root/reference be imported on CPU in the build container.
 
-Only `tests/golden/make_golden.py` (fixture generation) and `oracle/validate_against_reference.py`
-import this module.  It is never imported by the product package (`audiocraft_amd/`), by
-`bench.py`, by `__graft_entry__.smoke()` or by the `-m gpu` tests: /root/reference does not exist
-on the GPU box.  Recipe documented in SURVEY.md section 8(c) / Appendix A.
+Only the fixture generators under `tests/golden/`, `oracle/validate_against_reference.py` and
+`oracle/ref_baseline.py` (bench.py's cpu_baseline leg, taken only where `available()`) import this
+module.  It is never imported by the product package (`audiocraft_amd/`), by
+`__graft_entry__.smoke()` or by the `-m gpu` tests: /root/reference does not exist on the GPU box.  Recipe documented in SURVEY.md section 8(c) / Appendix A.
 
 Importing this module registers stub modules for the third-party packages the reference imports
 but that are not installed here (xformers, flashy, omegaconf, julius, ...).  No arithmetic on the

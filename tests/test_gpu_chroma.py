@@ -128,3 +128,26 @@ def test_resample_kernel_vs_oracle(C):
     assert out.shape == (3, 1, 3200)
     assert torch.allclose(out, resample_frac(w, 44100, 32000).mean(dim=-2, keepdim=True))
     assert convert_audio(w, 32000, 32000, 2) is w
+
+
+def test_chroma_conditioner_resamples_and_downmixes(C):
+    """A 44.1 kHz 2-channel melody loaded on the HOST (the usual case: MusicGen.generate_with_chroma hands over what
+    audio_read returned): the conditioner converts it like the reference's `_get_stemmed_wav` ends (conditioners.py:675,
+    demucs.audio.convert_audio -> the conditioner's rate, one channel) -- resampled on the device, mean over channels --
+    instead of raising.  Oracle: oracle/resample.py then oracle/chroma.py."""
+    from oracle import resample as ors
+    from audiocraft_amd.data_audio_utils import resample_frac
+    from audiocraft_amd.modules.conditioners import ChromaStemConditioner, WavCondition
+    cond = ChromaStemConditioner(output_dim=32, sample_rate=32000, n_chroma=12, radix2_exp=14, duration=30., device='cuda')
+    sig = _signals(44100, 3 * 44100, 1)                                  # [5, T]
+    stereo = np.stack([sig[[0, 1, 4]], 0.5 * sig[[1, 4, 0]]], axis=1)    # [3, 2, T]: different content per channel
+    wav = torch.from_numpy(stereo)                                       # CPU tensor
+    got = cond._compute_wav_embedding(wav, 44100).cpu().numpy()
+    mono = ors.resample_frac(stereo, 44100, 32000).mean(axis=1)          # resample each channel, then down-mix
+    ref = och.chroma_extract(mono.astype(np.float32), 32000, 12, 14, argmax=True)
+    assert got.shape == ref.shape
+    assert (got.argmax(-1) == ref.argmax(-1)).mean() > 0.97              # tonal rows; near ties are covered above
+    # a host tensor comes back on the host from the resampler, a device tensor stays on the device
+    y = resample_frac(wav, 44100, 32000)
+    assert y.device.type == 'cpu' and y.shape == (3, 2, int(np.floor(3 * 44100 * 32000 / 44100)))
+    assert torch.allclose(y, resample_frac(wav.cuda(), 44100, 32000).cpu())

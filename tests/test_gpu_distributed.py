@@ -56,3 +56,118 @@ def test_sharded_generation_on_rccl_matches_single_device(B_global):
         tokens, wav = out[rank]
         assert torch.equal(tokens, ref_t.cpu()), f"rank {rank}: gathered tokens differ from the single-device result"
         assert torch.allclose(wav, ref_w.cpu(), atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The RCCL path above needs two GPUs and the 1-GPU test box skips it.  What CAN be executed on one device is everything
+# except the transport: `generate_sharded` itself, with the REAL kernels, driven through a fake 2-rank process group --
+# two threads of this process, one model replica each, `torch.distributed`'s entry points replaced by an in-memory
+# mailbox that moves exactly the tensors the collectives would move (the packed header + payload of the broadcast, the
+# padded shards of the all-gather).  GPU work is serialised by the mailbox itself: rank 1 is released from the
+# broadcast only when rank 0 has reached its all-gather.
+# ----------------------------------------------------------------------------------------------------------------------
+class _LoopbackGroup:
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.tls = threading.local()
+        self.cv = threading.Condition()
+        self.bcast = []                 # broadcast payloads in call order (src deposits, others copy)
+        self.gather = {}                # all_gather call index -> {rank: tensor}
+        self.rank0_in_gather = False
+        self.log = []
+
+    # -- the torch.distributed surface audiocraft_amd.distributed uses
+    def is_initialized(self):
+        return True
+
+    def get_rank(self):
+        return self.tls.rank
+
+    def get_world_size(self):
+        return self.world
+
+    def broadcast(self, tensor, src=0):
+        r = self.tls.rank
+        idx = self.tls.n_bcast = getattr(self.tls, 'n_bcast', -1) + 1
+        with self.cv:
+            if r == src:
+                self.bcast.append(tensor.detach().clone())
+                self.log.append(('broadcast', idx, tuple(tensor.shape), str(tensor.dtype)))
+                self.cv.notify_all()
+            else:
+                ok = self.cv.wait_for(lambda: len(self.bcast) > idx and self.rank0_in_gather, timeout=600)
+                assert ok, "loopback broadcast timed out"
+                assert self.bcast[idx].shape == tensor.shape and self.bcast[idx].dtype == tensor.dtype, \
+                    "receiver's buffer does not match what the source sent (header / layout mismatch)"
+                tensor.copy_(self.bcast[idx])
+
+    def all_gather(self, bufs, tensor):
+        r = self.tls.rank
+        idx = self.tls.n_gather = getattr(self.tls, 'n_gather', -1) + 1
+        with self.cv:
+            self.gather.setdefault(idx, {})[r] = tensor.detach().clone()
+            if r == 0:
+                self.rank0_in_gather = True
+            self.cv.notify_all()
+            ok = self.cv.wait_for(lambda: len(self.gather[idx]) == self.world, timeout=600)
+            assert ok, "loopback all_gather timed out"
+            for j in range(self.world):
+                assert bufs[j].shape == self.gather[idx][j].shape, "all_gather needs equal shapes on every rank"
+                bufs[j].copy_(self.gather[idx][j])
+
+
+def test_sharded_path_fake_two_ranks_real_kernels(monkeypatch):
+    """generate_sharded on a fake 2-rank group, real kernels, ONE device: shard 0 and shard 1 of an uneven global batch
+    (5 prompts -> 3 + 2), conditions through pack -> broadcast -> unpack, tokens and audio through the padded all-gather;
+    the gathered result must equal the unsharded greedy result bit for bit (tokens) / to 1e-5 (audio)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import threading
+    import torch.distributed as dist
+    from audiocraft_amd import distributed as adist
+    from audiocraft_amd.models.musicgen import MusicGen
+    B_global, T, world = 5, 20, 2
+    descriptions = [f'prompt {i}' * (1 + i % 3) for i in range(B_global)]
+    torch.manual_seed(0)
+    ref_model = MusicGen.get_pretrained('debug', 'cuda')
+    ref_t, ref_w = adist.generate_sharded(ref_model, descriptions, B_global, T, decode=True,
+                                          generation_params={'use_sampling': False})
+    group = _LoopbackGroup(world)
+    for name in ('is_initialized', 'get_rank', 'get_world_size', 'broadcast', 'all_gather'):
+        monkeypatch.setattr(dist, name, getattr(group, name))
+    models = []
+    for _ in range(world):           # identical replicas (weights replicated, prompts sharded)
+        torch.manual_seed(0)
+        models.append(MusicGen.get_pretrained('debug', 'cuda'))
+    out, errors = {}, []
+
+    def run(rk):
+        try:
+            group.tls.rank = rk
+            torch.cuda.set_device(0)
+            tokens, wav = adist.generate_sharded(models[rk], descriptions if rk == 0 else None, B_global, T, decode=True,
+                                                 gather_audio=True, generation_params={'use_sampling': False})
+            torch.cuda.synchronize()
+            out[rk] = (tokens.cpu(), wav.cpu())
+        except BaseException as e:   # noqa: BLE001 -- re-raised in the main thread
+            errors.append((rk, e))
+            with group.cv:           # never leave the other rank waiting
+                group.rank0_in_gather = True
+                group.cv.notify_all()
+
+    threads = [threading.Thread(target=run, args=(rk,)) for rk in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(900)
+    assert not errors, errors
+    # two broadcasts whatever the number of conditions (fixed-layout header, one payload), two all-gathers (tokens, audio)
+    assert [e[0] for e in group.log] == ['broadcast', 'broadcast'] and group.log[0][3] == 'torch.int64'
+    assert sorted(group.gather) == [0, 1] and all(len(v) == world for v in group.gather.values())
+    assert group.gather[0][0].shape[0] == 3           # ceil(5 / 2) padded rows per rank
+    for rk in range(world):
+        tokens, wav = out[rk]
+        assert tokens.shape == (B_global, 4, T)
+        assert torch.equal(tokens, ref_t.cpu()), f"rank {rk}: gathered tokens differ from the unsharded result"
+        assert torch.allclose(wav, ref_w.cpu(), atol=1e-5)
