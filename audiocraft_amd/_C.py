@@ -56,7 +56,8 @@ class LMState(C.Structure):
                 ('S', i32), ('n_pos', i32), ('gen_sequence', vp), ('seq_mask', vp), ('prepend', vp), ('pos', vp),
                 ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
-                ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32)]
+                ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32),
+                ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -86,14 +87,15 @@ class LinearDesc(C.Structure):
                 ('a_stats_np', i32), ('a_stats_cnt', i32), ('w', vp), ('wdtype', i32), ('bias', vp), ('residual', vp),
                 ('out', vp), ('out_mode', i32), ('act', i32), ('stats_out', vp), ('ksplit', i32), ('M', i32), ('N', i32), ('K', i32),
                 ('a_lo', vp), ('colsum', vp), ('xt_hi', vp), ('xt_lo', vp), ('a_rbs', i32), ('a_lo_rbs', i32),
-                ('xt_rbs', i32), ('xt_lo_rbs', i32), ('lo_K', i32), ('w_half', i32)]
+                ('xt_rbs', i32), ('xt_lo_rbs', i32), ('lo_K', i32), ('w_half', i32), ('a_shift', vp), ('xt_shift', vp), ('mean_out', vp)]
 
 
 class AttnDesc(C.Structure):
     _fields_ = [('q', vp), ('k_cache', vp), ('v_cache', vp), ('kvdtype', i32), ('out', vp), ('out_mode', i32),
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
                 ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('cache_rows', i32), ('q_stats', vp), ('q_stats_np', i32),
-                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp), ('past_context', i32)]
+                ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp), ('past_context', i32),
+                ('q_shift', vp), ('active_rows', i32)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
@@ -259,7 +261,7 @@ def linear(a, w: TiledWeight, out, ln_g=None, ln_b=None, eps=1e-5, bias=None, re
 
 def linear_desc(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0, cnt=0, stats_out=None, bias=None,
                 residual=None, act=0, eps=1e-5, ksplit=1, a_lo=None, colsum=None, xt_hi=None, xt_lo=None, a_rbs=0,
-                a_lo_rbs=0, xt_rbs=0, xt_lo_rbs=0, lo_K=0, K=None) -> LinearDesc:
+                a_lo_rbs=0, xt_rbs=0, xt_lo_rbs=0, lo_K=0, K=None, a_shift=None, xt_shift=None, mean_out=None) -> LinearDesc:
     """acmi_linear_desc (include/acmi.h).  K overrides w.K when the weight was tiled with a padded K.
     The descriptor holds raw device pointers: the caller keeps the tensors alive until the launch."""
     d = LinearDesc()
@@ -271,6 +273,7 @@ def linear_desc(a, w: TiledWeight, out, M, a_mode, out_mode, a_stats=None, np_=0
     d.a_lo, d.colsum, d.xt_hi, d.xt_lo = ptr(a_lo), ptr(colsum), ptr(xt_hi), ptr(xt_lo)
     d.a_rbs, d.a_lo_rbs, d.xt_rbs, d.xt_lo_rbs, d.lo_K = a_rbs, a_lo_rbs, xt_rbs, xt_lo_rbs, lo_K
     d.w_half = 1 if getattr(w, 'half', False) else 0
+    d.a_shift, d.xt_shift, d.mean_out = ptr(a_shift), ptr(xt_shift), ptr(mean_out)
     return d
 
 
@@ -291,7 +294,8 @@ def linear_pair(plain: LinearDesc, xcat: LinearDesc):
 
 
 def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False, out_rbs=0, out_col0=0,
-                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5, len_rows=None, past_context=0):
+                q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5, len_rows=None, past_context=0,
+                q_shift=None, active_rows=0):
     """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True; out_rbs / out_col0
     place the head outputs inside a wider buffer).  q_colsum: LayerNorm hook on q (acmi_attn_desc)."""
     cache_rows, H, Tcap, hd = k_cache.shape
@@ -306,6 +310,7 @@ def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_
     d.q_colsum, d.q_bias = ptr(q_colsum), ptr(q_bias)
     d.len_rows = ptr(len_rows)
     d.past_context = int(past_context)
+    d.q_shift, d.active_rows = ptr(q_shift), int(active_rows)
     check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')
     return out
 

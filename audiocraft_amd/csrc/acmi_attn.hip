@@ -33,6 +33,8 @@ struct AttnArgs {
     // optional LayerNorm hook on q (the cross-attention query arrives as x W'^T, see acmi_linear_pair):
     //   q <- rstd[b] (q - mean[b] colsum) + bias, mean / rstd of row b from the (mean, M2) partials of x
     const float* q_stats; int q_np, q_cnt, q_K; float q_eps; const float* q_colsum; const float* q_bias;
+    const float* q_shift;  // shift of the raw row behind q (acmi_attn_desc.q_shift), or NULL
+    int active_rows;       // > 0: cache rows >= active_rows are skipped (their output stays as the caller left it)
 };
 
 template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
@@ -52,14 +54,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
     const int b0 = b % p.rpp, pidx = b / p.rpp;   // several positions per call (prefill): cache row, position index
+    if (p.active_rows > 0 && b0 >= p.active_rows) return;   // null condition: K = V = 0, the output is exactly 0 (workgroup uniform)
     const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len)) : (p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len);
 
     float qv[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * DPL + e];
     // LayerNorm hook: everything it needs is requested here, consumed after the first K / V chunk is in flight
-    float qcs[DPL], qb[DPL], spm[2], spq[2];
+    float qcs[DPL], qb[DPL], spm[2], spq[2], qsh = 0.f;
     if (QN) {
+        qsh = *(p.q_shift != nullptr ? p.q_shift + b : p.q_stats);   // unconditional request; dropped below without a shift
 #pragma unroll
         for (int e = 0; e < DPL; ++e) {
             qcs[e] = p.q_colsum[h * HD + c * DPL + e];
@@ -101,8 +105,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
         const float d0 = spm[0] - mean, d1 = spm[1] - mean;
         const float q2 = (v0 ? spq[0] + (float)p.q_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)p.q_cnt * d1 * d1 : 0.f);
         const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.q_K + p.q_eps);
+        const float meff = mean - (p.q_shift != nullptr ? qsh : 0.f);   // q was built on the row minus its shift
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - mean * qcs[e]) + qb[e];
+        for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - meff * qcs[e]) + qb[e];
     }
     for (int t0 = start + wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
         float s[NI];
@@ -185,7 +190,9 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
         const int need = (a.len + chunk - 1) / chunk;
         while (nwv > 1 && nwv / 2 >= need) nwv /= 2;
     }
-    dim3 grid(a.H, Beff), block(64 * nwv);
+    // rows past active_rows do nothing: with one position per call (query row == cache row) they are not even launched
+    const int rows = (a.active_rows > 0 && Beff == a.rpp) ? a.active_rows : Beff;
+    dim3 grid(a.H, rows), block(64 * nwv);
 #define ACMI_ATTN_CASE(HD)                                                                              \
     case HD:                                                                                            \
         if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a);  \
@@ -232,7 +239,10 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
         a.q_eps = c.eps; a.q_colsum = c.q_colsum;
         a.q_bias = c.q_bias != nullptr ? c.q_bias : nullptr;
         ACMI_REQUIRE(c.q_bias != nullptr, "acmi_attn_decode: q_bias is required with q_colsum (pass zeros for none)");
+        a.q_shift = c.q_shift;
     }
+    ACMI_REQUIRE(c.active_rows >= 0 && c.active_rows <= a.rpp, "acmi_attn_decode: active_rows=%d outside [0, %d]", c.active_rows, a.rpp);
+    a.active_rows = c.active_rows;
     return c.kvdtype == ACMI_BF16 ? launch_attn_t<bf16_t>(a, c.Beff, c.hd, (hipStream_t)stream)
                                   : launch_attn_t<float>(a, c.Beff, c.hd, (hipStream_t)stream);
 }

@@ -186,9 +186,12 @@ __device__ __forceinline__ void rowstat_load(const float* __restrict__ stats, in
         pm[i] = t.x; pq[i] = t.y;
     }
 }
+// dst gets (mean - shift, rstd): `shift` is what the row's raw fragments were stored with (0 without one), so the
+// epilogue's rstd * (acc - dst[0] * colsum) is the LayerNorm of the unshifted row.  mean_dst (or NULL): the plain mean.
 template <int NS>
 __device__ __forceinline__ void rowstat_finish(const float (&pm)[16], const float (&pq)[16], int np, int cnt, int K, float eps,
-                                               int lane, float* __restrict__ dst /* [4][2] */) {
+                                               int lane, float* __restrict__ dst /* [4][2] */, float shift = 0.f,
+                                               float* __restrict__ mean_dst = nullptr) {
     const int jj = lane & 15;
     float sm = 0.f;
 #pragma unroll
@@ -203,8 +206,9 @@ __device__ __forceinline__ void rowstat_finish(const float (&pm)[16], const floa
     }
     q2 = row16_sum(q2);
     if (jj == 0) {
-        dst[(lane >> 4) * 2] = mean;
+        dst[(lane >> 4) * 2] = mean - shift;
         dst[(lane >> 4) * 2 + 1] = 1.0f / sqrtf(q2 / (float)K + eps);
+        if (mean_dst != nullptr) *mean_dst = mean;
     }
 }
 
@@ -322,12 +326,14 @@ struct TlExtras {
     float pm[16], pq[16];   // LN > 0: (mean, M2) partials of this lane's statistics row (the first NS of them)
     float bias, colsum, res;  // epilogue operands of this thread's first output element
     int tpos;                 // QKV: the position the new K / V rows are stored at
+    float sh, osh;            // shift of this lane's statistics row (consumer) / of this thread's first output row (producer)
 };
 
 // everything a chunk needs besides the weight stream; evaluated AFTER the weight requests are out (see tl_chunk)
 struct TlLate {
     const u32x4* at; const u32x4* al; int mts, mtl, mtv;
     const float* st_ptr; const float* pb; const float* pc; const float* pr; const int* ppos;
+    const float* psh; const float* posh;
 };
 
 template <typename WT, int MT, int LN, int NT, int NS, int C, typename LateFn>
@@ -385,7 +391,7 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
             ex.pm[i] = t.x; ex.pq[i] = t.y;
         }
     }
-    ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos;
+    ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos; ex.sh = *L.psh; ex.osh = *L.posh;
     __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
 #pragma unroll
     for (int i = 0; i < C; ++i)
@@ -427,7 +433,7 @@ __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __res
 #pragma unroll
         for (int u = 0; u < MT; ++u) av[u][i] = (at + (min(u, mtv - 1) * mts + ko))[lane];
     }
-    ex.bias = *pb; ex.res = *pr;
+    ex.bias = *pb; ex.res = *pr; ex.osh = *L.posh;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < C; ++i)
@@ -491,6 +497,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             L.pc = p.colsum != nullptr ? p.colsum + egn : own;
             L.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
             L.ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+            L.psh = (FOLD && p.a_shift != nullptr) ? p.a_shift + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), p.M - 1) : own;
+            L.posh = p.xt_shift != nullptr ? p.xt_shift + egm : own;
             return L;
         };
         TlExtras ex;
@@ -535,10 +543,19 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
 #pragma unroll
             for (int i = 0; i < NS; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
-            if (wave < ngroups) rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8);
+            // the row means also go to mean_out (the shift of the next producers of x): first n-tile's workgroup only
+            const bool wmean = p.mean_out != nullptr && wgtile == 0;
+            if (wave < ngroups) {
+                const int row = mg + wave * 4 + (lane >> 4);
+                rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8,
+                                   p.a_shift != nullptr ? ex.sh : 0.f, (wmean && row < p.M) ? p.mean_out + row : nullptr);
+            }
             for (int g = wave + nw; g < ngroups; g += nw) {
+                const int row = mg + g * 4 + (lane >> 4);
                 rowstat_load<NS>(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
-                rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8);
+                rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8,
+                                   p.a_shift != nullptr ? p.a_shift[min(row, p.M - 1)] : 0.f,
+                                   (wmean && row < p.M) ? p.mean_out + row : nullptr);
             }
         }
         __syncthreads();
@@ -585,13 +602,15 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
             if (!valid) continue;
             if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
                 const size_t ti = tiled_index<WT>(gm, gn, p.xt_nkc);
+                // single-term form: relative to the row's shift (include/acmi.h, acmi_linear_desc.xt_shift)
+                const float vs = p.xt_shift != nullptr ? v - (first ? ex.osh : p.xt_shift[gm]) : v;
                 if (sizeof(WT) == 2) {
-                    const bf16_t hi = f32_to_bf16(v);
+                    const bf16_t hi = f32_to_bf16(vs);
                     reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
                     if (p.xt_lo != nullptr)
-                        reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<WT>(gm, gn, p.xt_lo_nkc)] = f32_to_bf16(v - bf16_to_f32(hi));
+                        reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<WT>(gm, gn, p.xt_lo_nkc)] = f32_to_bf16(vs - bf16_to_f32(hi));
                 } else {
-                    reinterpret_cast<float*>(p.xt_hi)[ti] = v;
+                    reinterpret_cast<float*>(p.xt_hi)[ti] = vs;
                 }
             }
             if (p.qkv) {
@@ -813,6 +832,10 @@ static int desc_to_args(const acmi_linear_desc& c, LinArgs& p) {
         ACMI_REQUIRE(p.xt_nkc >= (c.N + kt - 1) / kt && p.xt_lo_nkc >= (c.N + kt - 1) / kt,
                      "acmi_linear: xt_rbs=%d / xt_lo_rbs=%d too small for N=%d", c.xt_rbs, c.xt_lo_rbs, c.N);
     }
+    ACMI_REQUIRE(c.a_shift == nullptr || c.colsum != nullptr, "acmi_linear: a_shift needs the folded LayerNorm (colsum)");
+    ACMI_REQUIRE(c.mean_out == nullptr || c.colsum != nullptr, "acmi_linear: mean_out needs the folded LayerNorm (colsum)");
+    ACMI_REQUIRE(c.xt_shift == nullptr || c.xt_hi != nullptr, "acmi_linear: xt_shift needs xt_hi");
+    p.a_shift = c.a_shift; p.xt_shift = c.xt_shift; p.mean_out = c.mean_out;
     p.stats_out = c.stats_out; p.ksplit = c.ksplit; p.w_half = c.w_half;
     p.w = c.w; p.bias = c.bias; p.residual = c.residual; p.out = c.out; p.out_mode = c.out_mode; p.act = c.act;
     p.M = c.M; p.N = c.N; p.K = c.K;

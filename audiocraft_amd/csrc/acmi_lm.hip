@@ -27,6 +27,7 @@ struct EmbedArgs {
     float* x; int d;
     float* stats;  // [M][1][2]: (mean, M2) of every produced row (one partial of d elements)
     void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
+    float* shift_out;  // [M] or NULL: single-term fragments bf16(x - mean), the row mean stored here (acmi_lm_state.xshift)
 };
 
 // BF16: element type of the tables; KQ >= n_q: codebook tables read per row (compile time, so that every load of a phase
@@ -80,7 +81,21 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
         if (is_prepend) v = pre[i];
         v += p.pos_scale * pv[i];
         p.x[(size_t)m * p.d + cch] = v;
+        loc[i] = v;
+        cnt = i + 1;
+        sum += v;
+    }
+    // two-pass (mean, M2) of the row for the first LayerNorm
+    const float mean = block_sum(sum, sred) / (float)p.d;
+    const float shift = p.shift_out != nullptr ? mean : 0.f;   // single-term fragments are stored relative to the row mean
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= cnt) break;
+        const int cch = (int)threadIdx.x + i * 256;
+        q += (loc[i] - mean) * (loc[i] - mean);
         if (p.xt_hi != nullptr) {
+            const float v = loc[i] - shift;
             if (BF16) {
                 const size_t ti = tiled_index<bf16_t>(m, cch, p.xt_nkc);
                 const bf16_t hi = f32_to_bf16(v);
@@ -91,18 +106,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
                 reinterpret_cast<float*>(p.xt_hi)[tiled_index<float>(m, cch, p.xt_nkc)] = v;
             }
         }
-        loc[i] = v;
-        cnt = i + 1;
-        sum += v;
     }
-    // two-pass (mean, M2) of the row for the first LayerNorm
-    const float mean = block_sum(sum, sred) / (float)p.d;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (i < cnt) q += (loc[i] - mean) * (loc[i] - mean);
     q = block_sum(q, sred);
-    if (threadIdx.x == 0) { p.stats[(size_t)m * 2] = mean; p.stats[(size_t)m * 2 + 1] = q; }
+    if (threadIdx.x == 0) {
+        p.stats[(size_t)m * 2] = mean; p.stats[(size_t)m * 2 + 1] = q;
+        if (p.shift_out != nullptr) p.shift_out[m] = mean;
+    }
 }
 
 // create_sin_embedding (transformer.py:70-89): one block per position, computed once per run geometry
@@ -403,15 +412,18 @@ static int ln_mode_of(const acmi_lm_model* m, const acmi_lm_state* s) {
     }
     if (want == LN_FOLD) {
         const bool have = m->cs_head != nullptr && m->layers[0].cs_qkv != nullptr && m->layers[0].cs_ff1 != nullptr &&
-                          (m->wdtype != ACMI_BF16 || s->xlo != nullptr) && m->dim / 16 <= 128 && m->dim % 16 == 0;
+                          (m->wdtype != ACMI_BF16 || s->xlo != nullptr || s->xshift != nullptr) && m->dim / 16 <= 128 &&
+                          m->dim % 16 == 0;
         return have ? LN_FOLD : LN_TILE;
     }
     return LN_TILE;
 }
-static bool fold_uses_lo() {  // experiment switch: ACMI_LN_LO=0 drops the low part of the bf16 pair
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ACMI_LN_LO"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v == 1;
+// bf16 weights: the raw x fragments are single-term with a per-row shift when the state carries `xshift` (default), the
+// hi / lo pair of 0.1.2 otherwise or with ACMI_LN_LO=1 (A/B switch); ACMI_LN_LO=0 without xshift = hi only, unshifted.
+static int fold_lo_env() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("ACMI_LN_LO"); v = e == nullptr ? -1 : (e[0] == '0' ? 0 : 1); }
+    return v;
 }
 
 // ---- the step's GEMM chain ---------------------------------------------------------------------------
@@ -470,6 +482,10 @@ struct StepCtx {
     void* xh; void* xl;        // fragments of the current x
     int np, cnt;               // statistics partials of the current x: np partials of cnt elements
     int rows;                  // rows of this call (Beff x positions)
+    // single-term mode (acmi_lm_state.xshift): xsh = the shift the CURRENT x fragments were stored with, nsh = the shift
+    // this layer's producers store with (the means the layer's QKV launch wrote); both NULL in hi / lo mode
+    const float* xsh; float* nsh;
+    bool use_lo;               // bf16 hi / lo pair
 };
 
 // out = act(LayerNorm(x) W'^T + bias): folded into the GEMM, or standardisation kernel + plain GEMM
@@ -477,8 +493,9 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
     const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
     p.a_tiled = 1; p.w = w; p.bias = bias; p.M = c.rows; p.N = N; p.K = m->dim;
     if (c.lnm == LN_FOLD) {
-        p.a = c.xh; p.a_rbs = c.rbs; p.a_lo = (m->wdtype == ACMI_BF16 && fold_uses_lo()) ? c.xl : nullptr;
+        p.a = c.xh; p.a_rbs = c.rbs; p.a_lo = c.use_lo ? c.xl : nullptr;
         p.a_stats = s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
+        p.a_shift = c.xsh;
     } else {
         int rc = acmi_launch_ln_tile(s->x, c.xh, m->wdtype, c.rows, m->dim, m->eps, nullptr, 0, c.st);
         if (rc) return rc;
@@ -494,7 +511,8 @@ static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs
     p.M = c.rows; p.N = m->dim; p.K = K;
     if (c.lnm == LN_FOLD) {
         p.stats_out = s->stats;
-        p.xt_hi = xh; p.xt_lo = m->wdtype == ACMI_BF16 ? xl : nullptr; p.xt_nkc = c.rbs; p.xt_lo_nkc = c.nkc_d;
+        p.xt_hi = xh; p.xt_lo = c.use_lo ? xl : nullptr; p.xt_nkc = c.rbs; p.xt_lo_nkc = c.nkc_d;
+        p.xt_shift = c.nsh;
     }
 }
 static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool w_half = false) {
@@ -503,6 +521,7 @@ static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool 
     p.w_half = w_half;
     int rc = acmi_launch_lin(p, c.m->wdtype, c.st);
     c.cnt = w_half ? 8 : 16; c.np = c.m->dim / c.cnt;   // 8-feature workgroups leave 8-element partials
+    c.xsh = c.nsh;                                       // the fragments of the new x carry this layer's shift
     return rc;
 }
 
@@ -528,11 +547,19 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     c.rbs = s->x_rbs > 0 ? s->x_rbs : c.nkc_d;
     ACMI_REQUIRE(c.rbs >= c.nkc_d, "acmi_lm_step: x_rbs=%d < %d K tiles of d", c.rbs, c.nkc_d);
     c.xh = s->xn; c.xl = s->xlo; c.np = 1; c.cnt = d; c.rows = M;
+    // bf16 fragments of x: ACMI_LN_LO=1 -> hi / lo pair; else with `xshift` (and not ACMI_LN_SHIFT=0) -> single term, per-row
+    // shift (default); else ACMI_LN_LO=0 / ACMI_LN_SHIFT=0 -> single term, unshifted (A/B only); else the hi / lo pair
+    static const bool shift_off = getenv("ACMI_LN_SHIFT") != nullptr && getenv("ACMI_LN_SHIFT")[0] == '0';
+    const bool foldbf = c.lnm == LN_FOLD && wbf;
+    const bool shifted = foldbf && s->xshift != nullptr && fold_lo_env() != 1 && !shift_off;
+    c.use_lo = foldbf && !shifted && s->xlo != nullptr && (fold_lo_env() == 1 || (fold_lo_env() == -1 && !shift_off));
+    float* const shbuf[2] = {s->xshift, s->xshift != nullptr ? s->xshift + M : nullptr};
+    c.xsh = nullptr; c.nsh = nullptr;
     // Cross-attention query without a launch of its own (include/acmi.h, acmi_linear_pair): needs the folded
     // LayerNorm, the [W_cq' | W_cq' W_out] matrices, xh buffers wide enough for [x | att] and a second pair.
     static const bool pair_enabled = !(getenv("ACMI_CROSS_FUSED") != nullptr && getenv("ACMI_CROSS_FUSED")[0] == '0');
     const bool pair = pair_enabled && m->cross_attention && c.lnm == LN_FOLD && m->layers[0].w_qkvx != nullptr &&
-                      m->layers[0].w_mq != nullptr && s->xn2 != nullptr && (!wbf || s->xlo2 != nullptr) && s->r != nullptr &&
+                      m->layers[0].w_mq != nullptr && s->xn2 != nullptr && (!c.use_lo || s->xlo2 != nullptr) && s->r != nullptr &&
                       c.rbs >= 2 * c.nkc_d;
     void* const xh2[2] = {s->xn, s->xn2};
     void* const xl2[2] = {s->xlo, s->xlo2};
@@ -543,7 +570,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.Beff = s->Beff; e.K = m->n_q; e.S = s->S; e.card = m->card;
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
-    if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = wbf ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
+    if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = c.use_lo ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
+    if (shifted) { e.shift_out = shbuf[0]; c.xsh = shbuf[0]; }
 #define ACMI_EMBED_CASE(KQv)                                                                        \
     if (m->n_q <= KQv) {                                                                           \
         if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
@@ -555,9 +583,12 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
 
     for (int li = 0; li < m->num_layers; ++li) {
         const acmi_lm_layer& L = m->layers[li];
+        const float* const sh_l = c.xsh;   // shift of the layer's input fragments (the cross-attention query's r is built on them)
+        if (shifted) c.nsh = shbuf[(li + 1) & 1];
         // norm1 -> QKV ; K, V appended in place at position g, q to scratch
         {
             LinArgs a = {};
+            a.mean_out = c.nsh;   // single-term mode: the row means of x0 = the shift of this layer's producers
             a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
             a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
             if (pair) {   // + the x0 part of the cross-attention query as a fourth, raw block of features -> r
@@ -591,6 +622,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
             ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.Beff = M; ca.H = H; ca.hd = hd; ca.Tcap = s->Lc;
             ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows;
+            ca.active_rows = (pair && s->cross_active_rows > 0 && s->cross_active_rows < s->Beff) ? s->cross_active_rows : 0;
             if (pair) {
                 // ONE launch: x1 = x0 + att W_out^T (fragments of x1 into the other buffer pair) and
                 // r += att (W_cq' W_out)^T, which completes r = x1 W_cq'^T (its x0 part came out of the QKV launch)
@@ -600,10 +632,11 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs;
                 p1.w = L.w_mq; p1.residual = s->r; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = d;
                 if ((rc = acmi_launch_pair(p0, p1, m->wdtype, st))) return rc;
-                cur ^= 1; c.xh = xh2[cur]; c.xl = xl2[cur]; c.np = d / 16; c.cnt = 16;
-                // the cross-attention kernel applies norm_cross to r from the statistics of x1
+                cur ^= 1; c.xh = xh2[cur]; c.xl = xl2[cur]; c.np = d / 16; c.cnt = 16; c.xsh = c.nsh;
+                // the cross-attention kernel applies norm_cross to r from the statistics of x1; r = (x1 - shift of x0's
+                // fragments) W_cq'^T, since its x0 part was accumulated on them
                 ca.q = s->r; ca.q_stats = s->stats; ca.q_stats_np = c.np; ca.q_stats_cnt = c.cnt; ca.eps = m->eps;
-                ca.q_colsum = L.cs_cq; ca.q_bias = L.b_cq;
+                ca.q_colsum = L.cs_cq; ca.q_bias = L.b_cq; ca.q_shift = sh_l;
             } else {
                 if ((rc = gemm_produce_x(c, s->att, L.w_out, d))) return rc;
                 LinArgs a = {};

@@ -35,6 +35,8 @@ struct LinArgs {
     int w_half;   // the weight is in half-tile order (8 features x 2 K tiles per 1 KB unit): 8-feature workgroups
     float* r_out; // QKV scatter with N = 4d: the fourth block of features is stored raw (no LayerNorm epilogue) to r_out [M, d]
     int rpp;      // QKV scatter: rows per position (row gm = position gm / rpp of the call, cache row gm % rpp)
+    // single-term raw activations with a per-row shift (include/acmi.h, acmi_linear_desc.a_shift / xt_shift / mean_out)
+    const float* a_shift; const float* xt_shift; float* mean_out;
 };
 
 template <typename WT> struct WTr {

@@ -389,6 +389,8 @@ class LMModel(nn.Module):
         for name in ('xlo', 'xlo2'):
             run[name] = _C.tiled_activation_buffer(rows, d, self.weight_dtype, dev)
         run['x_rbs'] = 2 * dp // kt
+        # single-term fragments (bf16 weights): per-row shifts, two alternating halves (acmi_lm_state.xshift)
+        run['xshift'] = torch.zeros(2 * rows, **f32)
         run['r'] = torch.zeros(rows, d, **f32)
         run['att'] = _C.tiled_activation_buffer(rows, d, self.weight_dtype, dev)
         run['hidden'] = _C.tiled_activation_buffer(rows, self.ffn_dim, self.weight_dtype, dev)
@@ -422,6 +424,9 @@ class LMModel(nn.Module):
         st.stats = run['stats'].data_ptr()
         st.xn, st.xlo, st.xn2, st.xlo2 = (run[k].data_ptr() for k in ('xn', 'xlo', 'xn2', 'xlo2'))
         st.x_rbs, st.r = run['x_rbs'], run['r'].data_ptr()
+        st.xshift = run['xshift'].data_ptr() if self.weight_dtype == torch.bfloat16 else None
+        st.cross_active_rows = 0
+        st.pf_xn, st.pf_vt, st.pf_tcap = None, None, 0
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None
         st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)
@@ -589,7 +594,15 @@ class LMModel(nn.Module):
         run['seq_mask'].copy_(mask.to(torch.uint8))
         run['pos'].zero_()
         if cross_src is not None:
-            self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
+            cross_src = cross_src.to(device=dev, dtype=torch.float32).contiguous()
+            self._project_cross_kv(run, cross_src)
+            # Rows whose source is all zero (null conditions: the `uncond` half of the CFG batch, conditioners.py:492-506)
+            # have K = V = 0 (no in_proj bias, checked at pack time): their cross-attention block adds exactly 0.  When
+            # they sit at the tail of the batch the attention launch skips them; `att` must then read as zeros there.
+            live = (cross_src != 0).flatten(1).any(dim=1).nonzero()
+            n_live = int(live.max()) + 1 if live.numel() else 0
+            state.cross_active_rows = n_live if 0 < n_live < run['Beff'] else 0
+            run['att'].zero_()
 
         # ---- prefill: prepended condition rows and prompt steps, PREFILL_CHUNK positions per call, no sampling
         self._set_first_call(state, P + start_offset_sequence)

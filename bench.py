@@ -72,7 +72,11 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     cat = torch.zeros(B_eff, 2 * dp, device=dev)
     cat[:, :d], cat[:, dp:dp + d] = rnd(d), rnd(d)
     xh = [_C.tile_matrix(cat, wd), _C.tile_matrix(cat, wd)]
-    xl = [_C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if wd == torch.bfloat16 else None for _ in range(2)]
+    # bf16: single-term fragments with a per-row shift (the default of acmi_lm_step), or the hi / lo pair (ACMI_LN_LO=1)
+    hilo = wd == torch.bfloat16 and os.environ.get('ACMI_LN_LO', '') == '1'
+    xl = [_C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if hilo else None for _ in range(2)]
+    shifts = [torch.zeros(B_eff, device=dev), torch.zeros(B_eff, device=dev)] if (wd == torch.bfloat16 and not hilo) else None
+    layer_no = 0
     np_ = max(1, d // 16)                                     # statistics partials of the current x (cnt elements each)
     stats = torch.zeros(B_eff, max(1, d // 8), 2, device=dev)
     stats[..., 1] = 16.0
@@ -87,17 +91,24 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     def wbytes(w):
         return w.N * w.K * w.data.element_size()
 
-    def consume(w, out, out_mode, colsum, bias, act=0):
-        # LayerNorm(x) @ W'^T: raw fragments + statistics + column sums
+    def sh_in():    # shift the current x fragments were stored with / the one this layer's producers use
+        return None if shifts is None else shifts[layer_no & 1]
+
+    def sh_out():
+        return None if shifts is None else shifts[(layer_no + 1) & 1]
+
+    def consume(w, out, out_mode, colsum, bias, act=0, first_of_layer=False, produced=True, publish=True):
+        # LayerNorm(x) @ W'^T: raw fragments + statistics + column sums; the QKV launch also publishes the row means
         nonlocal launches, nbytes
         _C.linear_ex(xh[cur], w, out, B_eff, _C.A_TILED, out_mode, a_stats=stats, np_=np_, cnt=d // np_, bias=bias, act=act,
-                     a_lo=xl[cur], colsum=colsum, a_rbs=rbs)
+                     a_lo=xl[cur], colsum=colsum, a_rbs=rbs, a_shift=sh_out() if produced and not first_of_layer else sh_in(),
+                     mean_out=sh_out() if (first_of_layer and publish) else None)
         launches += 1
         nbytes += wbytes(w)
 
     def produce_desc(a, w, a_rbs, dst):
         return _C.linear_desc(a, w, x, B_eff, _C.A_TILED, _C.OUT_F32, residual=x0, stats_out=stats, xt_hi=xh[dst],
-                              xt_lo=xl[dst], a_rbs=a_rbs, xt_rbs=rbs)
+                              xt_lo=xl[dst], a_rbs=a_rbs, xt_rbs=rbs, xt_shift=sh_out())
 
     def produce(a, w):
         # x = x0 + a @ W^T, also written as raw fragments and statistics partials (of 16 elements; of 8 when the weight
@@ -110,12 +121,12 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
 
     def one_position():
         # the same GEMM launches acmi_lm_step issues for one position (same shapes, operand layouts, weights)
-        nonlocal launches, nbytes, cur, np_
-        for ent in pk['per_layer']:
+        nonlocal launches, nbytes, cur, np_, layer_no
+        for layer_no, ent in enumerate(pk['per_layer']):
             if 'w_qkvx' in ent:
                 # QKV + the x0 part of the cross-attention query (a fourth block of features), then the out projection
                 # and the att part of that query in one launch (acmi_linear_pair); acmi_lm_layer.w_qkvx / w_mq
-                consume(ent['w_qkvx'], qkv, _C.OUT_F32, ent['cs_qkvx'], ent['b_qkvx'])
+                consume(ent['w_qkvx'], qkv, _C.OUT_F32, ent['cs_qkvx'], ent['b_qkvx'], first_of_layer=True)
                 att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
                 p0 = produce_desc(att_half, ent['w_out'], rbs, cur ^ 1)
                 p1 = _C.linear_desc(att_half, ent['w_mq'], q, B_eff, _C.A_TILED, _C.OUT_F32, residual=q, a_rbs=rbs)
@@ -128,7 +139,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                 cur ^= 1
                 produce(catt, ent['w_cout'])
             else:
-                consume(ent['w_qkv'], qkv, _C.OUT_F32, ent['cs_qkv'], ent['b_qkv'])
+                consume(ent['w_qkv'], qkv, _C.OUT_F32, ent['cs_qkv'], ent['b_qkv'], first_of_layer=True)
                 att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
                 _C.linear_launch(produce_desc(att_half, ent['w_out'], rbs, cur))
                 launches += 1
@@ -136,7 +147,8 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                 np_ = d // 16
             consume(ent['w_ff1'], h, _C.OUT_TILED, ent['cs_ff1'], ent['b_ff1'], act=1)
             produce(hid, ent['w_ff2h'] if 'w_ff2h' in ent and B_eff <= 32 else ent['w_ff2'])
-        consume(pk['w_head'], logits, _C.OUT_F32, pk['cs_head'], pk['b_head'])
+        layer_no += 1
+        consume(pk['w_head'], logits, _C.OUT_F32, pk['cs_head'], pk['b_head'], first_of_layer=True, publish=False)   # shift = the last layer's
 
     one_position()  # warm
     torch.cuda.synchronize()

@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 120 /* 0.1.2: cross-attention query split between the QKV launch (x0 part) and the out-projection
-                            launch; half-tile (8-feature) workgroups for FFN2 */
+#define ACMI_VERSION 130 /* 0.1.3: single-term raw activations with a per-row shift (acmi_linear_desc.a_shift / xt_shift /
+                            mean_out, acmi_lm_state.xshift), cross-attention restricted to the rows with a non-null
+                            condition (active_rows), prefill as MFMA-tiled GEMMs + causal prefill attention */
 
 #define ACMI_OK 0
 #define ACMI_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -242,6 +243,19 @@ typedef struct {
      * past_context): the reference's dropped-keys counter starts at 0 after that call (transformer.py:294-297), so
      * its later rotary positions lag by the keys the first call dropped.  0 / 0 = positions as they are. */
     int rope_first, rope_shift;
+    float* xshift;          /* device float[2 * rows] (rows = Beff * max n_pos) or NULL.  Not NULL with bf16 weights: the raw
+                               fragments of x are SINGLE-TERM, bf16(x - c[row]) (acmi_linear_desc.xt_shift), c = the row mean
+                               at the layer's input, kept in the two halves of this buffer alternately (the QKV launch
+                               of layer l writes the shift layer l's producers use); xlo / xlo2 are then unused.
+                               NULL: hi / lo pairs as in 0.1.2 */
+    int cross_active_rows;  /* > 0: the cross-attention source of CFG rows >= cross_active_rows is all zero (null
+                               conditions, conditioners.py:492-506): their keys / values are 0 and the block adds
+                               exactly 0 to x, so the attention launch skips them (acmi_attn_desc.active_rows); the
+                               caller zero-initialises `att`.  0 = run every row */
+    /* ACMI_STEP_PREFILL through the MFMA-tiled path (n_pos > 1): scratch, or all NULL / 0 = the decode kernels on extra rows */
+    void* pf_xn;            /* tiled activation [rows_pad, d_pad] in wdtype: standardised rows (acmi_ln_tile) */
+    void* pf_vt;            /* [Beff, H, hd, pf_tcap] in kvdtype: V of the positions of this call, time-minor */
+    int pf_tcap;            /* positions pf_vt holds per (row, head): >= pos[0] + n_pos, a multiple of 32 */
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0
@@ -336,6 +350,18 @@ typedef struct {
      * a_lo / ksplit), N % 8 == 0, K % (2 KT) == 0 and M <= 32.  With stats_out the partials are of 8 elements:
      * stats_out[(m * (N / 8) + j) * 2 ..], and the consumer passes a_stats_np = N / 8 (<= 256), a_stats_cnt = 8. */
     int w_half;
+    /* Per-row SHIFT of a single-term raw activation (bf16 weights, folded LayerNorm without a_lo).  A raw row stored as
+     * bf16(x) carries a rounding error of 2^-9 |x|; relative to the row's standard deviation -- what the LayerNorm divides
+     * by -- that grows with |mean| / std.  Storing bf16(x - c) with c close to the row mean bounds it by 2^-9 |x - c|
+     * whatever the mean, and the LayerNorm algebra absorbs c exactly:
+     *     LN(x) W'^T = rstd * ((x - c) W'^T - (mean - c) * colsum) + b.
+     *   xt_shift (producer, with xt_hi; device float[M] or NULL): the raw tiled copy is xt_hi = bf16(v - xt_shift[row])
+     *     (xt_lo, if also given, the remainder of v - xt_shift[row]);
+     *   a_shift  (consumer, with colsum; device float[M] or NULL): the shift the rows of `a` were stored with;
+     *   mean_out (consumer, with colsum; device float[M] or NULL): the row means this launch combines from a_stats are
+     *     also written here (by the workgroup of the first n-tile) -- the shift for the NEXT producers of x.
+     * In acmi_lm_step c = the mean of the row at the layer's input (one sub-layer earlier; exact for the embedding). */
+    const float* a_shift; const float* xt_shift; float* mean_out;
 } acmi_linear_desc;
 int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
 
@@ -376,6 +402,12 @@ typedef struct {
     const int* len_rows;    /* device int[cache_rows] or NULL: per-cache-row length (overrides len / len_dev; `len` must
                                still be given: it sizes the launch and bounds every row's length) */
     int past_context;       /* > 0: only the last past_context + 1 positions of the row's length are attended to */
+    const float* q_shift;   /* with q_colsum: per-row shift the raw row behind q was stored with (acmi_linear_desc.a_shift):
+                               q <- rstd (q - (mean - q_shift[b]) * q_colsum) + q_bias; NULL = 0 */
+    int active_rows;        /* > 0: only query rows whose cache row (b % cache_rows) is < active_rows are computed, the
+                               output of the others is left untouched -- cross-attention with null conditions at the tail
+                               of the batch ([cond; uncond]: K = V = 0 there, their attention output is exactly 0, so the
+                               caller zeroes those rows of `out` once and never runs them); 0 = all rows */
 } acmi_attn_desc;
 int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 

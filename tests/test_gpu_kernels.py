@@ -613,3 +613,83 @@ def test_sample_top_p_full_card_and_ties(C):
         top[~support] = 0
         heavy = top > 0.01
         assert seen[heavy].all()
+
+
+@pytest.mark.parametrize('M,d,N2', [(16, 1536, 4608), (5, 512, 96), (33, 2048, 512), (64, 1536, 256), (33, 1536, 4608)])
+@pytest.mark.parametrize('half', [False, True])
+def test_linear_single_term_with_row_shift(C, M, d, N2, half):
+    """Single-term raw activations made |mean| / std-proof (acmi_linear_desc.xt_shift / a_shift / mean_out): rows with
+    mean / std = 40.  The producer stores bf16(x1 - c[row]) with c NEAR the row mean (the mean one sub-layer earlier in
+    acmi_lm_step), the consumer applies rstd (acc - (mean - c) colsum): as accurate as a bf16 LayerNorm output, where
+    the unshifted single term is off by the ratio |mean| / std; and the consumer publishes the row means (mean_out)."""
+    if half and M > 32:
+        pytest.skip("8-feature workgroups serve calls of <= 32 rows")
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(M + d + 7)
+    K1 = 128
+    a = torch.randn(M, K1, generator=g)
+    w1 = torch.randn(d, K1, generator=g) / math.sqrt(K1)
+    x0 = torch.randn(M, d, generator=g) + 40.0 * (1 + torch.arange(M).float()[:, None] / M)   # large, row-dependent mean
+    w2 = torch.randn(N2, d, generator=g) / math.sqrt(d)
+    b2 = 0.1 * torch.randn(N2, generator=g)
+    x1_ref = x0 + a.to(dt).float() @ w1.to(dt).float().t()
+    ref = F.layer_norm(x1_ref, (d,), None, None, 1e-5) @ w2.to(dt).float().t() + b2
+    shift = (x0.mean(1) + 0.3 * torch.randn(M, generator=g)).cuda()     # close to, not equal to, the mean of x1
+    x = x0.cuda().clone()
+    cnt = 8 if half else 16
+    stats = torch.zeros(M, d // cnt, 2, device='cuda')
+    hi = C.tiled_activation_buffer(M, d, dt, 'cuda')
+    C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w1.cuda(), dt, half=half), x, M, C.A_TILED, C.OUT_F32,
+                stats_out=stats, residual=x, xt_hi=hi, xt_shift=shift)
+    assert rel(x.cpu(), x1_ref) < 1e-5
+    assert torch.equal(C.untile_matrix(hi, M, d).float(), (x - shift[:, None]).to(dt).float())
+    w2t = C.TiledWeight(w2.cuda(), dt)
+    colsum = w2.to(dt).double().sum(1).float().cuda()
+    out = torch.empty(M, N2, device='cuda')
+    means = torch.full((M,), float('nan'), device='cuda')
+    C.linear_ex(hi, w2t, out, M, C.A_TILED, C.OUT_F32, a_stats=stats, np_=d // cnt, cnt=cnt, bias=b2.cuda(), colsum=colsum,
+                a_shift=shift, mean_out=means)
+    r = rel(out.cpu(), ref)
+    assert r < 6e-3, f"shifted single term: rel-L2 {r}"
+    assert torch.allclose(means.cpu(), x1_ref.mean(1), rtol=1e-6, atol=1e-4)
+    # the same without the shift: the error scales with |mean| / std (this is what the shift removes)
+    hi0 = C.tiled_activation_buffer(M, d, dt, 'cuda')
+    x2 = x0.cuda().clone()
+    C.linear_ex(C.tile_matrix(a.cuda(), dt), C.TiledWeight(w1.cuda(), dt, half=half), x2, M, C.A_TILED, C.OUT_F32,
+                stats_out=stats, residual=x2, xt_hi=hi0)
+    out0 = torch.empty(M, N2, device='cuda')
+    C.linear_ex(hi0, w2t, out0, M, C.A_TILED, C.OUT_F32, a_stats=stats, np_=d // cnt, cnt=cnt, bias=b2.cuda(), colsum=colsum)
+    r0 = rel(out0.cpu(), ref)
+    print(f"[single-term] M={M} d={d}: rel-L2 shifted {r:.2e}, unshifted {r0:.2e} (mean / std ~ 40-80)")
+    assert r0 > 5 * r
+
+
+def test_attention_query_shift_and_active_rows(C):
+    """acmi_attn_desc.q_shift: q built on the row minus its shift, q <- rstd (q - (mean - shift) colsum) + bias;
+    active_rows: query rows past it are neither launched nor written."""
+    g = torch.Generator().manual_seed(13)
+    Beff, H, hd, Lc, dmodel = 6, 4, 64, 9, 256
+    d = H * hd
+    x = torch.randn(Beff, dmodel, generator=g) * 2 + 5.0
+    shift = x.mean(1) + 0.2 * torch.randn(Beff, generator=g)
+    wq = torch.randn(d, dmodel, generator=g) / math.sqrt(dmodel)
+    bias = 0.1 * torch.randn(d, generator=g)
+    k = torch.randn(Beff, H, Lc, hd, generator=g)
+    v = torch.randn(Beff, H, Lc, hd, generator=g)
+    q_ref = F.layer_norm(x, (dmodel,), None, None, 1e-5) @ wq.t() + bias
+    out_ref = torch.empty(Beff, d, device='cuda')
+    C.attn_decode(q_ref.cuda(), k.cuda(), v.cuda(), out_ref, Lc)
+    xb = x.view(Beff, dmodel // 16, 16)
+    mb = xb.mean(-1)
+    stats = torch.stack([mb, ((xb - mb[..., None]) ** 2).sum(-1)], dim=-1).contiguous().cuda()
+    out = torch.full((Beff, d), 7.0, device='cuda')
+    C.attn_decode(((x - shift[:, None]) @ wq.t()).cuda(), k.cuda(), v.cuda(), out, Lc, q_stats=stats, q_np=dmodel // 16,
+                  q_cnt=16, q_colsum=wq.sum(1).cuda(), q_bias=bias.cuda(), q_shift=shift.cuda(), active_rows=4)
+    assert rel(out[:4].cpu(), out_ref[:4].cpu()) < 1e-5
+    assert (out[4:] == 7.0).all()          # untouched
+    # several positions per call (prefill layout: row = position * cache_rows + cache row): rows are skipped by cache row
+    q2 = torch.cat([q_ref, q_ref], dim=0).cuda()
+    out2 = torch.full((2 * Beff, d), 7.0, device='cuda')
+    C.attn_decode(q2, k.cuda(), v.cuda(), out2, Lc, active_rows=4)
+    assert rel(out2[:4].cpu(), out_ref[:4].cpu()) < 1e-6 and rel(out2[Beff:Beff + 4].cpu(), out_ref[:4].cpu()) < 1e-6
+    assert (out2[4:Beff] == 7.0).all() and (out2[Beff + 4:] == 7.0).all()
