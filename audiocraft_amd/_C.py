@@ -95,7 +95,7 @@ class AttnDesc(C.Structure):
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
                 ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('cache_rows', i32), ('q_stats', vp), ('q_stats_np', i32),
                 ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp), ('past_context', i32),
-                ('q_shift', vp), ('active_rows', i32)]
+                ('q_shift', vp), ('active_rows', i32), ('pos_minor_rows', i32)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
@@ -108,9 +108,12 @@ _sample = _sig('acmi_sample', [vp, vp, vp, i32, i32, i32, i32, f32, f32, i32, f3
 _chroma = _sig('acmi_chroma', [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp])
 _chroma_frames = _sig('acmi_chroma_frames', [i32, i32])
 
+_linear_big = _sig('acmi_linear_big', [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
+_attn_prefill = _sig('acmi_attn_prefill', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
+
 _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp])
 
-EXPORTS = ['acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
+EXPORTS = ['acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
@@ -380,3 +383,23 @@ def resample_frac(x: torch.Tensor, kernel: torch.Tensor, old_sr: int, new_sr: in
     y = torch.empty(rows, out_len, device=x.device, dtype=torch.float32)
     check(_resample(ptr(x), ptr(y), ptr(kernel), rows, T, out_len, old_sr, new_sr, width, stream()), 'acmi_resample_frac')
     return y
+
+
+def linear_big(a, w: TiledWeight, out, M, bias=None, a_rbs=0, act=0, accumulate=False, out_ld=0):
+    """MFMA-tiled GEMM of the prefill (acmi_linear_big): a = tiled activation buffer (M rows, a multiple of 16), out = f32
+    row-major [M, N] (accumulate: out += result) or a tiled activation buffer in w.dtype (then act 1 = exact GELU)."""
+    out_mode = OUT_F32 if out.dtype == torch.float32 and out.dim() == 2 else OUT_TILED
+    check(_linear_big(ptr(a), a_rbs, ptr(w.data), dtype_code(w.dtype), ptr(bias), ptr(out), out_mode, out_ld, act,
+                      int(accumulate), M, w.N, w.K, stream()), 'acmi_linear_big')
+    return out
+
+
+def attn_prefill(q, k_cache, vt, out, npos, npos_pad, pos, past_context=0, out_rbs=0):
+    """Causal prefill attention (acmi_attn_prefill): q [rows * npos_pad, H * hd] f32 position-minor, k_cache [rows, H, Tcap, hd],
+    vt [rows, H, hd, vt_tcap] (V time-minor), pos: device int32 tensor (pos[0] = first position) -> out (tiled buffer)."""
+    rows, H, Tcap, hd = k_cache.shape
+    assert vt.shape[:3] == (rows, H, hd) and vt.dtype == k_cache.dtype
+    check(_attn_prefill(ptr(q), ptr(k_cache), ptr(vt), dtype_code(k_cache.dtype), ptr(out), dtype_code(out.dtype), out_rbs,
+                        rows, H, hd, Tcap, vt.shape[3], npos, npos_pad, ptr(pos), int(past_context), stream()),
+          'acmi_attn_prefill')
+    return out

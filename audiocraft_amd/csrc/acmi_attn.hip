@@ -35,6 +35,7 @@ struct AttnArgs {
     const float* q_stats; int q_np, q_cnt, q_K; float q_eps; const float* q_colsum; const float* q_bias;
     const float* q_shift;  // shift of the raw row behind q (acmi_attn_desc.q_shift), or NULL
     int active_rows;       // > 0: cache rows >= active_rows are skipped (their output stays as the caller left it)
+    int pm_n;              // > 0: position-minor query rows (row = cache row * pm_n + position), else row = position * rpp + cache row
 };
 
 template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
-    const int b0 = b % p.rpp, pidx = b / p.rpp;   // several positions per call (prefill): cache row, position index
+    const int b0 = p.pm_n > 0 ? b / p.pm_n : b % p.rpp;   // several positions per call (prefill): cache row,
+    const int pidx = p.pm_n > 0 ? b % p.pm_n : b / p.rpp;  // position index
     if (p.active_rows > 0 && b0 >= p.active_rows) return;   // null condition: K = V = 0, the output is exactly 0 (workgroup uniform)
     const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len)) : (p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len);
 
@@ -84,21 +86,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 
     const int nwv = blockDim.x >> 6;  // 1, 2 or 4 waves share the positions of this (row, head)
     // K and V of a whole chunk are requested together (2 * NI wide loads in flight per lane); the first chunk
-    // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x)
-    rawv kr[NI], vr[NI];
-    auto load_kv = [&](int t0) {
+    // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x).  TWO register sets: while
+    // one chunk is multiplied the wave's next one is already in flight (a (row, head) is one workgroup of <= 4 waves and a
+    // CU holds 1.5 of them: without this the memory system idles during every chunk's arithmetic and vice versa).
+    rawv kr[NI], vr[NI], kr2[NI], vr2[NI];
+    auto load_kv = [&](int t0, rawv (&kd)[NI], rawv (&vd)[NI]) {
         // branch free: lanes past the end re-read the last position (their scores are masked below); a per-lane
         // zero fill would write the registers of loads still in flight and make every load wait for the previous
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = min(t0 + i * PPI + pp, len - 1);
-            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
-            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
+            kd[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
+            vd[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
     };
     const int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
-    load_kv(start + wave * CH);
+    const int tstep = nwv * CH;                    // distance between two chunks of this wave
+    load_kv(start + wave * CH, kr, vr);
+    if (start + wave * CH + tstep < len) load_kv(start + wave * CH + tstep, kr2, vr2);   // wave-uniform branch
     if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
         const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
         const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
@@ -109,14 +115,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - meff * qcs[e]) + qb[e];
     }
-    for (int t0 = start + wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
+    auto chunk = [&](int t0, const rawv (&kd)[NI], const rawv (&vd)[NI]) {   // online-softmax update with the chunk at t0
         float s[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = t0 + i * PPI + pp;
             float part = 0.f;
 #pragma unroll
-            for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kr[i][e]), part);
+            for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kd[i][e]), part);
             part = group_sum<LPP>(part);
             s[i] = (t < len) ? part * scale : -INFINITY;
         }
@@ -137,10 +143,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             const float pr = (t < len) ? expf(s[i] - m_new) : 0.f;
             l += pr;
 #pragma unroll
-            for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vr[i][e]), o[e]);
+            for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vd[i][e]), o[e]);
         }
         m = m_new;
-        if (t0 + nwv * CH < len) load_kv(t0 + nwv * CH);
+    };
+    for (int t0 = start + wave * CH; t0 < len; t0 += 2 * tstep) {   // kr / vr hold the chunk at t0, kr2 / vr2 the one at t0 + tstep
+        chunk(t0, kr, vr);
+        if (t0 + 2 * tstep < len) load_kv(t0 + 2 * tstep, kr, vr);
+        if (t0 + tstep < len) {
+            chunk(t0 + tstep, kr2, vr2);
+            if (t0 + 3 * tstep < len) load_kv(t0 + 3 * tstep, kr2, vr2);
+        }
     }
 #pragma unroll
     for (int off = LPP; off < 64; off <<= 1) {
@@ -243,6 +256,9 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
     }
     ACMI_REQUIRE(c.active_rows >= 0 && c.active_rows <= a.rpp, "acmi_attn_decode: active_rows=%d outside [0, %d]", c.active_rows, a.rpp);
     a.active_rows = c.active_rows;
+    ACMI_REQUIRE(c.pos_minor_rows >= 0 && (c.pos_minor_rows == 0 || c.Beff == a.rpp * c.pos_minor_rows),
+                 "acmi_attn_decode: pos_minor_rows=%d does not match %d query rows over %d cache rows", c.pos_minor_rows, c.Beff, a.rpp);
+    a.pm_n = c.pos_minor_rows;
     return c.kvdtype == ACMI_BF16 ? launch_attn_t<bf16_t>(a, c.Beff, c.hd, (hipStream_t)stream)
                                   : launch_attn_t<float>(a, c.Beff, c.hd, (hipStream_t)stream);
 }

@@ -28,6 +28,8 @@ struct EmbedArgs {
     float* stats;  // [M][1][2]: (mean, M2) of every produced row (one partial of d elements)
     void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
     float* shift_out;  // [M] or NULL: single-term fragments bf16(x - mean), the row mean stored here (acmi_lm_state.xshift)
+    int npos_pad, npos; // > 0: position-minor rows of the MFMA-tiled prefill (row = cache row * npos_pad + position; pad
+                        // rows repeat the last position: finite, never stored to the caches); 0: row = position * Beff + cache row
 };
 
 // BF16: element type of the tables; KQ >= n_q: codebook tables read per row (compile time, so that every load of a phase
@@ -37,7 +39,9 @@ template <bool BF16, int KQ>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     __shared__ float sred[4];
     const int m = blockIdx.x;              // row = position-of-the-call * Beff + CFG row
-    const int pidx = m / p.Beff, m0 = m - pidx * p.Beff;
+    int pidx, m0;
+    if (p.npos_pad > 0) { m0 = m / p.npos_pad; pidx = min(m - m0 * p.npos_pad, p.npos - 1); }
+    else { pidx = m / p.Beff; m0 = m - pidx * p.Beff; }
     const int g = *p.pos + pidx;
     const int b = m0 % p.B;
     float loc[8];  // d <= 2048
@@ -436,12 +440,15 @@ static int fold_lo_env() {
 struct RopeArgs {
     float* q; void* kc; int kv_bf16; int H, hd, Tcap, d, rpp; const int* pos;
     const float* freq; const float* decay; float scale, base; int first, shift;
+    int npos_pad, npos;   // > 0: position-minor rows (see EmbedArgs); pad rows are skipped
 };
 
 __global__ __launch_bounds__(1024) void rope_qk_kernel(const RopeArgs p) {
     const int gm = blockIdx.x, pi = threadIdx.x, half = p.hd >> 1;
     const int h = pi / half, i = pi - h * half;
-    const int pidx = gm / p.rpp, brow = gm - pidx * p.rpp;      // several positions per call (prefill)
+    int pidx, brow;                                             // several positions per call (prefill)
+    if (p.npos_pad > 0) { brow = gm / p.npos_pad; pidx = gm - brow * p.npos_pad; if (pidx >= p.npos) return; }
+    else { pidx = gm / p.rpp; brow = gm - pidx * p.rpp; }
     const int tpos = *p.pos + pidx;
     const int rp = tpos >= p.first ? tpos - p.shift : tpos;     // rotary position (acmi_lm_state.rope_first / rope_shift)
     float sn, cs;
@@ -525,9 +532,110 @@ static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool 
     return rc;
 }
 
+// ---- the prompt / prefix positions through ONE forward: MFMA-tiled GEMMs + causal prefill attention (acmi_prefill.hip)
+// Same arithmetic as the reference's first streaming call (lm.py:540-543): per layer LayerNorm (its own launch: rows
+// standardised into the weight's element type; the affine part lives in the folded matrices) -> QKV GEMM whose epilogue
+// appends K / V to the caches -> causal attention over [0, position] -> out projection accumulating onto x -> cross
+// attention (the decode kernel on every row: the source is short) -> FFN.  Rows are position-minor (include/acmi.h).
+static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStream_t st) {
+    const int npos = s->n_pos, npp = (npos + 15) / 16 * 16, M = s->Beff * npp;
+    const int d = m->dim, H = m->num_heads, hd = d / H, F = m->ffn_dim;
+    const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16, kt = wbf ? 32 : 16;
+    const int nkc_d = d / kt;
+    ACMI_REQUIRE(d % (2 * kt) == 0 && F % (2 * kt) == 0, "acmi_lm_step: the tiled prefill needs d and ffn to be multiples of %d", 2 * kt);
+    ACMI_REQUIRE(s->pf_vt != nullptr && s->pf_tcap % 32 == 0 && s->pf_tcap >= npos, "acmi_lm_step: pf_vt / pf_tcap=%d for %d positions",
+                 s->pf_tcap, npos);
+    ACMI_REQUIRE(m->layers[0].w_qkv != nullptr && m->layers[0].b_qkv != nullptr && m->layers[0].b_ff1 != nullptr,
+                 "acmi_lm_step: the tiled prefill needs the folded-LayerNorm matrices");
+    int rc;
+    EmbedArgs e = {};
+    for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
+    e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.Beff = s->Beff; e.K = m->n_q; e.S = s->S; e.card = m->card;
+    e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
+    e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
+    e.npos_pad = npp; e.npos = npos;
+#define ACMI_EMBED_CASE(KQv)                                                                        \
+    if (m->n_q <= KQv) {                                                                           \
+        if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
+        else hipLaunchKernelGGL((embed_kernel<false, KQv>), dim3(M), dim3(256), 0, st, e);         \
+    } else
+    ACMI_EMBED_CASE(4) ACMI_EMBED_CASE(8) ACMI_EMBED_CASE(16) {}
+#undef ACMI_EMBED_CASE
+    if ((rc = acmi_check_launch("embed_kernel"))) return rc;
+
+    auto big = [&](const void* a, const void* w, const float* bias, int N, int K, int epi) {
+        BigArgs b = {};
+        b.a = a; b.w = w; b.bias = bias; b.M = M; b.N = N; b.K = K; b.epi = epi;
+        return b;
+    };
+    for (int li = 0; li < m->num_layers; ++li) {
+        const acmi_lm_layer& L = m->layers[li];
+        if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
+        {
+            BigArgs b = big(s->pf_xn, L.w_qkv, L.b_qkv, 3 * d, d, ACMI_BIG_QKV);
+            b.q_out = s->q; b.k_cache = L.k_cache; b.v_cache = L.v_cache; b.vt = s->pf_vt; b.kv_bf16 = kvbf;
+            b.H = H; b.hd = hd; b.Tcap = s->Tmax; b.d = d; b.npos = npos; b.npos_pad = npp; b.vt_tcap = s->pf_tcap; b.pos = s->pos;
+            if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
+        }
+        if (li == m->num_layers - 1) break;   // the last layer only owes its K / V: no position of this call is sampled from
+        if (m->rope_freq != nullptr) {
+            RopeArgs ra = {};
+            ra.q = s->q; ra.kc = L.k_cache; ra.kv_bf16 = kvbf; ra.H = H; ra.hd = hd; ra.Tcap = s->Tmax; ra.d = d; ra.rpp = s->Beff;
+            ra.pos = s->pos; ra.freq = m->rope_freq; ra.decay = m->rope_decay; ra.scale = m->rope_scale; ra.base = m->rope_base;
+            ra.first = s->rope_first > 0 ? s->rope_first : 0x7fffffff; ra.shift = s->rope_shift;
+            ra.npos_pad = npp; ra.npos = npos;
+            hipLaunchKernelGGL(rope_qk_kernel, dim3(M), dim3(d / 2), 0, st, ra);
+            if ((rc = acmi_check_launch("rope_qk_kernel"))) return rc;
+        }
+        {
+            PrefillAttnArgs pa = {};
+            pa.q = s->q; pa.k_cache = L.k_cache; pa.vt = s->pf_vt; pa.out = s->att; pa.out_bf16 = wbf; pa.out_rbs = nkc_d;
+            pa.H = H; pa.Tcap = s->Tmax; pa.vt_tcap = s->pf_tcap; pa.npos = npos; pa.npos_pad = npp; pa.pos = s->pos;
+            pa.past_context = m->past_context;
+            if ((rc = acmi_launch_prefill_attn(pa, m->kvdtype, hd, s->Beff, st))) return rc;
+        }
+        {
+            BigArgs b = big(s->att, L.w_out, nullptr, d, d, ACMI_BIG_RESID);
+            b.out = s->x; b.ldo = d;
+            if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
+        }
+        if (m->cross_attention) {
+            ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache && L.w_cq && L.b_cq, "acmi_lm_step: cross-attention operands missing");
+            if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
+            BigArgs b = big(s->pf_xn, L.w_cq, L.b_cq, d, d, ACMI_BIG_F32);
+            b.out = s->q; b.ldo = d;
+            if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
+            acmi_attn_desc ca = {};
+            ca.q = s->q; ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
+            ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.out_rbs = nkc_d; ca.Beff = M; ca.H = H; ca.hd = hd;
+            ca.Tcap = s->Lc; ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows; ca.pos_minor_rows = npp;
+            if ((rc = acmi_attn_decode_ex(&ca, (void*)st))) return rc;
+            BigArgs c = big(s->att, L.w_cout, nullptr, d, d, ACMI_BIG_RESID);
+            c.out = s->x; c.ldo = d;
+            if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;
+        }
+        if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
+        {
+            BigArgs b = big(s->pf_xn, L.w_ff1, L.b_ff1, F, d, ACMI_BIG_TILED);
+            b.out_t = s->hidden; b.out_rbs = F / kt; b.act = 1;
+            if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
+            BigArgs c = big(s->hidden, L.w_ff2, nullptr, d, F, ACMI_BIG_RESID);
+            c.out = s->x; c.ldo = d;
+            if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;
+        }
+    }
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, s->pos, npos);
+    return acmi_check_launch("advance_kernel");
+}
+
 extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int mode, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ACMI_REQUIRE(m && s, "acmi_lm_step: null argument");
+    if (mode == ACMI_STEP_PREFILL && s->pf_xn != nullptr && s->n_pos > 1) {
+        ACMI_REQUIRE(m->dim % m->num_heads == 0 && m->n_q <= 16 && s->use_cfg >= ACMI_CFG_NONE && s->use_cfg <= ACMI_CFG_DOUBLE &&
+                     s->Beff == s->B * (s->use_cfg + 1), "acmi_lm_step: bad geometry");
+        return lm_prefill_big(m, s, st);
+    }
     // rows of this call: Beff per position; a PREFILL call may run several consecutive positions at once (row
     // p * Beff + b = position pos[0] + p of CFG row b): K / V of all of them are in the cache before any attends
     const int npos = (mode == ACMI_STEP_PREFILL && s->n_pos > 1) ? s->n_pos : 1;

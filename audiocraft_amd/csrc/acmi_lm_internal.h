@@ -57,3 +57,30 @@ int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st);                 // 
 int acmi_launch_pair(LinArgs& p0, LinArgs& p1, int wdtype, hipStream_t st);  // two tiled GEMMs, one launch
 int acmi_launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps, const float* slabs, int nslabs,
                         hipStream_t st);
+
+// ---- prefill (acmi_prefill.hip): MFMA-tiled GEMM on tiled operands + causal prefill attention
+enum { ACMI_BIG_F32 = 0, ACMI_BIG_RESID = 1, ACMI_BIG_TILED = 2, ACMI_BIG_QKV = 3 };
+
+struct BigArgs {
+    const void* a; int a_rbs;   // tiled activation [M / 16][a_rbs][64 lanes][16 B]
+    const void* w;              // tiled weight [ceil(N / 16)][NKC][64][16 B]
+    const float* bias;          // [N] f32 or NULL
+    int M, N, K, NKC;           // M: rows, a multiple of 16 (row blocks past it are never read)
+    int epi, act;               // ACMI_BIG_*; act 1 = exact GELU (tiled epilogue)
+    float* out; int ldo;        // F32 / RESID: row-major f32 [M, ldo] (RESID: out += result)
+    void* out_t; int out_rbs;   // TILED: tiled activation in the weight's element type, K tiles per 16-row block
+    // QKV (N = 3 d): q -> q_out [M, d] f32; K / V -> caches [rows, H, Tcap, hd] at position pos[0] + p of cache row
+    // row / npos_pad (p = row % npos_pad < npos); V also time-minor into vt [rows, H, hd, vt_tcap]
+    float* q_out; void* k_cache; void* v_cache; void* vt;
+    int kv_bf16, H, hd, Tcap, d, npos, npos_pad, vt_tcap; const int* pos;
+};
+int acmi_launch_big(BigArgs& a, int wdtype, hipStream_t st);
+
+struct PrefillAttnArgs {
+    const float* q;             // [rows * npos_pad, H * hd] f32, position-minor rows
+    const void* k_cache;        // [rows, H, Tcap, hd]
+    const void* vt;             // [rows, H, hd, vt_tcap]
+    void* out; int out_bf16, out_rbs;   // tiled activation [rows * npos_pad, H * hd]
+    int H, Tcap, vt_tcap, npos, npos_pad; const int* pos; int past_context; float scale;
+};
+int acmi_launch_prefill_attn(PrefillAttnArgs& a, int kvdtype, int hd, int Beff, hipStream_t st);

@@ -1,0 +1,434 @@
+// Prefill of the MusicGen LM for gfx950 (CDNA4, wave64): the prompt / prepended-condition positions of a generate run
+// through ONE forward, like the reference does (audiocraft/models/lm.py:540-543, modules/transformer.py:233-264, 362-414,
+// models/genmodel.py:233-262), instead of position by position through the decode kernels.
+//
+//   lin_big_kernel        MFMA-tiled GEMM  out[M, N] = a[M, K] W[N, K]^T  on the SAME tiled operands the decode step uses
+//                         (1 KB A / B fragments, include/acmi.h): 128 x 128 workgroup tiles, 4 waves of 64 x 64, K in steps
+//                         of two fragments, fragments staged through LDS in fragment order (every ds_read_b128 is lane
+//                         linear: conflict free), epilogues: f32 / residual add / tiled (+ GELU) / QKV scatter into the KV
+//                         cache (+ V time-minor for the prefill attention).
+//   attn_prefill_kernel   causal attention of all prompt positions of a (cache row, head): flash-style over the K cache,
+//                         S^T = K Q^T so that a query's scores sit in one lane column, P feeds the second MFMA straight
+//                         from registers (its k slots are matched by the load pattern of the time-minor V), online softmax.
+//
+// Row layout of every prefill activation: POSITION-MINOR and padded, row = cache_row * npos_pad + position (npos_pad =
+// positions rounded up to 16), so that a 16-row MFMA block is 16 consecutive positions of ONE cache row: the QKV
+// epilogue then stores 4 consecutive positions of V^T with one 8-byte store and never straddles cache rows.
+#include "acmi_lm_internal.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+__device__ __forceinline__ void big_mma(const u32x4& a, const u32x4& b, f32x4& acc, bf16_t) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void big_mma(const u32x4& a, const u32x4& b, f32x4& acc, float) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+}
+__device__ __forceinline__ float big_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// =====================================================================================================
+// MFMA-tiled GEMM on tiled operands
+// =====================================================================================================
+template <typename WT, int EPI>
+__global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x 32 fragments x 1 KB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7, nb = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // workgroup b runs on XCD b % 8: one contiguous run of tiles per L2
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int MT16 = p.M >> 4, NT16 = (p.N + 15) >> 4;
+    const u32x4* __restrict__ A = reinterpret_cast<const u32x4*>(p.a);
+    const u32x4* __restrict__ W = reinterpret_cast<const u32x4*>(p.w);
+
+    // the 8 fragments of a stage this wave moves: waves 0, 1 the activation's (row block wave * 4 + i / 2, K fragment i & 1),
+    // waves 2, 3 the weight's; LDS fragment index = wave * 8 + i in both cases
+    size_t base[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        if (wave < 2) base[h] = (size_t)min(tm * 8 + wave * 4 + h, MT16 - 1) * p.a_rbs * 64 + lane;
+        else base[h] = (size_t)min(tn * 8 + (wave - 2) * 4 + h, NT16 - 1) * p.NKC * 64 + lane;
+    }
+    const u32x4* __restrict__ src = wave < 2 ? A : W;
+    u32x4* lds = reinterpret_cast<u32x4*>(smem);
+    const int nks = p.NKC >> 1;
+    u32x4 st[8];
+    auto fetch = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = src[base[i >> 1] + (size_t)(2 * ks + (i & 1)) * 64];
+    };
+    auto stash = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds[(stage * 32 + wave * 8 + i) * 64 + lane] = st[i];
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const bool more = ks + 1 < nks;
+        if (more) fetch(ks + 1);                    // in flight while this stage is multiplied
+        const u32x4* sb = lds + (ks & 1) * 32 * 64 + lane;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sb[((wm * 4 + i) * 2 + kc) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sb[(16 + (wn * 4 + j) * 2 + kc) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) big_mma(a[i], b[j], acc[i][j], WT());
+        }
+        if (more) stash((ks + 1) & 1);              // the other buffer: every wave left it at the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (kg, n) of tile (i, j) holds rows kg * 4 + r, column n
+    const int nl = lane & 15, kg = lane >> 4;
+    const int row0 = tm * 128 + wm * 64 + kg * 4, col0 = tn * 128 + wn * 64 + nl;
+    // every operand of the epilogue is requested before the first one is used (a load left inside the store loops is a
+    // memory round trip per element: 64 of them per lane)
+    int pos0 = 0;
+    if (EPI == ACMI_BIG_QKV) pos0 = *p.pos;
+    float biasv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) biasv[j] = p.bias != nullptr ? p.bias[min(col0 + j * 16, p.N - 1)] : 0.f;
+    if (EPI == ACMI_BIG_RESID) {   // out += acc: the old values in two batches of 32 loads in flight (register budget: two
+#pragma unroll
+        for (int jh = 0; jh < 4; jh += 2) {   // workgroups per CU)
+            float old[4][2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        old[i][j][r] = p.out[(size_t)min(row0 + i * 16 + r, p.M - 1) * p.ldo + min(col0 + (jh + j) * 16, p.N - 1)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jh + j][r] += old[i][j][r];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = col0 + j * 16;
+        if (col >= p.N) continue;
+        const float bias = biasv[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rb = row0 + i * 16;           // first of this lane's 4 rows
+            if (rb >= p.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias;
+            if (EPI == ACMI_BIG_F32 || EPI == ACMI_BIG_RESID) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.out[(size_t)(rb + r) * p.ldo + col] = v[r];
+            } else if (EPI == ACMI_BIG_TILED) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = p.act == 1 ? big_gelu(v[r]) : v[r];
+                    st_f32(reinterpret_cast<WT*>(p.out_t) + tiled_index<WT>(rb + r, col, p.out_rbs), y);
+                }
+            } else {   // QKV: q to scratch, K / V appended to the cache, V also time-minor (4 positions = one store)
+                const int part = col / p.d, f = col - part * p.d;
+                if (part == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p.q_out[(size_t)(rb + r) * p.d + f] = v[r];
+                } else {
+                    const int h = f / p.hd, dd = f - h * p.hd;
+                    const int brow = rb / p.npos_pad, pidx = rb - brow * p.npos_pad;   // 4 rows = positions pidx .. pidx + 3 of one cache row
+                    void* cache = part == 1 ? p.k_cache : p.v_cache;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (pidx + r >= p.npos) continue;
+                        const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + pos0 + pidx + r) * p.hd + dd;
+                        if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v[r]);
+                        else reinterpret_cast<float*>(cache)[ci] = v[r];
+                    }
+                    if (part == 2 && p.vt != nullptr) {   // pad positions get the (finite) values of the pad rows: never attended to
+                        const size_t vi = (((size_t)brow * p.H + h) * p.hd + dd) * p.vt_tcap + pos0 + pidx;
+                        if (p.kv_bf16) {
+                            bf16_t* dst = reinterpret_cast<bf16_t*>(p.vt) + vi;
+                            if (((pos0 + pidx) & 3) == 0) {
+                                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dst[r] = f32_to_bf16(v[r]);
+                            }
+                        } else {
+                            float* dst = reinterpret_cast<float*>(p.vt) + vi;
+                            if (((pos0 + pidx) & 3) == 0) {
+                                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dst[r] = v[r];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename WT>
+static int launch_big_t(const BigArgs& a, hipStream_t st) {
+    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const size_t lds = 2 * 32 * 1024;
+#define ACMI_BIG_CASE(E)                                                                                                  \
+    case E: {                                                                                                             \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E>),                                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {               \
+                acmi_set_error("acmi_linear_big: cannot set the dynamic LDS limit");                                      \
+                return ACMI_ELAUNCH;                                                                                      \
+            }                                                                                                             \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((lin_big_kernel<WT, E>), dim3(tiles), dim3(256), lds, st, a);                                  \
+        break;                                                                                                            \
+    }
+    switch (a.epi) {
+        ACMI_BIG_CASE(ACMI_BIG_F32)
+        ACMI_BIG_CASE(ACMI_BIG_RESID)
+        ACMI_BIG_CASE(ACMI_BIG_TILED)
+        ACMI_BIG_CASE(ACMI_BIG_QKV)
+        default:
+            acmi_set_error("acmi_linear_big: bad epilogue %d", a.epi);
+            return ACMI_EINVAL;
+    }
+#undef ACMI_BIG_CASE
+    return acmi_check_launch("lin_big_kernel");
+}
+
+int acmi_launch_big(BigArgs& a, int wdtype, hipStream_t st) {
+    const int kt = wdtype == ACMI_BF16 ? 32 : 16;
+    ACMI_REQUIRE(a.M > 0 && a.M % 16 == 0 && a.N > 0 && a.K > 0, "acmi_linear_big: M=%d must be a positive multiple of 16 (N=%d K=%d)",
+                 a.M, a.N, a.K);
+    a.NKC = (a.K + kt - 1) / kt;
+    ACMI_REQUIRE(a.NKC % 2 == 0, "acmi_linear_big: K=%d must span an even number of %d-column tiles", a.K, kt);
+    if (a.a_rbs <= 0) a.a_rbs = a.NKC;
+    ACMI_REQUIRE(a.a_rbs >= a.NKC, "acmi_linear_big: a_rbs=%d < %d K tiles", a.a_rbs, a.NKC);
+    return wdtype == ACMI_BF16 ? launch_big_t<bf16_t>(a, st) : launch_big_t<float>(a, st);
+}
+
+extern "C" int acmi_linear_big(const void* a, int a_rbs, const void* w, int wdtype, const float* bias, void* out, int out_mode,
+                               int out_ld, int act, int accumulate, int M, int N, int K, void* stream) {
+    BigArgs p = {};
+    p.a = a; p.a_rbs = a_rbs; p.w = w; p.bias = bias; p.M = M; p.N = N; p.K = K; p.act = act;
+    ACMI_REQUIRE(out_mode == ACMI_OUT_F32 || out_mode == ACMI_OUT_TILED, "acmi_linear_big: out_mode %d unsupported", out_mode);
+    ACMI_REQUIRE(!(accumulate && out_mode != ACMI_OUT_F32), "acmi_linear_big: accumulate needs an f32 row-major output");
+    ACMI_REQUIRE(act == 0 || out_mode == ACMI_OUT_TILED, "acmi_linear_big: the activation is fused into the tiled epilogue only");
+    if (out_mode == ACMI_OUT_F32) {
+        p.epi = accumulate ? ACMI_BIG_RESID : ACMI_BIG_F32;
+        p.out = reinterpret_cast<float*>(out); p.ldo = out_ld > 0 ? out_ld : N;
+    } else {
+        const int kt = wdtype == ACMI_BF16 ? 32 : 16;
+        p.epi = ACMI_BIG_TILED; p.out_t = out; p.out_rbs = out_ld > 0 ? out_ld : (N + kt - 1) / kt;
+    }
+    return acmi_launch_big(p, wdtype, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+// causal prefill attention
+// =====================================================================================================
+// One wave = 16 consecutive query positions of one (cache row, head); a workgroup = 4 such waves (no LDS, no barrier).
+// S^T[t, q] = sum_d K[t, d] Q[q, d]: MFMA A operand = K rows straight from the cache (lane (kg, m = t): 16 bytes of row t),
+// B operand = the wave's queries (lane (kg, n = q)).  In the C layout lane (kg, q) then holds the scores of keys
+// t0 + tt * 16 + kg * 4 + r (tt < TT, r < 4) of ITS query: softmax statistics are per lane column (4 lanes, xor 16 / 32),
+// and the probabilities are already the B operand of the second MFMA  O^T[d, q] = sum_t V^T[d, t] P[q, t]  if that MFMA's
+// k slot (kg, j = tt * 4 + r) means key t0 + tt * 16 + kg * 4 + r -- which is how the A operand is fetched from the
+// time-minor V: lane (kg, m = d) reads keys t0 + tt * 16 + kg * 4 .. + 3 of row d (8 bytes per tt in bf16).
+template <typename KT, int HD>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillAttnArgs p) {
+    constexpr int E = 16 / (int)sizeof(KT);       // elements per lane of a fragment: 8 (bf16) / 4 (f32)
+    constexpr int KTILE = 4 * E;                  // k columns per fragment: 32 / 16
+    constexpr int TT = KTILE / 16;                // 16-key score tiles per probability fragment: 2 / 1
+    constexpr int NKD = (HD + KTILE - 1) / KTILE; // fragments along the head dimension
+    constexpr int ND = (HD + 15) / 16;            // 16-row tiles of O^T
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nl = lane & 15, kg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * 16;   // first query position (index inside this call) of the wave
+    if (q0 >= p.npos) return;
+    const int pos0 = *p.pos;
+    const int d = p.H * HD;
+    const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.k_cache) + ((size_t)b * p.H + h) * p.Tcap * HD;
+    const KT* __restrict__ vt = reinterpret_cast<const KT*>(p.vt) + ((size_t)b * p.H + h) * HD * p.vt_tcap;
+
+    // queries as B fragments: lane (kg, n) holds Q[q0 + n][kc * KTILE + kg * E .. + E), scaled, in the cache's element type
+    const int qi = min(q0 + nl, p.npos - 1);
+    const float* qrow = p.q + ((size_t)b * p.npos_pad + qi) * d + h * HD;
+    u32x4 qf[NKD];
+#pragma unroll
+    for (int c = 0; c < NKD; ++c) {
+        float t[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int f = c * KTILE + kg * E + e;
+            t[e] = f < HD ? qrow[min(f, HD - 1)] : 0.f;
+        }
+        if (sizeof(KT) == 2) {
+            qf[c] = u32x4{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2 % E], t[3 % E]), pack_bf16x2(t[4 % E], t[5 % E]),
+                          pack_bf16x2(t[6 % E], t[7 % E])};
+        } else {
+            qf[c] = u32x4{__float_as_uint(t[0]), __float_as_uint(t[1]), __float_as_uint(t[2 % E]), __float_as_uint(t[3 % E])};
+        }
+    }
+    const int tq = pos0 + q0 + nl;                 // absolute position of this lane's query (keys <= tq are visible)
+    const int tq_last = pos0 + min(q0 + 15, p.npos - 1);
+    int t_first = 0;
+    if (p.past_context > 0) t_first = max(0, pos0 + q0 - p.past_context) / KTILE * KTILE;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = t_first; t0 <= tq_last; t0 += KTILE) {
+        // K fragments (A operand of S^T) and V^T fragments (A operand of O^T) of this key block: all requested up front
+        u32x4 kf[TT][NKD];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int t = min(t0 + tt * 16 + nl, p.Tcap - 1);
+#pragma unroll
+            for (int c = 0; c < NKD; ++c) {
+                const int f = c * KTILE + kg * E;   // first head feature of this lane's 16 bytes
+                kf[tt][c] = f < HD ? *reinterpret_cast<const u32x4*>(kc + (size_t)t * HD + f) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        u32x4 vf[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int dd = min(i * 16 + nl, HD - 1);
+            const KT* vrow = vt + (size_t)dd * p.vt_tcap + t0 + kg * 4;   // keys t0 + tt * 16 + kg * 4 .. + 3
+            if (sizeof(KT) == 2) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                vf[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            } else {
+                vf[i] = *reinterpret_cast<const u32x4*>(vrow);
+            }
+        }
+        // scores of this lane's query against keys t0 + tt * 16 + kg * 4 + r
+        f32x4 s[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NKD; ++c) big_mma(kf[tt][c], qf[c], s[tt], KT());
+        }
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + tt * 16 + kg * 4 + r;
+                const bool vis = t <= tq && (p.past_context <= 0 || t >= tq - p.past_context);
+                s[tt][r] = vis ? s[tt][r] * p.scale : -INFINITY;
+                cmax = fmaxf(cmax, s[tt][r]);
+            }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m_run, cmax);
+        // a query with no visible key so far (its window starts in a later block) keeps m = -inf: alpha = 1, p = 0
+        const float alpha = m_new == -INFINITY ? 1.f : expf(m_run - m_new);
+        float psum = 0.f, pr[TT * 4];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = s[tt][r] == -INFINITY ? 0.f : expf(s[tt][r] - m_new);
+                pr[tt * 4 + r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        u32x4 pf;
+        if (sizeof(KT) == 2) {
+            pf = u32x4{pack_bf16x2(pr[0], pr[1]), pack_bf16x2(pr[2], pr[3]), pack_bf16x2(pr[4 % (TT * 4)], pr[5 % (TT * 4)]),
+                       pack_bf16x2(pr[6 % (TT * 4)], pr[7 % (TT * 4)])};
+        } else {
+            pf = u32x4{__float_as_uint(pr[0]), __float_as_uint(pr[1]), __float_as_uint(pr[2]), __float_as_uint(pr[3])};
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
+            big_mma(vf[i], pf, o[i], KT());
+        }
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    // O^T: lane (kg, n = q) holds head features i * 16 + kg * 4 + r -> 4 consecutive columns of the tiled output row
+    const int q = q0 + nl;
+    if (q >= p.npos) return;
+    const int row = b * p.npos_pad + q;
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int f = i * 16 + kg * 4;
+        if (f >= HD) continue;
+        const int col = h * HD + f;
+        if (p.out_bf16) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + tiled_index<bf16_t>(row, col, p.out_rbs);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[i][0] * inv, o[i][1] * inv), pack_bf16x2(o[i][2] * inv, o[i][3] * inv));
+        } else {
+            float* dst = reinterpret_cast<float*>(p.out) + tiled_index<float>(row, col, p.out_rbs);
+            *reinterpret_cast<float4*>(dst) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+        }
+    }
+}
+
+int acmi_launch_prefill_attn(PrefillAttnArgs& a, int kvdtype, int hd, int Beff, hipStream_t st) {
+    ACMI_REQUIRE(a.npos > 0 && a.npos_pad >= a.npos && a.npos_pad % 16 == 0, "acmi_attn_prefill: bad npos=%d npos_pad=%d", a.npos, a.npos_pad);
+    ACMI_REQUIRE(a.vt_tcap % 32 == 0 && a.vt_tcap > 0, "acmi_attn_prefill: vt_tcap=%d must be a positive multiple of 32", a.vt_tcap);
+    ACMI_REQUIRE(hd % 4 == 0, "acmi_attn_prefill: head dim %d", hd);
+    a.scale = 1.0f / sqrtf((float)hd);
+    dim3 grid((a.npos + 63) / 64, a.H, Beff), block(256);
+#define ACMI_PFA_CASE(HDv)                                                                                              \
+    case HDv:                                                                                                           \
+        if (kvdtype == ACMI_BF16) hipLaunchKernelGGL((attn_prefill_kernel<bf16_t, HDv>), grid, block, 0, st, a);        \
+        else hipLaunchKernelGGL((attn_prefill_kernel<float, HDv>), grid, block, 0, st, a);                              \
+        break;
+    switch (hd) {
+        ACMI_PFA_CASE(8)
+        ACMI_PFA_CASE(16)
+        ACMI_PFA_CASE(32)
+        ACMI_PFA_CASE(64)
+        ACMI_PFA_CASE(128)
+        default:
+            acmi_set_error("acmi_attn_prefill: head dim %d unsupported (8, 16, 32, 64, 128)", hd);
+            return ACMI_EINVAL;
+    }
+#undef ACMI_PFA_CASE
+    return acmi_check_launch("attn_prefill_kernel");
+}
+
+extern "C" int acmi_attn_prefill(const float* q, const void* k_cache, const void* vt, int kvdtype, void* out, int out_dtype,
+                                 int out_rbs, int Beff, int H, int hd, int Tcap, int vt_tcap, int npos, int npos_pad,
+                                 const int* pos, int past_context, void* stream) {
+    PrefillAttnArgs a = {};
+    a.q = q; a.k_cache = k_cache; a.vt = vt; a.out = out; a.out_bf16 = out_dtype == ACMI_BF16;
+    const int kt = out_dtype == ACMI_BF16 ? 32 : 16;
+    a.out_rbs = out_rbs > 0 ? out_rbs : (H * hd + kt - 1) / kt;
+    a.H = H; a.Tcap = Tcap; a.vt_tcap = vt_tcap; a.npos = npos; a.npos_pad = npos_pad; a.pos = pos; a.past_context = past_context;
+    ACMI_REQUIRE(pos != nullptr && Beff > 0 && H > 0 && Tcap > 0, "acmi_attn_prefill: bad arguments");
+    return acmi_launch_prefill_attn(a, kvdtype, hd, Beff, (hipStream_t)stream);
+}

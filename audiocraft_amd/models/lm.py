@@ -665,9 +665,60 @@ class LMModel(nn.Module):
         if self.past_context and self.positional_embedding != 'sin' and n_first > self.past_context:
             state.rope_first, state.rope_shift = int(n_first), int(n_first - self.past_context)
 
+    PREFILL_MAX_POSITIONS = 4096   # one MFMA-tiled call covers at most this many positions (activations: Beff x this rows)
+
+    def _big_prefill_ok(self, n_positions: int) -> bool:
+        """The MFMA-tiled prefill (acmi_lm_step with pf_xn: ONE forward over all prompt / prefix positions, like the
+        reference's first streaming call, lm.py:540-543) serves a prefill that starts an empty stream when the geometry
+        fits its tiles; ACMI_PREFILL=chunk forces the decode kernels on PREFILL_CHUNK positions per call (A/B, tests)."""
+        import os
+        mode = os.environ.get('ACMI_PREFILL', '')
+        if mode == 'chunk':
+            return False
+        kt = _C._tile_params(self.weight_dtype)[1]
+        hd = self.dim // self.num_heads
+        fits = (self.dim % (2 * kt) == 0 and self.ffn_dim % (2 * kt) == 0 and hd in (8, 16, 32, 64, 128)
+                and self.kv_dtype == self.weight_dtype and n_positions <= self.PREFILL_MAX_POSITIONS)
+        return fits and n_positions >= (2 if mode == 'big' else 4)
+
+    def _prefill_big(self, desc, state, run, n_positions: int):
+        dev = self.device
+        Beff, d, H = run['Beff'], self.dim, self.num_heads
+        npp = -(-n_positions // 16) * 16
+        tcap = -(-n_positions // 32) * 32
+        rows = Beff * npp
+        pf = run.get('pf')
+        if pf is None or pf['rows'] < rows or pf['tcap'] < tcap:
+            f32 = dict(device=dev, dtype=torch.float32)
+            rows_a, tcap_a = max(rows, pf['rows'] if pf else 0), max(tcap, pf['tcap'] if pf else 0)
+            run['pf'] = pf = None   # release the previous scratch first
+            pf = {'rows': rows_a, 'tcap': tcap_a,
+                  'x': torch.zeros(rows_a, d, **f32), 'q': torch.zeros(rows_a, d, **f32),
+                  'stats': torch.zeros(rows_a, 2, **f32),
+                  'xn': _C.tiled_activation_buffer(rows_a, d, self.weight_dtype, dev),
+                  'att': _C.tiled_activation_buffer(rows_a, d, self.weight_dtype, dev),
+                  'hidden': _C.tiled_activation_buffer(rows_a, self.ffn_dim, self.weight_dtype, dev),
+                  'vt': torch.zeros(Beff * H * (d // H) * tcap_a, device=dev, dtype=self.kv_dtype)}
+            run['pf'] = pf
+        saved = (state.x, state.q, state.stats, state.att, state.hidden)
+        state.x, state.q, state.stats = pf['x'].data_ptr(), pf['q'].data_ptr(), pf['stats'].data_ptr()
+        state.att, state.hidden = pf['att'].data_ptr(), pf['hidden'].data_ptr()
+        state.pf_xn, state.pf_vt, state.pf_tcap = pf['xn'].data_ptr(), pf['vt'].data_ptr(), tcap
+        state.n_pos = n_positions
+        try:
+            _C.lm_step(desc, state, _C.STEP_PREFILL)
+        finally:
+            state.x, state.q, state.stats, state.att, state.hidden = saved
+            state.pf_xn, state.pf_vt, state.pf_tcap = None, None, 0
+            state.n_pos = 1
+
     def _prefill(self, desc, state, n_positions: int):
-        """Run `n_positions` input-only positions (prepended conditions, prompt tokens): the same kernels as a
-        decode position, several consecutive positions per call as extra rows (acmi_lm_state.n_pos)."""
+        """Run `n_positions` input-only positions (prepended conditions, prompt tokens) from the start of an empty stream
+        (every caller has just zeroed the position counter): one MFMA-tiled forward over all of them when the geometry
+        allows (`_big_prefill_ok`), else the same kernels as a decode position, several consecutive positions per call as
+        extra rows (acmi_lm_state.n_pos)."""
+        if n_positions > 0 and self._big_prefill_ok(n_positions):
+            return self._prefill_big(desc, state, self._run, n_positions)
         done = 0
         while done < n_positions:
             state.n_pos = min(self.PREFILL_CHUNK, n_positions - done)

@@ -252,9 +252,12 @@ typedef struct {
                                conditions, conditioners.py:492-506): their keys / values are 0 and the block adds
                                exactly 0 to x, so the attention launch skips them (acmi_attn_desc.active_rows); the
                                caller zero-initialises `att`.  0 = run every row */
-    /* ACMI_STEP_PREFILL through the MFMA-tiled path (n_pos > 1): scratch, or all NULL / 0 = the decode kernels on extra rows */
-    void* pf_xn;            /* tiled activation [rows_pad, d_pad] in wdtype: standardised rows (acmi_ln_tile) */
-    void* pf_vt;            /* [Beff, H, hd, pf_tcap] in kvdtype: V of the positions of this call, time-minor */
+    /* ACMI_STEP_PREFILL through the MFMA-tiled path: pf_xn != NULL and n_pos > 1 (all NULL / 0 = the decode kernels on
+     * n_pos * Beff extra rows).  Every activation buffer of this struct (x, q, att, hidden, stats) then holds
+     * Beff * npos_pad rows, npos_pad = n_pos rounded up to 16, POSITION-MINOR (row = cache_row * npos_pad + position); att
+     * and hidden with exactly ceil(d / KT) resp. ceil(ffn / KT) K tiles per row block; xn / xlo / r / logits unused. */
+    void* pf_xn;            /* tiled activation [Beff * npos_pad, d_pad] in wdtype: standardised rows (acmi_ln_tile) */
+    void* pf_vt;            /* [Beff, H, hd, pf_tcap] in kvdtype, zero-initialised: V of this call's positions, time-minor */
     int pf_tcap;            /* positions pf_vt holds per (row, head): >= pos[0] + n_pos, a multiple of 32 */
 } acmi_lm_state;
 
@@ -408,8 +411,34 @@ typedef struct {
                                output of the others is left untouched -- cross-attention with null conditions at the tail
                                of the batch ([cond; uncond]: K = V = 0 there, their attention output is exactly 0, so the
                                caller zeroes those rows of `out` once and never runs them); 0 = all rows */
+    int pos_minor_rows;     /* > 0: the Beff = cache_rows * pos_minor_rows query rows are position-minor (row = cache row *
+                               pos_minor_rows + position: the layout of the MFMA-tiled prefill) instead of position-major */
 } acmi_attn_desc;
 int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Prefill: the prompt / prepended-condition positions through ONE forward (reference lm.py:540-543,
+ * transformer.py:233-264, 362-414; every > 30 s window of genmodel.py:233-262 starts with a 600-token prompt)
+ * ------------------------------------------------------------------------------------------
+ * Activations of a prefill call are POSITION-MINOR and padded: row = cache_row * npos_pad + position, npos_pad = the
+ * call's positions rounded up to a multiple of 16 (pad rows are computed and never stored to the caches). */
+
+/* MFMA-tiled GEMM on the decode step's operand layouts: out[M, N] = a[M, K] W[N, K]^T + bias.  a: tiled activation (a_rbs K
+ * tiles per 16-row block, 0 = ceil(K / KT)), w: tiled weight, both in `wdtype`; M a multiple of 16, K an even number of KT
+ * tiles.  out_mode ACMI_OUT_F32: row-major f32 with leading dimension out_ld (0 = N), `accumulate` != 0 adds to it (the
+ * residual stream); ACMI_OUT_TILED: tiled activation in wdtype with out_ld K tiles per row block (0 = ceil(N / KT)),
+ * act 1 = exact GELU.  128 x 128 workgroup tiles, fragments staged through LDS. */
+int acmi_linear_big(const void* a, int a_rbs, const void* w, int wdtype, const float* bias, void* out, int out_mode,
+                    int out_ld, int act, int accumulate, int M, int N, int K, void* stream);
+
+/* Causal attention of npos consecutive positions pos[0] .. pos[0] + npos - 1 of every (cache row, head) over keys
+ * [0, position] (past_context > 0: the last past_context + 1 of them), the F.scaled_dot_product_attention(is_causal) of
+ * transformer.py:412-414 for a multi-step first call.  q [Beff * npos_pad, H * hd] f32 (position-minor rows), k_cache
+ * [Beff, H, Tcap, hd] and vt [Beff, H, hd, vt_tcap] (V time-minor, vt_tcap a multiple of 32, >= pos[0] + npos; entries past
+ * the last position must be finite) in `kvdtype` -> out: tiled activation [Beff * npos_pad, H * hd] in out_dtype. */
+int acmi_attn_prefill(const float* q, const void* k_cache, const void* vt, int kvdtype, void* out, int out_dtype,
+                      int out_rbs, int Beff, int H, int hd, int Tcap, int vt_tcap, int npos, int npos_pad,
+                      const int* pos, int past_context, void* stream);
 
 /* Scatter rows [Beff, L, H*hd] f32 into a [Beff, H, Tcap, hd] cache at positions [t0, t0+L). */
 int acmi_kv_store(const float* src, void* cache, int kvdtype, int Beff, int H, int hd, int Tcap,

@@ -8,21 +8,25 @@ What is timed is the body of the reference's autoregressive loop, exactly as `LM
 (audiocraft/models/lm.py:536-565): `LMModel._sample_next_token` inside `with lm.streaming()` -- `[seq; seq]` CFG batch,
 transformer forward on the streaming state (its `torch.cat` KV cache included), CFG mix, softmax / top-k / multinomial.
 """
+import os
 import time
 import typing as tp
 
 import torch
 
-from . import refstubs
+REF_ROOT = os.environ.get('AUDIOCRAFT_REFERENCE', '/root/reference')
 
 
 def available() -> bool:
-    return refstubs.available()
+    """True where the reference tree exists.  Importing this module never touches it: oracle/refstubs.py (which installs
+    the import stubs and REQUIRES the tree) is imported by the functions below, i.e. only after `available()` said yes."""
+    return os.path.isdir(os.path.join(REF_ROOT, 'audiocraft'))
 
 
 def build_reference_lm(sd: dict, dim: int, num_heads: int, num_layers: int, n_q: int, card: int, cross_attention: bool):
     """The reference `LMModel` with MusicGen's configuration (config/model/lm/musicgen_lm.yaml over default.yaml) and the
     given reference-format state dict (transformer / embeddings / heads; conditioner weights are not on the timed path)."""
+    from . import refstubs  # noqa: F401  (installs the import stubs; needs the reference tree)
     from audiocraft.models.lm import LMModel
     from audiocraft.modules.codebooks_patterns import DelayedPatternProvider
     from audiocraft.modules.conditioners import ConditionFuser, ConditioningProvider, TextConditioner
@@ -89,6 +93,7 @@ def time_reference_positions(lm, B: int, cross: torch.Tensor, top_k: int, early_
 @torch.no_grad()
 def time_reference_codec_decode(csd: dict, B: int, frames: int, generator=None) -> float:
     """Seconds for `EncodecModel.decode` of [B, 4, frames] codes at the EnCodec-32 kHz geometry (reference modules)."""
+    from . import refstubs  # noqa: F401
     from audiocraft.models.encodec import EncodecModel
     from audiocraft.modules.seanet import SEANetDecoder, SEANetEncoder
     from audiocraft.quantization.vq import ResidualVectorQuantizer

@@ -693,3 +693,73 @@ def test_attention_query_shift_and_active_rows(C):
     C.attn_decode(q2, k.cuda(), v.cuda(), out2, Lc, active_rows=4)
     assert rel(out2[:4].cpu(), out_ref[:4].cpu()) < 1e-6 and rel(out2[Beff:Beff + 4].cpu(), out_ref[:4].cpu()) < 1e-6
     assert (out2[4:Beff] == 7.0).all() and (out2[Beff + 4:] == 7.0).all()
+
+
+@pytest.mark.parametrize('M,N,K', [(16, 96, 64), (128, 128, 128), (272, 1536, 512), (48, 4608, 1536), (608, 200, 256)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_linear_big_vs_torch(C, M, N, K, dt):
+    """acmi_linear_big (the prefill's MFMA-tiled GEMM, 128 x 128 tiles, on the decode step's tiled operands): plain f32
+    output with bias, accumulation onto a residual stream, tiled output with GELU; partial tiles in M and N."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = 0.1 * torch.randn(N, generator=g)
+    x0 = torch.randn(M, N, generator=g)
+    ref = a.to(dt).float() @ w.to(dt).float().t() + bias
+    tol = 2e-6 if dt == torch.float32 else 1e-5
+    at, wt = C.tile_matrix(a.cuda(), dt), C.TiledWeight(w.cuda(), dt)
+    out = torch.full((M, N), float('nan'), device='cuda')
+    C.linear_big(at, wt, out, M, bias=bias.cuda())
+    assert rel(out.cpu(), ref) < tol
+    acc = x0.cuda().clone()
+    C.linear_big(at, wt, acc, M, accumulate=True)
+    assert rel(acc.cpu(), x0 + ref - bias) < tol
+    kt = 32 if dt == torch.bfloat16 else 16
+    if N % kt == 0:
+        tiled = C.tiled_activation_buffer(M, N, dt, 'cuda')
+        C.linear_big(at, wt, tiled, M, bias=bias.cuda(), act=1)
+        got = C.untile_matrix(tiled, M, N).float().cpu()
+        assert rel(got, F.gelu(ref).to(dt).float()) < (2e-6 if dt == torch.float32 else 3e-3)
+    # a wider activation buffer (K tiles between row blocks > K / KT): only the first K columns are read
+    wide = torch.cat([a, torch.randn(M, 2 * kt, generator=g)], dim=1)
+    out2 = torch.empty(M, N, device='cuda')
+    C.linear_big(C.tile_matrix(wide.cuda(), dt), wt, out2, M, bias=bias.cuda(), a_rbs=(K + 2 * kt) // kt)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize('kvdt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Beff,H,hd,npos,pos0,window', [(3, 4, 64, 37, 0, 0), (2, 2, 16, 70, 0, 0), (2, 3, 8, 33, 0, 0),
+                                                         (2, 4, 64, 100, 0, 25), (2, 2, 64, 21, 32, 0), (1, 2, 128, 130, 0, 0)])
+def test_attn_prefill_vs_torch(C, kvdt, Beff, H, hd, npos, pos0, window):
+    """acmi_attn_prefill: causal attention of npos consecutive positions over the K cache and the time-minor V, position-
+    minor padded rows, partial last query block, optional window, optional earlier context (pos0 > 0, all of it present in
+    both K and V^T)."""
+    g = torch.Generator().manual_seed(Beff * 100 + hd + npos)
+    Ttot = pos0 + npos
+    Tcap, tcap = Ttot + 5, -(-Ttot // 32) * 32
+    npp = -(-npos // 16) * 16
+    d = H * hd
+    q = torch.randn(Beff, npp, d, generator=g)
+    k = torch.randn(Beff, H, Tcap, hd, generator=g).to(kvdt)
+    v = torch.randn(Beff, H, Ttot, hd, generator=g).to(kvdt)
+    vt = torch.zeros(Beff, H, hd, tcap, dtype=kvdt)
+    vt[..., :Ttot] = v.transpose(2, 3)
+    qh = q[:, :npos].view(Beff, npos, H, hd).permute(0, 2, 1, 3)
+    qh = qh.to(kvdt).float()                                   # the kernel rounds q to the cache's element type
+    s = torch.einsum('bhqd,bhtd->bhqt', qh, k[:, :, :Ttot].float()) / math.sqrt(hd)
+    tq = pos0 + torch.arange(npos)[:, None]
+    tk = torch.arange(Ttot)[None, :]
+    vis = tk <= tq
+    if window > 0:
+        vis = vis & (tk >= tq - window)
+    s = s.masked_fill(~vis, float('-inf'))
+    ref = torch.einsum('bhqt,bhtd->bhqd', s.softmax(-1), v.float()).permute(0, 2, 1, 3).reshape(Beff, npos, d)
+    for odt in (torch.float32, torch.bfloat16):
+        out = C.tiled_activation_buffer(Beff * npp, d, odt, 'cuda')
+        pos = torch.tensor([pos0, 0, 0, 0], dtype=torch.int32, device='cuda')
+        C.attn_prefill(q.reshape(Beff * npp, d).cuda(), k.cuda(), vt.cuda(), out, npos, npp, pos, past_context=window)
+        got = C.untile_matrix(out, Beff * npp, d).float().cpu().view(Beff, npp, d)
+        tol = 2e-6 if (kvdt == torch.float32 and odt == torch.float32) else 1.5e-2
+        r = rel(got[:, :npos], ref)
+        assert r < tol, f"out {odt}: rel-L2 {r}"
+        assert got[:, npos:].abs().sum() == 0                  # pad rows are not written

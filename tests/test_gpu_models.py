@@ -189,7 +189,15 @@ def build_lm(cfg, sd, weight_dtype=torch.float32):
     return lm
 
 
-def test_lm_text_vs_reference_golden():
+@pytest.fixture(params=['big', 'chunk'])
+def prefill_mode(request, monkeypatch):
+    """Both prefill paths against the same reference goldens: 'big' = ONE MFMA-tiled forward over the prompt / prefix
+    (acmi_prefill.hip; forced from 2 positions on), 'chunk' = the decode kernels on 8 positions per call."""
+    monkeypatch.setenv('ACMI_PREFILL', request.param)
+    return request.param
+
+
+def test_lm_text_vs_reference_golden(prefill_mode):
     cfg, sd, a = load_golden('lm_text')
     lm = build_lm(cfg, sd)
     ones = torch.ones(a['cross_src'].shape[:2], dtype=torch.int64)
@@ -216,7 +224,7 @@ def test_lm_text_vs_reference_golden():
 
 
 @pytest.mark.parametrize('name', ['lm_rope', 'lm_sin_rope'])
-def test_lm_rope_past_context_layer_scale_vs_reference_golden(name):
+def test_lm_rope_past_context_layer_scale_vs_reference_golden(name, prefill_mode):
     """Rotary positions (+ xPos decay) applied by the QKV launch, the bounded receptive field of the attention kernel
     and LayerScale folded into the branch matrices, against goldens from the unmodified reference (custom attention:
     tests/golden/make_rope_golden.py); lm_rope's 9-step prompt exceeds past_context = 6, which exercises the windowed
@@ -245,7 +253,7 @@ def test_lm_rope_past_context_layer_scale_vs_reference_golden(name):
     assert rel(l16, a['tf_logits']) < 3e-2
 
 
-def test_lm_melody_vs_reference_golden():
+def test_lm_melody_vs_reference_golden(prefill_mode):
     cfg, sd, a = load_golden('lm_melody')
     lm = build_lm(cfg, sd)
     P, Lc = cfg['P'], cfg['Lc']
@@ -406,7 +414,7 @@ def test_lm_two_step_cfg_vs_reference_golden():
     assert torch.equal(toks2.cpu(), a['greedy_tokens'])   # an all-zero source contributes exactly 0 at any length
 
 
-def test_lm_double_cfg_vs_reference_golden():
+def test_lm_double_cfg_vs_reference_golden(prefill_mode):
     """cfg_coef_beta (MusicGen-Style double CFG, lm.py:362-376): 3B rows [text + wav; wav; null]."""
     cfg, sd, a = load_golden('lm_double_cfg')
     lm = build_lm(cfg, sd)
@@ -576,3 +584,84 @@ def test_t5_conditioner_real_huggingface_path(tmp_path):
     assert torch.equal(mask.cpu(), ref_mask) and mask.shape[1] == ins['input_ids'].shape[1]
     assert torch.allclose(emb.cpu(), ref, atol=2e-5, rtol=1e-4), (emb.cpu() - ref).abs().max()
     assert (emb[2] == 0).all() and (emb[1, int(ref_mask[1].sum()):] == 0).all()   # null prompt and padding: exact zeros
+
+
+# ------------------------------------------------------------------------------------------ prefill as one forward
+
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize('variant', ['text', 'prefix', 'rope_window'])
+def test_prefill_one_forward_matches_oracle_and_chunk_path(wdt, tol, variant, monkeypatch):
+    """The MFMA-tiled prefill (one forward over prompt + prefix: tiled GEMMs with the QKV scatter epilogue, causal prefill
+    attention over the K cache and the time-minor V) at a mid-size geometry (d 256, 4 heads of 64, 4 layers), 3 samples
+    (6 CFG rows), a 37-token prompt (npos_pad 48: pad rows, a ragged last query block): the first decode steps'
+    CFG logits against the oracle teacher-forced with the device's tokens, and against the 8-positions-per-call path.
+    'prefix': no cross-attention, 21 prepended rows; 'rope_window': rotary positions + past_context 20 (< prompt:
+    the lagging rotary offsets of the reference's long first call)."""
+    from audiocraft_amd.models import builders
+    from oracle import patterns as opat
+    torch.manual_seed(0)
+    cross = variant != 'prefix'
+    extra = dict(positional_embedding='rope', past_context=20, xpos=True) if variant == 'rope_window' else {}
+    conds = {'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 64, 'length': 6}}
+    if not cross:
+        conds['self_wav'] = {'kind': 'chroma', 'embedder': 'synthetic', 'n_frames': 15}
+    cfg = dict(dim=256, num_heads=4, num_layers=4, n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0, conditioners=conds,
+               fuser={'cross': ['description']} if cross else {'prepend': ['self_wav', 'description']}, **extra)
+    lm = builders.get_lm_model(cfg, 'cuda', wdt)
+    with torch.no_grad():
+        for k, prm in lm.named_parameters():
+            if 'norm' in k:
+                prm.add_(0.1 * torch.randn_like(prm))
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    if wdt == torch.bfloat16:
+        sd = {k: (v.bfloat16().float() if v.dim() == 2 and 'output_proj' not in k else v) for k, v in sd.items()}
+    oc = olm.LMConfig(dim=256, num_heads=4, num_layers=4, n_q=4, card=2048, cross_attention=cross, **extra)
+    B, T0, T = 3, 37, 44
+    g = torch.Generator().manual_seed(7)
+    if cross:
+        src = torch.randn(2 * B, 6, 256, generator=g)
+        src[B:] = 0
+        ct = {'description': (src.cuda(), torch.ones(2 * B, 6, dtype=torch.int64).cuda())}
+        cross_src, prepend = src, None
+    else:
+        pre = torch.randn(2 * B, 21, 256, generator=g)
+        ones = lambda n: torch.ones(2 * B, n, dtype=torch.int64).cuda()   # noqa: E731
+        ct = {'self_wav': (pre[:, :15].cuda(), ones(15)), 'description': (pre[:, 15:].cuda(), ones(6))}
+        cross_src, prepend = None, pre
+    prompt = torch.randint(0, 2048, (B, 4, T0), generator=g)
+    out = {}
+    for mode in ('big', 'chunk'):
+        monkeypatch.setenv('ACMI_PREFILL', mode)
+        toks, lg = lm.generate(prompt.cuda(), [], max_gen_len=T, use_sampling=False, condition_tensors=ct,
+                               return_logits=True, check=True)
+        out[mode] = (toks.cpu(), lg.cpu())
+    toks, lg = out['big']
+    assert torch.equal(toks[..., :T0], prompt)
+    # the first decode step's logits depend on nothing but the prefill: the two paths agree to rounding
+    r_paths = rel(lg[:, :, 0], out['chunk'][1][:, :, 0])
+    if variant == 'rope_window':
+        # A first call longer than past_context makes the reference's later rotary positions lag (transformer.py:294-313),
+        # which only its STREAMING evaluation shows: compare with the oracle's own generate (f32: free running, identical
+        # tokens); in bf16 the two device paths are compared with each other (the chunk path is pinned to the reference
+        # golden `lm_rope`, same situation)
+        if wdt == torch.float32:
+            ref_t, ref = olm.generate(sd, oc, prompt, B, cross_src, max_gen_len=T, use_sampling=False, return_logits=True)
+            assert torch.equal(toks, ref_t)
+            r = rel(lg, ref)
+        else:
+            r = rel(lg[:, :, 0], out['chunk'][1][:, :, 0])
+        r_chunk = float('nan')
+    else:
+        # oracle, teacher-forced with the device's tokens (batch forward == the reference's multi-step first call + steps)
+        seq, _ = opat.build_pattern_sequence(toks, 2048)
+        S = seq.shape[-1]
+        steps = lg.shape[2]
+        pair = torch.cat([seq, seq], dim=0)[..., :S - 1]
+        ref = olm.cfg_mix(olm.lm_forward(sd, oc, pair, cross_src, prepend), 3.0)[:, :, S - 1 - steps:]
+        r = rel(lg, ref)
+        r_chunk = rel(out['chunk'][1], ref) if torch.equal(out['chunk'][0], toks) else float('nan')
+    print(f"[parity] prefill one-forward, {variant}, {wdt}: CFG logits vs oracle rel-L2 {r:.3e} (chunk path {r_chunk:.3e}), "
+          f"first step big vs chunk {r_paths:.3e}")
+    assert r < tol and r_paths < 2 * tol, (r, r_paths)
+    if wdt == torch.float32:
+        assert torch.equal(toks, out['chunk'][0])

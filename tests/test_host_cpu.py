@@ -525,3 +525,16 @@ def test_audio_write_and_normalisation(tmp_path):
         audio_write(tmp_path / 'x', wav, sr, format='aiff')
     with pytest.raises(ValueError):
         audio_write(tmp_path / 'x', torch.zeros(1, 1, 10), sr)
+
+
+def test_bench_cpu_baseline_imports_without_the_reference_tree():
+    """bench.py's cpu_baseline leg imports oracle.ref_baseline on every box; where /root/reference does not exist (the GPU
+    box) that import must succeed and report `available() == False` (kind "port"), not raise."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, AUDIOCRAFT_REFERENCE='/nonexistent/reference')
+    code = ("import sys; sys.path.insert(0, %r); from oracle import ref_baseline as rb; "
+            "assert rb.available() is False; import bench; print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
