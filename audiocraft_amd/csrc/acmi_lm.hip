@@ -577,7 +577,6 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             b.H = H; b.hd = hd; b.Tcap = s->Tmax; b.d = d; b.npos = npos; b.npos_pad = npp; b.vt_tcap = s->pf_tcap; b.pos = s->pos;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
         }
-        if (li == m->num_layers - 1) break;   // the last layer only owes its K / V: no position of this call is sampled from
         if (m->rope_freq != nullptr) {
             RopeArgs ra = {};
             ra.q = s->q; ra.kc = L.k_cache; ra.kv_bf16 = kvbf; ra.H = H; ra.hd = hd; ra.Tcap = s->Tmax; ra.d = d; ra.rpp = s->Beff;
@@ -587,6 +586,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             hipLaunchKernelGGL(rope_qk_kernel, dim3(M), dim3(d / 2), 0, st, ra);
             if ((rc = acmi_check_launch("rope_qk_kernel"))) return rc;
         }
+        if (li == m->num_layers - 1) break;   // the last layer only owes its K / V: no position of this call is sampled from
         {
             PrefillAttnArgs pa = {};
             pa.q = s->q; pa.k_cache = L.k_cache; pa.vt = s->pf_vt; pa.out = s->att; pa.out_bf16 = wbf; pa.out_rbs = nkc_d;

@@ -677,8 +677,10 @@ class LMModel(nn.Module):
             return False
         kt = _C._tile_params(self.weight_dtype)[1]
         hd = self.dim // self.num_heads
+        rows = (self._run['Beff'] if self._run else 1) * (-(-n_positions // 16) * 16)
         fits = (self.dim % (2 * kt) == 0 and self.ffn_dim % (2 * kt) == 0 and hd in (8, 16, 32, 64, 128)
-                and self.kv_dtype == self.weight_dtype and n_positions <= self.PREFILL_MAX_POSITIONS)
+                and self.kv_dtype == self.weight_dtype and n_positions <= self.PREFILL_MAX_POSITIONS
+                and rows <= 65535)   # one launch row per grid.y entry of the cross-attention kernel
         return fits and n_positions >= (2 if mode == 'big' else 4)
 
     def _prefill_big(self, desc, state, run, n_positions: int):
