@@ -38,7 +38,9 @@ struct AttnArgs {
     int pm_n;              // > 0: position-minor query rows (row = cache row * pm_n + position), else row = position * rpp + cache row
 };
 
-template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
+// QN: LayerNorm hook on q (separate instantiation: no branch around its loads); DB: two register sets of K / V chunks
+// (the next chunk in flight while one is multiplied); DB = false is the single-set form kept for same-box A/B (ACMI_ATTN_DB=0)
+template <typename KT, int HD, bool QN, bool DB>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const float* __restrict__ q = p.q;
     const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.kc);
@@ -103,8 +105,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     };
     const int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
     const int tstep = nwv * CH;                    // distance between two chunks of this wave
-    load_kv(start + wave * CH, kr, vr);
-    if (start + wave * CH + tstep < len) load_kv(start + wave * CH + tstep, kr2, vr2);   // wave-uniform branch
+    const int tw0 = start + wave * CH;             // this wave's first chunk
+    const int nch = tw0 < len ? (len - tw0 + tstep - 1) / tstep : 0;   // chunks of this wave (wave uniform)
+    load_kv(tw0, kr, vr);
     if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
         const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
         const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
@@ -147,13 +150,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
         }
         m = m_new;
     };
-    for (int t0 = start + wave * CH; t0 < len; t0 += 2 * tstep) {   // kr / vr hold the chunk at t0, kr2 / vr2 the one at t0 + tstep
-        chunk(t0, kr, vr);
-        if (t0 + 2 * tstep < len) load_kv(t0 + 2 * tstep, kr, vr);
-        if (t0 + tstep < len) {
-            chunk(t0 + tstep, kr2, vr2);
-            if (t0 + 3 * tstep < len) load_kv(t0 + 3 * tstep, kr2, vr2);
+    // Two register sets: kr / vr hold chunk ic, kr2 / vr2 chunk ic + 1.  The steady-state loop is entered only with both in
+    // flight and its body is STRAIGHT LINE (both refills are known to exist), so that the compiler's wait counts stay exact
+    // across the back edge -- with a branch around a refill, or a conditional prefetch in front of the loop, it falls back to
+    // vmcnt(0) at the join and the prefetch overlaps nothing.  The last 2 - 3 chunks, and short rows, are peeled.
+    if constexpr (!DB) {
+        for (int c = 0; c < nch; ++c) {
+            chunk(tw0 + c * tstep, kr, vr);
+            if (c + 1 < nch) load_kv(tw0 + (c + 1) * tstep, kr, vr);
         }
+    } else if (nch >= 4) {
+        load_kv(tw0 + tstep, kr2, vr2);
+        int ic = 0;
+        do {
+            chunk(tw0 + ic * tstep, kr, vr);
+            load_kv(tw0 + (ic + 2) * tstep, kr, vr);
+            chunk(tw0 + (ic + 1) * tstep, kr2, vr2);
+            load_kv(tw0 + (ic + 3) * tstep, kr2, vr2);
+            ic += 2;
+        } while (ic + 3 < nch);
+        const bool three = nch - ic == 3;   // 2 or 3 chunks left, the first two loaded
+        chunk(tw0 + ic * tstep, kr, vr);
+        if (three) load_kv(tw0 + (ic + 2) * tstep, kr, vr);
+        chunk(tw0 + (ic + 1) * tstep, kr2, vr2);
+        if (three) chunk(tw0 + (ic + 2) * tstep, kr, vr);
+    } else {   // 0 .. 3 chunks (a wave past the row's end has none: its loads re-read the last position, masked)
+        if (nch >= 2) load_kv(tw0 + tstep, kr2, vr2);
+        if (nch >= 1) chunk(tw0, kr, vr);
+        if (nch >= 3) load_kv(tw0 + 2 * tstep, kr, vr);
+        if (nch >= 2) chunk(tw0 + tstep, kr2, vr2);
+        if (nch >= 3) chunk(tw0 + 2 * tstep, kr, vr);
     }
 #pragma unroll
     for (int off = LPP; off < 64; off <<= 1) {
@@ -206,10 +232,13 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     // rows past active_rows do nothing: with one position per call (query row == cache row) they are not even launched
     const int rows = (a.active_rows > 0 && Beff == a.rpp) ? a.active_rows : Beff;
     dim3 grid(a.H, rows), block(64 * nwv);
+    // the LayerNorm-hook form is the cross-attention of the decode step: its source is a chunk or two long, one register set
+    static const bool db = !(getenv("ACMI_ATTN_DB") != nullptr && getenv("ACMI_ATTN_DB")[0] == '0');
 #define ACMI_ATTN_CASE(HD)                                                                              \
     case HD:                                                                                            \
-        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false>), grid, block, 0, st, a);            \
+        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true, false>), grid, block, 0, st, a);  \
+        else if (db) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false, true>), grid, block, 0, st, a);   \
+        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false, false>), grid, block, 0, st, a);     \
         break;
     switch (hd) {
         ACMI_ATTN_CASE(4)

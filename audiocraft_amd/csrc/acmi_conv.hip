@@ -332,8 +332,14 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
             }
             __syncthreads();
             if (*s_abort) return;   // workgroup-uniform (written before the barrier): the host finds err != 0 and raises
-            // the WHOLE gather is complete (barrier above): re-arm this workgroup's slots of step t + 1 (header comment)
-            if (owner) __hip_atomic_store(hrearm + (size_t)bidx * H + j, LSTM_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the WHOLE gather is complete (barrier above): re-arm this workgroup's slots of step t + 1 (header comment).
+            // The 4 units of a row are 4 consecutive lanes (uu = tid & 3): ONE 16-byte write-through store by the first of
+            // them instead of four 4-byte ones (a scalar sc1 store is a fabric write of its own, ~6x the cost per byte).
+            const unsigned slot_off = (unsigned)(((size_t)bidx * H + j0) * 4u);   // byte offset of (row, units j0 .. j0 + 3) in a buffer
+            if (owner && uu == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY}, rs,
+                                                       (unsigned)(((t + 1) % 3) * BH * 4) + slot_off, 0, 16 /* sc1 */);
+            (void)hrearm;
             // ---- 16 rows x H against nb hidden vectors: W from registers, h from LDS
             float acc[LSTM_BB];
 #pragma unroll
@@ -356,6 +362,7 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
                 for (int q = 0; q < LSTM_BB; ++q) gs[r * LSTM_BB + q] = acc[q];
             }
             __syncthreads();
+            float c_hn = 0.f;   // this thread's new hidden value (owners)
             if (owner) {
                 const float gi = gs[(0 * 4 + uu) * LSTM_BB + bb] + gin[0];
                 const float gf = gs[(1 * 4 + uu) * LSTM_BB + bb] + gin[1];
@@ -370,10 +377,21 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
                 const float hn = og * tanhf(cn);
                 c_reg = cn;
                 if (!one_pass) cst[si] = cn;   // private to this workgroup
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm store of the previous step has landed
-                __hip_atomic_store(hnext + si, __float_as_uint(hn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c_hn = hn;
+            }
+            {   // publish h_t: the quad's 4 units as one 16-byte write-through store (all lanes take part in the exchange)
+                const unsigned h0 = __float_as_uint(dpp_f32<0x00>(c_hn)), h1 = __float_as_uint(dpp_f32<0x55>(c_hn));
+                const unsigned h2 = __float_as_uint(dpp_f32<0xAA>(c_hn)), h3 = __float_as_uint(dpp_f32<0xFF>(c_hn));
+                if (owner && uu == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm store of the previous step has landed
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{h0, h1, h2, h3}, rs, (unsigned)((t % 3) * BH * 4) + slot_off, 0,
+                                                           16 /* sc1 */);
+                }
+                (void)hnext;
+            }
+            if (owner) {   // the output row after the publish: nothing on the recurrence's critical path waits for this store
                 const size_t yi = ((size_t)bidx * H + j) * T + t;
-                y[yi] = skip ? hn + skip[yi] : hn;
+                y[yi] = skip ? c_hn + skip[yi] : c_hn;
             }
             __syncthreads();
         }

@@ -336,23 +336,37 @@ struct TlLate {
     const float* psh; const float* posh;
 };
 
-template <typename WT, int MT, int LN, int NT, int NS, int C, typename LateFn>
+// LDS-DMA form of the weight stream (A/B variant, ACMI_LIN_DMA=1): the fragment goes global -> LDS without passing through
+// VGPRs (global_load_lds_dwordx4, 1 KB per wave instruction, non-temporal), into the workgroup's LDS image of its weight
+// slice at the fragment's own slot; the wave that requested it reads it back (ds_read_b128, lane linear) once its vmcnt
+// has covered the request -- no barrier: a wave only ever reads what it requested itself.
+__device__ __forceinline__ void glds_frag_nt(const u32x4* gsrc_lane, unsigned char* lds_slot) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_slot, 16, 0, 2 /* nt */);
+}
+
+template <typename WT, int MT, int LN, int NT, int NS, int C, bool DMA, typename LateFn>
 __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, int kc0, int ks, int np,
-                                         const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex) {
+                                         const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex,
+                                         unsigned char* wl = nullptr, int kloc0 = 0, int kcs = 0) {
     constexpr bool HL = LN == 2 || LN == 3;
     const int lane = threadIdx.x & 63;
     const int wts = p.NKC * 64;  // fragment lanes between the NT adjacent n-tiles of this workgroup
-    u32x4 bv[NT][C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
+    u32x4 bv[DMA ? 1 : NT][DMA ? 1 : C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
     // Request order: all weight fragments first -- they come from HBM, the activation fragments from L2, and the HBM
     // requests should be on their way as early as possible (FFN2 10.5 -> 9.9 us; whole position 2.57 -> 2.50 ms; with
     // (weight, activations) pairs in consumption order only the hi / lo variants in isolation were 0.1-0.2 us faster).
     constexpr bool WFIRST = ACMI_TL_WFIRST(LN);
+    static_assert(!DMA || ACMI_TL_WFIRST(LN), "the LDS-DMA form issues the whole weight run first");
     if (WFIRST) {
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const int ko = (kc0 + i * ks) * 64;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (DMA) glds_frag_nt(wt + (t * wts + ko) + lane, wl + (size_t)(t * kcs + kloc0 + i) * 1024);
+                else bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
+            }
         }
         // The weight requests need four kernel arguments and ~20 instructions of address arithmetic; the ~100
         // instructions (and two more scalar-load round trips) that set up the activation, statistics and epilogue
@@ -370,9 +384,11 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         const int ko = (kc0 + i * ks) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
-        if (!WFIRST) {
+        if constexpr (!DMA) {
+            if (!WFIRST) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
+                for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
+            }
         }
 #pragma unroll
         for (int u = 0; u < MT; ++u) {  // row blocks beyond M re-read the last valid one (their results are dropped)
@@ -393,6 +409,7 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
     }
     ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos; ex.sh = *L.psh; ex.osh = *L.posh;
     __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA writes (and everything else) have landed
 #pragma unroll
     for (int i = 0; i < C; ++i)
 #pragma unroll
@@ -400,8 +417,11 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
             if (LN == 3 && kc0 + i * ks >= p.lo_split) lv[u][i] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                mma_frag(av[u][i], bv[t][i], acc[t * MT + u], WT());
-                if (HL) mma_frag(lv[u][i], bv[t][i], acc[t * MT + u], WT());
+                u32x4 b;
+                if constexpr (DMA) b = *reinterpret_cast<const u32x4*>(wl + (size_t)(t * kcs + kloc0 + i) * 1024 + lane * 16);
+                else b = bv[t][i];
+                mma_frag(av[u][i], b, acc[t * MT + u], WT());
+                if (HL) mma_frag(lv[u][i], b, acc[t * MT + u], WT());
             }
         }
 }
@@ -413,13 +433,16 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 // B operand of TWO MFMAs: with the A fragment 2u the accumulator columns 0-7 are feature sums, with A fragment 2u + 1
 // the columns 8-15 are (the other columns hold products of mismatched K ranges and are dropped).  Two accumulators per
 // row block, merged at the end by a rotation of 8 lanes.  No LayerNorm variants: the producers of x are plain GEMMs.
-template <typename WT, int MT, int C, typename LateFn>
+template <typename WT, int MT, int C, bool DMA, typename LateFn>
 __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __restrict__ wt, int ku0, const LateFn& late_fn,
-                                            f32x4 (&acc)[2 * MT], TlExtras& ex) {
+                                            f32x4 (&acc)[2 * MT], TlExtras& ex, unsigned char* wl = nullptr, int kloc0 = 0) {
     const int lane = threadIdx.x & 63;
-    u32x4 bv[C], av[MT][2 * C];
+    u32x4 bv[DMA ? 1 : C], av[MT][2 * C];
 #pragma unroll
-    for (int i = 0; i < C; ++i) bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
+    for (int i = 0; i < C; ++i) {
+        if constexpr (DMA) glds_frag_nt(wt + (ku0 + i) * 64 + lane, wl + (size_t)(kloc0 + i) * 1024);
+        else bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
@@ -435,18 +458,23 @@ __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __res
     }
     ex.bias = *pb; ex.res = *pr; ex.osh = *L.posh;
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < C; ++i)
+    for (int i = 0; i < C; ++i) {
+        u32x4 b;
+        if constexpr (DMA) b = *reinterpret_cast<const u32x4*>(wl + (size_t)(kloc0 + i) * 1024 + lane * 16);
+        else b = bv[i];
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            mma_frag(av[u][2 * i], bv[i], acc[2 * u], WT());
-            mma_frag(av[u][2 * i + 1], bv[i], acc[2 * u + 1], WT());
+            mma_frag(av[u][2 * i], b, acc[2 * u], WT());
+            mma_frag(av[u][2 * i + 1], b, acc[2 * u + 1], WT());
         }
+    }
 }
 
 // NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
 // the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs.
-template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false>
+template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false, bool DMA = false>
 __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, const int kslice, const int ksp) {
     static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
     static_assert(!HT || (NT == 1 && LN == 0), "half-tile workgroups: plain GEMM, one (half) n-tile");
@@ -456,13 +484,16 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
     // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
     // VGPRs of a 2-waves-per-SIMD launch
-    constexpr int CQ = HT ? 52 / (1 + 2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (NT + MT * D));
+    // (LDS-DMA form: the weight fragments hold no registers, the budget is the activation's alone)
+    constexpr int CQ = DMA ? (HT ? 52 / (2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (MT * D)))
+                           : (HT ? 52 / (1 + 2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (NT + MT * D)));
     constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
     float* red = reinterpret_cast<float*>(smem);        // [NT MT][nw][256] partial accumulators
     float* rowstat = red + (size_t)NT * MT * nw * 256;  // [16 MT][2] mean, rstd
+    unsigned char* wl = reinterpret_cast<unsigned char*>(rowstat + 32 * MT);   // DMA: [NT][kcs] KB image of the weight slice
     const int n0 = ntile * (HT ? 8 : 16), NKC = HT ? p.NKC >> 1 : p.NKC;   // HT: K counted in 1 KB weight units
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
     const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
@@ -509,8 +540,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         int kc = kbeg + wave * p.fpw, rem = p.fpw;
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            if constexpr (HT) tl_chunk_ht<WT, MT, Cn>(p, wt, kc, late, accs, ex);                                       \
-            else tl_chunk<WT, MT, LN, NT, NS, Cn>(p, wt, kc, ks, p.a_np, late, accs, ex);                               \
+            if constexpr (HT) tl_chunk_ht<WT, MT, Cn, DMA>(p, wt, kc, late, accs, ex, wl, kc - kbeg);                   \
+            else tl_chunk<WT, MT, LN, NT, NS, Cn, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, wl, kc - kbeg, kcs);      \
             kc += Cn * ks; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -524,8 +555,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
 #undef ACMI_TL_RUN
         kc = kbeg + nw * p.fpw + wave;
         if (kc < kbeg + kcs) {  // ragged tail: the first kcs % nw waves own one more fragment
-            if constexpr (HT) tl_chunk_ht<WT, MT, 1>(p, wt, kc, late, accs, ex);
-            else tl_chunk<WT, MT, LN, NT, NS, 1>(p, wt, kc, ks, p.a_np, late, accs, ex);
+            if constexpr (HT) tl_chunk_ht<WT, MT, 1, DMA>(p, wt, kc, late, accs, ex, wl, kc - kbeg);
+            else tl_chunk<WT, MT, LN, NT, NS, 1, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, wl, kc - kbeg, kcs);
         }
         if constexpr (HT) {  // columns 0-7 of the even accumulators + columns 8-15 of the odd ones, rotated onto 0-7
 #pragma unroll
@@ -638,19 +669,19 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     }
 }
 
-template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false>
+template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false, bool DMA = false>
 __global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
-    tl_body<WT, MT, LN, NT, NS, HT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+    tl_body<WT, MT, LN, NT, NS, HT, DMA>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
 }
 
 // Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
 // (plain), the rest run p1 (LN 3: x | a concatenated along K, no LayerNorm).  Used for
 //   x1 = x0 + att W_out^T   and   r = [x0 | att] [W_cq' | W_cq' W_out]^T  (= x1 W_cq'^T, the cross-attention
 // query before its LayerNorm statistics are applied), see acmi_lm_step.
-template <typename WT, int MT, int LNB>
+template <typename WT, int MT, int LNB, bool DMA = false>
 __global__ __launch_bounds__(512) void lin_pair_kernel(const LinArgs p0, const LinArgs p1, const int tiles0) {
-    if ((int)blockIdx.x < tiles0) tl_body<WT, MT, 0>(p0, (int)blockIdx.x, 0, 1);
-    else tl_body<WT, MT, LNB>(p1, (int)blockIdx.x - tiles0, 0, 1);
+    if ((int)blockIdx.x < tiles0) tl_body<WT, MT, 0, 1, 8, false, DMA>(p0, (int)blockIdx.x, 0, 1);
+    else tl_body<WT, MT, LNB, 1, 8, false, DMA>(p1, (int)blockIdx.x - tiles0, 0, 1);
 }
 
 // Workgroup size.  (1) Waves are not free: the dispatcher starts ~1.25 waves / ns (a 288-workgroup x 16-wave
@@ -683,17 +714,18 @@ static int tiled_prepare(LinArgs& a) {
     return ACMI_OK;
 }
 
-template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false>
-static int launch_tiled_t(LinArgs& a, hipStream_t st) {
-    const int gx = HT ? a.N / 8 : (a.N + 15) / 16 / NT;
-    const int wgs = gx * a.ksplit, frags = (HT ? a.NKC / 2 : a.NKC) / a.ksplit;
-    const int nw = tiled_waves(wgs, frags * NT);
-    a.kcs = frags; a.fpw = frags / nw;
-    const size_t lds = (size_t)NT * MT * nw * 1024 + (size_t)MT * 128;
+// A/B switch: ACMI_LIN_DMA=1 streams the weights through LDS-DMA (calls of <= 16 rows, whose weight slice fits the LDS)
+static bool lin_dma_wanted() {
+    static const bool v = getenv("ACMI_LIN_DMA") != nullptr && getenv("ACMI_LIN_DMA")[0] == '1';
+    return v;
+}
+
+template <typename WT, int MT, int LN, int NT, int NS, bool HT, bool DMA>
+static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {  // 2 n-tiles x 4 row blocks x 8 waves: just above the default dynamic LDS limit
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT, DMA>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
                 return ACMI_ELAUNCH;
@@ -701,9 +733,23 @@ static int launch_tiled_t(LinArgs& a, hipStream_t st) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
+    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT, DMA>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
                        dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_tiled_kernel");
+}
+
+template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false>
+static int launch_tiled_t(LinArgs& a, hipStream_t st) {
+    const int gx = HT ? a.N / 8 : (a.N + 15) / 16 / NT;
+    const int wgs = gx * a.ksplit, frags = (HT ? a.NKC / 2 : a.NKC) / a.ksplit;
+    const int nw = tiled_waves(wgs, frags * NT);
+    a.kcs = frags; a.fpw = frags / nw;
+    const size_t lds = (size_t)NT * MT * nw * 1024 + (size_t)MT * 128;
+    if constexpr (MT == 1 && LN != 3) {
+        const size_t lds_dma = lds + (size_t)NT * frags * 1024;
+        if (lin_dma_wanted() && lds_dma <= 160 * 1024) return launch_tiled_k<WT, MT, LN, NT, NS, HT, true>(a, gx, nw, lds_dma, st);
+    }
+    return launch_tiled_k<WT, MT, LN, NT, NS, HT, false>(a, gx, nw, lds, st);
 }
 
 template <typename WT>
@@ -769,6 +815,22 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
     const int mt = p0.M > 32 ? 4 : (p0.M > 16 ? 2 : 1);
     const size_t lds = (size_t)mt * nw * 1024 + (size_t)mt * 128;
     const dim3 grid(t0 + t1, 1, (p0.M + 16 * mt - 1) / (16 * mt)), block(nw * 64);
+    if (mt == 1 && !hl && lin_dma_wanted()) {   // LDS-DMA form (A/B): both halves keep their weight slice's image in LDS
+        const size_t lds_dma = lds + (size_t)(p0.NKC > p1.NKC ? p0.NKC : p1.NKC) * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_pair_kernel<WT, 1, 0, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                acmi_set_error("acmi_linear_pair: cannot raise the dynamic LDS limit");
+                return ACMI_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        if (lds_dma <= 160 * 1024) {
+            hipLaunchKernelGGL((lin_pair_kernel<WT, 1, 0, true>), grid, block, lds_dma, st, p0, p1, t0);
+            return acmi_check_launch("lin_pair_kernel");
+        }
+    }
 #define ACMI_PAIR_CASE(MTv)                                                                              \
     if (mt == MTv) {                                                                                     \
         if (hl) hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 3>), grid, block, lds, st, p0, p1, t0);      \

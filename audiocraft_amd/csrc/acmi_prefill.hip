@@ -57,42 +57,79 @@ __global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
     const u32x4* __restrict__ src = wave < 2 ? A : W;
     u32x4* lds = reinterpret_cast<u32x4*>(smem);
     const int nks = p.NKC >> 1;
-    u32x4 st[8];
-    auto fetch = [&](int ks) {
+    // Two register sets: the fragments of stage ks + 2 are requested while stage ks is multiplied and stage ks + 1 (requested
+    // one step earlier) is written to the other LDS buffer -- a request has two steps (~2 x 500 MFMA cycles) to come back
+    // instead of one.  The steady-state loop is entered only with its prefetch in flight and its body is straight line, so
+    // that the compiler's vmcnt counts stay exact (cf. attn_decode_kernel); short K and the last stages are peeled.
+    u32x4 sa[8], sb[8];
+    auto fetch = [&](int ks, u32x4 (&st)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = src[base[i >> 1] + (size_t)(2 * ks + (i & 1)) * 64];
+        __builtin_amdgcn_sched_barrier(0);   // the requests stay HERE (the scheduler otherwise sinks them below the MFMAs, next to their use)
     };
-    auto stash = [&](int stage) {
+    auto stash = [&](int stage, const u32x4 (&st)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lds[(stage * 32 + wave * 8 + i) * 64 + lane] = st[i];
+        for (int i = 0; i < 8; ++i) lds[((stage & 1) * 32 + wave * 8 + i) * 64 + lane] = st[i];
     };
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int ks = 0; ks < nks; ++ks) {
-        const bool more = ks + 1 < nks;
-        if (more) fetch(ks + 1);                    // in flight while this stage is multiplied
-        const u32x4* sb = lds + (ks & 1) * 32 * 64 + lane;
+    auto compute = [&](int ks) {
+        const u32x4* sb_ = lds + (ks & 1) * 32 * 64 + lane;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             u32x4 a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sb[((wm * 4 + i) * 2 + kc) * 64];
+            for (int i = 0; i < 4; ++i) a[i] = sb_[((wm * 4 + i) * 2 + kc) * 64];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sb[(16 + (wn * 4 + j) * 2 + kc) * 64];
+            for (int j = 0; j < 4; ++j) b[j] = sb_[(16 + (wn * 4 + j) * 2 + kc) * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) big_mma(a[i], b[j], acc[i][j], WT());
         }
-        if (more) stash((ks + 1) & 1);              // the other buffer: every wave left it at the previous barrier
+        __builtin_amdgcn_sched_barrier(0);   // the LDS writes of the next stage (and their vmcnt waits) stay behind the MFMAs
+    };
+
+    fetch(0, sa);
+    stash(0, sa);
+    if (nks >= 4) {
+        fetch(1, sa);
         __syncthreads();
+        int ks = 0;
+        do {                                  // sa = stage ks + 1 in flight
+            fetch(ks + 2, sb);
+            compute(ks);
+            stash(ks + 1, sa);                // the other buffer: every wave left it at the previous barrier
+            __syncthreads();
+            fetch(ks + 3, sa);
+            compute(ks + 1);
+            stash(ks + 2, sb);
+            __syncthreads();
+            ks += 2;
+        } while (ks + 3 < nks);
+        const bool three = nks - ks == 3;     // 2 or 3 stages left: ks in LDS, ks + 1 in sa
+        if (three) fetch(ks + 2, sb);
+        compute(ks);
+        stash(ks + 1, sa);
+        __syncthreads();
+        compute(ks + 1);
+        if (three) {
+            stash(ks + 2, sb);
+            __syncthreads();
+            compute(ks + 2);
+        }
+    } else {
+        __syncthreads();
+        for (int ks = 0; ks < nks; ++ks) {
+            const bool more = ks + 1 < nks;
+            if (more) fetch(ks + 1, sa);
+            compute(ks);
+            if (more) stash(ks + 1, sa);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane (kg, n) of tile (i, j) holds rows kg * 4 + r, column n

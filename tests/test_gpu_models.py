@@ -626,7 +626,9 @@ def test_prefill_one_forward_matches_oracle_and_chunk_path(wdt, tol, variant, mo
     else:
         pre = torch.randn(2 * B, 21, 256, generator=g)
         ones = lambda n: torch.ones(2 * B, n, dtype=torch.int64).cuda()   # noqa: E731
-        ct = {'self_wav': (pre[:, :15].cuda(), ones(15)), 'description': (pre[:, 15:].cuda(), ones(6))}
+        # dict order as the reference's ConditioningProvider yields it: every 'prepend' condition goes IN FRONT of what has
+        # been fused so far (conditioners.py:1730-1741) => rows [self_wav; description; tokens]
+        ct = {'description': (pre[:, 15:].cuda(), ones(6)), 'self_wav': (pre[:, :15].cuda(), ones(15))}
         cross_src, prepend = None, pre
     prompt = torch.randint(0, 2048, (B, 4, T0), generator=g)
     out = {}
