@@ -20,9 +20,10 @@ struct ConvArgs {
     const float* x; const float* w; const float* bias; const float* res; float* y;
     int Tq;    // GEMM columns per batch item
     int CIC;   // input channels per K chunk
-    int KCE;   // CIC * ksize rounded up to even
-    int KCP;   // LDS row pitch of the weight tile (odd)
+    int KCE;   // CIC * ksize rounded up to a multiple of 16 (one block of the inner loop = 8 MFMAs = 16 k)
+    int KCP;   // LDS row pitch (floats) of one parity plane of the weight tile: KCE / 2 rounded up to 4 (mod 64)
     int LP;    // LDS row pitch of one (channel, phase) input row
+    int XSZ;   // floats of the staged input span, rounded up to a multiple of 4 (the offset table behind it is read 16 B at a time)
 };
 
 __device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow, int pos) {
@@ -38,20 +39,28 @@ __device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow
     return v;
 }
 
+// NTQ: 64-column (time) tiles per workgroup.  The weight tile of a K chunk is staged ONCE and multiplied with NTQ input
+// spans in turn (NTQ accumulators): with one tile per workgroup the 32 KB weight tile was re-staged from L2 for every 64
+// output samples and that traffic (~35 KB per 1.7 us of MFMA work per workgroup) co-bounded the kernel.
+template <int NTQ>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const acmi_conv_desc& d = a.d;
     const int s = d.stride, ks = d.ksize;
-    float* Ws = smem;                                   // [64][KCP]
-    float* Xs = Ws + 64 * a.KCP;                        // [CIC][s][LP]
-    int* koff = reinterpret_cast<int*>(Xs + a.CIC * s * a.LP);  // [KCE]
+    // The MFMA's two k slots are the two halves of the wave (kk = lane >> 5): half kk consumes k = 2 u + kk.  Weights and
+    // the k -> LDS offset table are therefore stored DE-INTERLEAVED BY PARITY, so that the 8 values a lane needs for a block
+    // of 8 MFMAs (16 k) are contiguous: two ds_read_b128 each instead of 8 + 8 dependent ds_read_b32 (the table lookup in
+    // front of every input read was a second LDS latency on the critical path of every MFMA).
+    float* Ws = smem;                                   // [2 parities][64][KCP]
+    float* Xs = Ws + 2 * 64 * a.KCP;                    // [CIC][s][LP]
+    int* koff = reinterpret_cast<int*>(Xs + a.XSZ);     // [2 parities][KCE / 2]
+    const int KH = a.KCE >> 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, kk = lane >> 5;
-    const int q0 = blockIdx.x * 64, m0 = blockIdx.y * 64, b = blockIdx.z;
+    const int qb = blockIdx.x * 64 * NTQ, m0 = blockIdx.y * 64, b = blockIdx.z;
     const int span = 63 * s + (ks - 1) * d.dilation + 1;
-    const int base_in = q0 * s - d.pad_left;
     const int KC = a.CIC * ks;
 
     for (int kl = tid; kl < a.KCE; kl += 256) {
@@ -61,12 +70,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const int jd = j * d.dilation;
             off = (ci * s + jd % s) * a.LP + jd / s;
         }
-        koff[kl] = off;
+        koff[(kl & 1) * KH + (kl >> 1)] = off;
     }
 
-    f32x16 acc;
+    f32x16 acc[NTQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const size_t wpitch = (size_t)d.Cin * ks;
     for (int ci0 = 0; ci0 < d.Cin; ci0 += a.CIC) {
@@ -78,55 +89,77 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const int mrow = m0 + r;
             const float* wsrc = a.w + (size_t)mrow * wpitch + (size_t)ci0 * ks;
             for (int kl = lane; kl < a.KCE; kl += 64)
-                Ws[r * a.KCP + kl] = (mrow < d.Cout && kl < kvalid) ? wsrc[kl] : 0.f;
+                Ws[((kl & 1) * 64 + r) * a.KCP + (kl >> 1)] = (mrow < d.Cout && kl < kvalid) ? wsrc[kl] : 0.f;
         }
-        // ---- input span, phase de-interleaved
-        for (int ci = wave; ci < a.CIC; ci += 4) {
-            const float* xrow = a.x + ((size_t)b * d.Cin + ci0 + ci) * d.Tin;
-            float* dst = Xs + (size_t)ci * s * a.LP;
-            if (s == 1) {
-                for (int rel = lane; rel < span; rel += 64)
-                    dst[rel] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
-            } else {
-                for (int rel = lane; rel < span; rel += 64) {
-                    const int qq = rel / s, ph = rel - qq * s;
-                    dst[ph * a.LP + qq] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+#pragma unroll
+        for (int t = 0; t < NTQ; ++t) {
+            const int q0 = qb + t * 64;
+            if (t > 0) {
+                if (q0 >= a.Tq) break;     // block uniform: no column of this tile exists
+                __syncthreads();           // every wave is done with the previous tile's span
+            }
+            const int base_in = q0 * s - d.pad_left;
+            // ---- input span, phase de-interleaved
+            for (int ci = wave; ci < a.CIC; ci += 4) {
+                const float* xrow = a.x + ((size_t)b * d.Cin + ci0 + ci) * d.Tin;
+                float* dst = Xs + (size_t)ci * s * a.LP;
+                if (s == 1) {
+                    for (int rel = lane; rel < span; rel += 64)
+                        dst[rel] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+                } else {
+                    for (int rel = lane; rel < span; rel += 64) {
+                        const int qq = rel / s, ph = rel - qq * s;
+                        dst[ph * a.LP + qq] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+                    }
                 }
             }
-        }
-        __syncthreads();
-        const float* wp = Ws + (wr * 32 + li) * a.KCP + kk;
-        const float* xp = Xs + wc * 32 + li;
-        for (int k2 = 0; k2 < a.KCE; k2 += 2) {
-            const float av = wp[k2];
-            const float bv = xp[koff[k2 + kk]];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            __syncthreads();
+            const float* wp = Ws + (kk * 64 + wr * 32 + li) * a.KCP;   // this lane's row of its parity plane
+            const int* kp = koff + kk * KH;
+            const float* xp = Xs + wc * 32 + li;
+            for (int kb = 0; kb < KH; kb += 8) {   // 8 MFMAs: k = 2 (kb + u) + kk, u = 0 .. 7, ascending (the fmaf chain of a scalar loop)
+                const float4 wa = *reinterpret_cast<const float4*>(wp + kb), wb = *reinterpret_cast<const float4*>(wp + kb + 4);
+                const int4 oa = *reinterpret_cast<const int4*>(kp + kb), ob = *reinterpret_cast<const int4*>(kp + kb + 4);
+                const float x0 = xp[oa.x], x1 = xp[oa.y], x2 = xp[oa.z], x3 = xp[oa.w];
+                const float x4 = xp[ob.x], x5 = xp[ob.y], x6 = xp[ob.z], x7 = xp[ob.w];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x0, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, x3, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.x, x4, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.y, x5, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.z, x6, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb.w, x7, acc[t], 0, 0, 0);
+            }
         }
     }
 
     // ---- epilogue
-    const int q = q0 + wc * 32 + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const int mrow = m0 + wr * 32 + row;
-        if (mrow >= d.Cout) continue;
-        float v = acc[r];
-        if (d.shuffle <= 1) {
-            if (q < d.Tout) {
-                const size_t oi = ((size_t)b * d.Cout + mrow) * d.Tout + q;
-                if (a.bias) v += a.bias[mrow];
-                if (a.res) v += a.res[oi];
-                a.y[oi] = v;
-            }
-        } else {
-            const int co = mrow / d.shuffle, ph = mrow - co * d.shuffle;
-            const long long o = (long long)q * d.shuffle + ph - d.trim_left;
-            if (o >= 0 && o < d.Tout && q < a.Tq) {
-                const size_t oi = ((size_t)b * (d.Cout / d.shuffle) + co) * d.Tout + (size_t)o;
-                if (a.bias) v += a.bias[co];
-                if (a.res) v += a.res[oi];
-                a.y[oi] = v;
+    for (int t = 0; t < NTQ; ++t) {
+        const int q = qb + t * 64 + wc * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int mrow = m0 + wr * 32 + row;
+            if (mrow >= d.Cout) continue;
+            float v = acc[t][r];
+            if (d.shuffle <= 1) {
+                if (q < d.Tout) {
+                    const size_t oi = ((size_t)b * d.Cout + mrow) * d.Tout + q;
+                    if (a.bias) v += a.bias[mrow];
+                    if (a.res) v += a.res[oi];
+                    a.y[oi] = v;
+                }
+            } else {
+                const int co = mrow / d.shuffle, ph = mrow - co * d.shuffle;
+                const long long o = (long long)q * d.shuffle + ph - d.trim_left;
+                if (o >= 0 && o < d.Tout && q < a.Tq) {
+                    const size_t oi = ((size_t)b * (d.Cout / d.shuffle) + co) * d.Tout + (size_t)o;
+                    if (a.bias) v += a.bias[co];
+                    if (a.res) v += a.res[oi];
+                    a.y[oi] = v;
+                }
             }
         }
     }
@@ -154,13 +187,20 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     const int lp = 64 + ((d.ksize - 1) * d.dilation) / d.stride + 2;
     while (cic > 1 && (size_t)cic * d.stride * lp * 4 > 24 * 1024) cic >>= 1;
     a.CIC = cic;
-    a.KCE = (cic * d.ksize + 1) & ~1;
-    a.KCP = a.KCE | 1;
+    a.KCE = (cic * d.ksize + 15) & ~15;
+    a.KCP = (a.KCE / 2 + 63) / 64 * 64 + 4;   // = 4 (mod 64): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank slots
     a.LP = lp;
-    const size_t lds = ((size_t)64 * a.KCP + (size_t)a.CIC * d.stride * a.LP + a.KCE) * sizeof(float);
+    a.XSZ = (a.CIC * d.stride * a.LP + 3) & ~3;
+    const size_t lds = ((size_t)2 * 64 * a.KCP + (size_t)a.XSZ + a.KCE) * sizeof(float);
     ACMI_REQUIRE(lds <= 64 * 1024, "acmi_conv1d: LDS budget exceeded (%zu B)", lds);
-    dim3 grid((a.Tq + 63) / 64, (d.Cout + 63) / 64, d.B), block(256);
-    hipLaunchKernelGGL(conv_mfma_kernel, grid, block, lds, (hipStream_t)stream, a);
+    // column tiles per workgroup: as many as keep >= 2 workgroups per CU in flight (4, 2 or 1); ACMI_CONV_NTQ forces one
+    const int tq = (a.Tq + 63) / 64, my = (d.Cout + 63) / 64;
+    static const int want = getenv("ACMI_CONV_NTQ") ? atoi(getenv("ACMI_CONV_NTQ")) : 0;
+    int ntq = want == 1 || want == 2 || want == 4 ? want : ((long)tq * my * d.B >= 4 * 512 ? 4 : ((long)tq * my * d.B >= 2 * 512 ? 2 : 1));
+    dim3 grid((tq + ntq - 1) / ntq, my, d.B), block(256);
+    if (ntq == 4) hipLaunchKernelGGL(conv_mfma_kernel<4>, grid, block, lds, (hipStream_t)stream, a);
+    else if (ntq == 2) hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
     return acmi_check_launch("conv_mfma_kernel");
 }
 
