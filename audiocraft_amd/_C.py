@@ -40,7 +40,7 @@ class LMLayer(C.Structure):
     _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_xcq', vp), ('w_ff1', vp), ('w_ff2', vp),
                 ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp),
-                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp)]
+                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp), ('cvt_cache', vp)]
 
 
 class LMModelDesc(C.Structure):
@@ -57,7 +57,7 @@ class LMState(C.Structure):
                 ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32),
-                ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32)]
+                ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32), ('cvt_tcap', i32)]
 
 
 def _sig(name, argtypes, restype=i32):

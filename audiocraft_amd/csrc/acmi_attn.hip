@@ -38,9 +38,7 @@ struct AttnArgs {
     int pm_n;              // > 0: position-minor query rows (row = cache row * pm_n + position), else row = position * rpp + cache row
 };
 
-// QN: LayerNorm hook on q (separate instantiation: no branch around its loads); DB: two register sets of K / V chunks
-// (the next chunk in flight while one is multiplied); DB = false is the single-set form kept for same-box A/B (ACMI_ATTN_DB=0)
-template <typename KT, int HD, bool QN, bool DB>
+template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
 __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const float* __restrict__ q = p.q;
     const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.kc);
@@ -56,8 +54,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const int h = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
-    const int b0 = p.pm_n > 0 ? b / p.pm_n : b % p.rpp;   // several positions per call (prefill): cache row,
-    const int pidx = p.pm_n > 0 ? b % p.pm_n : b / p.rpp;  // position index
+    // several positions per call (prefill): cache row b0 and position index pidx of query row b (one division either way)
+    const int dv = p.pm_n > 0 ? p.pm_n : p.rpp, qd = b / dv, rm = b - qd * dv;
+    const int b0 = p.pm_n > 0 ? qd : rm, pidx = p.pm_n > 0 ? rm : qd;
     if (p.active_rows > 0 && b0 >= p.active_rows) return;   // null condition: K = V = 0, the output is exactly 0 (workgroup uniform)
     const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len)) : (p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len);
 
@@ -88,26 +87,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 
     const int nwv = blockDim.x >> 6;  // 1, 2 or 4 waves share the positions of this (row, head)
     // K and V of a whole chunk are requested together (2 * NI wide loads in flight per lane); the first chunk
-    // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x).  TWO register sets: while
-    // one chunk is multiplied the wave's next one is already in flight (a (row, head) is one workgroup of <= 4 waves and a
-    // CU holds 1.5 of them: without this the memory system idles during every chunk's arithmetic and vice versa).
-    rawv kr[NI], vr[NI], kr2[NI], vr2[NI];
-    auto load_kv = [&](int t0, rawv (&kd)[NI], rawv (&vd)[NI]) {
+    // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x).
+    // (Round 3 tried a second register set -- the next chunk in flight while one is multiplied, with exact vmcnt counts in
+    // the steady state: 27.4 us at t = 1500 either way, +0.4 ... 0.8 us at every length from the longer prologue and the
+    // 214 VGPRs.  The slope of this kernel, 0.0159 us per position = 6.2 TB/s, IS the copy bandwidth of the chip: what is
+    // left is the fixed 3.6 us, 1.55 of them the kernel boundary.  profiles/r03_attn_microbench.log)
+    rawv kr[NI], vr[NI];
+    auto load_kv = [&](int t0) {
         // branch free: lanes past the end re-read the last position (their scores are masked below); a per-lane
         // zero fill would write the registers of loads still in flight and make every load wait for the previous
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = min(t0 + i * PPI + pp, len - 1);
-            kd[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
-            vd[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
+            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
+            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
     };
     const int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
-    const int tstep = nwv * CH;                    // distance between two chunks of this wave
-    const int tw0 = start + wave * CH;             // this wave's first chunk
-    const int nch = tw0 < len ? (len - tw0 + tstep - 1) / tstep : 0;   // chunks of this wave (wave uniform)
-    load_kv(tw0, kr, vr);
+    load_kv(start + wave * CH);
     if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
         const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
         const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
@@ -118,14 +116,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - meff * qcs[e]) + qb[e];
     }
-    auto chunk = [&](int t0, const rawv (&kd)[NI], const rawv (&vd)[NI]) {   // online-softmax update with the chunk at t0
+    for (int t0 = start + wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
         float s[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int t = t0 + i * PPI + pp;
             float part = 0.f;
 #pragma unroll
-            for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kd[i][e]), part);
+            for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kr[i][e]), part);
             part = group_sum<LPP>(part);
             s[i] = (t < len) ? part * scale : -INFINITY;
         }
@@ -146,40 +144,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             const float pr = (t < len) ? expf(s[i] - m_new) : 0.f;
             l += pr;
 #pragma unroll
-            for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vd[i][e]), o[e]);
+            for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vr[i][e]), o[e]);
         }
         m = m_new;
-    };
-    // Two register sets: kr / vr hold chunk ic, kr2 / vr2 chunk ic + 1.  The steady-state loop is entered only with both in
-    // flight and its body is STRAIGHT LINE (both refills are known to exist), so that the compiler's wait counts stay exact
-    // across the back edge -- with a branch around a refill, or a conditional prefetch in front of the loop, it falls back to
-    // vmcnt(0) at the join and the prefetch overlaps nothing.  The last 2 - 3 chunks, and short rows, are peeled.
-    if constexpr (!DB) {
-        for (int c = 0; c < nch; ++c) {
-            chunk(tw0 + c * tstep, kr, vr);
-            if (c + 1 < nch) load_kv(tw0 + (c + 1) * tstep, kr, vr);
-        }
-    } else if (nch >= 4) {
-        load_kv(tw0 + tstep, kr2, vr2);
-        int ic = 0;
-        do {
-            chunk(tw0 + ic * tstep, kr, vr);
-            load_kv(tw0 + (ic + 2) * tstep, kr, vr);
-            chunk(tw0 + (ic + 1) * tstep, kr2, vr2);
-            load_kv(tw0 + (ic + 3) * tstep, kr2, vr2);
-            ic += 2;
-        } while (ic + 3 < nch);
-        const bool three = nch - ic == 3;   // 2 or 3 chunks left, the first two loaded
-        chunk(tw0 + ic * tstep, kr, vr);
-        if (three) load_kv(tw0 + (ic + 2) * tstep, kr, vr);
-        chunk(tw0 + (ic + 1) * tstep, kr2, vr2);
-        if (three) chunk(tw0 + (ic + 2) * tstep, kr, vr);
-    } else {   // 0 .. 3 chunks (a wave past the row's end has none: its loads re-read the last position, masked)
-        if (nch >= 2) load_kv(tw0 + tstep, kr2, vr2);
-        if (nch >= 1) chunk(tw0, kr, vr);
-        if (nch >= 3) load_kv(tw0 + 2 * tstep, kr, vr);
-        if (nch >= 2) chunk(tw0 + tstep, kr2, vr2);
-        if (nch >= 3) chunk(tw0 + 2 * tstep, kr, vr);
+        if (t0 + nwv * CH < len) load_kv(t0 + nwv * CH);
     }
 #pragma unroll
     for (int off = LPP; off < 64; off <<= 1) {
@@ -232,13 +200,10 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     // rows past active_rows do nothing: with one position per call (query row == cache row) they are not even launched
     const int rows = (a.active_rows > 0 && Beff == a.rpp) ? a.active_rows : Beff;
     dim3 grid(a.H, rows), block(64 * nwv);
-    // the LayerNorm-hook form is the cross-attention of the decode step: its source is a chunk or two long, one register set
-    static const bool db = !(getenv("ACMI_ATTN_DB") != nullptr && getenv("ACMI_ATTN_DB")[0] == '0');
 #define ACMI_ATTN_CASE(HD)                                                                              \
     case HD:                                                                                            \
-        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true, false>), grid, block, 0, st, a);  \
-        else if (db) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false, true>), grid, block, 0, st, a);   \
-        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false, false>), grid, block, 0, st, a);     \
+        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false>), grid, block, 0, st, a);            \
         break;
     switch (hd) {
         ACMI_ATTN_CASE(4)

@@ -42,7 +42,10 @@ __device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow
 // NTQ: 64-column (time) tiles per workgroup.  The weight tile of a K chunk is staged ONCE and multiplied with NTQ input
 // spans in turn (NTQ accumulators): with one tile per workgroup the 32 KB weight tile was re-staged from L2 for every 64
 // output samples and that traffic (~35 KB per 1.7 us of MFMA work per workgroup) co-bounded the kernel.
-template <int NTQ>
+// PK: the parity-plane LDS layout + 8-MFMA blocks below (A/B variant, ACMI_CONV_PARITY=1); !PK: weights [64][KCP odd], one
+// offset table, one (weight, offset, input) read triple per MFMA -- measured faster (the compiler software-pipelines the
+// short loop; the block form exposes its LDS latency once per 8 MFMAs): profiles/r03_codec_bench_*.jsonl.
+template <int NTQ, bool PK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const acmi_conv_desc& d = a.d;
@@ -51,9 +54,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // the k -> LDS offset table are therefore stored DE-INTERLEAVED BY PARITY, so that the 8 values a lane needs for a block
     // of 8 MFMAs (16 k) are contiguous: two ds_read_b128 each instead of 8 + 8 dependent ds_read_b32 (the table lookup in
     // front of every input read was a second LDS latency on the critical path of every MFMA).
-    float* Ws = smem;                                   // [2 parities][64][KCP]
-    float* Xs = Ws + 2 * 64 * a.KCP;                    // [CIC][s][LP]
-    int* koff = reinterpret_cast<int*>(Xs + a.XSZ);     // [2 parities][KCE / 2]
+    float* Ws = smem;                                   // PK: [2 parities][64][KCP]; else [64][KCP]
+    float* Xs = Ws + (PK ? 2 : 1) * 64 * a.KCP;         // [CIC][s][LP]
+    int* koff = reinterpret_cast<int*>(Xs + a.XSZ);     // PK: [2 parities][KCE / 2]; else [KCE]
     const int KH = a.KCE >> 1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const int jd = j * d.dilation;
             off = (ci * s + jd % s) * a.LP + jd / s;
         }
-        koff[(kl & 1) * KH + (kl >> 1)] = off;
+        koff[PK ? (kl & 1) * KH + (kl >> 1) : kl] = off;
     }
 
     f32x16 acc[NTQ];
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const int mrow = m0 + r;
             const float* wsrc = a.w + (size_t)mrow * wpitch + (size_t)ci0 * ks;
             for (int kl = lane; kl < a.KCE; kl += 64)
-                Ws[((kl & 1) * 64 + r) * a.KCP + (kl >> 1)] = (mrow < d.Cout && kl < kvalid) ? wsrc[kl] : 0.f;
+                Ws[PK ? ((kl & 1) * 64 + r) * a.KCP + (kl >> 1) : r * a.KCP + kl] = (mrow < d.Cout && kl < kvalid) ? wsrc[kl] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
@@ -114,10 +117,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 }
             }
             __syncthreads();
+            const float* xp = Xs + wc * 32 + li;
+            if constexpr (!PK) {
+                const float* wq = Ws + (wr * 32 + li) * a.KCP + kk;
+                for (int k2 = 0; k2 < a.KCE; k2 += 2) {
+                    const float av = wq[k2];
+                    const float bv = xp[koff[k2 + kk]];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
             const float* wp = Ws + (kk * 64 + wr * 32 + li) * a.KCP;   // this lane's row of its parity plane
             const int* kp = koff + kk * KH;
-            const float* xp = Xs + wc * 32 + li;
-            for (int kb = 0; kb < KH; kb += 8) {   // 8 MFMAs: k = 2 (kb + u) + kk, u = 0 .. 7, ascending (the fmaf chain of a scalar loop)
+            for (int kb = 0; PK && kb < KH; kb += 8) {   // 8 MFMAs: k = 2 (kb + u) + kk, u = 0 .. 7, ascending (the fmaf chain of a scalar loop)
                 const float4 wa = *reinterpret_cast<const float4*>(wp + kb), wb = *reinterpret_cast<const float4*>(wp + kb + 4);
                 const int4 oa = *reinterpret_cast<const int4*>(kp + kb), ob = *reinterpret_cast<const int4*>(kp + kb + 4);
                 const float x0 = xp[oa.x], x1 = xp[oa.y], x2 = xp[oa.z], x3 = xp[oa.w];
@@ -165,6 +176,69 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Convolutions with ONE or TWO output channels (the decoder's last conv: 64 -> 1 channel, k = 7, on the full-rate
+// signal).  As a 64-row MFMA tile 63 of 64 rows are padding -- that launch alone was ~1/5 of the EnCodec-32k decode.
+// Here: 256 threads x 4 consecutive outputs; per chunk of 8 input channels the span (ELU, padding applied on load, like
+// conv_fetch everywhere) sits in LDS and a thread slides a 12-float window (three ds_read_b128) over its 4 outputs x KS
+// taps; the weights are wave-uniform (scalar loads).  stride = dilation = 1.
+// -----------------------------------------------------------------------------------------------------
+template <int CO, int KS>
+__global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvArgs a) {
+    constexpr int TO = 4, CIC = 8, NOUT = 256 * TO, SP = NOUT + 12;   // row pitch: a multiple of 4 floats
+    __shared__ __attribute__((aligned(16))) float xs[CIC * SP];
+    const acmi_conv_desc& d = a.d;
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int q0 = blockIdx.x * NOUT, base_in = q0 - d.pad_left;
+    float acc[CO][TO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int o = 0; o < TO; ++o) acc[c][o] = 0.f;
+    for (int ci0 = 0; ci0 < d.Cin; ci0 += CIC) {
+        __syncthreads();
+        for (int idx = tid; idx < CIC * (NOUT + KS - 1); idx += 256) {
+            const int ci = idx / (NOUT + KS - 1), rel = idx - ci * (NOUT + KS - 1);
+            const bool live = ci0 + ci < d.Cin;
+            const float* xrow = a.x + ((size_t)b * d.Cin + min(ci0 + ci, d.Cin - 1)) * d.Tin;
+            xs[ci * SP + rel] = live ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < CIC; ++ci) {
+            const float4 w0 = *reinterpret_cast<const float4*>(xs + ci * SP + tid * TO);
+            const float4 w1 = *reinterpret_cast<const float4*>(xs + ci * SP + tid * TO + 4);
+            const float4 w2 = *reinterpret_cast<const float4*>(xs + ci * SP + tid * TO + 8);
+            const float win[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+            const int cig = min(ci0 + ci, d.Cin - 1);   // rows past Cin hold zeros: any finite weight will do
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const float* wr = a.w + ((size_t)c * d.Cin + cig) * KS;   // wave uniform -> scalar loads
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const float wv = wr[j];
+#pragma unroll
+                    for (int o = 0; o < TO; ++o) acc[c][o] = fmaf(wv, win[o + j], acc[c][o]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        const float bias = a.bias ? a.bias[c] : 0.f;
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            const int q = q0 + tid * TO + o;
+            if (q < d.Tout) {
+                const size_t oi = ((size_t)b * CO + c) * d.Tout + q;
+                float v = acc[c][o] + bias;
+                if (a.res) v += a.res[oi];
+                a.y[oi] = v;
+            }
+        }
+    }
+}
+
 extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float* w, const float* bias,
                            const float* residual, float* y, void* stream) {
     ACMI_REQUIRE(dp != nullptr, "acmi_conv1d: null descriptor");
@@ -179,6 +253,14 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     if (d.B == 0 || d.Tout <= 0) return ACMI_OK;
     ConvArgs a;
     a.d = d; a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+    static const bool fewout_ok = !(getenv("ACMI_CONV_FEWOUT") != nullptr && getenv("ACMI_CONV_FEWOUT")[0] == '0');
+    if (fewout_ok && d.Cout <= 2 && d.ksize == 7 && d.stride == 1 && d.dilation == 1 && d.shuffle == 1) {
+        a.Tq = d.Tout; a.CIC = a.KCE = a.KCP = a.LP = a.XSZ = 0;
+        dim3 grid((d.Tout + 1023) / 1024, 1, d.B), block(256);
+        if (d.Cout == 1) hipLaunchKernelGGL((conv_fewout_kernel<1, 7>), grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_fewout_kernel<2, 7>), grid, block, 0, (hipStream_t)stream, a);
+        return acmi_check_launch("conv_fewout_kernel");
+    }
     a.Tq = d.shuffle > 1 ? (int)(((long long)d.Tout + d.trim_left + d.shuffle - 1) / d.shuffle) : d.Tout;
     int cic = 128 / d.ksize;
     if (cic < 1) cic = 1;
@@ -186,21 +268,31 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     // keep the staged input span within the LDS budget
     const int lp = 64 + ((d.ksize - 1) * d.dilation) / d.stride + 2;
     while (cic > 1 && (size_t)cic * d.stride * lp * 4 > 24 * 1024) cic >>= 1;
+    static const bool parity = getenv("ACMI_CONV_PARITY") != nullptr && getenv("ACMI_CONV_PARITY")[0] == '1';
     a.CIC = cic;
-    a.KCE = (cic * d.ksize + 15) & ~15;
-    a.KCP = (a.KCE / 2 + 63) / 64 * 64 + 4;   // = 4 (mod 64): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank slots
     a.LP = lp;
     a.XSZ = (a.CIC * d.stride * a.LP + 3) & ~3;
-    const size_t lds = ((size_t)2 * 64 * a.KCP + (size_t)a.XSZ + a.KCE) * sizeof(float);
+    size_t lds;
+    if (parity) {
+        a.KCE = (cic * d.ksize + 15) & ~15;
+        a.KCP = (a.KCE / 2 + 63) / 64 * 64 + 4;   // = 4 (mod 64): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank slots
+        lds = ((size_t)2 * 64 * a.KCP + (size_t)a.XSZ + a.KCE) * sizeof(float);
+    } else {
+        a.KCE = (cic * d.ksize + 1) & ~1;
+        a.KCP = a.KCE | 1;
+        lds = ((size_t)64 * a.KCP + (size_t)a.XSZ + a.KCE) * sizeof(float);
+    }
     ACMI_REQUIRE(lds <= 64 * 1024, "acmi_conv1d: LDS budget exceeded (%zu B)", lds);
     // column tiles per workgroup: as many as keep >= 2 workgroups per CU in flight (4, 2 or 1); ACMI_CONV_NTQ forces one
     const int tq = (a.Tq + 63) / 64, my = (d.Cout + 63) / 64;
     static const int want = getenv("ACMI_CONV_NTQ") ? atoi(getenv("ACMI_CONV_NTQ")) : 0;
     int ntq = want == 1 || want == 2 || want == 4 ? want : ((long)tq * my * d.B >= 4 * 512 ? 4 : ((long)tq * my * d.B >= 2 * 512 ? 2 : 1));
     dim3 grid((tq + ntq - 1) / ntq, my, d.B), block(256);
-    if (ntq == 4) hipLaunchKernelGGL(conv_mfma_kernel<4>, grid, block, lds, (hipStream_t)stream, a);
-    else if (ntq == 2) hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, block, lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, block, lds, (hipStream_t)stream, a);
+#define ACMI_CONV_LAUNCH(N)                                                                                   \
+    if (parity) hipLaunchKernelGGL((conv_mfma_kernel<N, true>), grid, block, lds, (hipStream_t)stream, a);    \
+    else hipLaunchKernelGGL((conv_mfma_kernel<N, false>), grid, block, lds, (hipStream_t)stream, a);
+    if (ntq == 4) { ACMI_CONV_LAUNCH(4) } else if (ntq == 2) { ACMI_CONV_LAUNCH(2) } else { ACMI_CONV_LAUNCH(1) }
+#undef ACMI_CONV_LAUNCH
     return acmi_check_launch("conv_mfma_kernel");
 }
 

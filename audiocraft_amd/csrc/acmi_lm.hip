@@ -591,7 +591,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             PrefillAttnArgs pa = {};
             pa.q = s->q; pa.k_cache = L.k_cache; pa.vt = s->pf_vt; pa.out = s->att; pa.out_bf16 = wbf; pa.out_rbs = nkc_d;
             pa.H = H; pa.Tcap = s->Tmax; pa.vt_tcap = s->pf_tcap; pa.npos = npos; pa.npos_pad = npp; pa.pos = s->pos;
-            pa.past_context = m->past_context;
+            pa.past_context = m->past_context; pa.causal = 1;
             if ((rc = acmi_launch_prefill_attn(pa, m->kvdtype, hd, s->Beff, st))) return rc;
         }
         {
@@ -605,11 +605,20 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             BigArgs b = big(s->pf_xn, L.w_cq, L.b_cq, d, d, ACMI_BIG_F32);
             b.out = s->q; b.ldo = d;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
-            acmi_attn_desc ca = {};
-            ca.q = s->q; ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
-            ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.out_rbs = nkc_d; ca.Beff = M; ca.H = H; ca.hd = hd;
-            ca.Tcap = s->Lc; ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows; ca.pos_minor_rows = npp;
-            if ((rc = acmi_attn_decode_ex(&ca, (void*)st))) return rc;
+            if (L.cvt_cache != nullptr && s->cvt_tcap >= s->Lc) {
+                // the same MFMA attention kernel, non-causal over the Lc source positions (V time-minor: built once per generate)
+                PrefillAttnArgs pa = {};
+                pa.q = s->q; pa.k_cache = L.ck_cache; pa.vt = L.cvt_cache; pa.out = s->att; pa.out_bf16 = wbf; pa.out_rbs = nkc_d;
+                pa.H = H; pa.Tcap = s->Lc; pa.vt_tcap = s->cvt_tcap; pa.npos = npos; pa.npos_pad = npp; pa.pos = s->pos;
+                pa.causal = 0; pa.klen = s->Lc; pa.klen_rows = s->cross_len_rows;
+                if ((rc = acmi_launch_prefill_attn(pa, m->kvdtype, hd, s->Beff, st))) return rc;
+            } else {
+                acmi_attn_desc ca = {};
+                ca.q = s->q; ca.k_cache = L.ck_cache; ca.v_cache = L.cv_cache; ca.kvdtype = m->kvdtype; ca.out = s->att;
+                ca.out_mode = ACMI_OUT_TILED; ca.out_dtype = m->wdtype; ca.out_rbs = nkc_d; ca.Beff = M; ca.H = H; ca.hd = hd;
+                ca.Tcap = s->Lc; ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows; ca.pos_minor_rows = npp;
+                if ((rc = acmi_attn_decode_ex(&ca, (void*)st))) return rc;
+            }
             BigArgs c = big(s->att, L.w_cout, nullptr, d, d, ACMI_BIG_RESID);
             c.out = s->x; c.ldo = d;
             if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;

@@ -82,5 +82,8 @@ struct PrefillAttnArgs {
     const void* vt;             // [rows, H, hd, vt_tcap]
     void* out; int out_bf16, out_rbs;   // tiled activation [rows * npos_pad, H * hd]
     int H, Tcap, vt_tcap, npos, npos_pad; const int* pos; int past_context; float scale;
+    // non-causal form (cross-attention of the prefill): every query sees keys [0, klen) of its cache row
+    // (klen_rows[row] when given, else klen); causal == 0 selects it
+    int causal; int klen; const int* klen_rows;
 };
 int acmi_launch_prefill_attn(PrefillAttnArgs& a, int kvdtype, int hd, int Beff, hipStream_t st);

@@ -329,10 +329,12 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillAttnArgs
             qf[c] = u32x4{__float_as_uint(t[0]), __float_as_uint(t[1]), __float_as_uint(t[2 % E]), __float_as_uint(t[3 % E])};
         }
     }
-    const int tq = pos0 + q0 + nl;                 // absolute position of this lane's query (keys <= tq are visible)
-    const int tq_last = pos0 + min(q0 + 15, p.npos - 1);
+    // causal: keys <= the query's absolute position are visible; non-causal (cross-attention): keys [0, klen) of the row
+    const int klen = p.causal ? 0 : (p.klen_rows != nullptr ? max(1, min(p.klen_rows[b], p.klen)) : p.klen);
+    const int tq = p.causal ? pos0 + q0 + nl : klen - 1;
+    const int tq_last = p.causal ? pos0 + min(q0 + 15, p.npos - 1) : klen - 1;
     int t_first = 0;
-    if (p.past_context > 0) t_first = max(0, pos0 + q0 - p.past_context) / KTILE * KTILE;
+    if (p.causal && p.past_context > 0) t_first = max(0, pos0 + q0 - p.past_context) / KTILE * KTILE;
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 o[ND];
 #pragma unroll
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillAttnArgs
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int t = t0 + tt * 16 + kg * 4 + r;
-                const bool vis = t <= tq && (p.past_context <= 0 || t >= tq - p.past_context);
+                const bool vis = t <= tq && (!p.causal || p.past_context <= 0 || t >= tq - p.past_context);
                 s[tt][r] = vis ? s[tt][r] * p.scale : -INFINITY;
                 cmax = fmaxf(cmax, s[tt][r]);
             }
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillAttnArgs
 int acmi_launch_prefill_attn(PrefillAttnArgs& a, int kvdtype, int hd, int Beff, hipStream_t st) {
     ACMI_REQUIRE(a.npos > 0 && a.npos_pad >= a.npos && a.npos_pad % 16 == 0, "acmi_attn_prefill: bad npos=%d npos_pad=%d", a.npos, a.npos_pad);
     ACMI_REQUIRE(a.vt_tcap % 32 == 0 && a.vt_tcap > 0, "acmi_attn_prefill: vt_tcap=%d must be a positive multiple of 32", a.vt_tcap);
+    ACMI_REQUIRE(a.causal || (a.klen > 0 && a.klen <= a.Tcap && a.klen <= a.vt_tcap), "acmi_attn_prefill: klen=%d outside the caches", a.klen);
     ACMI_REQUIRE(hd % 4 == 0, "acmi_attn_prefill: head dim %d", hd);
     a.scale = 1.0f / sqrtf((float)hd);
     dim3 grid((a.npos + 63) / 64, a.H, Beff), block(256);
@@ -466,6 +469,7 @@ extern "C" int acmi_attn_prefill(const float* q, const void* k_cache, const void
     const int kt = out_dtype == ACMI_BF16 ? 32 : 16;
     a.out_rbs = out_rbs > 0 ? out_rbs : (H * hd + kt - 1) / kt;
     a.H = H; a.Tcap = Tcap; a.vt_tcap = vt_tcap; a.npos = npos; a.npos_pad = npos_pad; a.pos = pos; a.past_context = past_context;
+    a.causal = 1;
     ACMI_REQUIRE(pos != nullptr && Beff > 0 && H > 0 && Tcap > 0, "acmi_attn_prefill: bad arguments");
     return acmi_launch_prefill_attn(a, kvdtype, hd, Beff, (hipStream_t)stream);
 }

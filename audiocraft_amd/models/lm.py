@@ -368,11 +368,15 @@ class LMModel(nn.Module):
         if self.has_cross_attention:
             run['ck'] = torch.zeros(self.num_layers, Beff, H, max(Lc, 1), hd, device=dev, dtype=self.kv_dtype)
             run['cv'] = torch.zeros(self.num_layers, Beff, H, max(Lc, 1), hd, device=dev, dtype=self.kv_dtype)
+            # the values once more, time-minor and zero padded to 32 positions: the prefill's cross-attention (acmi_lm_layer.cvt_cache)
+            run['cvt_tcap'] = -(-max(Lc, 1) // 32) * 32
+            run['cvt'] = torch.zeros(self.num_layers, Beff, H, hd, run['cvt_tcap'], device=dev, dtype=self.kv_dtype)
         for li in range(self.num_layers):
             L = pk['layers'][li]
             L.k_cache, L.v_cache = run['k'][li].data_ptr(), run['v'][li].data_ptr()
             if self.has_cross_attention:
                 L.ck_cache, L.cv_cache = run['ck'][li].data_ptr(), run['cv'][li].data_ptr()
+                L.cvt_cache = run['cvt'][li].data_ptr()
         # activation rows: one decode position = Beff rows; a prefill call runs PREFILL_CHUNK consecutive positions
         # (prompt / prepended-condition rows) at once through the same kernels
         rows = Beff * self.PREFILL_CHUNK
@@ -427,6 +431,7 @@ class LMModel(nn.Module):
         st.xshift = run['xshift'].data_ptr() if self.weight_dtype == torch.bfloat16 else None
         st.cross_active_rows = 0
         st.pf_xn, st.pf_vt, st.pf_tcap = None, None, 0
+        st.cvt_tcap = run.get('cvt_tcap', 0) if self.has_cross_attention else 0
         st.hidden, st.logits = run['hidden'].data_ptr(), run['logits'].data_ptr()
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None
         st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)
@@ -446,6 +451,7 @@ class LMModel(nn.Module):
             _C.kv_store(tmp.view(Beff, Lc, d), run['ck'][li], 0)
             _C.linear(flat, ent['w_cv'], tmp)
             _C.kv_store(tmp.view(Beff, Lc, d), run['cv'][li], 0)
+        run['cvt'][..., :Lc].copy_(run['cv'].transpose(3, 4))   # [L, Beff, H, hd, Lc]: one strided copy per generate
 
     # ------------------------------------------------------------------------------------- conditions
     def _cfg_condition_tensors(self, conditions: tp.List[ConditioningAttributes], cfg_coef_beta=None,

@@ -169,6 +169,8 @@ typedef struct {
     const void* w_mq;       /* [d, d] = w_cq' W_out, computed in f32, then rounded */
     const void* w_ff2h;     /* w_ff2 in half-tile order (acmi_linear_desc.w_half), used for calls of <= 32 rows when d / 8 <= 256
                                and the FFN width is a multiple of 2 KT; NULL = always the 16-feature form */
+    const void* cvt_cache;  /* cross-attention values TIME-MINOR [Beff, H, hd, cvt_tcap] in kvdtype (acmi_lm_state.cvt_tcap; zero
+                               beyond Lc), for the MFMA-tiled prefill's cross-attention; NULL = it runs the decode kernel per row */
 } acmi_lm_layer;
 
 typedef struct {
@@ -259,6 +261,7 @@ typedef struct {
     void* pf_xn;            /* tiled activation [Beff * npos_pad, d_pad] in wdtype: standardised rows (acmi_ln_tile) */
     void* pf_vt;            /* [Beff, H, hd, pf_tcap] in kvdtype, zero-initialised: V of this call's positions, time-minor */
     int pf_tcap;            /* positions pf_vt holds per (row, head): >= pos[0] + n_pos, a multiple of 32 */
+    int cvt_tcap;           /* time extent of acmi_lm_layer.cvt_cache: a multiple of 32, >= Lc (0 = none) */
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0

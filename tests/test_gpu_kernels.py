@@ -98,6 +98,9 @@ CONV_CASES = [
     (16, 16, 3, 1, 4, True, 'reflect', 77),
     (8, 8, 7, 1, 1, False, 'reflect', 3),      # shorter than the padding: pad1d's zero-extension rule
     (64, 1, 7, 1, 1, False, 'constant', 640),
+    (64, 1, 7, 1, 1, False, 'constant', 4099),   # the few-output-channel kernel: several 1024-sample blocks, ragged tail
+    (20, 2, 7, 1, 1, True, 'reflect', 1500),     # ... two channels, Cin not a multiple of its 8-channel chunk, causal + reflect
+    (64, 1, 7, 1, 2, False, 'constant', 300),    # dilated: stays on the MFMA kernel
     (1024, 128, 7, 1, 1, False, 'constant', 50),
     (128, 1024, 7, 1, 1, True, 'constant', 75),
 ]
