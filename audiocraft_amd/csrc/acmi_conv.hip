@@ -42,9 +42,8 @@ __device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow
 // NTQ: 64-column (time) tiles per workgroup.  The weight tile of a K chunk is staged ONCE and multiplied with NTQ input
 // spans in turn (NTQ accumulators): with one tile per workgroup the 32 KB weight tile was re-staged from L2 for every 64
 // output samples and that traffic (~35 KB per 1.7 us of MFMA work per workgroup) co-bounded the kernel.
-// PK: the parity-plane LDS layout + 8-MFMA blocks below (A/B variant, ACMI_CONV_PARITY=1); !PK: weights [64][KCP odd], one
-// offset table, one (weight, offset, input) read triple per MFMA -- measured faster (the compiler software-pipelines the
-// short loop; the block form exposes its LDS latency once per 8 MFMAs): profiles/r03_codec_bench_*.jsonl.
+// PK: the parity-plane LDS layout + 8-MFMA blocks below (default); !PK: weights [64][KCP odd], one offset table, one
+// (weight, offset, input) read triple per MFMA (ACMI_CONV_PARITY=0, the round-2 inner loop, kept for A/B).
 template <int NTQ, bool PK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -268,7 +267,10 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     // keep the staged input span within the LDS budget
     const int lp = 64 + ((d.ksize - 1) * d.dilation) / d.stride + 2;
     while (cic > 1 && (size_t)cic * d.stride * lp * 4 > 24 * 1024) cic >>= 1;
-    static const bool parity = getenv("ACMI_CONV_PARITY") != nullptr && getenv("ACMI_CONV_PARITY")[0] == '1';
+    // inner-loop form: parity planes + 8-MFMA blocks (default), or one read triple per MFMA (ACMI_CONV_PARITY=0, A/B).  With
+    // one column tile per workgroup the plain form was 4 % faster; with the weight tile reused over 4 column tiles the
+    // block form is (EnCodec-32k, 8 x 30 s: encode 73.1 vs 75.6 ms, decode 75.4 vs 77.8 ms; profiles/r03_codec_bench_*.jsonl)
+    static const bool parity = !(getenv("ACMI_CONV_PARITY") != nullptr && getenv("ACMI_CONV_PARITY")[0] == '0');
     a.CIC = cic;
     a.LP = lp;
     a.XSZ = (a.CIC * d.stride * a.LP + 3) & ~3;
