@@ -40,7 +40,8 @@ class LMLayer(C.Structure):
     _fields_ = [('w_qkv', vp), ('w_out', vp), ('w_cq', vp), ('w_cout', vp), ('w_xcq', vp), ('w_ff1', vp), ('w_ff2', vp),
                 ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp),
-                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp), ('cvt_cache', vp)]
+                ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp),
+                ('b_out', vp), ('b_cout', vp), ('b_ff2', vp), ('b_mq', vp), ('cvt_cache', vp)]
 
 
 class LMModelDesc(C.Structure):

@@ -512,8 +512,10 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
 }
 
 // describes x <- x + a W^T (in place on the f32 copy), also emitted as fragments into (xh, xl) + statistics
-static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs, const void* w, int K, void* xh, void* xl) {
+static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs, const void* w, int K, void* xh, void* xl,
+                                const float* bias = nullptr) {
     const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
+    p.bias = bias;
     p.a = a; p.a_tiled = 1; p.a_rbs = a_rbs; p.w = w; p.residual = s->x; p.out = s->x; p.out_mode = ACMI_OUT_F32;
     p.M = c.rows; p.N = m->dim; p.K = K;
     if (c.lnm == LN_FOLD) {
@@ -522,9 +524,9 @@ static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs
         p.xt_shift = c.nsh;
     }
 }
-static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool w_half = false) {
+static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool w_half = false, const float* bias = nullptr) {
     LinArgs p = {};
-    gemm_produce_x_args(c, p, a, 0, w, K, c.xh, c.xl);
+    gemm_produce_x_args(c, p, a, 0, w, K, c.xh, c.xl, bias);
     p.w_half = w_half;
     int rc = acmi_launch_lin(p, c.m->wdtype, c.st);
     c.cnt = w_half ? 8 : 16; c.np = c.m->dim / c.cnt;   // 8-feature workgroups leave 8-element partials
@@ -595,7 +597,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             if ((rc = acmi_launch_prefill_attn(pa, m->kvdtype, hd, s->Beff, st))) return rc;
         }
         {
-            BigArgs b = big(s->att, L.w_out, nullptr, d, d, ACMI_BIG_RESID);
+            BigArgs b = big(s->att, L.w_out, L.b_out, d, d, ACMI_BIG_RESID);
             b.out = s->x; b.ldo = d;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
         }
@@ -619,7 +621,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
                 ca.Tcap = s->Lc; ca.len = s->Lc; ca.cache_rows = s->Beff; ca.len_rows = s->cross_len_rows; ca.pos_minor_rows = npp;
                 if ((rc = acmi_attn_decode_ex(&ca, (void*)st))) return rc;
             }
-            BigArgs c = big(s->att, L.w_cout, nullptr, d, d, ACMI_BIG_RESID);
+            BigArgs c = big(s->att, L.w_cout, L.b_cout, d, d, ACMI_BIG_RESID);
             c.out = s->x; c.ldo = d;
             if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;
         }
@@ -628,7 +630,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             BigArgs b = big(s->pf_xn, L.w_ff1, L.b_ff1, F, d, ACMI_BIG_TILED);
             b.out_t = s->hidden; b.out_rbs = F / kt; b.act = 1;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
-            BigArgs c = big(s->hidden, L.w_ff2, nullptr, d, F, ACMI_BIG_RESID);
+            BigArgs c = big(s->hidden, L.w_ff2, L.b_ff2, d, F, ACMI_BIG_RESID);
             c.out = s->x; c.ldo = d;
             if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;
         }
@@ -732,7 +734,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         if ((rc = acmi_attn_decode_ex(&sa, stream))) return rc;
 
         if (!m->cross_attention) {
-            if ((rc = gemm_produce_x(c, s->att, L.w_out, d))) return rc;
+            if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
         } else {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache, "acmi_lm_step: cross-attention caches missing");
             acmi_attn_desc ca = {};
@@ -745,8 +747,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 // r += att (W_cq' W_out)^T, which completes r = x1 W_cq'^T (its x0 part came out of the QKV launch)
                 LinArgs p0 = {}, p1 = {};
                 const void* att_half = reinterpret_cast<const unsigned char*>(c.xh) + (size_t)c.nkc_d * 1024;  // K tile nkc_d
-                gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1]);
-                p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs;
+                gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1], L.b_out);
+                p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs; p1.bias = L.b_mq;
                 p1.w = L.w_mq; p1.residual = s->r; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = d;
                 if ((rc = acmi_launch_pair(p0, p1, m->wdtype, st))) return rc;
                 cur ^= 1; c.xh = xh2[cur]; c.xl = xl2[cur]; c.np = d / 16; c.cnt = 16; c.xsh = c.nsh;
@@ -755,14 +757,14 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 ca.q = s->r; ca.q_stats = s->stats; ca.q_stats_np = c.np; ca.q_stats_cnt = c.cnt; ca.eps = m->eps;
                 ca.q_colsum = L.cs_cq; ca.q_bias = L.b_cq; ca.q_shift = sh_l;
             } else {
-                if ((rc = gemm_produce_x(c, s->att, L.w_out, d))) return rc;
+                if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
                 LinArgs a = {};
                 a.out = s->q; a.out_mode = ACMI_OUT_F32;
                 if ((rc = gemm_ln_x(c, a, L.w_cq, L.b_cq, L.cs_cq, d))) return rc;
                 ca.q = s->q;
             }
             if ((rc = acmi_attn_decode_ex(&ca, stream))) return rc;
-            if ((rc = gemm_produce_x(c, s->att, L.w_cout, d))) return rc;
+            if ((rc = gemm_produce_x(c, s->att, L.w_cout, d, false, L.b_cout))) return rc;
         }
         {   // norm2 -> linear1 + GELU -> hidden (A-fragment order) ; linear2 -> x
             LinArgs a = {};
@@ -773,7 +775,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             static const bool half_ok = !(getenv("ACMI_FFN2_HALF") != nullptr && getenv("ACMI_FFN2_HALF")[0] == '0');
             const bool half = half_ok && L.w_ff2h != nullptr && c.lnm == LN_FOLD && M <= 32 && d % 8 == 0 && d / 8 <= 256 &&
                               F % (2 * c.kt) == 0;
-            if ((rc = gemm_produce_x(c, s->hidden, half ? L.w_ff2h : L.w_ff2, F, half))) return rc;
+            if ((rc = gemm_produce_x(c, s->hidden, half ? L.w_ff2h : L.w_ff2, F, half, L.b_ff2))) return rc;
         }
     }
     if (mode == ACMI_STEP_DECODE) {

@@ -270,16 +270,23 @@ class LMModel(nn.Module):
         layers = (_C.LMLayer * self.num_layers)()
         pk: dict = {'keep': keep, 'layers': layers, 'per_layer': []}
         for li, layer in enumerate(self.transformer.layers):
-            for b in (layer.self_attn.out_proj.bias, layer.linear2.bias):
-                if b is not None and bool((b != 0).any()):
-                    raise NotImplementedError("out_proj / linear2 biases are not wired into acmi_lm_step; "
-                                              "MusicGen checkpoints have none (bias_attn = bias_ff = false)")
+            def scaled_bias(b, name):   # bias of a residual branch's last projection, times the branch's LayerScale
+                if b is None:
+                    return None
+                ls = getattr(layer, name, None)
+                b32 = b.detach().to(device=dev, dtype=torch.float32)
+                return Fp(b32 if ls is None else b32 * ls.scale.detach().to(device=dev, dtype=torch.float32))
+
             def scaled(w, name):   # LayerScale: x + s * (a W^T) = x + a (diag(s) W)^T, folded into the matrix (f32, then rounded)
                 ls = getattr(layer, name, None)
                 w32 = w.detach().to(device=dev, dtype=torch.float32)
                 return w32 if ls is None else w32 * ls.scale.detach().to(device=dev, dtype=torch.float32)[:, None]
             w_out32, w_ff2_32 = scaled(layer.self_attn.out_proj.weight, 'layer_scale_1'), scaled(layer.linear2.weight, 'layer_scale_2')
             ent = {'w_out': W(w_out32), 'w_ff2': W(w_ff2_32)}
+            for key, b, name in (('b_out', layer.self_attn.out_proj.bias, 'layer_scale_1'), ('b_ff2', layer.linear2.bias, 'layer_scale_2')):
+                sb = scaled_bias(b, name)
+                if sb is not None:
+                    ent[key] = sb
             kt2 = 64 if wd == torch.bfloat16 else 32
             if d % 8 == 0 and d // 8 <= 256 and self.ffn_dim % kt2 == 0:
                 # 8-feature workgroups for FFN2 in calls of <= 32 rows (acmi_lm_layer.w_ff2h): a second copy of the weight
@@ -288,10 +295,11 @@ class LMModel(nn.Module):
             ent['w_ff1'], ent['b_ff1'], ent['cs_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
             if layer.cross_attention is not None:
                 ca = layer.cross_attention
-                if ca.in_proj_bias is not None and bool((ca.in_proj_bias != 0).any()):
-                    raise NotImplementedError("cross-attention in_proj_bias is not wired into acmi_lm_step")
-                ipw = ca.in_proj_weight
-                ent['w_cq'], ent['b_cq'], ent['cs_cq'] = folded(ipw[:d], layer.norm_cross)
+                ipw, ipb = ca.in_proj_weight, ca.in_proj_bias
+                ent['w_cq'], ent['b_cq'], ent['cs_cq'] = folded(ipw[:d], layer.norm_cross, None if ipb is None else ipb[:d])
+                if ipb is not None:   # k / v biases: added when the cross-attention caches are filled (_project_cross_kv)
+                    ent['b_ck'], ent['b_cv'] = Fp(ipb[d:2 * d]), Fp(ipb[2 * d:])
+                    pk['cross_kv_bias'] = pk.get('cross_kv_bias', False) or bool((ipb[d:] != 0).any())
                 # x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T: the x0 part is a fourth block of
                 # output features of the QKV launch (raw, no LayerNorm epilogue), the att part rides in the out-projection
                 # launch (include/acmi.h, acmi_lm_layer.w_qkvx / w_mq)
@@ -303,11 +311,16 @@ class LMModel(nn.Module):
                 ent['b_qkvx'] = Fp(torch.cat([ent['b_qkv'], torch.zeros(d, device=dev)]))
                 ent['cs_qkvx'] = Fp(torch.cat([ent['cs_qkv'], torch.zeros(d, device=dev)]))
                 ent['w_mq'] = W(wq @ w_out32)
+                if 'b_out' in ent:   # r = x1 W_cq'^T with x1 = x0 + att W_out^T + b_out
+                    ent['b_mq'] = Fp(wq @ ent['b_out'])
+                sb = scaled_bias(ca.out_proj.bias, 'layer_scale_cross')
+                if sb is not None:
+                    ent['b_cout'] = sb
                 ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]),
                             'w_cout': W(scaled(ca.out_proj.weight, 'layer_scale_cross'))})
             L = layers[li]
             for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
-                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h'):
+                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h', 'b_out', 'b_cout', 'b_ff2', 'b_mq'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]
@@ -447,9 +460,9 @@ class LMModel(nn.Module):
         tmp = torch.empty(Beff * Lc, d, device=flat.device, dtype=torch.float32)
         for li in range(self.num_layers):
             ent = pk['per_layer'][li]
-            _C.linear(flat, ent['w_ck'], tmp)
+            _C.linear(flat, ent['w_ck'], tmp, bias=ent.get('b_ck'))
             _C.kv_store(tmp.view(Beff, Lc, d), run['ck'][li], 0)
-            _C.linear(flat, ent['w_cv'], tmp)
+            _C.linear(flat, ent['w_cv'], tmp, bias=ent.get('b_cv'))
             _C.kv_store(tmp.view(Beff, Lc, d), run['cv'][li], 0)
         run['cvt'][..., :Lc].copy_(run['cv'].transpose(3, 4))   # [L, Beff, H, hd, Lc]: one strided copy per generate
 
@@ -607,6 +620,8 @@ class LMModel(nn.Module):
             # they sit at the tail of the batch the attention launch skips them; `att` must then read as zeros there.
             live = (cross_src != 0).flatten(1).any(dim=1).nonzero()
             n_live = int(live.max()) + 1 if live.numel() else 0
+            if self._packed.get('cross_kv_bias', False):
+                n_live = run['Beff']     # k / v biases: a null source no longer means K = V = 0
             state.cross_active_rows = n_live if 0 < n_live < run['Beff'] else 0
             run['att'].zero_()
 

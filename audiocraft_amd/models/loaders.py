@@ -73,7 +73,8 @@ def parse_cfg(text_or_dict) -> dict:
     return _resolve(cfg)
 
 
-TRANSFORMER_OPTIONS = ('positional_embedding', 'xpos', 'past_context', 'layer_scale', 'positional_scale', 'max_period')
+TRANSFORMER_OPTIONS = ('positional_embedding', 'xpos', 'past_context', 'layer_scale', 'positional_scale', 'max_period',
+                       'bias_ff', 'bias_attn', 'bias_proj')   # biases: true in config/model/lm/default.yaml, false in the releases
 
 
 def lm_cfg_from_xp(cfg: dict) -> dict:

@@ -169,6 +169,12 @@ typedef struct {
     const void* w_mq;       /* [d, d] = w_cq' W_out, computed in f32, then rounded */
     const void* w_ff2h;     /* w_ff2 in half-tile order (acmi_linear_desc.w_half), used for calls of <= 32 rows when d / 8 <= 256
                                and the FFN width is a multiple of 2 KT; NULL = always the 16-feature form */
+    /* Biases of the layer's OUTPUT projections (transformer.py:190-209 bias_attn, :497-498 bias_ff: on by default in the
+     * reference's LM config, off in every released MusicGen), f32 [d] each or NULL; with LayerScale already multiplied by
+     * the branch's scale.  b_mq = W_cq' b_out completes the split cross-attention query (r = x1 W_cq'^T with
+     * x1 = x0 + att W_out^T + b_out).  (The in_proj / linear1 biases are part of b_qkv / b_cq / b_ff1 above; the cross
+     * attention's k / v biases are applied when its caches are filled.) */
+    const float* b_out; const float* b_cout; const float* b_ff2; const float* b_mq;
     const void* cvt_cache;  /* cross-attention values TIME-MINOR [Beff, H, hd, cvt_tcap] in kvdtype (acmi_lm_state.cvt_tcap; zero
                                beyond Lc), for the MFMA-tiled prefill's cross-attention; NULL = it runs the decode kernel per row */
 } acmi_lm_layer;

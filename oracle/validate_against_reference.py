@@ -8,6 +8,7 @@ Checks (each prints a line and the script exits non-zero on the first failure):
   lm       mid-size LMModel (d 256, 4 layers, 8 heads, cross-attention, card 2048, seeded random weights with perturbed
            LayerNorm parameters): reference `LMModel.forward` (batch) and `LMModel.generate` (greedy, CFG; plain, two_step_cfg)
            vs oracle.lm.lm_forward / generate  -> logits rel-L2 <= 1e-5, tokens identical
+  bias     the reference's default transformer configuration: every projection bias on (+ LayerScale)
   melody   prepend-conditioned LMModel (no cross-attention) incl. double CFG (cfg_coef_beta)
   stereo   8 codebooks with delays [0,0,1,1,2,2,3,3]
   codec    EncodecModel at the 32 kHz geometry with n_filters 16 (all layers, LSTM, RVQ 4 x 2048) on 0.7 s of audio:
@@ -137,6 +138,38 @@ def check_lm():
                           null_cross_src=n1['description'][0])
     assert torch.equal(toks2, otoks2)
     print(f"lm      ok: batch forward rel-L2 {r:.1e}, greedy tokens identical (plain + two_step_cfg), step logits rel-L2 {r2:.1e}")
+
+
+def check_bias():
+    """Every bias of the reference's default transformer configuration (bias_ff / bias_attn / bias_proj true) + LayerScale:
+    the oracle's handling of in_proj / out_proj / cross k, v / linear1, 2 / head biases against the reference."""
+    torch.manual_seed(31)
+    dim, B = 128, 3
+    lm = LMModel(DelayedPatternProvider(4, delays=[0, 1, 2, 3]), ConditioningProvider({'description': _Text(32, dim, 5)}),
+                 ConditionFuser({'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []}),
+                 n_q=4, card=256, dim=dim, num_heads=4, hidden_scale=4, norm='layer_norm', norm_first=True, bias_proj=True,
+                 weight_init='gaussian', depthwise_init='current', zero_bias_init=False, cfg_coef=3.0, num_layers=3,
+                 dropout=0., activation='gelu', bias_ff=True, bias_attn=True, causal=True, custom=False, memory_efficient=True,
+                 attention_as_float32=False, cross_attention=True, positional_embedding='sin', layer_scale=0.5).eval()
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            if '.norm' in k or k.startswith('out_norm') or k.endswith('bias'):
+                p.add_(0.1 * torch.randn_like(p))
+    sd = {k: v.detach() for k, v in lm.state_dict().items()}
+    assert 'transformer.layers.0.cross_attention.in_proj_bias' in sd and 'transformer.layers.0.linear2.bias' in sd
+    oc = olm.LMConfig(dim=dim, num_heads=4, num_layers=3, n_q=4, card=256, cross_attention=True)
+    conds = [ConditioningAttributes(text={'description': f'c{i}'}) for i in range(B)]
+    null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+    ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+    seq = torch.randint(0, 257, (2 * B, 4, 11))
+    with torch.no_grad():
+        ref = lm.forward(seq, [], ct)
+    got = olm.lm_forward(sd, oc, seq, ct['description'][0])
+    assert rel(got, ref) < 1e-5, rel(got, ref)
+    toks = lm.generate(None, conds, max_gen_len=12, use_sampling=False)
+    otoks = olm.generate(sd, oc, None, B, ct['description'][0], max_gen_len=12, use_sampling=False)
+    assert torch.equal(toks, otoks)
+    print(f"bias    ok: all projection biases + LayerScale: batch forward rel-L2 {rel(got, ref):.1e}, greedy tokens identical")
 
 
 def check_rope():
@@ -272,7 +305,7 @@ def check_epic():
           f"{(odec - dec).abs().max().item():.1e}")
 
 
-CHECKS = {'epic': check_epic, 'lm': check_lm, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
+CHECKS = {'epic': check_epic, 'lm': check_lm, 'bias': check_bias, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)

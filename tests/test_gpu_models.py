@@ -667,3 +667,48 @@ def test_prefill_one_forward_matches_oracle_and_chunk_path(wdt, tol, variant, mo
     assert r < tol and r_paths < 2 * tol, (r, r_paths)
     if wdt == torch.float32:
         assert torch.equal(toks, out['chunk'][0])
+
+
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_lm_with_projection_biases_vs_oracle(wdt, tol, prefill_mode):
+    """The reference's DEFAULT transformer configuration has biases everywhere (config/model/lm/default.yaml: bias_ff,
+    bias_attn, bias_proj true; the released MusicGen checkpoints turn them off): in_proj / out_proj of self- and
+    cross-attention (incl. the k / v biases of the cross-attention source, so that a null condition no longer means
+    K = V = 0 and no row may be skipped), linear1 / linear2, the heads; with LayerScale on top.  Prompt + CFG generate
+    through both prefill paths vs the oracle."""
+    from audiocraft_amd.models import builders
+    from oracle import patterns as opat
+    torch.manual_seed(0)
+    cfg = dict(dim=256, num_heads=4, num_layers=3, n_q=4, card=1024, hidden_scale=4, cfg_coef=3.0, bias_ff=True, bias_attn=True,
+               bias_proj=True, layer_scale=0.5,
+               conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 64, 'length': 6}},
+               fuser={'cross': ['description']})
+    lm = builders.get_lm_model(cfg, 'cuda', wdt)
+    with torch.no_grad():
+        for k, prm in lm.named_parameters():
+            if 'norm' in k or k.endswith('bias'):
+                prm.add_(0.1 * torch.randn_like(prm))
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    assert 'transformer.layers.0.self_attn.out_proj.bias' in sd and 'transformer.layers.0.cross_attention.in_proj_bias' in sd
+    assert 'transformer.layers.0.linear2.bias' in sd and 'linears.0.bias' in sd
+    if wdt == torch.bfloat16:
+        sd = {k: (v.bfloat16().float() if v.dim() == 2 and 'output_proj' not in k else v) for k, v in sd.items()}
+    oc = olm.LMConfig(dim=256, num_heads=4, num_layers=3, n_q=4, card=1024, cross_attention=True)
+    B, T0, T = 3, 9, 16
+    g = torch.Generator().manual_seed(11)
+    src = torch.randn(2 * B, 6, 256, generator=g)
+    src[B:] = 0
+    ct = {'description': (src.cuda(), torch.ones(2 * B, 6, dtype=torch.int64).cuda())}
+    prompt = torch.randint(0, 1024, (B, 4, T0), generator=g)
+    toks, lg = lm.generate(prompt.cuda(), [], max_gen_len=T, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    toks, lg = toks.cpu(), lg.cpu()
+    seq, _ = opat.build_pattern_sequence(toks, 1024)
+    S, steps = seq.shape[-1], lg.shape[2]
+    ref = olm.cfg_mix(olm.lm_forward(sd, oc, torch.cat([seq, seq], 0)[..., :S - 1], src), 3.0)[:, :, S - 1 - steps:]
+    r = rel(lg, ref)
+    print(f"[parity] LM with every bias + LayerScale, {wdt}, prefill {prefill_mode}: CFG logits rel-L2 {r:.3e}")
+    assert r < tol, r
+    if wdt == torch.float32:
+        ref_t = olm.generate(sd, oc, prompt, B, src, max_gen_len=T, use_sampling=False)
+        assert torch.equal(toks, ref_t)
