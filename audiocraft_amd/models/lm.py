@@ -214,14 +214,27 @@ class LMModel(nn.Module):
 
     def _invalidate(self):
         """Drop the packed kernel weights, the run state and any captured graph (they hold raw device pointers)."""
+        if getattr(self, '_masters_released', False) and not getattr(self, '_loading', False):
+            raise RuntimeError("the f32 master weights were released (release_master_weights): load_state_dict() before moving "
+                               "or re-packing the model")
         self._packed = None
         self._run = None
         self._graph_keepalive = None
         self._stream = None
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        self._invalidate()
-        return super().load_state_dict(state_dict, strict=strict, **kw)
+        self._loading = True
+        try:
+            if getattr(self, '_masters_released', False):   # give the parameters their storage back first
+                for name, p in self.named_parameters():
+                    if name in self._master_shapes:
+                        shape, dtype = self._master_shapes[name]
+                        p.data = torch.empty(shape, device=p.device, dtype=dtype)
+                self._masters_released = False
+            self._invalidate()
+            return super().load_state_dict(state_dict, strict=strict, **kw)
+        finally:
+            self._loading = False
 
     def _apply(self, fn, *args, **kw):   # .to() / .cuda() / .float(): parameters move, the packs must be rebuilt
         result = super()._apply(fn, *args, **kw)
@@ -356,10 +369,78 @@ class LMModel(nn.Module):
         desc.pos_table = None
         desc.w_head, desc.b_head, desc.cs_head = w_head.data_ptr(), b_head.data_ptr(), cs_head.data_ptr()
         pk.update({'desc': desc, 'emb_arr': emb_arr, 'w_head': w_head, 'b_head': b_head, 'cs_head': cs_head,
-                   'pos_freq': pos_freq})
+                   'pos_freq': pos_freq, 'embs': embs})
         self._packed = pk
         self._run = None
         return pk
+
+    # ------------------------------------------------------------------------------------- opt-in: drop the f32 masters
+    def release_master_weights(self):
+        """Opt-in memory saving for serving: free the f32 master copies of the big matrices (the transformer's projections,
+        the embedding tables, the heads: 7.4 GB for MusicGen-medium) once the kernel-side packs exist.  The model keeps
+        generating from the packs; `state_dict()` re-materialises the matrices from them on demand -- exact to the packed
+        element type (bf16 packs give back the bf16-rounded weights the kernels compute with; the LayerNorm / LayerScale
+        folds are divided out again) -- and `load_state_dict` restores full masters.  Moving the model (`.to()`) or
+        changing dtypes afterwards needs a fresh `load_state_dict` first."""
+        if getattr(self, '_masters_released', False):
+            return
+        self._packed or self._pack()
+        self._master_shapes = {}
+        for name, p in self.named_parameters():
+            if p.dim() == 2 and not name.startswith('condition_provider.'):
+                self._master_shapes[name] = (tuple(p.shape), p.dtype)
+                p.data = torch.empty(0, device=p.device, dtype=p.dtype)
+        self._masters_released = True
+
+    def _rematerialise(self, name: str) -> torch.Tensor:
+        """The matrix `name` of the reference's state dict, rebuilt from the packs (see release_master_weights)."""
+        pk = self._packed
+        assert pk is not None, "the packs are gone: load_state_dict() first"
+        d = self.dim
+        shape, dtype = self._master_shapes[name]
+
+        def plain(tw, rows=None):
+            m = _C.untile_matrix(tw.data, tw.N, tw.K).float()
+            return m if rows is None else m[rows]
+
+        def norm_w(mod):
+            return mod.weight.detach().float()
+
+        parts = name.split('.')
+        if parts[0] == 'emb':
+            return pk['embs'][int(parts[1])].float().to(dtype)
+        if parts[0] == 'linears':
+            k = int(parts[1])
+            return (plain(pk['w_head'], slice(k * self.card, (k + 1) * self.card)) / norm_w(self.out_norm)[None, :]).to(dtype)
+        li = int(parts[2])
+        layer, ent = self.transformer.layers[li], pk['per_layer'][li]
+        key = '.'.join(parts[3:])
+
+        def unscale(m, ls_name):
+            ls = getattr(layer, ls_name, None)
+            return m if ls is None else m / ls.scale.detach().float()[:, None]
+        if key == 'self_attn.in_proj_weight':
+            return (plain(ent['w_qkv']) / norm_w(layer.norm1)[None, :]).to(dtype)
+        if key == 'self_attn.out_proj.weight':
+            return unscale(plain(ent['w_out']), 'layer_scale_1').to(dtype)
+        if key == 'linear1.weight':
+            return (plain(ent['w_ff1']) / norm_w(layer.norm2)[None, :]).to(dtype)
+        if key == 'linear2.weight':
+            return unscale(plain(ent['w_ff2']), 'layer_scale_2').to(dtype)
+        if key == 'cross_attention.in_proj_weight':
+            q = plain(ent['w_cq']) / norm_w(layer.norm_cross)[None, :]
+            return torch.cat([q, plain(ent['w_ck']), plain(ent['w_cv'])], dim=0).to(dtype)
+        if key == 'cross_attention.out_proj.weight':
+            return unscale(plain(ent['w_cout']), 'layer_scale_cross').to(dtype)
+        raise KeyError(name)
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if getattr(self, '_masters_released', False):
+            prefix = kwargs.get('prefix', args[1] if len(args) > 1 else '')
+            for name in self._master_shapes:
+                sd[prefix + name] = self._rematerialise(name)
+        return sd
 
     # ------------------------------------------------------------------------------------- run state
     def _prepare_run(self, B: int, use_cfg: int, Tmax: int, Lc: int, S: int):
