@@ -221,3 +221,60 @@ def test_resample_oracle_properties():
     assert ors.resample_frac(x, 32000, 32000) is not None and np.array_equal(ors.resample_frac(x, 32000, 32000), x)
     up = ors.resample_frac(x[1:2, :4410], 16000, 32000)
     assert up.shape == (1, 8820)
+
+
+# ------------------------------------------------------------------------------------------ MultiBandDiffusion (row f-4)
+
+def _mbd_cfg(cfg):
+    from oracle import mbd as ombd
+    return ombd.UnetConfig(**{k: cfg[k] for k in ('chin', 'hidden', 'depth', 'growth', 'max_channels', 'num_steps', 'emb_all_layers',
+                                                  'bilstm', 'codec_dim', 'kernel', 'stride', 'norm_groups', 'res_blocks')})
+
+
+@pytest.mark.parametrize('name', ['mbd_unet', 'mbd_unet_bilstm'])
+def test_oracle_mbd_unet_vs_reference_golden(name):
+    """oracle.mbd.unet_forward == the reference's DiffusionUnet.forward (tensor steps and an int step)"""
+    from oracle import mbd as ombd
+    cfg, sd, a = load_golden(name)
+    uc = _mbd_cfg(cfg)
+    est = ombd.unet_forward(sd, uc, a['x'], a['step'], a['condition'])
+    assert est.shape == a['estimate'].shape
+    assert torch.allclose(est, a['estimate'], atol=2e-5, rtol=1e-4), (est - a['estimate']).abs().max()
+    est1 = ombd.unet_forward(sd, uc, a['x'][:1], 42, a['condition'][:1])
+    assert torch.allclose(est1, a['estimate_step42'], atol=2e-5, rtol=1e-4)
+
+
+def test_oracle_mbd_process_vs_reference_golden():
+    """The sub-sampled reverse process + MultiBandProcessor.return_sample / project_sample == the reference (with its
+    torch.randn_like draws replayed)."""
+    from oracle import mbd as ombd
+    cfg, sd, a = load_golden('mbd_process')
+    uc = _mbd_cfg(cfg)
+    sc = ombd.ScheduleConfig(**cfg['schedule'])
+    pc = cfg['processor']
+    ps = ombd.ProcessorState(n_bands=pc['n_bands'], sample_rate=pc['sample_rate'], power_std=pc['power_std'], counts=a['proc_counts'],
+                             sum_x=a['proc_sum_x'], sum_x2=a['proc_sum_x2'], sum_target_x2=a['proc_sum_target_x2'])
+    model = lambda x, step, cond: ombd.unet_forward(sd, uc, x, step, cond)   # noqa: E731
+    out = ombd.generate_subsampled(model, sc, a['initial'], cfg['step_list'], a['condition'], list(a['noises']), ps)
+    assert torch.allclose(out, a['sample'], atol=2e-5, rtol=1e-4), (out - a['sample']).abs().max()
+    assert torch.allclose(ombd.project_sample(ps, a['sample']), a['projected'], atol=2e-5, rtol=1e-4)
+
+
+def test_oracle_split_bands_closed_forms():
+    """julius.SplitBands restated (parity-unpinned against the binary): the bands sum to the input exactly, a constant
+    signal lives in band 0 only, a tone near Nyquist lives in the last band."""
+    from oracle import mbd as ombd
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 4000, generator=g)
+    bands = ombd.split_bands(x, 16000, 6)
+    assert bands.shape == (6, 2, 1, 4000)
+    assert torch.allclose(bands.sum(0), x, atol=1e-5)
+    const = ombd.split_bands(torch.ones(1, 1, 3000), 16000, 6)
+    assert torch.allclose(const[0], torch.ones(1, 1, 3000), atol=1e-4) and const[1:].abs().max() < 1e-4
+    t = torch.arange(8000) / 16000.0
+    tone = torch.sin(2 * torch.pi * 7000.0 * t).view(1, 1, -1)
+    tb = ombd.split_bands(tone, 16000, 6)
+    energy = tb.pow(2).mean(dim=(1, 2, 3))
+    assert energy.argmax() == 5 and energy[5] > 0.9 * energy.sum()
+    cut = ombd.mel_frequencies(7, 0, 8000.)
+    assert cut[0] == 0 and abs(float(cut[-1]) - 8000.) < 1e-2 and (cut[1:] > cut[:-1]).all()
