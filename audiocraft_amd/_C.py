@@ -112,9 +112,20 @@ _chroma_frames = _sig('acmi_chroma_frames', [i32, i32])
 _linear_big = _sig('acmi_linear_big', [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp])
 _attn_prefill = _sig('acmi_attn_prefill', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
 
+_gn_work = _sig('acmi_group_norm_work_floats', [i32, i32, i32, i32], C.c_size_t)
+_group_norm = _sig('acmi_group_norm', [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp])
+_channel_add = _sig('acmi_channel_add', [vp, vp, vp, i32, i32, i32, vp])
+_add_cropped = _sig('acmi_add_cropped', [vp, i32, vp, vp, i32, i32, vp])
+_interp_add = _sig('acmi_interp_add', [vp, vp, i32, i32, i32, vp])
+_ddpm_step = _sig('acmi_ddpm_step', [vp, vp, vp, vp, C.c_size_t, f32, f32, f32, f32, f32, f32, vp])
+_fir_bank = _sig('acmi_fir_bank', [vp, vp, vp, i32, i32, i32, i32, vp])
+_band_stats = _sig('acmi_band_stats', [vp, vp, vp, i32, C.c_size_t, i32, vp])
+_band_mix = _sig('acmi_band_mix', [vp, vp, vp, vp, i32, C.c_size_t, f32, vp])
+
 _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp])
 
-EXPORTS = ['acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
+EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
+           'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
@@ -403,4 +414,67 @@ def attn_prefill(q, k_cache, vt, out, npos, npos_pad, pos, past_context=0, out_r
     check(_attn_prefill(ptr(q), ptr(k_cache), ptr(vt), dtype_code(k_cache.dtype), ptr(out), dtype_code(out.dtype), out_rbs,
                         rows, H, hd, Tcap, vt.shape[3], npos, npos_pad, ptr(pos), int(past_context), stream()),
           'acmi_attn_prefill')
+    return out
+
+
+# ---------------------------------------------------------------------------------- MultiBandDiffusion pieces
+
+def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-5, relu: bool = False,
+               out: torch.Tensor = None) -> torch.Tensor:
+    """nn.GroupNorm (+ ReLU) on x [B, C, T] f32 (acmi_group_norm)."""
+    B, Cc, T = x.shape
+    y = torch.empty_like(x) if out is None else out
+    work = torch.empty(int(_gn_work(B, Cc, T, groups)), device=x.device, dtype=torch.float32)
+    check(_group_norm(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(work), B, Cc, T, groups, eps, int(relu), stream()), 'acmi_group_norm')
+    return y
+
+
+def channel_add(z: torch.Tensor, table: torch.Tensor, steps: torch.Tensor):
+    B, Cc, T = z.shape
+    check(_channel_add(ptr(z), ptr(table), ptr(steps), B, Cc, T, stream()), 'acmi_channel_add')
+    return z
+
+
+def add_cropped(a: torch.Tensor, s: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """a[..., :T] + s for a [B, C, Ta >= T], s [B, C, T]."""
+    B, Cc, T = s.shape
+    out = torch.empty_like(s) if out is None else out
+    check(_add_cropped(ptr(a), a.shape[-1], ptr(s), ptr(out), B * Cc, T, stream()), 'acmi_add_cropped')
+    return out
+
+
+def interp_add(z: torch.Tensor, ce: torch.Tensor):
+    B, Cc, T = z.shape
+    check(_interp_add(ptr(z), ptr(ce), B * Cc, T, ce.shape[-1], stream()), 'acmi_interp_add')
+    return z
+
+
+def ddpm_step(current, estimate, noise, out, c_est, sqrt_alpha, sigma, clip, est_scale, out_scale):
+    check(_ddpm_step(ptr(current), ptr(estimate), ptr(noise), ptr(out), current.numel(), c_est, sqrt_alpha, sigma, clip, est_scale,
+                     out_scale, stream()), 'acmi_ddpm_step')
+    return out
+
+
+def fir_bank(x: torch.Tensor, filters: torch.Tensor) -> torch.Tensor:
+    """x [rows, T] f32, filters [n, 2 half + 1] -> [n, rows, T] (replicate padding)."""
+    rows, T = x.shape
+    n, K = filters.shape
+    y = torch.empty(n, rows, T, device=x.device, dtype=torch.float32)
+    check(_fir_bank(ptr(x), ptr(filters), ptr(y), rows, T, n, (K - 1) // 2, stream()), 'acmi_fir_bank')
+    return y
+
+
+def band_stats(x: torch.Tensor, lows: torch.Tensor, chunks: int = 64) -> torch.Tensor:
+    """-> HOST [n_bands, 2] f64 (sum, sum of squares) of the SplitBands bands of x (flattened) given its low-passes
+    [n_bands - 1, n]; the kernel leaves `chunks` f64 partials per band, summed here in a fixed order."""
+    n_bands, n = lows.shape[0] + 1, x.numel()
+    part = torch.empty(n_bands, chunks, 2, device=x.device, dtype=torch.float64)
+    check(_band_stats(ptr(x), ptr(lows), ptr(part), n_bands, n, chunks, stream()), 'acmi_band_stats')
+    return part.cpu().sum(dim=1)
+
+
+def band_mix(x: torch.Tensor, lows: torch.Tensor, gains: torch.Tensor, offset: float = 0.0) -> torch.Tensor:
+    out = torch.empty_like(x)
+    check(_band_mix(ptr(x), ptr(lows) if lows is not None else None, ptr(gains), ptr(out), gains.numel(), x.numel(), float(offset),
+                    stream()), 'acmi_band_mix')
     return out

@@ -4,6 +4,7 @@ import importlib
 
 _EXPORTS = {
     'MusicGen': 'musicgen', 'AudioGen': 'audiogen', 'BaseGenModel': 'genmodel', 'LMModel': 'lm',
+    'MultiBandDiffusion': 'multibanddiffusion', 'DiffusionUnet': 'unet',
     'CompressionModel': 'encodec', 'EncodecModel': 'encodec', 'InterleaveStereoCompressionModel': 'encodec',
 }
 __all__ = sorted(_EXPORTS)

@@ -142,6 +142,23 @@ def audiogen_lm_cfg(scale: str = 'medium', synthetic: bool = True, text_len: int
     return cfg
 
 
+def get_diffusion_model(cfg: dict):
+    """reference builders.py:291-295"""
+    from .unet import DiffusionUnet
+    return DiffusionUnet(chin=cfg['channels'], num_steps=cfg['schedule']['num_steps'], **cfg['diffusion_unet'])
+
+
+def get_processor(cfg: dict, sample_rate: int = 24000):
+    """reference builders.py:298-306"""
+    from ..modules.diffusion_schedule import MultiBandProcessor, SampleProcessor
+    sample_processor = SampleProcessor()
+    if cfg['use']:
+        kw = {k: v for k, v in cfg.items() if k not in ('use', 'name')}
+        if cfg['name'] == "multi_band_processor":
+            sample_processor = MultiBandProcessor(sample_rate=sample_rate, **kw)
+    return sample_processor
+
+
 def get_debug_compression_model(device='cuda', sample_rate: int = 32000) -> EncodecModel:
     """reference builders.py:257-288: n_filters 4, ratios [10, 8, 16] (or [10, 8, 8] at 16 kHz), RVQ 4 x 400."""
     assert sample_rate in [16000, 32000]

@@ -183,6 +183,36 @@ def load_compression_model(file_or_id: str, device='cuda'):
     return model
 
 
+def load_mbd_ckpt(file_or_id: str, filename: tp.Optional[str] = None):
+    """reference loaders.py:175-178"""
+    return _get_state_dict(file_or_id, filename or 'mbd.pt')
+
+
+def load_diffusion_models(file_or_id: str, device='cuda', filename: tp.Optional[str] = None):
+    """reference loaders.py:181-203: one (DiffusionUnet, sample processor, cfg) per band from a MultiBandDiffusion package
+    {'sample_rate', 'n_bands', i: {'cfg', 'model_state', 'processor_state'}}.  `cfg` may be an OmegaConf node (released
+    files; OmegaConf is needed to unpickle those), a dict or YAML text; it is returned as a plain dict."""
+    pkg = load_mbd_ckpt(file_or_id, filename=filename)
+    models, processors, cfgs = [], [], []
+    sample_rate = pkg['sample_rate']
+    for i in range(pkg['n_bands']):
+        cfg = pkg[i]['cfg']
+        if not isinstance(cfg, (dict, str)):
+            from omegaconf import OmegaConf   # only reachable when the pickle itself needed it
+            cfg = OmegaConf.to_container(cfg, resolve=True)
+        cfg = parse_cfg(cfg)
+        model = builders.get_diffusion_model(cfg)
+        model.load_state_dict(pkg[i]['model_state'])
+        model.to(device)
+        processor = builders.get_processor(cfg=cfg['processor'], sample_rate=sample_rate)
+        processor.load_state_dict(pkg[i]['processor_state'])
+        processor.to(device)
+        models.append(model)
+        processors.append(processor)
+        cfgs.append(cfg)
+    return models, processors, cfgs
+
+
 def export_lm(lm, path: str, xp_cfg: dict):
     """Write an LM checkpoint in the reference export format (utils/export.py:58-79) -- used by tests."""
     torch.save({'best_state': {k: v.detach().cpu() for k, v in lm.state_dict().items()},

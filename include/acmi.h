@@ -485,6 +485,50 @@ int acmi_chroma(const float* wav, int B, int T, int wav_stride, int radix2_exp, 
 int acmi_resample_frac(const float* x, float* y, const float* kernel, int rows, int T, int Tout, int old_sr, int new_sr,
                        int width, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * MultiBandDiffusion decoder option: what its U-Net and reverse process need besides
+ * acmi_conv1d (every Conv1d / ConvTranspose1d of audiocraft/models/unet.py) and acmi_lstm_layer (its BiLSTM bottleneck)
+ * ------------------------------------------------------------------------------------------ */
+
+/* nn.GroupNorm(groups, C) on x [B, C, T] f32 (statistics over C / groups channels x T per batch item, eps inside the square
+ * root, affine gamma / beta [C]) followed, with relu != 0, by the nn.ReLU every GroupNorm of unet.py:32-104 is followed by.
+ * work: acmi_group_norm_work_floats(B, C, T, groups) floats of scratch.  y may alias x. */
+size_t acmi_group_norm_work_floats(int B, int C, int T, int groups);
+int acmi_group_norm(const float* x, const float* gamma, const float* beta, float* y, float* work, int B, int C, int T,
+                    int groups, float eps, int relu, void* stream);
+
+/* z[b, c, t] += table[steps[b], c]: the diffusion-step embedding added after an encoder layer (unet.py:176-181).
+ * table [num_steps, C] f32, steps [B] int64. */
+int acmi_channel_add(float* z, const float* table, const int64_t* steps, int B, int C, int T, void* stream);
+
+/* out[row, t] = a[row, t] + s[row, t], t < T, a with row pitch Ta >= T (the decoder input `z[:, :, :s.shape[2]] + s`,
+ * unet.py:209-212).  out may alias s. */
+int acmi_add_cropped(const float* a, int Ta, const float* s, float* out, int rows, int T, void* stream);
+
+/* z[row, t] += ce[row, min(floor(t * (Tc / T)), Tc - 1)]: `z += F.interpolate(condition_emb, T)` (nearest, unet.py:191-193) */
+int acmi_interp_add(float* z, const float* ce, int rows, int T, int Tc, void* stream);
+
+/* One step of NoiseSchedule.generate / generate_subsampled (diffusion_schedule.py:205-230, 251-268):
+ *   out = clamp((current - c_est * (estimate * est_scale)) / sqrt_alpha + sigma * noise, -clip, clip) * out_scale
+ * c_est = (1 - alpha) / sqrt(1 - alpha_bar); noise NULL = no noise term; clip <= 0 = no clamp; n elements; out may alias current. */
+int acmi_ddpm_step(const float* current, const float* estimate, const float* noise, float* out, size_t n, float c_est,
+                   float sqrt_alpha, float sigma, float clip, float est_scale, float out_scale, void* stream);
+
+/* julius.LowPassFilters as a direct FIR bank (replicate padding): y[f, row, t] = sum_k filters[f, k] x[row, clamp(t + k - half)],
+ * filters [n_filters, 2 half + 1] built by the host (windowed sinc at mel-spaced cut-offs); x [rows, T] -> y [n_filters, rows, T].
+ * The low-passes behind julius.SplitBands (MultiBandProcessor, MultiBandDiffusion.re_eq). */
+int acmi_fir_bank(const float* x, const float* filters, float* y, int rows, int T, int n_filters, int half, void* stream);
+
+/* Per-band (sum, sum of squares) of SplitBands' output from x [n] and its n_bands - 1 low-passes lows [n_bands - 1, n] (band 0 =
+ * low 0, band i = low i - low i-1, band n_bands-1 = x - low n_bands-2), as f64 chunk partials [n_bands, chunks, 2] the host sums
+ * in order: the `.std()` of every band in re_eq (multibanddiffusion.py:160-163). */
+int acmi_band_stats(const float* x, const float* lows, double* partials, int n_bands, size_t n, int chunks, void* stream);
+
+/* out = sum_i gains[i] * band_i + offset with the bands as above, i.e. gains[n-1] x + sum_i (gains[i] - gains[i+1]) low_i + offset:
+ * MultiBandProcessor.return_sample / project_sample (diffusion_schedule.py:91-109) and the recombination of re_eq. */
+int acmi_band_mix(const float* x, const float* lows, const float* gains, float* out, int n_bands, size_t n, float offset,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif
