@@ -73,7 +73,10 @@ _last_error = _sig('acmi_last_error', [], C.c_char_p)
 _rvq_norms = _sig('acmi_rvq_codebook_norms', [vp, vp, i32, i32, i32, vp])
 _rvq_encode = _sig('acmi_rvq_encode', [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
 _rvq_decode = _sig('acmi_rvq_decode', [vp, vp, vp, i32, i32, i32, i32, i32, vp])
-_conv1d = _sig('acmi_conv1d', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp])
+_conv1d = _sig('acmi_conv1d', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp])
+_conv1d_tile = _sig('acmi_conv1d_tile_weights', [C.POINTER(ConvDesc), vp, vp, vp])
+_conv1d_wfloats = _sig('acmi_conv1d_weight_floats', [C.POINTER(ConvDesc)], C.c_size_t)
+_conv1d_work = _sig('acmi_conv1d_work_floats', [C.POINTER(ConvDesc)], C.c_size_t)
 _lstm_layer = _sig('acmi_lstm_layer', [vp, vp, vp, vp, vp, i32, i32, i32, vp])
 _lstm_work = _sig('acmi_lstm_work_floats', [i32, i32], C.c_size_t)
 _lm_step = _sig('acmi_lm_step', [C.POINTER(LMModelDesc), C.POINTER(LMState), i32, vp])
@@ -126,7 +129,7 @@ _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32
 
 EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
-           'acmi_conv1d', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
+           'acmi_conv1d', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
 
@@ -188,8 +191,26 @@ def rvq_decode(codes: torch.Tensor, codebooks: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def conv1d_tile_weights(desc: ConvDesc, w: torch.Tensor) -> torch.Tensor:
+    """w [Cout_rows, Cin, ksize] f32 -> the tiled image acmi_conv1d stages (depends on the descriptor's Cout, Cin, ksize, stride,
+    dilation, shuffle only).  Once per model: modules keep the result."""
+    n = int(_conv1d_wfloats(C.byref(desc)))
+    if n == 0:
+        raise AcmiError(f"acmi_conv1d_weight_floats: {_last_error().decode()}")
+    wt = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(_conv1d_tile(C.byref(desc), ptr(w), ptr(wt), stream()), 'acmi_conv1d_tile_weights')
+    return wt
+
+
+def conv1d_tiled(desc: ConvDesc, x, wt, bias, residual, y):
+    n = int(_conv1d_work(C.byref(desc)))
+    work = torch.empty(n, device=x.device, dtype=torch.float32) if n else None
+    check(_conv1d(C.byref(desc), ptr(x), ptr(wt), ptr(bias), ptr(residual), ptr(y), ptr(work), stream()), 'acmi_conv1d')
+
+
 def conv1d(desc: ConvDesc, x, w, bias, residual, y):
-    check(_conv1d(C.byref(desc), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), stream()), 'acmi_conv1d')
+    """Convenience for one-off calls with raw weights (tests, the LSTM input projections): tiles `w` every time."""
+    conv1d_tiled(desc, x, conv1d_tile_weights(desc, w), bias, residual, y)
 
 
 def lstm_layer(gates_in, w_hh, skip, y, work, B, H, T):

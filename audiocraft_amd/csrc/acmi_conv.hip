@@ -1,15 +1,24 @@
-// SEANet convolution kernels for gfx950: implicit-GEMM Conv1d / ConvTranspose1d in exact f32 on the
+// SEANet / diffusion-U-Net convolution kernels for gfx950: implicit-GEMM Conv1d / ConvTranspose1d in exact f32 on the
 // matrix cores (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain), plus the LSTM recurrence.
 //
-// conv_mfma_kernel: GEMM rows = output channels (for transposed convs: (channel, phase) pairs of the
-// polyphase decomposition), GEMM cols = output time steps, K = Cin * ksize.  A 64 x 64 output tile per
-// 256-thread workgroup (4 waves, 2 x 2 of 32 x 32); per K chunk the weight tile and the input span
-// (with halo) are staged through LDS with coalesced reads; padding (zero / reflect, asymmetric,
-// "extra" right padding), the ELU that precedes every SEANet conv, bias, the resnet skip add and the
-// transposed-conv trim + phase interleave are all folded into the load / store index math.
-// The input span is stored de-interleaved by stride phase so that the MFMA B-operand reads of a
-// strided conv hit 32 consecutive LDS banks.
-// Reference: audiocraft/modules/conv.py:47-88,185-243; audiocraft/modules/seanet.py:16-60.
+// Three kernels per convolution, the first once per model:
+//   conv_tile_weights_kernel   weights -> the LDS image the main kernel stages: [row tile of 64 output rows][K chunk]
+//                              [k parity][64][KCP], zero padded (rows past Cout, k past the chunk): staging a weight tile is
+//                              a linear 16-byte copy.  Done when the model is loaded (acmi_conv1d_tile_weights).
+//   conv_pack_kernel           input [B, Cin, Tin] -> Xp [B, Cin_pad, stride, Qp]: padding (zero / reflect, asymmetric,
+//                              "extra" right padding) materialised, the ELU that precedes every SEANet conv applied ONCE per
+//                              element, time de-interleaved by stride phase, rows 16-byte aligned: staging an input span is
+//                              a copy of contiguous 16-byte pieces.  (Round 2/3 did padding + ELU + phase split per element
+//                              inside the main kernel, once per 64-row output tile: the staging arithmetic -- ~40 VALU
+//                              instructions per element incl. expm1f, 43 elements per thread per K chunk -- took longer than
+//                              the 64 MFMAs it fed; the convolutions ran at 20-29 % of the f32 MFMA rate.)
+//   conv_mfma_kernel           GEMM rows = output channels (transposed convs: (channel, phase) pairs of the polyphase
+//                              decomposition), cols = output time steps, K = Cin * ksize.  64 x (64 NTQ) output tile per
+//                              256-thread workgroup (4 waves, 2 x 2 of 32 x 32); per K chunk the weight tile and per
+//                              (chunk, column tile) the input span go HBM/L2 -> registers -> LDS one phase AHEAD of the MFMA
+//                              loop that consumes them; bias, the resnet skip add and the transposed-conv trim + phase
+//                              interleave are folded into the store index math.
+// Reference: audiocraft/modules/conv.py:47-88,185-243; audiocraft/modules/seanet.py:16-60; audiocraft/models/unet.py:32-104.
 #include "acmi_common.h"
 
 #include <math.h>
@@ -17,14 +26,66 @@
 
 struct ConvArgs {
     acmi_conv_desc d;
-    const float* x; const float* w; const float* bias; const float* res; float* y;
+    const float* x;    // main kernel: the packed input Xp; few-output kernel: the raw input
+    const float* w;    // main kernel: the tiled weight image; few-output kernel: the raw weights
+    const float* bias; const float* res; float* y;
     int Tq;    // GEMM columns per batch item
     int CIC;   // input channels per K chunk
     int KCE;   // CIC * ksize rounded up to a multiple of 16 (one block of the inner loop = 8 MFMAs = 16 k)
     int KCP;   // LDS row pitch (floats) of one parity plane of the weight tile: KCE / 2 rounded up to 4 (mod 64)
-    int LP;    // LDS row pitch of one (channel, phase) input row
-    int XSZ;   // floats of the staged input span, rounded up to a multiple of 4 (the offset table behind it is read 16 B at a time)
+    int LP;    // LDS / Xp piece length (floats, a multiple of 4) of one (channel, phase) input row: 64 + halo
+    int XSZ;   // floats of the staged input span = CIC * stride * LP
+    int nchunks, cin_pad;   // K chunks; Cin rounded up to whole chunks (rows of Xp per batch item)
+    long long Qp;           // row pitch of Xp (floats, a multiple of 4)
+    unsigned lp4_magic;     // ceil(2^32 / (LP / 4))
 };
+
+// geometry shared by the weight tiler, the packer and the main kernel
+struct ConvGeom {
+    bool fewout;
+    int cic, nchunks, KCE, KCP, LP, XSZ, Tq, tq, my;
+    long long Qp;
+    size_t wt_floats, work_floats, lds;
+};
+
+static int conv_geometry(const acmi_conv_desc& d, ConvGeom& g) {
+    ACMI_REQUIRE(d.B >= 0 && d.Cin > 0 && d.Cout > 0 && d.ksize > 0 && d.stride > 0 && d.dilation > 0, "acmi_conv1d: bad shape");
+    ACMI_REQUIRE(d.ksize <= 128, "acmi_conv1d: ksize=%d unsupported (max 128)", d.ksize);
+    ACMI_REQUIRE(d.shuffle >= 1 && d.Cout % d.shuffle == 0, "acmi_conv1d: Cout=%d not divisible by shuffle=%d", d.Cout, d.shuffle);
+    ACMI_REQUIRE(d.shuffle == 1 || (d.stride == 1 && d.dilation == 1), "acmi_conv1d: shuffle needs stride=dilation=1");
+    ACMI_REQUIRE(d.pad_mode == ACMI_PAD_ZERO || d.reflect_len >= d.Tin, "acmi_conv1d: reflect_len < Tin");
+    static const bool fewout_ok = !(getenv("ACMI_CONV_FEWOUT") != nullptr && getenv("ACMI_CONV_FEWOUT")[0] == '0');
+    g.fewout = fewout_ok && d.Cout <= 2 && d.ksize == 7 && d.stride == 1 && d.dilation == 1 && d.shuffle == 1;
+    g.Tq = d.shuffle > 1 ? (int)(((long long)d.Tout + d.trim_left + d.shuffle - 1) / d.shuffle) : d.Tout;
+    if (g.fewout) {
+        g.cic = g.nchunks = g.KCE = g.KCP = g.LP = g.XSZ = g.tq = g.my = 0; g.Qp = 0; g.lds = 0;
+        g.wt_floats = (size_t)d.Cout * d.Cin * d.ksize;   // the raw weights
+        g.work_floats = 0;
+        return ACMI_OK;
+    }
+    int cic = 128 / d.ksize;
+    if (cic < 1) cic = 1;
+    if (cic > d.Cin) cic = d.Cin;
+    // one (channel, phase) piece of the staged span: 64 outputs + the halo of the taps, rounded up to 16 bytes
+    const int lp = (64 + ((d.ksize - 1) * d.dilation) / d.stride + 2 + 3) & ~3;
+    while (cic > 1 && (size_t)cic * d.stride * lp * 4 > 24 * 1024) cic >>= 1;   // LDS budget == the 6 x 16 B staging registers per thread
+    ACMI_REQUIRE((size_t)cic * d.stride * lp * 4 <= 24 * 1024, "acmi_conv1d: ksize %d x dilation %d x stride %d exceeds the staged span",
+                 d.ksize, d.dilation, d.stride);
+    g.cic = cic;
+    g.nchunks = (d.Cin + cic - 1) / cic;
+    g.LP = lp;
+    g.XSZ = cic * d.stride * lp;
+    g.KCE = (cic * d.ksize + 15) & ~15;
+    g.KCP = (g.KCE / 2 + 63) / 64 * 64 + 4;   // = 4 (mod 64): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank slots
+    g.lds = ((size_t)2 * 64 * g.KCP + (size_t)g.XSZ + g.KCE) * sizeof(float);
+    ACMI_REQUIRE(g.lds <= 64 * 1024, "acmi_conv1d: LDS budget exceeded (%zu B)", g.lds);
+    g.tq = (g.Tq + 63) / 64;
+    g.my = (d.Cout + 63) / 64;
+    g.Qp = (long long)((g.tq + 3) & ~3) * 64 + lp;   // every column tile a workgroup may touch, plus the halo
+    g.wt_floats = (size_t)g.my * g.nchunks * 2 * 64 * g.KCP;
+    g.work_floats = (size_t)d.B * g.nchunks * cic * d.stride * (size_t)g.Qp;
+    return ACMI_OK;
+}
 
 __device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow, int pos) {
     const acmi_conv_desc& d = a.d;
@@ -39,30 +100,73 @@ __device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow
     return v;
 }
 
-// NTQ: 64-column (time) tiles per workgroup.  The weight tile of a K chunk is staged ONCE and multiplied with NTQ input
-// spans in turn (NTQ accumulators): with one tile per workgroup the 32 KB weight tile was re-staged from L2 for every 64
-// output samples and that traffic (~35 KB per 1.7 us of MFMA work per workgroup) co-bounded the kernel.
-// PK: the parity-plane LDS layout + 8-MFMA blocks below (default); !PK: weights [64][KCP odd], one offset table, one
-// (weight, offset, input) read triple per MFMA (ACMI_CONV_PARITY=0, the round-2 inner loop, kept for A/B).
-template <int NTQ, bool PK>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+// ---- weights [Cout, Cin, ks] -> [my][nchunks][2 parities][64][KCP]
+struct TileWArgs { const float* w; float* wt; int Cout, Cin, ks, cic, nchunks, KCE, KCP; size_t total; };
+
+__global__ __launch_bounds__(256) void conv_tile_weights_kernel(const TileWArgs p) {
+    const size_t wpitch = (size_t)p.Cin * p.ks;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < p.total; o += (size_t)gridDim.x * 256) {
+        const int col = (int)(o % p.KCP);
+        size_t t = o / p.KCP;
+        const int r = (int)(t % 64); t /= 64;
+        const int plane = (int)(t % 2); t /= 2;
+        const int chunk = (int)(t % p.nchunks);
+        const int rt = (int)(t / p.nchunks);
+        const int kl = 2 * col + plane, ci0 = chunk * p.cic, mrow = rt * 64 + r;
+        const int kvalid = min(p.cic, p.Cin - ci0) * p.ks;
+        p.wt[o] = (col < p.KCE / 2 && kl < kvalid && mrow < p.Cout) ? p.w[(size_t)mrow * wpitch + (size_t)ci0 * p.ks + kl] : 0.f;
+    }
+}
+
+// ---- input [B, Cin, Tin] -> Xp [B, cin_pad, stride, Qp]:  Xp[b][ci][u % s][u / s] = ELU(pad(x))[b][ci][u - pad_left]
+__global__ __launch_bounds__(256) void conv_pack_kernel(const ConvArgs a, float* xp) {
+    const acmi_conv_desc& d = a.d;
+    const int ci = blockIdx.y, b = blockIdx.z, s = d.stride;
+    const long long n = (long long)s * a.Qp;
+    const long long u0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float* dst = xp + ((size_t)b * a.cin_pad + ci) * (size_t)n;
+    const float* xrow = a.x + ((size_t)b * d.Cin + min(ci, d.Cin - 1)) * d.Tin;
+    if (s == 1) {
+        if (u0 >= n) return;     // n is a multiple of 4
+        float4 v;
+        const int pos = (int)u0 - d.pad_left;
+        if (ci < d.Cin) {
+            v.x = conv_fetch(a, xrow, pos); v.y = conv_fetch(a, xrow, pos + 1);
+            v.z = conv_fetch(a, xrow, pos + 2); v.w = conv_fetch(a, xrow, pos + 3);
+        } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dst + u0) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long u = (long long)blockIdx.x * 1024 + i * 256 + threadIdx.x;   // coalesced reads, phase-scattered writes
+            if (u < n) {
+                const long long qq = u / s;
+                dst[(u - qq * s) * a.Qp + qq] = ci < d.Cin ? conv_fetch(a, xrow, (int)u - d.pad_left) : 0.f;
+            }
+        }
+    }
+}
+
+// NTQ: 64-column (time) tiles per workgroup: the weight tile of a K chunk is staged ONCE and multiplied with NTQ input spans
+// in turn (NTQ accumulators).  XV: 16-byte input staging slots per thread (2, 4 or 6: CIC * stride * LP / 1024 rounded up).
+//
+// LDS: Ws [2 parities][64][KCP] | Xs [CIC * stride][LP] | koff [2 parities][KCE / 2].  The MFMA's two k slots are the two
+// halves of the wave (kk = lane >> 5): half kk consumes k = 2 u + kk.  Weights and the k -> LDS offset table are therefore
+// stored DE-INTERLEAVED BY PARITY, so that the 8 values a lane needs for a block of 8 MFMAs (16 k) are contiguous: two
+// ds_read_b128 each instead of 8 + 8 dependent ds_read_b32.
+template <int NTQ, int XV>
+__global__ __launch_bounds__(256, NTQ == 4 ? 2 : 3) void conv_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const acmi_conv_desc& d = a.d;
     const int s = d.stride, ks = d.ksize;
-    // The MFMA's two k slots are the two halves of the wave (kk = lane >> 5): half kk consumes k = 2 u + kk.  Weights and
-    // the k -> LDS offset table are therefore stored DE-INTERLEAVED BY PARITY, so that the 8 values a lane needs for a block
-    // of 8 MFMAs (16 k) are contiguous: two ds_read_b128 each instead of 8 + 8 dependent ds_read_b32 (the table lookup in
-    // front of every input read was a second LDS latency on the critical path of every MFMA).
-    float* Ws = smem;                                   // PK: [2 parities][64][KCP]; else [64][KCP]
-    float* Xs = Ws + (PK ? 2 : 1) * 64 * a.KCP;         // [CIC][s][LP]
-    int* koff = reinterpret_cast<int*>(Xs + a.XSZ);     // PK: [2 parities][KCE / 2]; else [KCE]
+    float* Ws = smem;
+    float* Xs = Ws + 2 * 64 * a.KCP;
+    int* koff = reinterpret_cast<int*>(Xs + a.XSZ);
     const int KH = a.KCE >> 1;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, kk = lane >> 5;
     const int qb = blockIdx.x * 64 * NTQ, m0 = blockIdx.y * 64, b = blockIdx.z;
-    const int span = 63 * s + (ks - 1) * d.dilation + 1;
     const int KC = a.CIC * ks;
 
     for (int kl = tid; kl < a.KCE; kl += 256) {
@@ -72,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const int jd = j * d.dilation;
             off = (ci * s + jd % s) * a.LP + jd / s;
         }
-        koff[PK ? (kl & 1) * KH + (kl >> 1) : kl] = off;
+        koff[(kl & 1) * KH + (kl >> 1)] = off;
     }
 
     f32x16 acc[NTQ];
@@ -81,57 +185,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const size_t wpitch = (size_t)d.Cin * ks;
-    for (int ci0 = 0; ci0 < d.Cin; ci0 += a.CIC) {
-        const int cic = min(a.CIC, d.Cin - ci0);
-        const int kvalid = cic * ks;
-        __syncthreads();
-        // ---- weight tile: 16 rows per wave, 64 consecutive k per pass
-        for (int r = wave; r < 64; r += 4) {
-            const int mrow = m0 + r;
-            const float* wsrc = a.w + (size_t)mrow * wpitch + (size_t)ci0 * ks;
-            for (int kl = lane; kl < a.KCE; kl += 64)
-                Ws[PK ? ((kl & 1) * 64 + r) * a.KCP + (kl >> 1) : r * a.KCP + kl] = (mrow < d.Cout && kl < kvalid) ? wsrc[kl] : 0.f;
-        }
+    // ---- staging through registers, one phase ahead (phase = (K chunk, column tile)); everything is a 16-byte copy
+    constexpr int WV = 9;                        // 2 * 64 * KCP / 4 = 2176 pieces for KCP = 68: 8.5 per thread
+    const int nw4 = 2 * 64 * a.KCP / 4, nx4 = a.XSZ / 4;
+    f32x4 wreg[WV], xreg[XV];   // native vectors: arrays of HIP's float4 struct stay in scratch memory
+    unsigned xsrc[XV];                           // piece j of this thread: element offset inside the chunk's rows of Xp
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        const unsigned f = min((unsigned)(j * 256 + tid), (unsigned)(nx4 - 1));
+        const unsigned row = __umulhi(f, a.lp4_magic);
+        xsrc[j] = row * (unsigned)a.Qp + (f - row * (unsigned)(a.LP >> 2)) * 4u;
+    }
+    const float* wt = a.w + (size_t)blockIdx.y * a.nchunks * (size_t)(nw4 * 4);
+    const float* xp = a.x + (size_t)b * a.cin_pad * s * (size_t)a.Qp + qb;
+    const unsigned wlast = (unsigned)min(8 * 256 + tid, nw4 - 1) * 4u;
+    const int ntl = min(NTQ, (a.Tq - qb + 63) / 64);   // live column tiles of this workgroup (block uniform)
+    const size_t xchunk = (size_t)a.CIC * s * (size_t)a.Qp;
+
+    auto issue_w = [&](int chunk) {
+        const float* src = wt + (size_t)chunk * (size_t)(nw4 * 4);
+#pragma unroll
+        for (int j = 0; j < WV - 1; ++j) wreg[j] = *reinterpret_cast<const f32x4*>(src + (j * 256 + tid) * 4);
+        wreg[WV - 1] = *reinterpret_cast<const f32x4*>(src + wlast);
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < WV - 1; ++j) *reinterpret_cast<f32x4*>(Ws + (j * 256 + tid) * 4) = wreg[j];
+        if ((WV - 1) * 256 + tid < nw4) *reinterpret_cast<f32x4*>(Ws + ((WV - 1) * 256 + tid) * 4) = wreg[WV - 1];
+    };
+    auto issue_x = [&](int chunk, int t) {
+        const float* src = xp + (size_t)chunk * xchunk + t * 64;
+#pragma unroll
+        for (int j = 0; j < XV; ++j) xreg[j] = *reinterpret_cast<const f32x4*>(src + xsrc[j]);
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int j = 0; j < XV; ++j)
+            if (j * 256 + tid < nx4) *reinterpret_cast<f32x4*>(Xs + (j * 256 + tid) * 4) = xreg[j];
+    };
+
+    issue_w(0);
+    issue_x(0, 0);
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const int nchunk = min(chunk + 1, a.nchunks - 1);   // past the last chunk: a redundant (unused) prefetch of the last one
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
-            const int q0 = qb + t * 64;
-            if (t > 0) {
-                if (q0 >= a.Tq) break;     // block uniform: no column of this tile exists
-                __syncthreads();           // every wave is done with the previous tile's span
-            }
-            const int base_in = q0 * s - d.pad_left;
-            // ---- input span, phase de-interleaved
-            for (int ci = wave; ci < a.CIC; ci += 4) {
-                const float* xrow = a.x + ((size_t)b * d.Cin + ci0 + ci) * d.Tin;
-                float* dst = Xs + (size_t)ci * s * a.LP;
-                if (s == 1) {
-                    for (int rel = lane; rel < span; rel += 64)
-                        dst[rel] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
-                } else {
-                    for (int rel = lane; rel < span; rel += 64) {
-                        const int qq = rel / s, ph = rel - qq * s;
-                        dst[ph * a.LP + qq] = ci < cic ? conv_fetch(a, xrow, base_in + rel) : 0.f;
-                    }
-                }
-            }
+            if (t >= ntl) break;       // block uniform: no column of this tile exists
+            __syncthreads();           // every wave is done with the previous phase's tiles
+            if (t == 0) store_w();
+            store_x();
             __syncthreads();
-            const float* xp = Xs + wc * 32 + li;
-            if constexpr (!PK) {
-                const float* wq = Ws + (wr * 32 + li) * a.KCP + kk;
-                for (int k2 = 0; k2 < a.KCE; k2 += 2) {
-                    const float av = wq[k2];
-                    const float bv = xp[koff[k2 + kk]];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                }
-            }
+            if (t == 0) issue_w(nchunk);
+            if (t + 1 < ntl) issue_x(chunk, t + 1);
+            else issue_x(nchunk, 0);
+            const float* xq = Xs + wc * 32 + li;
             const float* wp = Ws + (kk * 64 + wr * 32 + li) * a.KCP;   // this lane's row of its parity plane
             const int* kp = koff + kk * KH;
-            for (int kb = 0; PK && kb < KH; kb += 8) {   // 8 MFMAs: k = 2 (kb + u) + kk, u = 0 .. 7, ascending (the fmaf chain of a scalar loop)
+            for (int kb = 0; kb < KH; kb += 8) {   // 8 MFMAs: k = 2 (kb + u) + kk, u = 0 .. 7, ascending (the fmaf chain of a scalar loop)
                 const float4 wa = *reinterpret_cast<const float4*>(wp + kb), wb = *reinterpret_cast<const float4*>(wp + kb + 4);
                 const int4 oa = *reinterpret_cast<const int4*>(kp + kb), ob = *reinterpret_cast<const int4*>(kp + kb + 4);
-                const float x0 = xp[oa.x], x1 = xp[oa.y], x2 = xp[oa.z], x3 = xp[oa.w];
-                const float x4 = xp[ob.x], x5 = xp[ob.y], x6 = xp[ob.z], x7 = xp[ob.w];
+                const float x0 = xq[oa.x], x1 = xq[oa.y], x2 = xq[oa.z], x3 = xq[oa.w];
+                const float x4 = xq[ob.x], x5 = xq[ob.y], x6 = xq[ob.z], x7 = xq[ob.w];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x0, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x1, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x2, acc[t], 0, 0, 0);
@@ -238,62 +352,75 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvArgs a) {
     }
 }
 
-extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float* w, const float* bias,
-                           const float* residual, float* y, void* stream) {
+extern "C" size_t acmi_conv1d_weight_floats(const acmi_conv_desc* dp) {
+    ConvGeom g;
+    if (dp == nullptr || conv_geometry(*dp, g) != ACMI_OK) return 0;
+    return g.wt_floats;
+}
+
+extern "C" size_t acmi_conv1d_work_floats(const acmi_conv_desc* dp) {
+    ConvGeom g;
+    if (dp == nullptr || conv_geometry(*dp, g) != ACMI_OK) return 0;
+    return g.work_floats;
+}
+
+extern "C" int acmi_conv1d_tile_weights(const acmi_conv_desc* dp, const float* w, float* wt, void* stream) {
+    ACMI_REQUIRE(dp != nullptr && w != nullptr && wt != nullptr, "acmi_conv1d_tile_weights: null argument");
+    ConvGeom g;
+    if (int rc = conv_geometry(*dp, g)) return rc;
+    if (g.fewout) {   // the few-output kernel reads the weights as they are
+        if (hipMemcpyAsync(wt, w, g.wt_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+            acmi_set_error("acmi_conv1d_tile_weights: hipMemcpyAsync failed");
+            return ACMI_ELAUNCH;
+        }
+        return ACMI_OK;
+    }
+    TileWArgs p = {w, wt, dp->Cout, dp->Cin, dp->ksize, g.cic, g.nchunks, g.KCE, g.KCP, g.wt_floats};
+    const int blocks = (int)min((g.wt_floats + 255) / 256, (size_t)16384);
+    hipLaunchKernelGGL(conv_tile_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return acmi_check_launch("conv_tile_weights_kernel");
+}
+
+extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float* wt, const float* bias, const float* residual,
+                           float* y, float* work, void* stream) {
     ACMI_REQUIRE(dp != nullptr, "acmi_conv1d: null descriptor");
     const acmi_conv_desc& d = *dp;
-    ACMI_REQUIRE(d.B >= 0 && d.Cin > 0 && d.Cout > 0 && d.ksize > 0 && d.stride > 0 && d.dilation > 0,
-                 "acmi_conv1d: bad shape");
-    ACMI_REQUIRE(d.ksize <= 128, "acmi_conv1d: ksize=%d unsupported (max 128)", d.ksize);
-    ACMI_REQUIRE(d.shuffle >= 1 && d.Cout % d.shuffle == 0, "acmi_conv1d: Cout=%d not divisible by shuffle=%d", d.Cout,
-                 d.shuffle);
-    ACMI_REQUIRE(d.shuffle == 1 || (d.stride == 1 && d.dilation == 1), "acmi_conv1d: shuffle needs stride=dilation=1");
-    ACMI_REQUIRE(d.pad_mode == ACMI_PAD_ZERO || d.reflect_len >= d.Tin, "acmi_conv1d: reflect_len < Tin");
+    ConvGeom g;
+    if (int rc = conv_geometry(d, g)) return rc;
     if (d.B == 0 || d.Tout <= 0) return ACMI_OK;
     ConvArgs a;
-    a.d = d; a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
-    static const bool fewout_ok = !(getenv("ACMI_CONV_FEWOUT") != nullptr && getenv("ACMI_CONV_FEWOUT")[0] == '0');
-    if (fewout_ok && d.Cout <= 2 && d.ksize == 7 && d.stride == 1 && d.dilation == 1 && d.shuffle == 1) {
-        a.Tq = d.Tout; a.CIC = a.KCE = a.KCP = a.LP = a.XSZ = 0;
+    a.d = d; a.x = x; a.w = wt; a.bias = bias; a.res = residual; a.y = y;
+    a.Tq = g.Tq; a.CIC = g.cic; a.KCE = g.KCE; a.KCP = g.KCP; a.LP = g.LP; a.XSZ = g.XSZ;
+    a.nchunks = g.nchunks; a.cin_pad = g.nchunks * g.cic; a.Qp = g.Qp; a.lp4_magic = 0;
+    if (g.fewout) {
         dim3 grid((d.Tout + 1023) / 1024, 1, d.B), block(256);
         if (d.Cout == 1) hipLaunchKernelGGL((conv_fewout_kernel<1, 7>), grid, block, 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_fewout_kernel<2, 7>), grid, block, 0, (hipStream_t)stream, a);
         return acmi_check_launch("conv_fewout_kernel");
     }
-    a.Tq = d.shuffle > 1 ? (int)(((long long)d.Tout + d.trim_left + d.shuffle - 1) / d.shuffle) : d.Tout;
-    int cic = 128 / d.ksize;
-    if (cic < 1) cic = 1;
-    if (cic > d.Cin) cic = d.Cin;
-    // keep the staged input span within the LDS budget
-    const int lp = 64 + ((d.ksize - 1) * d.dilation) / d.stride + 2;
-    while (cic > 1 && (size_t)cic * d.stride * lp * 4 > 24 * 1024) cic >>= 1;
-    // inner-loop form: parity planes + 8-MFMA blocks (default), or one read triple per MFMA (ACMI_CONV_PARITY=0, A/B).  With
-    // one column tile per workgroup the plain form was 4 % faster; with the weight tile reused over 4 column tiles the
-    // block form is (EnCodec-32k, 8 x 30 s: encode 73.1 vs 75.6 ms, decode 75.4 vs 77.8 ms; profiles/r03_codec_bench_*.jsonl)
-    static const bool parity = !(getenv("ACMI_CONV_PARITY") != nullptr && getenv("ACMI_CONV_PARITY")[0] == '0');
-    a.CIC = cic;
-    a.LP = lp;
-    a.XSZ = (a.CIC * d.stride * a.LP + 3) & ~3;
-    size_t lds;
-    if (parity) {
-        a.KCE = (cic * d.ksize + 15) & ~15;
-        a.KCP = (a.KCE / 2 + 63) / 64 * 64 + 4;   // = 4 (mod 64): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte bank slots
-        lds = ((size_t)2 * 64 * a.KCP + (size_t)a.XSZ + a.KCE) * sizeof(float);
-    } else {
-        a.KCE = (cic * d.ksize + 1) & ~1;
-        a.KCP = a.KCE | 1;
-        lds = ((size_t)64 * a.KCP + (size_t)a.XSZ + a.KCE) * sizeof(float);
+    ACMI_REQUIRE(work != nullptr, "acmi_conv1d: work buffer (acmi_conv1d_work_floats) missing");
+    ACMI_REQUIRE(a.cin_pad <= 65535 && d.B <= 65535, "acmi_conv1d: Cin=%d / B=%d exceed the grid", d.Cin, d.B);
+    ACMI_REQUIRE((unsigned long long)a.cin_pad * d.stride * (unsigned long long)g.Qp < (1ULL << 32),
+                 "acmi_conv1d: one batch item of the packed input exceeds 2^32 elements");
+    {   // pack: padding + ELU + stride-phase split, once per element
+        const long long n = (long long)d.stride * g.Qp;
+        const long long per_block = 1024;
+        dim3 grid((unsigned)((n + per_block - 1) / per_block), a.cin_pad, d.B);
+        hipLaunchKernelGGL(conv_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, work);
     }
-    ACMI_REQUIRE(lds <= 64 * 1024, "acmi_conv1d: LDS budget exceeded (%zu B)", lds);
+    a.x = work;
+    a.lp4_magic = (unsigned)((0x100000000ULL + (unsigned)(g.LP / 4) - 1) / (unsigned)(g.LP / 4));
     // column tiles per workgroup: as many as keep >= 2 workgroups per CU in flight (4, 2 or 1); ACMI_CONV_NTQ forces one
-    const int tq = (a.Tq + 63) / 64, my = (d.Cout + 63) / 64;
     static const int want = getenv("ACMI_CONV_NTQ") ? atoi(getenv("ACMI_CONV_NTQ")) : 0;
-    int ntq = want == 1 || want == 2 || want == 4 ? want : ((long)tq * my * d.B >= 4 * 512 ? 4 : ((long)tq * my * d.B >= 2 * 512 ? 2 : 1));
-    dim3 grid((tq + ntq - 1) / ntq, my, d.B), block(256);
-#define ACMI_CONV_LAUNCH(N)                                                                                   \
-    if (parity) hipLaunchKernelGGL((conv_mfma_kernel<N, true>), grid, block, lds, (hipStream_t)stream, a);    \
-    else hipLaunchKernelGGL((conv_mfma_kernel<N, false>), grid, block, lds, (hipStream_t)stream, a);
-    if (ntq == 4) { ACMI_CONV_LAUNCH(4) } else if (ntq == 2) { ACMI_CONV_LAUNCH(2) } else { ACMI_CONV_LAUNCH(1) }
+    const long wgs = (long)g.tq * g.my * d.B;
+    const int ntq = want == 1 || want == 2 || want == 4 ? want : (wgs >= 4 * 512 ? 4 : (wgs >= 2 * 512 ? 2 : 1));
+    const int xv = (g.XSZ / 4 + 255) / 256;   // <= 6 by the 24 KB span budget
+    dim3 grid((g.tq + ntq - 1) / ntq, g.my, d.B), block(256);
+#define ACMI_CONV_LAUNCH(N, X) hipLaunchKernelGGL((conv_mfma_kernel<N, X>), grid, block, g.lds, (hipStream_t)stream, a)
+#define ACMI_CONV_LAUNCH_X(N)                                     \
+    if (xv <= 2) ACMI_CONV_LAUNCH(N, 2); else if (xv <= 4) ACMI_CONV_LAUNCH(N, 4); else ACMI_CONV_LAUNCH(N, 6)
+    if (ntq == 4) { ACMI_CONV_LAUNCH_X(4); } else if (ntq == 2) { ACMI_CONV_LAUNCH_X(2); } else { ACMI_CONV_LAUNCH_X(1); }
+#undef ACMI_CONV_LAUNCH_X
 #undef ACMI_CONV_LAUNCH
     return acmi_check_launch("conv_mfma_kernel");
 }

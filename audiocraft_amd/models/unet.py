@@ -29,8 +29,19 @@ class Output:
     sample: torch.Tensor
 
 
-def _conv1d(x: torch.Tensor, w: torch.Tensor, b: tp.Optional[torch.Tensor], stride: int = 1, padding: int = 0, dilation: int = 1,
-            residual: tp.Optional[torch.Tensor] = None, right_pad: int = 0) -> torch.Tensor:
+class _Tiles(dict):
+    """Per-module cache: conv name -> (stamp of the raw weights, weights in the layout acmi_conv1d stages)."""
+
+    def get_tiled(self, name: str, d, w: torch.Tensor) -> torch.Tensor:
+        stamp = (w.data_ptr(), w._version, d.Cout, d.Cin, d.ksize, d.stride, d.dilation, d.shuffle)
+        hit = self.get(name)
+        if hit is None or hit[0] != stamp:
+            hit = self[name] = (stamp, _C.conv1d_tile_weights(d, w))
+        return hit[1]
+
+
+def _conv1d(tiles: _Tiles, name: str, x: torch.Tensor, w: torch.Tensor, b: tp.Optional[torch.Tensor], stride: int = 1,
+            padding: int = 0, dilation: int = 1, residual: tp.Optional[torch.Tensor] = None, right_pad: int = 0) -> torch.Tensor:
     """nn.Conv1d(padding=padding, zero padding; `right_pad` more zeros on the right: F.pad before the conv) on x [B, Cin, T]."""
     B, Cin, T = x.shape
     Cout, _, k = w.shape
@@ -40,7 +51,7 @@ def _conv1d(x: torch.Tensor, w: torch.Tensor, b: tp.Optional[torch.Tensor], stri
     d.ksize, d.stride, d.dilation, d.pad_left = k, stride, dilation, padding
     d.pad_mode, d.reflect_len, d.elu_in, d.elu_alpha, d.shuffle, d.trim_left = _C.PAD_ZERO, T, 0, 0.0, 1, 0
     y = torch.empty(B, Cout, Tout, device=x.device, dtype=torch.float32)
-    _C.conv1d(d, x, w, b, residual, y)
+    _C.conv1d_tiled(d, x, tiles.get_tiled(name, d, w), b, residual, y)
     return y
 
 
@@ -52,7 +63,7 @@ def _polyphase(w: torch.Tensor, stride: int) -> tp.Tuple[torch.Tensor, int]:
     return wp.permute(1, 3, 0, 2).flip(-1).reshape(cout * stride, cin, ntaps).contiguous(), ntaps
 
 
-def _convtr1d(x: torch.Tensor, wq: torch.Tensor, ntaps: int, k: int, stride: int, padding: int) -> torch.Tensor:
+def _convtr1d(tiles: _Tiles, name: str, x: torch.Tensor, wq: torch.Tensor, ntaps: int, k: int, stride: int, padding: int) -> torch.Tensor:
     """nn.ConvTranspose1d(k, stride, padding, bias=False): (T - 1) s + k - 2 padding output samples."""
     B, Cin, T = x.shape
     cout = wq.shape[0] // stride
@@ -63,7 +74,7 @@ def _convtr1d(x: torch.Tensor, wq: torch.Tensor, ntaps: int, k: int, stride: int
     d.pad_mode, d.reflect_len, d.elu_in, d.elu_alpha = _C.PAD_ZERO, T, 0, 0.0
     d.shuffle, d.trim_left = stride, padding
     y = torch.empty(B, cout, Tout, device=x.device, dtype=torch.float32)
-    _C.conv1d(d, x, wq, None, None, y)
+    _C.conv1d_tiled(d, x, tiles.get_tiled(name, d, wq), None, None, y)
     return y
 
 
@@ -72,6 +83,7 @@ class ResBlock(nn.Module):
 
     def __init__(self, channels: int, kernel: int = 3, norm_groups: int = 4, dilation: int = 1, dropout: float = 0., device=None):
         super().__init__()
+        self._tiles = _Tiles()
         padding = dilation * (kernel - 1) // 2
         self.norm_groups, self.dilation, self.padding = norm_groups, dilation, padding
         self.norm1 = nn.GroupNorm(norm_groups, channels, device=device)
@@ -81,9 +93,9 @@ class ResBlock(nn.Module):
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
         h = _C.group_norm(x, self.norm1.weight, self.norm1.bias, self.norm_groups, self.norm1.eps, relu=True)
-        h = _conv1d(h, self.conv1.weight, self.conv1.bias, 1, self.padding, self.dilation)
+        h = _conv1d(self._tiles, 'conv1', h, self.conv1.weight, self.conv1.bias, 1, self.padding, self.dilation)
         h = _C.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm_groups, self.norm2.eps, relu=True, out=h)
-        return _conv1d(h, self.conv2.weight, self.conv2.bias, 1, self.padding, self.dilation, residual=x)
+        return _conv1d(self._tiles, 'conv2', h, self.conv2.weight, self.conv2.bias, 1, self.padding, self.dilation, residual=x)
 
 
 class EncoderLayer(nn.Module):
@@ -92,6 +104,7 @@ class EncoderLayer(nn.Module):
     def __init__(self, chin: int, chout: int, kernel: int = 4, stride: int = 2, norm_groups: int = 4, res_blocks: int = 1,
                  dropout: float = 0., device=None):
         super().__init__()
+        self._tiles = _Tiles()
         self.kernel, self.stride, self.norm_groups = kernel, stride, norm_groups
         self.conv = nn.Conv1d(chin, chout, kernel, stride, (kernel - stride) // 2, bias=False, device=device)
         self.norm = nn.GroupNorm(norm_groups, chout, device=device)
@@ -101,7 +114,7 @@ class EncoderLayer(nn.Module):
     def run(self, x: torch.Tensor) -> torch.Tensor:
         T = x.shape[-1]
         pad = (self.stride - (T % self.stride)) % self.stride
-        z = _conv1d(x, self.conv.weight, None, self.stride, (self.kernel - self.stride) // 2, right_pad=pad)
+        z = _conv1d(self._tiles, 'conv', x, self.conv.weight, None, self.stride, (self.kernel - self.stride) // 2, right_pad=pad)
         z = _C.group_norm(z, self.norm.weight, self.norm.bias, self.norm_groups, self.norm.eps, relu=True, out=z)
         for rb in self.res_blocks:
             z = rb.run(z)
@@ -114,6 +127,7 @@ class DecoderLayer(nn.Module):
     def __init__(self, chin: int, chout: int, kernel: int = 4, stride: int = 2, norm_groups: int = 4, res_blocks: int = 1,
                  dropout: float = 0., device=None):
         super().__init__()
+        self._tiles = _Tiles()
         self.kernel, self.stride, self.norm_groups = kernel, stride, norm_groups
         self.res_blocks = nn.Sequential(*[ResBlock(chin, norm_groups=norm_groups, dilation=2 ** idx, dropout=dropout, device=device)
                                           for idx in range(res_blocks)])
@@ -125,10 +139,11 @@ class DecoderLayer(nn.Module):
         for rb in self.res_blocks:
             x = rb.run(x)
         x = _C.group_norm(x, self.norm.weight, self.norm.bias, self.norm_groups, self.norm.eps, relu=True)
-        if self._prep is None or self._prep[2] is not self.convtr.weight:
+        stamp = (self.convtr.weight.data_ptr(), self.convtr.weight._version)
+        if self._prep is None or self._prep[2] != stamp:
             wq, ntaps = _polyphase(self.convtr.weight.detach().float(), self.stride)
-            self._prep = (wq, ntaps, self.convtr.weight)
-        return _convtr1d(x, self._prep[0], self._prep[1], self.kernel, self.stride, (self.kernel - self.stride) // 2)
+            self._prep = (wq, ntaps, stamp)
+        return _convtr1d(self._tiles, 'convtr', x, self._prep[0], self._prep[1], self.kernel, self.stride, (self.kernel - self.stride) // 2)
 
 
 class BLSTM(nn.Module):
@@ -136,6 +151,7 @@ class BLSTM(nn.Module):
 
     def __init__(self, dim: int, layers: int = 2, device=None):
         super().__init__()
+        self._tiles = _Tiles()
         self.dim, self.layers = dim, layers
         self.lstm = nn.LSTM(bidirectional=True, num_layers=layers, hidden_size=dim, input_size=dim, device=device)
         self.linear = nn.Linear(2 * dim, dim, device=device)
@@ -145,7 +161,7 @@ class BLSTM(nn.Module):
         B, _, T = x.shape
         H = self.dim
         p = lambda n: getattr(self.lstm, f'{n}_l{layer}{suffix}').detach().float()   # noqa: E731
-        gates = _conv1d(x, p('weight_ih').unsqueeze(-1).contiguous(), (p('bias_ih') + p('bias_hh')).contiguous())
+        gates = _conv1d(self._tiles, f'ih{layer}{suffix}', x, p('weight_ih').unsqueeze(-1).contiguous(), (p('bias_ih') + p('bias_hh')).contiguous())
         out = torch.empty(B, H, T, device=x.device, dtype=torch.float32)
         work = torch.zeros(_C.lstm_work_floats(B, H), device=x.device, dtype=torch.float32)
         _C.lstm_layer(gates, p('weight_hh').contiguous(), None, out, work, B, H, T)
@@ -159,7 +175,7 @@ class BLSTM(nn.Module):
             fw = self._direction(y, layer, '')
             bw = self._direction(y.flip(-1).contiguous(), layer, '_reverse').flip(-1)   # time reversal: data movement only
             y = torch.cat([fw, bw], dim=1)
-        return _conv1d(y, self.linear.weight.detach().float().unsqueeze(-1).contiguous(), self.linear.bias.detach().float())
+        return _conv1d(self._tiles, 'linear', y, self.linear.weight.detach().float().unsqueeze(-1).contiguous(), self.linear.bias.detach().float())
 
 
 class DiffusionUnet(nn.Module):
@@ -169,6 +185,7 @@ class DiffusionUnet(nn.Module):
                  num_steps: int = 1000, emb_all_layers=False, cross_attention: bool = False, bilstm: bool = False,
                  transformer: bool = False, codec_dim: tp.Optional[int] = None, device=None, **kwargs):
         super().__init__()
+        self._tiles = _Tiles()
         if transformer or cross_attention:
             raise NotImplementedError("DiffusionUnet(transformer=True): the non-causal transformer bottleneck is not implemented "
                                       "(no configuration of the reference enables it, config/model/score/basic.yaml)")
@@ -213,7 +230,7 @@ class DiffusionUnet(nn.Module):
             skips.append(z)
         if self.use_codec:
             assert condition is not None, "Model defined for conditionnal generation"
-            ce = _conv1d(condition.float().contiguous(), self.conv_codec.weight.detach().float(), self.conv_codec.bias.detach().float())
+            ce = _conv1d(self._tiles, 'conv_codec', condition.float().contiguous(), self.conv_codec.weight.detach().float(), self.conv_codec.bias.detach().float())
             assert ce.size(-1) <= 2 * z.size(-1), \
                 f"You are downsampling the conditionning with factor >=2 : {ce.size(-1)=} and {z.size(-1)=}"
             # the reference adds IN PLACE (`z += condition_emb`, unet.py:193) to the tensor it has just pushed onto `skips`:

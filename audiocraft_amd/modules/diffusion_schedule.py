@@ -167,6 +167,7 @@ class NoiseSchedule:
                  clip: float = 5., rescale: float = 1., device='cuda', beta_exp: float = 1, repartition: str = "power",
                  alpha_sigmoid: dict = {}, n_bands: tp.Optional[int] = None,
                  sample_processor: SampleProcessor = SampleProcessor(), noise_scale: float = 1.0, **kwargs):
+        beta_t0, beta_t1, beta_exp = float(beta_t0), float(beta_t1), float(beta_exp)   # YAML 1.1 reads '1e-05' as a string
         self.beta_t0, self.beta_t1 = beta_t0, beta_t1
         self.variance = variance
         self.num_steps = num_steps

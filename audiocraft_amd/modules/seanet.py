@@ -95,7 +95,7 @@ class StreamableConv1d(nn.Module):
         """y = conv(pad(ELU?(x))) + bias (+ residual); x [B, Cin, T] f32 on device."""
         B, Cin, T = x.shape
         assert Cin == self.in_channels
-        w, b = self._weights()
+        w, b = self._weights()[:2]
         k = (self.kernel_size - 1) * self.dilation + 1
         padding_total = k - self.stride
         extra = get_extra_padding_for_conv1d(T, k, self.stride, padding_total)
@@ -117,8 +117,14 @@ class StreamableConv1d(nn.Module):
         d.elu_in, d.elu_alpha = int(elu_alpha is not None), float(elu_alpha or 0.0)
         d.shuffle, d.trim_left = 1, 0
         y = torch.empty(B, self.out_channels, Tout, device=x.device, dtype=torch.float32)
-        _C.conv1d(d, x, w, b, residual, y)
+        _C.conv1d_tiled(d, x, self._tiled(d, w), b, residual, y)
         return y
+
+    def _tiled(self, d, w: torch.Tensor) -> torch.Tensor:
+        """The weights in the layout acmi_conv1d stages (made once; `invalidate_prepared` drops it with `_prep`)."""
+        if len(self._prep) == 2:
+            self._prep = self._prep + (_C.conv1d_tile_weights(d, w),)
+        return self._prep[2]
 
 
 class StreamableConvTranspose1d(nn.Module):
@@ -152,7 +158,7 @@ class StreamableConvTranspose1d(nn.Module):
 
     def run(self, x: torch.Tensor, elu_alpha: tp.Optional[float] = None) -> torch.Tensor:
         B, Cin, T = x.shape
-        w, b, ntaps = self._weights()
+        w, b, ntaps = self._weights()[:3]
         s, k = self.stride, self.kernel_size
         padding_total = k - s
         if self.causal:
@@ -168,7 +174,9 @@ class StreamableConvTranspose1d(nn.Module):
         d.elu_in, d.elu_alpha = int(elu_alpha is not None), float(elu_alpha or 0.0)
         d.shuffle, d.trim_left = s, pl
         y = torch.empty(B, self.out_channels, Tout, device=x.device, dtype=torch.float32)
-        _C.conv1d(d, x, w, b, None, y)
+        if len(self._prep) == 3:   # the staged layout of the polyphase weights, once
+            self._prep = self._prep + (_C.conv1d_tile_weights(d, w),)
+        _C.conv1d_tiled(d, x, self._prep[3], b, None, y)
         return y
 
 
@@ -203,16 +211,19 @@ class StreamableLSTM(nn.Module):
                 w_hh = getattr(p, f'weight_hh_l{layer}').detach().float().contiguous()
                 bias = (getattr(p, f'bias_ih_l{layer}').detach().float()
                         + getattr(p, f'bias_hh_l{layer}').detach().float()).contiguous()
-                self._prep.append((w_ih, w_hh, bias))
+                self._prep.append([w_ih, w_hh, bias, None])
         work = torch.zeros(_C.lstm_work_floats(B, H), device=x.device, dtype=torch.float32)
         d = _C.ConvDesc()
         d.B, d.Cin, d.Tin, d.Cout, d.Tout = B, H, T, 4 * H, T
         d.ksize, d.stride, d.dilation, d.pad_left = 1, 1, 1, 0
         d.pad_mode, d.reflect_len, d.elu_in, d.elu_alpha, d.shuffle, d.trim_left = _C.PAD_ZERO, T, 0, 0.0, 1, 0
         y = x
-        for layer, (w_ih, w_hh, bias) in enumerate(self._prep):
+        for layer, prep in enumerate(self._prep):
+            w_ih, w_hh, bias = prep[:3]
+            if prep[3] is None:
+                prep[3] = _C.conv1d_tile_weights(d, w_ih)
             gates = torch.empty(B, 4 * H, T, device=x.device, dtype=torch.float32)
-            _C.conv1d(d, y, w_ih, bias, None, gates)  # input projection for all T at once
+            _C.conv1d_tiled(d, y, prep[3], bias, None, gates)  # input projection for all T at once
             out = torch.empty(B, H, T, device=x.device, dtype=torch.float32)
             last = layer == self.num_layers - 1
             _C.lstm_layer(gates, w_hh, x if (self.skip and last) else None, out, work, B, H, T)

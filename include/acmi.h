@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 130 /* 0.1.3: single-term raw activations with a per-row shift (acmi_linear_desc.a_shift / xt_shift /
+#define ACMI_VERSION 140 /* 0.1.4: acmi_conv1d takes pre-tiled weights + a work buffer (acmi_conv1d_tile_weights /
+                            _weight_floats / _work_floats); MultiBandDiffusion entry points.  0.1.3: single-term raw activations with a per-row shift (acmi_linear_desc.a_shift / xt_shift /
                             mean_out, acmi_lm_state.xshift), cross-attention restricted to the rows with a non-null
                             condition (active_rows), prefill as MFMA-tiled GEMMs + causal prefill attention */
 
@@ -89,11 +90,20 @@ typedef struct {
 
 /* StreamableConv1d.forward (audiocraft/modules/conv.py:185-201: pad1d + F.conv1d + bias) and, with
  * shuffle > 1 and pre-arranged polyphase weights, StreamableConvTranspose1d.forward (:221-243:
- * F.conv_transpose1d + unpad1d).  Weights w [Cout_rows, Cin, ksize] f32 with weight-norm already
- * folded (conv.py:21-30), bias [Cout_rows / shuffle] or NULL, residual [B, Cout, Tout] or NULL
- * (the skip of SEANetResnetBlock.forward, audiocraft/modules/seanet.py:59-60). */
-int acmi_conv1d(const acmi_conv_desc* d, const float* x, const float* w, const float* bias,
-                const float* residual, float* y, void* stream);
+ * F.conv_transpose1d + unpad1d); also every nn.Conv1d / nn.ConvTranspose1d of the diffusion U-Net
+ * (audiocraft/models/unet.py:32-104).
+ *
+ * Weights are given PRE-TILED: acmi_conv1d_tile_weights turns w [Cout_rows, Cin, ksize] f32 (weight-norm already folded,
+ * conv.py:21-30) into the image the kernel stages (acmi_conv1d_weight_floats(d) floats; depends on Cout, Cin, ksize, stride,
+ * dilation, shuffle of the descriptor only -- not on B / Tin / Tout): once per model, not per call.
+ * work: acmi_conv1d_work_floats(d) floats of scratch (the padded, ELU'd, stride-phase-split copy of the input; 0 -- and work
+ * may be NULL -- for the convolutions with one or two output channels).  bias [Cout_rows / shuffle] or NULL, residual
+ * [B, Cout, Tout] or NULL (the skip of SEANetResnetBlock.forward, audiocraft/modules/seanet.py:59-60). */
+size_t acmi_conv1d_weight_floats(const acmi_conv_desc* d);
+size_t acmi_conv1d_work_floats(const acmi_conv_desc* d);
+int acmi_conv1d_tile_weights(const acmi_conv_desc* d, const float* w, float* wt, void* stream);
+int acmi_conv1d(const acmi_conv_desc* d, const float* x, const float* wt, const float* bias,
+                const float* residual, float* y, float* work, void* stream);
 
 /* nn.LSTM recurrence for one layer (audiocraft/modules/lstm.py:19-25): the input projection
  * gates_in [B, 4H, T] f32 (= W_ih x + b_ih + b_hh, computed with acmi_conv1d, ksize 1) is given;

@@ -19,7 +19,7 @@ from audiocraft_amd.models import builders  # noqa: E402
 
 HBM_PEAK, F32_MFMA_PEAK = 8.0e12, 157.3e12
 _acc = {'bytes': 0, 'flops': 0}
-_conv1d, _lstm = _C.conv1d, _C.lstm_layer
+_conv1d, _lstm = _C.conv1d_tiled, _C.lstm_layer
 
 
 def conv1d(d, x, w, bias, residual, y):
@@ -45,11 +45,11 @@ def run(name, cfg, B, seconds):
     import audiocraft_amd.modules.seanet as seanet
     for what, fn in (('encode', lambda: m.encode(wav)), ('decode', lambda: m.decode(codes))):
         _acc['bytes'] = _acc['flops'] = 0
-        _C.conv1d, _C.lstm_layer = conv1d, lstm_layer
-        seanet._C.conv1d, seanet._C.lstm_layer = conv1d, lstm_layer
+        _C.conv1d_tiled, _C.lstm_layer = conv1d, lstm_layer
+        seanet._C.conv1d_tiled, seanet._C.lstm_layer = conv1d, lstm_layer
         fn()
-        _C.conv1d, _C.lstm_layer = _conv1d, _lstm
-        seanet._C.conv1d, seanet._C.lstm_layer = _conv1d, _lstm
+        _C.conv1d_tiled, _C.lstm_layer = _conv1d, _lstm
+        seanet._C.conv1d_tiled, seanet._C.lstm_layer = _conv1d, _lstm
         torch.cuda.synchronize()
         reps = 3
         t0 = time.perf_counter()

@@ -14,7 +14,7 @@ from audiocraft_amd.models import builders  # noqa: E402
 import audiocraft_amd.modules.seanet as seanet  # noqa: E402
 
 rows = []
-_conv1d, _lstm = _C.conv1d, _C.lstm_layer
+_conv1d, _lstm = _C.conv1d_tiled, _C.lstm_layer
 
 
 def timed(fn):
@@ -46,8 +46,8 @@ wav = 0.1 * torch.randn(8, 1, 30 * 32000, device='cuda')
 codes, _ = m.encode(wav)
 m.decode(codes)
 torch.cuda.synchronize()
-_C.conv1d, _C.lstm_layer = conv1d, lstm_layer
-seanet._C.conv1d, seanet._C.lstm_layer = conv1d, lstm_layer
+_C.conv1d_tiled, _C.lstm_layer = conv1d, lstm_layer
+seanet._C.conv1d_tiled, seanet._C.lstm_layer = conv1d, lstm_layer
 (m.decode(codes) if what == 'decode' else m.encode(wav))
 torch.cuda.synchronize()
 tot = sum(r[1] for r in rows)

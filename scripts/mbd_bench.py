@@ -1,0 +1,80 @@
+"""MultiBandDiffusion cost at the released geometry (config/model/score/basic.yaml: hidden 48, depth 4, kernel 8, stride 4,
+growth 4; 128-d EnCodec condition at 50 Hz; 32 kHz): one U-Net forward, one reverse process of 20 steps, the 32-band EQ
+matching, and the oracle's U-Net forward on the host cores beside it.  Random weights, synthetic inputs.
+
+    python scripts/mbd_bench.py [--seconds 10] [--batch 1] [--cpu]     -> one JSON line
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seconds', type=float, default=10.)
+    ap.add_argument('--batch', type=int, default=1)
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--cpu', action='store_true', help="also time the oracle's U-Net forward on the host (1 s of audio)")
+    a = ap.parse_args()
+    from audiocraft_amd.models.unet import DiffusionUnet
+    from audiocraft_amd.modules.diffusion_schedule import MultiBandProcessor, NoiseSchedule, SplitBands
+    from audiocraft_amd import _C
+    torch.manual_seed(0)
+    kw = dict(chin=1, hidden=48, depth=4, growth=4., max_channels=10_000, num_steps=1000, emb_all_layers=True, bilstm=False,
+              codec_dim=128, kernel=8, stride=4, norm_groups=4, res_blocks=1)
+    m = DiffusionUnet(**kw).cuda()
+    T = int(a.seconds * 32000)
+    x = torch.randn(a.batch, 1, T, device='cuda')
+    cond = torch.randn(a.batch, 128, T // 640, device='cuda')
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    t_fwd = timed(lambda: m(x, 500, cond), a.reps)
+    proc = MultiBandProcessor(n_bands=4, sample_rate=32000, num_samples=1)
+    proc.load_state_dict({'counts': torch.ones(1), 'sum_x': torch.zeros(4), 'sum_x2': torch.ones(4), 'sum_target_x2': torch.ones(4)})
+    sched = NoiseSchedule(beta_t0=1e-5, beta_t1=0.029, beta_exp=7.5, num_steps=1000, sample_processor=proc.cuda())
+    t_proc = timed(lambda: sched.generate_subsampled(m, x, condition=cond), 1)
+    split = SplitBands(32000, 32)
+    ref = torch.randn_like(x)
+
+    def eq():
+        lows = split.lows(x)
+        st, st2 = split.stats(x, lows), split.stats(ref, split.lows(ref))
+        g = (st2[:, 1] / st[:, 1]).sqrt().float().cuda()
+        return _C.band_mix(x, lows, g)
+
+    t_eq = timed(eq, 3)
+    out = {'workload': f'MBD U-Net (hidden 48, depth 4, growth 4) B={a.batch} {a.seconds:g} s @ 32 kHz', 'unet_forward_ms': t_fwd * 1e3,
+           'reverse_process_20_steps_ms': t_proc * 1e3, 're_eq_32_bands_ms': t_eq * 1e3,
+           'four_band_decode_rtf': a.batch * a.seconds / (4 * t_proc + t_eq)}
+    if a.cpu:
+        from oracle import mbd as ombd
+        uc = ombd.UnetConfig(**kw)
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        xs, cs = x[:1, :, :32000].cpu(), cond[:1, :, :50].cpu()
+        ombd.unet_forward(sd, uc, xs[..., :3200], 500, cs[..., :5])
+        t0 = time.perf_counter()
+        ombd.unet_forward(sd, uc, xs, 500, cs)
+        t_cpu = time.perf_counter() - t0
+        t_gpu1 = timed(lambda: m(x[:1, :, :32000].contiguous(), 500, cond[:1, :, :50].contiguous()), a.reps)
+        out['cpu_oracle_forward_1s_ms'] = t_cpu * 1e3
+        out['gpu_forward_1s_ms'] = t_gpu1 * 1e3
+        out['cpu_threads'] = torch.get_num_threads()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

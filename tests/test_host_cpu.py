@@ -40,8 +40,16 @@ def test_argument_validation_without_gpu():
     d = _C.ConvDesc()
     d.B, d.Cin, d.Tin, d.Cout, d.Tout, d.ksize, d.stride, d.dilation = 1, 4, 10, 6, 10, 3, 1, 1
     d.shuffle = 4  # 6 % 4 != 0
-    rc = lib.acmi_conv1d(ctypes.byref(d), None, None, None, None, None, None)
+    rc = lib.acmi_conv1d(ctypes.byref(d), None, None, None, None, None, None, None)
     assert rc == -1 and b'shuffle' in lib.acmi_last_error()
+    assert lib.acmi_conv1d_weight_floats(ctypes.byref(d)) == 0 and lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 0   # same refusal
+    d.shuffle = 1
+    # sizes of the tiled weights / the packed-input scratch are pure host arithmetic: 42 channels x 3 taps per 128-wide K chunk
+    d.B, d.Cin, d.Tin, d.Cout, d.Tout, d.ksize = 2, 100, 1000, 70, 1000, 3
+    assert lib.acmi_conv1d_weight_floats(ctypes.byref(d)) == 2 * 3 * 2 * 64 * 68      # 2 row tiles x 3 chunks x 2 parities x 64 x KCP
+    assert lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 2 * 126 * (1024 + 68)       # B x Cin padded to whole chunks x (tiles + halo)
+    d.Cout, d.Cin, d.ksize = 1, 64, 7      # the few-output kernel: raw weights, no scratch
+    assert lib.acmi_conv1d_weight_floats(ctypes.byref(d)) == 64 * 7 and lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 0
     assert lib.acmi_lm_step(None, None, 0, None) == -1
     assert lib.acmi_ln_tile(None, None, 0, 4, 4096, ctypes.c_float(1e-5), None) == -1
     assert _C.lstm_work_floats(3, 8) == 5 * 3 * 8 + 4   # c + three hidden-state buffers + give-up counter
@@ -538,3 +546,38 @@ def test_bench_cpu_baseline_imports_without_the_reference_tree():
             "assert rb.available() is False; import bench; print('ok')" % ROOT)
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------ MultiBandDiffusion host logic
+
+@pytest.mark.parametrize('name', ['mbd_unet', 'mbd_unet_bilstm'])
+def test_diffusion_unet_takes_reference_state_dicts(name):
+    """DiffusionUnet's parameter names / shapes are the reference's (strict load of the golden's reference-made state dict);
+    there is no CPU forward."""
+    from conftest import load_golden
+    from audiocraft_amd.models.unet import DiffusionUnet
+    cfg, sd, _ = load_golden(name)
+    m = DiffusionUnet(**{k: cfg[k] for k in ('chin', 'hidden', 'depth', 'growth', 'max_channels', 'num_steps', 'emb_all_layers', 'bilstm',
+                                             'codec_dim', 'kernel', 'stride', 'norm_groups', 'res_blocks')})
+    m.load_state_dict(sd, strict=True)
+    assert set(m.state_dict()) == set(sd)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(torch.zeros(1, 1, 64), 3, torch.zeros(1, cfg['codec_dim'], 4))
+
+
+def test_band_filters_and_schedule_host_side():
+    """The host-built SplitBands filters equal the oracle's; the schedule's scalar side (betas, alpha-bar, YAML-string floats)."""
+    from oracle import mbd as ombd
+    from audiocraft_amd.modules.diffusion_schedule import NoiseSchedule, band_filters, betas_from_alpha_bar
+    for sr, n in ((32000, 32), (24000, 8), (16000, 4)):
+        cut = ombd.mel_frequencies(n + 1, 0, sr / 2)[1:-1] / sr
+        filt, half = ombd.lowpass_filters(cut)
+        mine, mhalf = band_filters(sr, n)
+        assert mhalf == half and torch.equal(mine, filt)
+        assert torch.allclose(mine.sum(1), torch.ones(n - 1), atol=1e-6)
+    s = NoiseSchedule(beta_t0='1e-05', beta_t1=0.029, beta_exp=7.5, num_steps=100, device='cpu')
+    sc = ombd.ScheduleConfig(beta_t0=1e-5, beta_t1=0.029, beta_exp=7.5, num_steps=100)
+    assert torch.equal(s.betas, sc.betas)
+    assert torch.equal(s.get_alpha_bar(41), ombd.alpha_bar_at(sc, 41))
+    ab = s.get_alpha_bar()[[0, 20, 40, 99]]
+    assert torch.allclose(1 - betas_from_alpha_bar(ab), torch.cat([ab[:1], ab[1:] / ab[:-1]]))
