@@ -14,6 +14,9 @@ Checks (each prints a line and the script exits non-zero on the first failure):
   codec    EncodecModel at the 32 kHz geometry with n_filters 16 (all layers, LSTM, RVQ 4 x 2048) on 0.7 s of audio:
            latents, codes (bit exact on the reference's own latents), decoded waveform
   epic     configs[0]: the reference EncodecModel at the full EnCodec-24 kHz geometry on assets/epic.wav (32 RVQ levels)
+  mbd      MultiBandDiffusion: the reference DiffusionUnet at the released geometry (hidden 48, depth 4, growth 4, kernel 8,
+           stride 4, all-layer embeddings, 128-d condition) on 0.5 s of 32 kHz audio, and with the BiLSTM bottleneck (depth 3);
+           the full DDPM reverse process (NoiseSchedule.generate, 6 steps) with the reference's draws replayed
   chroma   oracle.chroma against the reference ChromaExtractor arithmetic is NOT possible here: torchaudio / librosa are
            third-party and absent -- see oracle/chroma.py for how that row is pinned instead.
 """
@@ -305,7 +308,58 @@ def check_epic():
           f"{(odec - dec).abs().max().item():.1e}")
 
 
-CHECKS = {'epic': check_epic, 'lm': check_lm, 'bias': check_bias, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
+def check_mbd():
+    """The reference's DiffusionUnet / NoiseSchedule (julius only supplies SplitBands, not used here) vs oracle.mbd."""
+    from audiocraft.models.unet import DiffusionUnet
+    from audiocraft.modules.diffusion_schedule import NoiseSchedule
+    from . import mbd as ombd
+    for bilstm, depth, growth, T in ((False, 4, 4., 16000), (True, 3, 2., 8000)):
+        torch.manual_seed(8)
+        kw = dict(hidden=48, depth=depth, growth=growth, max_channels=10_000, emb_all_layers=True, bilstm=bilstm, codec_dim=128,
+                  kernel=8, stride=4, norm_groups=4, res_blocks=1)
+        m = DiffusionUnet(chin=1, num_steps=1000, **kw).eval()
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if 'norm' in k:
+                    p.add_(0.2 * torch.randn_like(p))
+        sd = {k: v.detach() for k, v in m.state_dict().items()}
+        uc = ombd.UnetConfig(chin=1, num_steps=1000, **kw)
+        x, cond, step = torch.randn(2, 1, T), torch.randn(2, 128, T // 640), torch.tensor([3, 977])
+        with torch.no_grad():
+            ref = m(x, step, condition=cond).sample
+        got = ombd.unet_forward(sd, uc, x, step, cond)
+        assert rel(got, ref) < 1e-5, rel(got, ref)
+        print(f"mbd     ok: DiffusionUnet hidden 48 depth {depth} growth {growth:g} bilstm {bilstm} on {T} samples: rel-L2 {rel(got, ref):.1e}")
+    ns = NoiseSchedule(beta_t0=1e-4, beta_t1=0.2, num_steps=6, variance='beta_tilde', clip=4., rescale=0.9, noise_scale=0.95, device='cpu')
+    g = torch.Generator().manual_seed(9)
+    init, cond = torch.randn(1, 1, 4000, generator=g), torch.randn(1, 128, 6, generator=g)
+    m6 = DiffusionUnet(chin=1, num_steps=6, **dict(kw, bilstm=False, depth=2)).eval()
+    sd6, uc6 = {k: v.detach() for k, v in m6.state_dict().items()}, ombd.UnetConfig(chin=1, num_steps=6, **dict(kw, bilstm=False, depth=2))
+    draws, real = [], torch.randn_like
+
+    def recorded(t, *a, **k):
+        draws.append(torch.randn(t.shape, generator=g))
+        return draws[-1]
+    torch.randn_like = recorded
+    try:
+        ref = ns.generate(m6, initial=init, condition=cond)
+    finally:
+        torch.randn_like = real
+    betas, cur = ns.betas, init
+    alpha_bar = (1 - betas).prod()
+    for i, step in enumerate(range(6)[::-1]):
+        est = ombd.unet_forward(sd6, uc6, cur, step, cond)
+        alpha = 1 - betas[step]
+        prev = (cur - (1 - alpha) / (1 - alpha_bar).sqrt() * est) / alpha.sqrt()
+        pab = (1 - betas[:step]).prod()
+        if step > 0:
+            prev = prev + ((1 - pab) / (1 - alpha_bar) * (1 - alpha)) ** 0.5 * draws[i] * 0.95
+        cur, alpha_bar = prev.clamp(-4., 4.), pab
+    assert (cur * 0.9 - ref).abs().max().item() < 2e-5
+    print(f"mbd     ok: NoiseSchedule.generate (6 steps, beta_tilde, clip, rescale, noise_scale) max abs {(cur * 0.9 - ref).abs().max().item():.1e}")
+
+
+CHECKS = {'epic': check_epic, 'mbd': check_mbd, 'lm': check_lm, 'bias': check_bias, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
