@@ -46,6 +46,32 @@ python scripts/codec_bench.py > $O/codec_bench.jsonl 2> $O/codec_bench.err
 python scripts/codec_layers.py decode > $O/codec_layers_decode.log 2>&1
 python scripts/codec_layers.py encode > $O/codec_layers_encode.log 2>&1
 tail -1 $O/codec_layers_decode.log | tee -a $O/progress.log
+log "conv kernels: MFMA-busy / traffic PMC over one EnCodec-32k decode (8 x 30 s)"
+cat > /tmp/dec.py <<'PY'
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from audiocraft_amd.models import builders
+m = builders.get_compression_model(builders.ENCODEC_32KHZ, 'cuda')
+codes = torch.randint(0, 2048, (8, 4, 1500), device='cuda')
+m.decode(codes)
+m.decode(codes)
+torch.cuda.synchronize()
+PY
+(cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d /tmp/pmc_conv -- python /tmp/dec.py $R > /dev/null 2>&1)
+python scripts/summarize_pmc.py $(find /tmp/pmc_conv -name "*counter_collection.csv" | head -1) | grep -E "kernel,|conv_|lstm" > $O/conv_pmc_mfma.csv
+cat $O/conv_pmc_mfma.csv | tee -a $O/progress.log
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d /tmp/pmcc_$c -- python /tmp/dec.py $R > /dev/null 2>&1)
+  python scripts/summarize_pmc.py $(find /tmp/pmcc_$c -name "*counter_collection.csv" | head -1) | grep -E "kernel,|conv_|lstm" > $O/conv_pmc_$c.csv
+done
+log "MultiBandDiffusion: cost + kernel stats"
+python scripts/mbd_bench.py --seconds 10 --cpu > $O/mbd_bench_10s.json 2> /dev/null; cat $O/mbd_bench_10s.json | tee -a $O/progress.log
+python scripts/mbd_bench.py --seconds 30 --batch 2 > $O/mbd_bench_30s_b2.json 2> /dev/null; cat $O/mbd_bench_30s_b2.json | tee -a $O/progress.log
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt3 -- python $R/scripts/mbd_bench.py --seconds 10 --reps 3 > /dev/null 2>&1)
+cp $(find /tmp/kt3 -name "*kernel_stats.csv" | head -1) $O/mbd_kernel_stats.csv
+python scripts/short_names.py $O/mbd_kernel_stats.csv | head -10 | tee -a $O/progress.log
+log "smoke"
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee -a $O/progress.log
 log "windowed 60 s generation: one-forward prefill vs chunk path"
 python scripts/window_bench.py > $O/window_60s.json 2> /dev/null; cat $O/window_60s.json | tee -a $O/progress.log
 ACMI_PREFILL=chunk python scripts/window_bench.py > $O/window_60s_chunk.json 2> /dev/null; cat $O/window_60s_chunk.json | tee -a $O/progress.log
