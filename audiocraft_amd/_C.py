@@ -129,7 +129,7 @@ _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32
 
 EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
-           'acmi_conv1d', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lm_step', 'acmi_linear',
+           'acmi_conv1d', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
 
@@ -215,6 +215,26 @@ def conv1d(desc: ConvDesc, x, w, bias, residual, y):
 
 def lstm_layer(gates_in, w_hh, skip, y, work, B, H, T):
     check(_lstm_layer(ptr(gates_in), ptr(w_hh), ptr(skip), ptr(y), ptr(work), B, H, T, stream()), 'acmi_lstm_layer')
+
+
+_lstm2 = _sig('acmi_lstm_stack2', [vp] * 8 + [i32] * 3 + [vp])
+_lstm2_work = _sig('acmi_lstm_stack2_work_floats', [i32] * 3, C.c_size_t)
+_lstm2_ok = _sig('acmi_lstm_stack2_supported', [i32] * 3)
+
+
+def lstm_stack2_supported(B, H, T) -> bool:
+    return bool(_lstm2_ok(B, H, T))
+
+
+def lstm_stack2(gates_in0, w_hh0, w_ih1, w_hh1, bias1, skip, y, B, H, T):
+    """Two-layer LSTM stack in one launch (layer 1 one step behind layer 0); raises if a workgroup gave up waiting."""
+    work = torch.empty(int(_lstm2_work(B, H, T)), device=y.device, dtype=torch.float32)
+    work[-4:].zero_()
+    check(_lstm2(ptr(gates_in0), ptr(w_hh0), ptr(w_ih1), ptr(w_hh1), ptr(bias1), ptr(skip), ptr(y), ptr(work), B, H, T, stream()),
+          'acmi_lstm_stack2')
+    if int(work[-4:].view(torch.int32)[0]) != 0:
+        raise AcmiError("acmi_lstm_stack2: the persistent LSTM kernel gave up waiting for a workgroup "
+                        "(set ACMI_LSTM_WAVE=0 for one launch per layer, ACMI_LSTM_PERSISTENT=0 for one per step)")
 
 
 def lstm_work_floats(B, H) -> int:

@@ -659,6 +659,252 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Two-layer wavefront: ONE launch for a 2-layer nn.LSTM stack (EnCodec's `lstm=2`).  2 x ceil(H / 4) workgroups: the first half
+// runs layer 0 exactly like lstm_persistent_kernel and additionally leaves every h1_t in a [T][B, H] exchange array (the
+// data is its own flag again: all slots start EMPTY, nothing is ever re-armed, so layer 1 may lag by any number of steps);
+// the second half runs layer 1 one step behind: per step it gathers h1_t (long since there), multiplies it with its register
+// resident slice of W_ih1 (the input projection that used to be a k = 1 convolution over all T between the two launches),
+// then does the recurrence step on its own rotating buffers.  2 T dependent all-gathers become T + 1.
+// Layer 0 never waits for layer 1 and is dispatched first: if only half of the grid is resident the launch degrades to
+// "layer 0, then layer 1" instead of dead-locking; the per-layer residency check is the same as for the single-layer form.
+// -----------------------------------------------------------------------------------------------------
+#define LSTM_WAVE2_WL 28   // W_ih1 values per thread kept in LDS at H > 512
+
+template <int KI>
+__global__ __launch_bounds__(256, 2) void lstm_wave2_kernel(const float* __restrict__ gates_in0, const float* __restrict__ w_hh0,
+                                                         const float* __restrict__ w_ih1, const float* __restrict__ w_hh1,
+                                                         const float* __restrict__ bias1, float* __restrict__ cst,
+                                                         const float* __restrict__ skip, float* __restrict__ y, unsigned* hbuf,
+                                                         unsigned* x01, unsigned* err, int B, int H, int T) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    constexpr int HP = 12;
+    constexpr int GV = KI > 32 ? 4 : 8;   // 16-byte groups a thread polls at once / k steps per LDS read batch: two weight slices
+    constexpr int MB = KI > 32 ? 4 : 8;   // (128 VGPRs at H = 1024) must leave room for two workgroups per CU (256 VGPRs)
+    float* hs = sh;                                // [16 KI >= H][HP]: the hidden vector being multiplied (h1_t, then h_{t-1} of this layer);
+                                                   // rows H .. 16 KI stay zero, so the k loop needs no clamp and its LDS addresses are
+                                                   // one register + immediates (64 clamped addresses were 64 more VGPRs)
+    float* gs = sh + (size_t)(16 * KI) * HP;       // [16][LSTM_BB] recurrent part of the gates
+    float* gsi = gs + 16 * LSTM_BB;                // [16][LSTM_BB] input part of the gates (layer 1)
+    int* s_abort = reinterpret_cast<int*>(gsi + 16 * LSTM_BB);
+    // Two weight slices at H = 1024 are 128 VGPRs per thread; with the ~145 the rest of the step needs that does not fit the 256
+    // a thread gets at two workgroups per CU (the compiler spilled ~150 of them to scratch and re-read 120 per step).  The last
+    // WL values of the W_ih1 slice live in LDS instead ([WL][256] floats behind the abort flag: conflict-free ds_read_b32).
+    constexpr int WL = KI > 32 ? LSTM_WAVE2_WL : 0;
+    float* wl = reinterpret_cast<float*>(s_abort + 4);
+    const int tid = threadIdx.x;
+    if (tid == 0) *s_abort = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    for (int idx = tid; idx < 16 * KI * HP; idx += 256) hs[idx] = 0.f;
+    __syncthreads();
+    if (*s_abort) return;
+    const int nwg = gridDim.x >> 1;
+    const int role = blockIdx.x >= nwg ? 1 : 0, g = blockIdx.x - role * nwg;   // block uniform
+    const int r = tid >> 4, ksl = tid & 15;
+    const int gate = r >> 2, u = r & 3;
+    const int j0 = g * 4;
+    const bool jvalid = j0 + u < H;
+    const size_t wrow_off = ((size_t)gate * H + (jvalid ? j0 + u : 0)) * H;
+    const float* wrow = (role ? w_hh1 : w_hh0) + wrow_off;
+    float wv[KI], wi[KI - WL];
+#pragma unroll
+    for (int i = 0; i < KI; ++i) wv[i] = (ksl + 16 * i < H) ? wrow[ksl + 16 * i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < KI - WL; ++i) wi[i] = (role && ksl + 16 * i < H) ? w_ih1[wrow_off + ksl + 16 * i] : 0.f;
+#pragma unroll
+    for (int i = KI - WL; i < KI; ++i) wl[(i - (KI - WL)) * 256 + tid] = (role && ksl + 16 * i < H) ? w_ih1[wrow_off + ksl + 16 * i] : 0.f;
+    const size_t BH = (size_t)B * H;
+    const int H4 = H >> 2;
+    const bool one_pass = B <= LSTM_BB;
+    float c_reg = 0.f;
+    float* cmy = cst + (size_t)role * BH;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hbuf + (size_t)role * 3 * BH, 0, (int)(3 * BH * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(x01, 0, (int)((size_t)T * BH * 4), 0x00020000);
+
+    // all-gather of nb rows x H values starting at element `off` of `src` into hs (k-major), rows past nb zeroed
+    auto gather = [&](const __amdgpu_buffer_rsrc_t src, unsigned off, int nb) {
+        const int ngr = nb * H4;
+        for (int base = 0; base < LSTM_BB * H4; base += 256 * GV) {
+            u32x4_t v[GV];
+            unsigned pending = 0;
+#pragma unroll
+            for (int i = 0; i < GV; ++i)
+                if (base + i * 256 + tid < ngr) pending |= 1u << i;
+            unsigned spins = 0;
+            while (pending) {
+#pragma unroll
+                for (int i = 0; i < GV; ++i)
+                    if (pending & (1u << i))
+                        v[i] = __builtin_amdgcn_raw_buffer_load_b128(src, (off + (unsigned)(base + i * 256 + tid) * 4u) * 4u, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int i = 0; i < GV; ++i)
+                    if ((pending & (1u << i)) && v[i][0] != LSTM_EMPTY && v[i][1] != LSTM_EMPTY && v[i][2] != LSTM_EMPTY &&
+                        v[i][3] != LSTM_EMPTY) {
+                        const int idx = base + i * 256 + tid, q = idx / H4, k = (idx - q * H4) * 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hs[(k + e) * HP + q] = __uint_as_float(v[i][e]);
+                        pending &= ~(1u << i);
+                    }
+                if (pending && (++spins & 0x3ffu) == 0u) {
+                    if (spins > 4000000u) { atomicAdd(err, 1u); *s_abort = 1; break; }
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *s_abort = 1; break; }
+                }
+            }
+        }
+        if (!one_pass)   // one pass: rows past nb were zeroed before the first step and are never written
+            for (int idx = tid; idx < (LSTM_BB - nb) * H; idx += 256) hs[(idx % H) * HP + nb + idx / H] = 0.f;
+    };
+    // Layer 1, one batch pass, H <= 512 (4 groups per thread): the gather of h1_{t+1} is ISSUED at the end of step t -- the data
+    // has been there for a step -- and completed at the start of step t + 1: its round trip to the memory side (~1.2 us) runs
+    // under the wait for the other workgroups' h2_t instead of in front of it.
+    constexpr bool PF = KI <= 32;
+    constexpr int GP = 4;
+    u32x4_t pv[GP];
+    unsigned ppend = 0;
+    auto prefetch_issue = [&](unsigned off, int nb) {
+        const int ngr = nb * H4;
+        ppend = 0;
+#pragma unroll
+        for (int i = 0; i < GP; ++i)
+            if (i * 256 + tid < ngr) {
+                ppend |= 1u << i;
+                pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (off + (unsigned)(i * 256 + tid) * 4u) * 4u, 0, 16 /* sc1 */);
+            }
+    };
+    auto prefetch_finish = [&](unsigned off, int nb) {
+        unsigned spins = 0;
+        bool reload = false;
+        while (ppend) {
+            if (reload) {
+#pragma unroll
+                for (int i = 0; i < GP; ++i)
+                    if (ppend & (1u << i))
+                        pv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (off + (unsigned)(i * 256 + tid) * 4u) * 4u, 0, 16 /* sc1 */);
+            }
+            reload = true;
+#pragma unroll
+            for (int i = 0; i < GP; ++i)
+                if ((ppend & (1u << i)) && pv[i][0] != LSTM_EMPTY && pv[i][1] != LSTM_EMPTY && pv[i][2] != LSTM_EMPTY &&
+                    pv[i][3] != LSTM_EMPTY) {
+                    const int idx = i * 256 + tid, q = idx / H4, kk = (idx - q * H4) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hs[(kk + e) * HP + q] = __uint_as_float(pv[i][e]);
+                    ppend &= ~(1u << i);
+                }
+            if (ppend && (++spins & 0x3ffu) == 0u) {
+                if (spins > 4000000u) { atomicAdd(err, 1u); *s_abort = 1; break; }
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *s_abort = 1; break; }
+            }
+        }
+    };
+    // 16 gate rows x H against the LSTM_BB vectors in hs -> dst [16][LSTM_BB]
+    auto matvec = [&](const auto& w, const int nreg, float* dst) {   // w[i] for i < nreg, the LDS tail behind it
+        float acc[LSTM_BB];
+#pragma unroll
+        for (int q = 0; q < LSTM_BB; ++q) acc[q] = 0.f;
+        const float* hk = hs + ksl * HP;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const float4 h0 = *reinterpret_cast<const float4*>(hk + i * 16 * HP);
+            const float4 h1 = *reinterpret_cast<const float4*>(hk + i * 16 * HP + 4);
+            const float wk = i < nreg ? w[i < nreg ? i : 0] : wl[(i - nreg) * 256 + tid];
+            acc[0] = fmaf(wk, h0.x, acc[0]); acc[1] = fmaf(wk, h0.y, acc[1]);
+            acc[2] = fmaf(wk, h0.z, acc[2]); acc[3] = fmaf(wk, h0.w, acc[3]);
+            acc[4] = fmaf(wk, h1.x, acc[4]); acc[5] = fmaf(wk, h1.y, acc[5]);
+            acc[6] = fmaf(wk, h1.z, acc[6]); acc[7] = fmaf(wk, h1.w, acc[7]);
+            if ((i & (MB - 1)) == MB - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < LSTM_BB; ++q) acc[q] = row16_sum(acc[q]);
+        if (ksl == 0) {
+#pragma unroll
+            for (int q = 0; q < LSTM_BB; ++q) dst[r * LSTM_BB + q] = acc[q];
+        }
+    };
+
+    float b1[4] = {0.f, 0.f, 0.f, 0.f};   // layer 1: this thread's four gate biases (one pass: fixed unit for the whole run)
+    if (role == 1 && (tid & 3) + j0 < H) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) b1[g4] = bias1[(size_t)g4 * H + j0 + (tid & 3)];
+    }
+    for (int t = 0; t < T; ++t) {
+        const unsigned prev_off = (unsigned)(((t + 2) % 3) * BH);
+        for (int b0 = 0; b0 < B; b0 += LSTM_BB) {
+            const int nb = min(LSTM_BB, B - b0);
+            const int uu = tid & 3, bb = tid >> 2, j = j0 + uu, bidx = b0 + bb;
+            const bool owner = tid < 4 * LSTM_BB && bb < nb && j < H;
+            float gin[4] = {0.f, 0.f, 0.f, 0.f};
+            if (role == 0) {
+                if (owner) {
+                    const size_t gbase = ((size_t)bidx * 4 * H + j) * T + t;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) gin[g4] = gates_in0[gbase + (size_t)g4 * H * T];
+                }
+            } else {
+                // input part of layer 1's gates: W_ih1 h1_t (+ bias); h1_t was published by layer 0 at least a step ago
+                if (PF && one_pass && t > 0) prefetch_finish((unsigned)((size_t)t * BH), nb);
+                else gather(rsx, (unsigned)((size_t)t * BH) + (unsigned)(b0 * H), nb);
+                __syncthreads();
+                if (*s_abort) return;
+                matvec(wi, KI - WL, gsi);
+                __syncthreads();       // gsi complete, every wave done with hs
+                if (owner) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) gin[g4] = gsi[(g4 * 4 + uu) * LSTM_BB + bb] + b1[g4];
+                }
+            }
+            // ---- the recurrence step of this layer (lstm_persistent_kernel's, see there)
+            if (t == 0) {
+                for (int idx = tid; idx < H * HP; idx += 256) hs[idx] = 0.f;
+            } else {
+                gather(rs, prev_off + (unsigned)(b0 * H), nb);
+            }
+            __syncthreads();
+            if (*s_abort) return;
+            const unsigned slot_off = (unsigned)(((size_t)bidx * H + j0) * 4u);
+            if (owner && uu == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY}, rs,
+                                                       (unsigned)(((t + 1) % 3) * BH * 4) + slot_off, 0, 16 /* sc1 */);
+            matvec(wv, KI, gs);
+            __syncthreads();
+            float c_hn = 0.f;
+            if (owner) {
+                const float gi = gs[(0 * 4 + uu) * LSTM_BB + bb] + gin[0];
+                const float gf = gs[(1 * 4 + uu) * LSTM_BB + bb] + gin[1];
+                const float gg = gs[(2 * 4 + uu) * LSTM_BB + bb] + gin[2];
+                const float go = gs[(3 * 4 + uu) * LSTM_BB + bb] + gin[3];
+                const float ig = 1.f / (1.f + expf(-gi));
+                const float fg = 1.f / (1.f + expf(-gf));
+                const float og = 1.f / (1.f + expf(-go));
+                const size_t si = (size_t)bidx * H + j;
+                const float cp = t == 0 ? 0.f : (one_pass ? c_reg : cmy[si]);
+                const float cn = fg * cp + ig * tanhf(gg);
+                const float hn = og * tanhf(cn);
+                c_reg = cn;
+                if (!one_pass) cmy[si] = cn;
+                c_hn = hn;
+            }
+            {
+                const unsigned h0 = __float_as_uint(dpp_f32<0x00>(c_hn)), h1 = __float_as_uint(dpp_f32<0x55>(c_hn));
+                const unsigned h2 = __float_as_uint(dpp_f32<0xAA>(c_hn)), h3 = __float_as_uint(dpp_f32<0xFF>(c_hn));
+                if (owner && uu == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-arm store of this step has landed
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{h0, h1, h2, h3}, rs, (unsigned)((t % 3) * BH * 4) + slot_off, 0,
+                                                           16 /* sc1 */);
+                    if (role == 0)   // the copy layer 1 reads, after the one this layer's own recurrence waits for
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{h0, h1, h2, h3}, rsx,
+                                                               (unsigned)((size_t)t * BH * 4) + slot_off, 0, 16 /* sc1 */);
+                }
+            }
+            if (owner && role == 1) {
+                const size_t yi = ((size_t)bidx * H + j) * T + t;
+                y[yi] = skip ? c_hn + skip[yi] : c_hn;
+            }
+            if (PF && role == 1 && one_pass && t + 1 < T) prefetch_issue((unsigned)((size_t)(t + 1) * BH), nb);
+            __syncthreads();
+        }
+    }
+}
+
 // work: 3 * B * H floats for the step form (h double buffer + c); the persistent form needs c (B * H floats), three
 // hidden-state buffers (3 * B * H floats) and an error word: 5 * B * H + 4 floats cover both
 extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H + 4; }
@@ -731,4 +977,70 @@ extern "C" int acmi_lstm_layer(const float* gates_in, const float* w_hh, const f
                            skip, y, B, H, T, t);
     }
     return acmi_check_launch("lstm_step_kernel");
+}
+
+
+// work of the two-layer form: [c: 2 B H][h buffers: 2 x 3 B H words][exchange: T B H words][err: 1 word (+ 3 pad)]
+extern "C" size_t acmi_lstm_stack2_work_floats(int B, int H, int T) {
+    if (B <= 0 || H <= 0 || T < 0) return 0;
+    return (size_t)8 * B * H + (size_t)T * B * H + 4;
+}
+
+static size_t lstm_wave2_lds(int H) {   // hs rows padded to the kernel's 16 KI (KI in {8, 16, 32, 64})
+    const int ki = (H + 15) / 16, kit = ki <= 8 ? 8 : ki <= 16 ? 16 : ki <= 32 ? 32 : 64;
+    return (size_t)(12 * 16 * kit + 32 * LSTM_BB) * sizeof(float) + 16 + (kit > 32 ? (size_t)LSTM_WAVE2_WL * 256 * sizeof(float) : 0);
+}
+
+template <int KI>
+static bool lstm_wave2_resident(int nwg, size_t lds) { return lstm_grid_resident(lstm_wave2_kernel<KI>, nwg, lds); }
+
+// can the two-layer launch run here at all (shape limits, per-layer residency)
+static bool lstm_wave2_can(int B, int H, int T, size_t lds) {
+    if (!lstm_persistent_ok(B, H) || T <= 0 || lds > 80 * 1024) return false;
+    if ((size_t)T * B * H * 4 >= (1ull << 31)) return false;   // the exchange array is addressed through one buffer descriptor
+    const int ki = (H + 15) / 16, nwg = (H + 3) / 4;
+    return ki <= 8 ? lstm_wave2_resident<8>(nwg, lds) : ki <= 16 ? lstm_wave2_resident<16>(nwg, lds)
+         : ki <= 32 ? lstm_wave2_resident<32>(nwg, lds) : lstm_wave2_resident<64>(nwg, lds);
+}
+
+// ... and should it (the advice acmi_lstm_stack2_supported gives the host)
+extern "C" int acmi_lstm_stack2_supported(int B, int H, int T) {
+    static int want = -1;   // ACMI_LSTM_WAVE: 0 never, 1 (default) where it was measured to win (H <= 512), 2 wherever it can run
+    if (want < 0) { const char* e = getenv("ACMI_LSTM_WAVE"); want = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1; }
+    if (!want || B <= 0 || H <= 0) return 0;
+    // H = 1024, B = 8: 15.5 us per wavefront step against 2 x 6.4 + the input projection (23.2 vs 20.3 ms per 1500 steps): two
+    // 32 KB gathers per layer-1 step, each in two rounds (register budget of two workgroups per CU), do not pay
+    if (want == 1 && H > 512) return 0;
+    return lstm_wave2_can(B, H, T, lstm_wave2_lds(H)) ? 1 : 0;
+}
+
+extern "C" int acmi_lstm_stack2(const float* gates_in0, const float* w_hh0, const float* w_ih1, const float* w_hh1,
+                                const float* bias1, const float* skip, float* y, float* work, int B, int H, int T, void* stream) {
+    ACMI_REQUIRE(B > 0 && H > 0 && T > 0, "acmi_lstm_stack2: bad shape");
+    const size_t lds = lstm_wave2_lds(H);
+    ACMI_REQUIRE(lds <= 80 * 1024, "acmi_lstm_stack2: H=%d too large", H);
+    ACMI_REQUIRE(lstm_wave2_can(B, H, T, lds), "acmi_lstm_stack2: not runnable here (ask acmi_lstm_stack2_supported first)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t BH = (size_t)B * H;
+    unsigned* hbuf = reinterpret_cast<unsigned*>(work + 2 * BH);
+    unsigned* x01 = hbuf + 6 * BH;
+    unsigned* err = x01 + (size_t)T * BH;
+    if (hipMemsetAsync(work, 0, sizeof(float) * 2 * BH, st) != hipSuccess ||
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, 6 * BH + (size_t)T * BH, st) != hipSuccess) {
+        acmi_set_error("acmi_lstm_stack2: hipMemsetAsync failed");
+        return ACMI_ELAUNCH;
+    }
+    dim3 grid(2 * ((H + 3) / 4)), block(256);
+    const int ki = (H + 15) / 16;
+#define ACMI_LSTM2_CASE(KIv)                                                                                              \
+    if (ki <= KIv) {                                                                                                      \
+        if (lds > 64 * 1024)   /* more dynamic LDS than the default per-workgroup limit: opt in */                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wave2_kernel<KIv>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+        hipLaunchKernelGGL(lstm_wave2_kernel<KIv>, grid, block, lds, st, gates_in0, w_hh0, w_ih1, w_hh1, bias1, work, skip, y, \
+                           hbuf, x01, err, B, H, T);                                                                      \
+    } else
+    ACMI_LSTM2_CASE(8) ACMI_LSTM2_CASE(16) ACMI_LSTM2_CASE(32) ACMI_LSTM2_CASE(64) {}
+#undef ACMI_LSTM2_CASE
+    return acmi_check_launch("lstm_wave2_kernel");
 }

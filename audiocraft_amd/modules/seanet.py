@@ -217,6 +217,16 @@ class StreamableLSTM(nn.Module):
         d.B, d.Cin, d.Tin, d.Cout, d.Tout = B, H, T, 4 * H, T
         d.ksize, d.stride, d.dilation, d.pad_left = 1, 1, 1, 0
         d.pad_mode, d.reflect_len, d.elu_in, d.elu_alpha, d.shuffle, d.trim_left = _C.PAD_ZERO, T, 0, 0.0, 1, 0
+        if self.num_layers == 2 and T > 0 and _C.lstm_stack2_supported(B, H, T):
+            # both layers in one launch, layer 1 a step behind layer 0 (T + 1 dependent steps instead of 2 T)
+            p0, p1 = self._prep
+            if p0[3] is None:
+                p0[3] = _C.conv1d_tile_weights(d, p0[0])
+            gates = torch.empty(B, 4 * H, T, device=x.device, dtype=torch.float32)
+            _C.conv1d_tiled(d, x, p0[3], p0[2], None, gates)
+            out = torch.empty(B, H, T, device=x.device, dtype=torch.float32)
+            _C.lstm_stack2(gates, p0[1], p1[0], p1[1], p1[2], x if self.skip else None, out, B, H, T)
+            return out
         y = x
         for layer, prep in enumerate(self._prep):
             w_ih, w_hh, bias = prep[:3]

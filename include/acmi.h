@@ -495,6 +495,19 @@ int acmi_chroma(const float* wav, int B, int T, int wav_stride, int radix2_exp, 
 int acmi_resample_frac(const float* x, float* y, const float* kernel, int rows, int T, int Tout, int old_sr, int new_sr,
                        int width, void* stream);
 
+/* A TWO-layer nn.LSTM stack (EnCodec's `lstm=2`, audiocraft/modules/lstm.py:19-25) as one launch: layer 1 runs one step behind
+ * layer 0 (T + 1 dependent steps instead of 2 T), its input projection W_ih1 h1_t + bias1 is computed inside the launch.
+ * gates_in0 [B, 4H, T] = W_ih0 x + b_ih0 + b_hh0 (acmi_conv1d, ksize 1); w_hh0, w_ih1, w_hh1 [4H, H] f32; bias1 [4H] =
+ * b_ih1 + b_hh1; skip [B, H, T] or NULL is added to the output y [B, H, T] of layer 1.
+ * acmi_lstm_stack2_supported: 1 when the launch can run on the current device (H % 4 == 0, H <= 1024, the residency rule of
+ * acmi_lstm_layer per layer: if only one layer's workgroups fit at a time the launch degrades to layer 0, then layer 1) AND is
+ * the faster form (H <= 512 by default; ACMI_LSTM_WAVE=2 lifts that, =0 answers 0); otherwise use two acmi_lstm_layer calls.  work: acmi_lstm_stack2_work_floats(B, H, T) floats; its LAST four
+ * words hold the give-up count: the caller zeroes them before the call and reads word 0 of them after it. */
+size_t acmi_lstm_stack2_work_floats(int B, int H, int T);
+int acmi_lstm_stack2_supported(int B, int H, int T);
+int acmi_lstm_stack2(const float* gates_in0, const float* w_hh0, const float* w_ih1, const float* w_hh1, const float* bias1,
+                     const float* skip, float* y, float* work, int B, int H, int T, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * MultiBandDiffusion decoder option: what its U-Net and reverse process need besides
  * acmi_conv1d (every Conv1d / ConvTranspose1d of audiocraft/models/unet.py) and acmi_lstm_layer (its BiLSTM bottleneck)

@@ -34,6 +34,15 @@ def lstm_layer(gates, w_hh, skip, out, work, B, H, T):
     return _lstm(gates, w_hh, skip, out, work, B, H, T)
 
 
+_lstm2 = _C.lstm_stack2
+
+
+def lstm_stack2(gates, w_hh0, w_ih1, w_hh1, bias1, skip, out, B, H, T):
+    _acc['bytes'] += 4 * (gates.numel() + out.numel() + (skip.numel() if skip is not None else 0))
+    _acc['flops'] += 3 * 2 * B * 4 * H * H * T
+    return _lstm2(gates, w_hh0, w_ih1, w_hh1, bias1, skip, out, B, H, T)
+
+
 def run(name, cfg, B, seconds):
     torch.manual_seed(0)
     m = builders.get_compression_model(cfg, 'cuda')
@@ -47,9 +56,11 @@ def run(name, cfg, B, seconds):
         _acc['bytes'] = _acc['flops'] = 0
         _C.conv1d_tiled, _C.lstm_layer = conv1d, lstm_layer
         seanet._C.conv1d_tiled, seanet._C.lstm_layer = conv1d, lstm_layer
+        _C.lstm_stack2 = seanet._C.lstm_stack2 = lstm_stack2
         fn()
         _C.conv1d_tiled, _C.lstm_layer = _conv1d, _lstm
         seanet._C.conv1d_tiled, seanet._C.lstm_layer = _conv1d, _lstm
+        _C.lstm_stack2 = seanet._C.lstm_stack2 = _lstm2
         torch.cuda.synchronize()
         reps = 3
         t0 = time.perf_counter()

@@ -39,6 +39,14 @@ def lstm_layer(gates, w_hh, skip, out, work, B, H, T):
     rows.append((f"lstm B {B} H {H} T {T}", ms, 2.0 * B * 4 * H * H * T))
 
 
+_lstm2 = _C.lstm_stack2
+
+
+def lstm_stack2(gates, w_hh0, w_ih1, w_hh1, bias1, skip, out, B, H, T):
+    ms = timed(lambda: _lstm2(gates, w_hh0, w_ih1, w_hh1, bias1, skip, out, B, H, T))
+    rows.append((f"lstm x2 (wavefront, incl. layer 1's input projection) B {B} H {H} T {T}", ms, 3 * 2.0 * B * 4 * H * H * T))
+
+
 what = sys.argv[1] if len(sys.argv) > 1 else 'decode'
 torch.manual_seed(0)
 m = builders.get_compression_model(builders.ENCODEC_32KHZ, 'cuda')
@@ -48,6 +56,7 @@ m.decode(codes)
 torch.cuda.synchronize()
 _C.conv1d_tiled, _C.lstm_layer = conv1d, lstm_layer
 seanet._C.conv1d_tiled, seanet._C.lstm_layer = conv1d, lstm_layer
+_C.lstm_stack2 = seanet._C.lstm_stack2 = lstm_stack2
 (m.decode(codes) if what == 'decode' else m.encode(wav))
 torch.cuda.synchronize()
 tot = sum(r[1] for r in rows)

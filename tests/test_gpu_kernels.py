@@ -143,9 +143,18 @@ def test_convtr1d_vs_oracle(C, Cin, Cout, k, stride, causal, trr, T):
     assert err < 2e-5, f"max abs err {err}"
 
 
-@pytest.mark.parametrize('B,H,T,layers', [(2, 32, 17, 2), (8, 1024, 20, 2), (3, 64, 5, 1), (11, 128, 9, 2)])
-def test_lstm_vs_oracle(C, B, H, T, layers):
+@pytest.mark.parametrize('wave', ['force', 'off'])
+@pytest.mark.parametrize('B,H,T,layers', [(2, 32, 17, 2), (8, 1024, 20, 2), (3, 64, 5, 1), (11, 128, 9, 2), (1, 512, 301, 2),
+                                          (8, 1024, 150, 2), (2, 100, 33, 2), (17, 512, 6, 2), (1, 4, 3, 2)])
+def test_lstm_vs_oracle(C, B, H, T, layers, wave, monkeypatch):
+    """StreamableLSTM (with its skip) against the oracle: the two-layer wavefront launch (acmi_lstm_stack2) and, with it switched
+    off on the host side, one acmi_lstm_layer launch per layer."""
     from audiocraft_amd.modules.seanet import StreamableLSTM
+    if wave == 'off':
+        monkeypatch.setattr(C, 'lstm_stack2_supported', lambda *a: False)
+    else:   # also where the library would advise against it (H = 1024: measured slower than two launches)
+        assert C.lstm_stack2_supported(B, min(H, 512), T)   # an idle whole MI355X holds every workgroup of these shapes
+        monkeypatch.setattr(C, 'lstm_stack2_supported', lambda *a: True)
     g = torch.Generator().manual_seed(H + T)
     m = StreamableLSTM(H, layers, device='cuda')
     sd = {}
