@@ -222,6 +222,26 @@ _lstm2_work = _sig('acmi_lstm_stack2_work_floats', [i32] * 3, C.c_size_t)
 _lstm2_ok = _sig('acmi_lstm_stack2_supported', [i32] * 3)
 
 
+# LSTM give-up words whose host-side check is postponed (a list while a hipGraph capture is running: reading a device word
+# synchronises, which a capture forbids; the owner of the capture checks them after each replay), else None
+_deferred_lstm_checks = None
+
+
+def defer_lstm_checks(sink):
+    global _deferred_lstm_checks
+    _deferred_lstm_checks = sink
+
+
+def lstm_check(err_word: torch.Tensor, what: str):
+    """err_word: the [1+] int32/f32 view whose first word counts the persistent kernels' bounded-spin give-ups."""
+    if _deferred_lstm_checks is not None:
+        _deferred_lstm_checks.append((err_word, what))
+        return
+    if int(err_word.view(torch.int32)[0]) != 0:
+        raise AcmiError(f"{what}: the persistent LSTM kernel gave up waiting for a workgroup (set ACMI_LSTM_WAVE=0 for one launch "
+                        "per layer, ACMI_LSTM_PERSISTENT=0 for one per time step)")
+
+
 def lstm_stack2_supported(B, H, T) -> bool:
     return bool(_lstm2_ok(B, H, T))
 
@@ -232,9 +252,7 @@ def lstm_stack2(gates_in0, w_hh0, w_ih1, w_hh1, bias1, skip, y, B, H, T):
     work[-4:].zero_()
     check(_lstm2(ptr(gates_in0), ptr(w_hh0), ptr(w_ih1), ptr(w_hh1), ptr(bias1), ptr(skip), ptr(y), ptr(work), B, H, T, stream()),
           'acmi_lstm_stack2')
-    if int(work[-4:].view(torch.int32)[0]) != 0:
-        raise AcmiError("acmi_lstm_stack2: the persistent LSTM kernel gave up waiting for a workgroup "
-                        "(set ACMI_LSTM_WAVE=0 for one launch per layer, ACMI_LSTM_PERSISTENT=0 for one per step)")
+    lstm_check(work[-4:], 'acmi_lstm_stack2')
 
 
 def lstm_work_floats(B, H) -> int:

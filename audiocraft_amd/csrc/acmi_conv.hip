@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
 #define LSTM_WAVE2_WL 28   // W_ih1 values per thread kept in LDS at H > 512
 
 template <int KI>
-__global__ __launch_bounds__(256, 2) void lstm_wave2_kernel(const float* __restrict__ gates_in0, const float* __restrict__ w_hh0,
+__global__ __launch_bounds__(256, KI > 32 ? 2 : 1) void lstm_wave2_kernel(const float* __restrict__ gates_in0, const float* __restrict__ w_hh0,
                                                          const float* __restrict__ w_ih1, const float* __restrict__ w_hh1,
                                                          const float* __restrict__ bias1, float* __restrict__ cst,
                                                          const float* __restrict__ skip, float* __restrict__ y, unsigned* hbuf,
@@ -753,9 +753,9 @@ __global__ __launch_bounds__(256, 2) void lstm_wave2_kernel(const float* __restr
         if (!one_pass)   // one pass: rows past nb were zeroed before the first step and are never written
             for (int idx = tid; idx < (LSTM_BB - nb) * H; idx += 256) hs[(idx % H) * HP + nb + idx / H] = 0.f;
     };
-    // Layer 1, one batch pass, H <= 512 (4 groups per thread): the gather of h1_{t+1} is ISSUED at the end of step t -- the data
-    // has been there for a step -- and completed at the start of step t + 1: its round trip to the memory side (~1.2 us) runs
-    // under the wait for the other workgroups' h2_t instead of in front of it.
+    // Layer 1, one batch pass, H <= 512 (4 groups per thread): the gather of h1_{t+1} is ISSUED during step t, as soon as h1_t
+    // has been consumed -- layer 0 runs ahead, the data is there -- and completed at the start of step t + 1: its round trip to
+    // the memory side (~1.2 us) runs under the recurrence step instead of in front of the next one.
     constexpr bool PF = KI <= 32;
     constexpr int GP = 4;
     u32x4_t pv[GP];
@@ -847,6 +847,8 @@ __global__ __launch_bounds__(256, 2) void lstm_wave2_kernel(const float* __restr
                 if (*s_abort) return;
                 matvec(wi, KI - WL, gsi);
                 __syncthreads();       // gsi complete, every wave done with hs
+                // h1_{t+1} (layer 0 runs ahead: it is there) requested NOW: its round trip hides under this whole step
+                if (PF && one_pass && t + 1 < T) prefetch_issue((unsigned)((size_t)(t + 1) * BH), nb);
                 if (owner) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) gin[g4] = gsi[(g4 * 4 + uu) * LSTM_BB + bb] + b1[g4];
@@ -899,7 +901,6 @@ __global__ __launch_bounds__(256, 2) void lstm_wave2_kernel(const float* __restr
                 const size_t yi = ((size_t)bidx * H + j) * T + t;
                 y[yi] = skip ? c_hn + skip[yi] : c_hn;
             }
-            if (PF && role == 1 && one_pass && t + 1 < T) prefetch_issue((unsigned)((size_t)(t + 1) * BH), nb);
             __syncthreads();
         }
     }
@@ -918,12 +919,22 @@ extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H
 // the first give-up raises a device-wide abort flag (the err word) that every workgroup polls, and the host raises.
 template <typename KernelT>
 static bool lstm_grid_resident(KernelT kernel, int grid, size_t lds_bytes) {
+    // answers are remembered per (kernel, grid, LDS, device): the queries are not free, and a call that arrives while its
+    // stream is being captured into a hipGraph must not need them
+    struct Seen { const void* k; int grid, dev; size_t lds; bool ok; };
+    static thread_local Seen seen[16];
+    static thread_local int n_seen = 0;
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
+    const void* kp = reinterpret_cast<const void*>(kernel);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].k == kp && seen[i].grid == grid && seen[i].dev == dev && seen[i].lds == lds_bytes) return seen[i].ok;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu <= 0) return false;
     if (per_cu > 1) per_cu -= 1;
-    return (long)grid <= (long)cus * per_cu;
+    const bool ok = (long)grid <= (long)cus * per_cu;
+    if (n_seen < 16) seen[n_seen++] = Seen{kp, grid, dev, lds_bytes, ok};
+    return ok;
 }
 
 static int lstm_persistent_ok(int B, int H) {

@@ -11,6 +11,7 @@
 #include "acmi_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 __global__ void rvq_norms_kernel(const float* __restrict__ cb, float* __restrict__ norms, int rows, int D) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,7 +30,11 @@ extern "C" int acmi_rvq_codebook_norms(const float* codebooks, float* norms, int
     return acmi_check_launch("rvq_norms_kernel");
 }
 
-template <int D>
+// SP = 1: every wave owns 16 rows and scans the whole codebook of a level (long inputs: thousands of waves hide the codebook
+// reads behind each other).  SP = 4 (few rows, e.g. one 10 s clip = 750 frames = 47 waves): the four waves of a workgroup share
+// 16 rows and scan a quarter of the codebook each, then merge their (best, index) pairs in code order -- a level costs a
+// quarter of the dependent codebook reads (65 -> ~20 us per level at 32 levels x 1024 codes x 128 dims, B T = 750).
+template <int D, int SP>
 __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ latents,
                                                          const float* __restrict__ codebooks,
                                                          const float* __restrict__ norms, int64_t* __restrict__ codes,
@@ -37,12 +42,16 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     constexpr int NKK = D / 16;  // 16-wide k groups; lane (row, kg) owns k = kk*16 + kg*4 + j
     __shared__ float s_x2[4][16];
     __shared__ int s_idx[4][16];
+    __shared__ float s_best[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nl = lane & 15, kg = lane >> 4;
-    const long long R = ((long long)blockIdx.x * 4 + wave) * 16 + nl;  // A-layout row of this lane
+    const long long R = (SP == 1 ? ((long long)blockIdx.x * 4 + wave) : (long long)blockIdx.x) * 16 + nl;  // A-layout row of this lane
     const long long NR = (long long)B * T;
     const bool rvalid = R < NR;
     const int rb = rvalid ? (int)(R / T) : 0, rt = rvalid ? (int)(R % T) : 0;
+    // this wave's slice of every codebook
+    const int span = SP == 1 ? bins : ((bins + 16 * SP - 1) / (16 * SP)) * 16;
+    const int c_lo = SP == 1 ? 0 : min(bins, wave * span), c_hi = SP == 1 ? bins : min(bins, c_lo + span);
 
     float xr[NKK * 4];
 #pragma unroll
@@ -70,14 +79,22 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
 
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bidx[4] = {0, 0, 0, 0};
-        for (int c0 = 0; c0 < bins; c0 += 16) {
+        // the 16 codes of the next iteration are requested before the MFMAs of the current one
+        float4 ev[NKK], en[NKK];
+        float e2 = 0.f, e2n = 0.f;
+        auto fetch = [&](int c0, float4 (&dst)[NKK], float& n2) {
             const int c = c0 + nl;
-            const bool cvalid = c < bins;
-            const float* erow = cb + (size_t)(cvalid ? c : 0) * D + kg * 4;
-            float4 ev[NKK];
+            const bool ok = c < c_hi;
+            const float* erow = cb + (size_t)(ok ? c : 0) * D + kg * 4;
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) ev[kk] = *reinterpret_cast<const float4*>(erow + kk * 16);
-            const float e2 = cvalid ? nq[c] : 0.f;
+            for (int kk = 0; kk < NKK; ++kk) dst[kk] = *reinterpret_cast<const float4*>(erow + kk * 16);
+            n2 = ok ? nq[c] : 0.f;
+        };
+        if (c_lo < c_hi) fetch(c_lo, ev, e2);
+        for (int c0 = c_lo; c0 < c_hi; c0 += 16) {
+            if (c0 + 16 < c_hi) fetch(c0 + 16, en, e2n);
+            const int c = c0 + nl;
+            const bool cvalid = c < c_hi;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
@@ -93,6 +110,9 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
                 const float dist = -__fadd_rn(t1, e2);
                 if (cvalid && dist > best[i]) { best[i] = dist; bidx[i] = c; }
             }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) ev[kk] = en[kk];
+            e2 = e2n;
         }
         // first-index argmax across the 16 lanes (codes c = nl mod 16) of each row group
 #pragma unroll
@@ -106,11 +126,20 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         }
         if (nl == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s_idx[wave][kg * 4 + i] = bidx[i];
+            for (int i = 0; i < 4; ++i) { s_idx[wave][kg * 4 + i] = bidx[i]; s_best[wave][kg * 4 + i] = best[i]; }
         }
         __syncthreads();
-        const int my = s_idx[wave][nl];
-        if (rvalid && kg == 0) codes[((size_t)rb * K + q) * T + rt] = (int64_t)my;
+        int my = s_idx[wave][nl];
+        if (SP > 1) {   // merge the slices in code order: a later slice wins only when strictly better (first index on ties)
+            float bv = s_best[0][nl];
+            my = s_idx[0][nl];
+#pragma unroll
+            for (int w = 1; w < SP; ++w) {
+                const float ov = s_best[w][nl];
+                if (ov > bv) { bv = ov; my = s_idx[w][nl]; }
+            }
+        }
+        if (rvalid && kg == 0 && (SP == 1 || wave == 0)) codes[((size_t)rb * K + q) * T + rt] = (int64_t)my;
         const float* erow = cb + (size_t)my * D + kg * 4;
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
@@ -126,11 +155,15 @@ extern "C" int acmi_rvq_encode(const float* latents, const float* codebooks, con
     ACMI_REQUIRE(B >= 0 && T >= 0 && K > 0 && bins > 0, "acmi_rvq_encode: bad shape");
     if ((long long)B * T == 0) return ACMI_OK;
     const long long rows = (long long)B * T;
-    dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    // few rows: four waves per 16 rows, each scanning a quarter of the codebook (ACMI_RVQ_SPLIT=0/1 forces a form)
+    static const int force = getenv("ACMI_RVQ_SPLIT") ? atoi(getenv("ACMI_RVQ_SPLIT")) : -1;
+    const bool split = force >= 0 ? force != 0 : rows <= 8192;
+    dim3 grid((unsigned)(split ? (rows + 15) / 16 : (rows + 63) / 64)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define ACMI_RVQ_CASE(DD)                                                                                          \
     case DD:                                                                                                       \
-        hipLaunchKernelGGL(rvq_encode_kernel<DD>, grid, block, 0, st, latents, codebooks, norms, codes, B, T, K, bins); \
+        if (split) hipLaunchKernelGGL((rvq_encode_kernel<DD, 4>), grid, block, 0, st, latents, codebooks, norms, codes, B, T, K, bins); \
+        else hipLaunchKernelGGL((rvq_encode_kernel<DD, 1>), grid, block, 0, st, latents, codebooks, norms, codes, B, T, K, bins); \
         break;
     switch (D) {
         ACMI_RVQ_CASE(16)

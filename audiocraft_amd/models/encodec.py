@@ -6,6 +6,7 @@ channels / frame_rate / sample_rate / cardinality / num_codebooks / total_codebo
 The HF / DAC / stereo-interleave wrappers of the reference are outside this path.
 """
 import math
+import os
 import typing as tp
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
@@ -13,6 +14,7 @@ from dataclasses import dataclass
 import torch
 from torch import nn
 
+from .. import _C
 from ..modules.seanet import invalidate_prepared
 from ..quantization.vq import BaseQuantizer
 
@@ -95,12 +97,63 @@ class EncodecModel(CompressionModel):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         result = super().load_state_dict(state_dict, strict=strict, **kw)
         invalidate_prepared(self)
+        self._graphs = {}
         return result
 
     def _apply(self, fn, *args, **kw):
         result = super()._apply(fn, *args, **kw)
         invalidate_prepared(self)
+        self._graphs = {}
         return result
+
+    # ---- short inputs: the SEANet passes as hipGraph replays.  Below ~1 M samples per call the ~70 convolution launches of a
+    # pass (two kernels, two allocations, one ctypes call each) cost more host time than GPU time (EnCodec-24k, 1 x 10 s:
+    # 1.9 ms of a 5 ms decode).  The second call with a shape captures the pass (torch.cuda.CUDAGraph is only the capture /
+    # replay plumbing; every node is an acmi kernel or a memset), later calls copy the input in and replay.
+    GRAPH_MAX_SAMPLES = int(os.environ.get('ACMI_CODEC_GRAPH_MAX', str(1 << 20)))   # 0: never
+    GRAPH_SLOTS = 6
+
+    def _seanet(self, which: str, net: nn.Module, x: torch.Tensor) -> torch.Tensor:
+        x = x.float().contiguous()
+        samples = x.shape[0] * x.shape[-1] * (self.decoder.hop_length if which == 'dec' else 1)
+        if not x.is_cuda or samples == 0 or samples > self.GRAPH_MAX_SAMPLES:
+            return net(x)
+        graphs = self.__dict__.setdefault('_graphs', {})
+        key = (which, tuple(x.shape))
+        entry = graphs.get(key)
+        if entry is None:          # first sight of the shape: eager (tiles the weights, fills the host-side caches)
+            while len(graphs) >= self.GRAPH_SLOTS:
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = False
+            return net(x)
+        if entry is False:
+            entry = graphs[key] = self._capture(net, x)
+        graph, static_in, static_out, checks = entry
+        static_in.copy_(x)
+        graph.replay()
+        out = static_out.clone()
+        if checks and bool(torch.stack([w.view(torch.int32)[0] for w, _ in checks]).any()):
+            raise _C.AcmiError(f"{checks[0][1]}: the persistent LSTM kernel gave up waiting for a workgroup "
+                               "(set ACMI_LSTM_WAVE=0 / ACMI_LSTM_PERSISTENT=0)")
+        return out
+
+    @staticmethod
+    def _capture(net: nn.Module, x: torch.Tensor):
+        static_in = x.clone()
+        checks: list = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            _C.defer_lstm_checks(checks)   # reading the LSTM's give-up word synchronises: done after every replay instead
+            graph.capture_begin()
+            try:
+                static_out = net(static_in)
+            finally:
+                graph.capture_end()
+                _C.defer_lstm_checks(None)
+        torch.cuda.current_stream().wait_stream(side)
+        return graph, static_in, static_out, checks
 
     total_codebooks = property(lambda self: self.quantizer.total_codebooks)
     num_codebooks = property(lambda self: self.quantizer.num_codebooks)
@@ -126,7 +179,7 @@ class EncodecModel(CompressionModel):
     def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
         assert x.dim() == 3
         x, scale = self.preprocess(x)
-        return self.quantizer.encode(self.encoder(x)), scale
+        return self.quantizer.encode(self._seanet('enc', self.encoder, x)), scale
 
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor):
@@ -135,7 +188,7 @@ class EncodecModel(CompressionModel):
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
         # the result keeps the encoder's extra right padding; callers trim to the length they expect
-        return self.postprocess(self.decoder(self.decode_latent(codes)), scale)
+        return self.postprocess(self._seanet('dec', self.decoder, self.decode_latent(codes)), scale)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> QuantizedResult:

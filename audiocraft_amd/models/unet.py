@@ -165,8 +165,7 @@ class BLSTM(nn.Module):
         out = torch.empty(B, H, T, device=x.device, dtype=torch.float32)
         work = torch.zeros(_C.lstm_work_floats(B, H), device=x.device, dtype=torch.float32)
         _C.lstm_layer(gates, p('weight_hh').contiguous(), None, out, work, B, H, T)
-        if int(work[5 * B * H:].view(torch.int32)[0]) != 0:
-            raise RuntimeError("acmi_lstm_layer: the persistent LSTM kernel gave up waiting for a workgroup")
+        _C.lstm_check(work[5 * B * H:], 'acmi_lstm_layer')
         return out
 
     def run(self, x: torch.Tensor) -> torch.Tensor:

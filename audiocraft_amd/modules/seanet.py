@@ -240,9 +240,7 @@ class StreamableLSTM(nn.Module):
             y = out
         # the persistent recurrence kernel counts bounded-spin give-ups of its all-gather in the last words of `work`
         # (never seen on an otherwise idle device; a non-zero count means the result is not to be trusted)
-        if int(work[5 * B * H:].view(torch.int32)[0]) != 0:
-            raise RuntimeError("acmi_lstm_layer: the persistent LSTM kernel gave up waiting for a workgroup "
-                               "(set ACMI_LSTM_PERSISTENT=0 to use the per-step kernel)")
+        _C.lstm_check(work[5 * B * H:], 'acmi_lstm_layer')
         return y
 
 

@@ -168,6 +168,33 @@ def test_encodec_random_lengths_roundtrip_shapes():
         assert m.decode(codes).shape[-1] >= length
 
 
+def test_encodec_graph_replay_matches_eager():
+    """Short inputs run the SEANet passes as hipGraph replays from the second call with a shape on (EncodecModel._seanet):
+    first (eager), second (capture + replay), third (replay) call and a call with other VALUES in the same shape all give the
+    eager result bit for bit; a different shape takes a slot of its own; load_state_dict drops the captured graphs."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(3)
+    m = builders.get_compression_model(builders.ENCODEC_24KHZ, 'cuda')
+    eager = builders.get_compression_model(builders.ENCODEC_24KHZ, 'cuda')
+    eager.load_state_dict(m.state_dict())
+    eager.GRAPH_MAX_SAMPLES = 0
+    g = torch.Generator().manual_seed(4)
+    a, b = (0.2 * torch.randn(2, 1, 24000, generator=g)).cuda(), (0.2 * torch.randn(2, 1, 24000, generator=g)).cuda()
+    c = (0.2 * torch.randn(1, 1, 7777, generator=g)).cuda()
+    for x in (a, a, a, b, c, c, b):
+        codes, _ = m.encode(x)
+        codes_e, _ = eager.encode(x)
+        assert torch.equal(codes, codes_e)
+        assert torch.equal(m.decode(codes), eager.decode(codes_e))
+    kinds = sorted(k[0] for k, v in m._graphs.items() if v is not False)
+    assert kinds == ['dec', 'dec', 'enc', 'enc'], m._graphs.keys()
+    m.load_state_dict(eager.state_dict())
+    assert m._graphs == {}
+    big = torch.zeros(8, 1, 240000).cuda()      # 1.9 M samples: above GRAPH_MAX_SAMPLES, always eager
+    m.encode(big), m.encode(big)
+    assert m._graphs == {}
+
+
 # ------------------------------------------------------------------------------------------ LM
 
 def build_lm(cfg, sd, weight_dtype=torch.float32):
