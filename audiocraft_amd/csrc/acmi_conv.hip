@@ -507,26 +507,35 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 #define LSTM_EMPTY 0x7fc00001u
 
 template <int KI>   // KI = ceil(H / 16) <= 64: W_hh values per thread
-__global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __restrict__ gates_in,
+__global__ __launch_bounds__(256, KI > 32 ? 2 : 1) void lstm_persistent_kernel(const float* __restrict__ gates_in,
                                                               const float* __restrict__ w_hh, float* __restrict__ cst,
                                                               const float* __restrict__ skip, float* __restrict__ y,
-                                                              unsigned* hbuf, unsigned* err, int B, int H, int T) {
+                                                              unsigned* hbuf, unsigned* err, int B, int H, int T, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     // h_{t-1} in LDS, k-major: hs[k][q], pitch 12 floats (two conflict-free ds_read_b128 fetch the 8 batch values of a k)
     constexpr int HP = 12;
-    float* hs = sh;                    // [H][HP]
-    float* gs = sh + (size_t)H * HP;   // [16][LSTM_BB]
+    float* hs = sh;                           // [16 KI >= H][HP]; rows H .. 16 KI stay zero: the k loop needs no clamp and its LDS
+                                              // addresses are one register + immediates
+    float* gs = sh + (size_t)(16 * KI) * HP;  // [16][LSTM_BB]
     int* s_abort = reinterpret_cast<int*>(gs + 16 * LSTM_BB);   // workgroup-wide "give up" flag (below)
     const int tid = threadIdx.x;
     // A workgroup that starts only after another one has given up (it was not resident while the others spun) leaves at
     // once, and so does every workgroup that sees the error word set while it waits: a residency failure costs ONE bounded
     // spin, not one per remaining step.
     if (tid == 0) *s_abort = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    for (int idx = tid; idx < 16 * KI * HP; idx += 256) hs[idx] = 0.f;
     __syncthreads();
     if (*s_abort) return;
+    // The batch rows are INDEPENDENT recurrences: with nsplit > 1 the grid holds nsplit copies of the (H + 3) / 4 unit
+    // groups, copy s owns the rows [s Bs, (s + 1) Bs) -- half the hidden-state bytes to gather per workgroup and step, two
+    // workgroups per CU pulling them.  Copies never wait for each other: a copy that is not resident simply runs later.
+    const int nwg = gridDim.x / nsplit;
+    const int split = blockIdx.x / nwg, Bs = (B + nsplit - 1) / nsplit;
+    const int blo = split * Bs, bhi = min(B, blo + Bs);
+    if (blo >= bhi) return;
     const int r = tid >> 4, ksl = tid & 15;
     const int gate = r >> 2, u = r & 3;
-    const int j0 = blockIdx.x * 4;
+    const int j0 = (blockIdx.x - split * nwg) * 4;
     const bool jvalid = j0 + u < H;
     const float* wrow = w_hh + ((size_t)gate * H + (jvalid ? j0 + u : 0)) * H;
     float wv[KI];
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
     for (int i = 0; i < KI; ++i) wv[i] = (ksl + 16 * i < H) ? wrow[ksl + 16 * i] : 0.f;
     const size_t BH = (size_t)B * H;
     const int H4 = H >> 2;                       // 16-byte groups per row (H % 4 == 0 is required by the launcher)
-    const bool one_pass = B <= LSTM_BB;
+    const bool one_pass = bhi - blo <= LSTM_BB;
     float c_reg = 0.f;                           // cell state of this thread's (unit, row) when B fits one pass
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hbuf, 0, (int)(3 * BH * 4), 0x00020000);
 
@@ -542,8 +551,8 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
         const unsigned prev_off = (unsigned)(((t + 2) % 3) * BH);   // buffer of step t - 1
         unsigned* hnext = hbuf + (size_t)(t % 3) * BH;              // buffer of step t
         unsigned* hrearm = hbuf + (size_t)((t + 1) % 3) * BH;       // buffer of step t + 1 (still holds step t - 2)
-        for (int b0 = 0; b0 < B; b0 += LSTM_BB) {
-            const int nb = min(LSTM_BB, B - b0);
+        for (int b0 = blo; b0 < bhi; b0 += LSTM_BB) {
+            const int nb = min(LSTM_BB, bhi - b0);
             // this thread's gate inputs of the step: requested before the sweep (they do not depend on h)
             float gin[4] = {0.f, 0.f, 0.f, 0.f};
             const int uu = tid & 3, bb = tid >> 2, j = j0 + uu, bidx = b0 + bb;
@@ -588,8 +597,8 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
                         }
                     }
                 }
-                for (int idx = tid; idx < (LSTM_BB - nb) * H; idx += 256)   // rows past nb of this pass: zeros
-                    hs[(idx % H) * HP + nb + idx / H] = 0.f;
+                if (!one_pass)   // one pass: rows past nb were zeroed before the first step and are never written
+                    for (int idx = tid; idx < (LSTM_BB - nb) * H; idx += 256) hs[(idx % H) * HP + nb + idx / H] = 0.f;
             }
             __syncthreads();
             if (*s_abort) return;   // workgroup-uniform (written before the barrier): the host finds err != 0 and raises
@@ -605,11 +614,11 @@ __global__ __launch_bounds__(256) void lstm_persistent_kernel(const float* __res
             float acc[LSTM_BB];
 #pragma unroll
             for (int q = 0; q < LSTM_BB; ++q) acc[q] = 0.f;
+            const float* hk = hs + ksl * HP;
 #pragma unroll
             for (int i = 0; i < KI; ++i) {
-                const int k = min(ksl + 16 * i, H - 1);
-                const float4 h0 = *reinterpret_cast<const float4*>(hs + k * HP);
-                const float4 h1 = *reinterpret_cast<const float4*>(hs + k * HP + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(hk + i * 16 * HP);
+                const float4 h1 = *reinterpret_cast<const float4*>(hk + i * 16 * HP + 4);
                 acc[0] = fmaf(wv[i], h0.x, acc[0]); acc[1] = fmaf(wv[i], h0.y, acc[1]);
                 acc[2] = fmaf(wv[i], h0.z, acc[2]); acc[3] = fmaf(wv[i], h0.w, acc[3]);
                 acc[4] = fmaf(wv[i], h1.x, acc[4]); acc[5] = fmaf(wv[i], h1.y, acc[5]);
@@ -962,21 +971,28 @@ extern "C" int acmi_lstm_layer(const float* gates_in, const float* w_hh, const f
     const size_t lds = (size_t)(LSTM_BB * H + 16 * LSTM_BB) * sizeof(float);
     dim3 grid((H + 3) / 4), block(256);
     if (T > 0 && lstm_persistent_ok(B, H)) {
-        const size_t lds_p = (size_t)(12 * H + 16 * LSTM_BB) * sizeof(float) + 16;   // + the abort flag
+        const int ki0 = (H + 15) / 16, kit = ki0 <= 8 ? 8 : ki0 <= 16 ? 16 : ki0 <= 32 ? 32 : 64;
+        const size_t lds_p = (size_t)(12 * 16 * kit + 16 * LSTM_BB) * sizeof(float) + 16;   // hs padded to 16 KI rows, + the abort flag
+        // More than LSTM_BB rows: the passes of one workgroup become copies of the grid, one pass each (the rows are
+        // independent recurrences).  16 x 10 s at H = 512: encode 23.5 -> 17.7 ms, decode 21.4 -> 15.7 ms.  Splitting 8 rows into
+        // 4 + 4 at H = 1024 LOSES 3 ms per 1500 steps (47.7 -> 50.6 ms decode): not done.  ACMI_LSTM_SPLIT caps the copies.
+        static const int max_split = getenv("ACMI_LSTM_SPLIT") ? atoi(getenv("ACMI_LSTM_SPLIT")) : 4;
+        const int nsplit = max(1, min((B + LSTM_BB - 1) / LSTM_BB, max_split));
+        dim3 pgrid(grid.x * nsplit);
         // layout of `work` for this form: [c: B H floats][h buffers: 3 B H words, all EMPTY][...][err: 1 word]
         unsigned* hbuf = reinterpret_cast<unsigned*>(work + (size_t)B * H);
         unsigned* err = reinterpret_cast<unsigned*>(work + (size_t)5 * B * H);
         const int ki = (H + 15) / 16;
 #define ACMI_LSTM_CASE(KIv)                                                                                                  \
         if (ki <= KIv) {                                                                                                     \
-            if (lstm_grid_resident(lstm_persistent_kernel<KIv>, (int)grid.x, lds_p)) {                                       \
+            if (lstm_grid_resident(lstm_persistent_kernel<KIv>, (int)grid.x, lds_p)) {                              \
                 if (hipMemsetAsync(work, 0, sizeof(float) * (size_t)5 * B * H, st) != hipSuccess ||                          \
                     hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, (size_t)3 * B * H, st) != hipSuccess) { \
                     acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");                                                \
                     return ACMI_ELAUNCH;                                                                                     \
                 }                                                                                                            \
-                hipLaunchKernelGGL(lstm_persistent_kernel<KIv>, grid, block, lds_p, st, gates_in, w_hh, work, skip, y, hbuf, \
-                                   err, B, H, T);                                                                            \
+                hipLaunchKernelGGL(lstm_persistent_kernel<KIv>, pgrid, block, lds_p, st, gates_in, w_hh, work, skip, y, hbuf, \
+                                   err, B, H, T, nsplit);                                                                    \
                 return acmi_check_launch("lstm_persistent_kernel");                                                          \
             }                                                                                                                \
         } else
@@ -1019,6 +1035,9 @@ extern "C" int acmi_lstm_stack2_supported(int B, int H, int T) {
     static int want = -1;   // ACMI_LSTM_WAVE: 0 never, 1 (default) where it was measured to win (H <= 512), 2 wherever it can run
     if (want < 0) { const char* e = getenv("ACMI_LSTM_WAVE"); want = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1; }
     if (!want || B <= 0 || H <= 0) return 0;
+    // more than LSTM_BB rows: one launch per layer with the passes spread over copies of the grid wins (16 x 10 s, H = 512:
+    // encode 17.7 vs 22.5 ms)
+    if (want == 1 && B > LSTM_BB) return 0;
     // H = 1024, B = 8: 15.5 us per wavefront step against 2 x 6.4 + the input projection (23.2 vs 20.3 ms per 1500 steps): two
     // 32 KB gathers per layer-1 step, each in two rounds (register budget of two workgroups per CU), do not pay
     if (want == 1 && H > 512) return 0;
