@@ -65,11 +65,12 @@ def main():
         uc = ombd.UnetConfig(**kw)
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         xs, cs = x[:1, :, :32000].cpu(), cond[:1, :, :50].cpu()
+        xg, cg = x[:1, :, :32000].contiguous(), cond[:1, :, :50].contiguous()
+        t_gpu1 = timed(lambda: m(xg, 500, cg), a.reps)      # before the host cores get busy (the launches are issued from Python)
         ombd.unet_forward(sd, uc, xs[..., :3200], 500, cs[..., :5])
         t0 = time.perf_counter()
         ombd.unet_forward(sd, uc, xs, 500, cs)
         t_cpu = time.perf_counter() - t0
-        t_gpu1 = timed(lambda: m(x[:1, :, :32000].contiguous(), 500, cond[:1, :, :50].contiguous()), a.reps)
         out['cpu_oracle_forward_1s_ms'] = t_cpu * 1e3
         out['gpu_forward_1s_ms'] = t_gpu1 * 1e3
         out['cpu_threads'] = torch.get_num_threads()
