@@ -38,6 +38,9 @@ struct ConvArgs {
     int nchunks, cin_pad;   // K chunks; Cin rounded up to whole chunks (rows of Xp per batch item)
     long long Qp;           // row pitch of Xp (floats, a multiple of 4)
     unsigned lp4_magic;     // ceil(2^32 / (LP / 4))
+    int ksplit;             // > 1: blockIdx.z = b * ksplit + part; part p multiplies the chunks [p cps, (p + 1) cps) into `part`
+    int cps;                // chunks per part
+    float* part;            // [ksplit][B][Cout rows][tq * 64] partial sums (GEMM layout)
 };
 
 // geometry shared by the weight tiler, the packer and the main kernel
@@ -46,6 +49,8 @@ struct ConvGeom {
     int cic, nchunks, KCE, KCP, LP, XSZ, Tq, tq, my;
     long long Qp;
     size_t wt_floats, work_floats, lds;
+    int ksplit;            // K parts of a launch that would not fill the chip otherwise
+    size_t pack_floats;    // work = [packed input: pack_floats][partial sums: ksplit * B * Cout * tq * 64 when ksplit > 1]
 };
 
 static int conv_geometry(const acmi_conv_desc& d, ConvGeom& g) {
@@ -60,7 +65,8 @@ static int conv_geometry(const acmi_conv_desc& d, ConvGeom& g) {
     if (g.fewout) {
         g.cic = g.nchunks = g.KCE = g.KCP = g.LP = g.XSZ = g.tq = g.my = 0; g.Qp = 0; g.lds = 0;
         g.wt_floats = (size_t)d.Cout * d.Cin * d.ksize;   // the raw weights
-        g.work_floats = 0;
+        g.work_floats = g.pack_floats = 0;
+        g.ksplit = 1;
         return ACMI_OK;
     }
     int cic = 128 / d.ksize;
@@ -83,7 +89,20 @@ static int conv_geometry(const acmi_conv_desc& d, ConvGeom& g) {
     g.my = (d.Cout + 63) / 64;
     g.Qp = (long long)((g.tq + 3) & ~3) * 64 + lp;   // every column tile a workgroup may touch, plus the halo
     g.wt_floats = (size_t)g.my * g.nchunks * 2 * 64 * g.KCP;
-    g.work_floats = (size_t)d.B * g.nchunks * cic * d.stride * (size_t)g.Qp;
+    g.pack_floats = (size_t)d.B * g.nchunks * cic * d.stride * (size_t)g.Qp;
+    // Few output tiles, long K (the 3072-wide U-Net convolutions on 1 s of audio: 96 workgroups x 74 chunks, 2.6 MB of weights
+    // each through one-phase-ahead staging = 0.25 ms): split K over up to 8 workgroups per tile, partial sums in GEMM layout,
+    // summed in a fixed order by conv_splitk_reduce_kernel (which also does the bias / skip / phase-interleave epilogue).
+    static const int ks_max = getenv("ACMI_CONV_KSPLIT") ? atoi(getenv("ACMI_CONV_KSPLIT")) : 8;
+    const long wgs1 = (long)g.tq * g.my * d.B;
+    g.ksplit = 1;
+    if (wgs1 > 0 && wgs1 < 640 && g.nchunks >= 8 && ks_max > 1) {
+        int ksp = (int)((1024 + wgs1 - 1) / wgs1);
+        if (ksp > ks_max) ksp = ks_max;
+        if (ksp > g.nchunks / 4) ksp = g.nchunks / 4;
+        if (ksp > 1) g.ksplit = ksp;
+    }
+    g.work_floats = g.pack_floats + (g.ksplit > 1 ? (size_t)g.ksplit * d.B * d.Cout * g.tq * 64 : 0);
     return ACMI_OK;
 }
 
@@ -166,7 +185,9 @@ __global__ __launch_bounds__(256, NTQ == 4 ? 2 : 3) void conv_mfma_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 31, kk = lane >> 5;
-    const int qb = blockIdx.x * 64 * NTQ, m0 = blockIdx.y * 64, b = blockIdx.z;
+    const int qb = blockIdx.x * 64 * NTQ, m0 = blockIdx.y * 64;
+    const int b = a.ksplit > 1 ? blockIdx.z / a.ksplit : blockIdx.z, kpart = a.ksplit > 1 ? blockIdx.z - b * a.ksplit : 0;
+    const int chunk_lo = kpart * a.cps, chunk_hi = min(a.nchunks, chunk_lo + a.cps);   // a.cps = nchunks when ksplit == 1
     const int KC = a.CIC * ks;
 
     for (int kl = tid; kl < a.KCE; kl += 256) {
@@ -224,10 +245,10 @@ __global__ __launch_bounds__(256, NTQ == 4 ? 2 : 3) void conv_mfma_kernel(const 
             if (j * 256 + tid < nx4) *reinterpret_cast<f32x4*>(Xs + (j * 256 + tid) * 4) = xreg[j];
     };
 
-    issue_w(0);
-    issue_x(0, 0);
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const int nchunk = min(chunk + 1, a.nchunks - 1);   // past the last chunk: a redundant (unused) prefetch of the last one
+    issue_w(min(chunk_lo, a.nchunks - 1));
+    issue_x(min(chunk_lo, a.nchunks - 1), 0);
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+        const int nchunk = min(chunk + 1, chunk_hi - 1);   // past the last chunk: a redundant (unused) prefetch of the last one
 #pragma unroll
         for (int t = 0; t < NTQ; ++t) {
             if (t >= ntl) break;       // block uniform: no column of this tile exists
@@ -268,6 +289,10 @@ __global__ __launch_bounds__(256, NTQ == 4 ? 2 : 3) void conv_mfma_kernel(const 
             const int mrow = m0 + wr * 32 + row;
             if (mrow >= d.Cout) continue;
             float v = acc[t][r];
+            if (a.ksplit > 1) {   // partial sum of this K part; q < tq * 64 always
+                a.part[(((size_t)kpart * d.B + b) * d.Cout + mrow) * ((size_t)gridDim.x * 64 * NTQ) + q] = v;
+                continue;
+            }
             if (d.shuffle <= 1) {
                 if (q < d.Tout) {
                     const size_t oi = ((size_t)b * d.Cout + mrow) * d.Tout + q;
@@ -285,6 +310,32 @@ __global__ __launch_bounds__(256, NTQ == 4 ? 2 : 3) void conv_mfma_kernel(const 
                     a.y[oi] = v;
                 }
             }
+        }
+    }
+}
+
+// sum of the K parts in part order + the epilogue of conv_mfma_kernel (bias, skip, transposed-conv trim + phase interleave)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a, int tqp) {
+    const acmi_conv_desc& d = a.d;
+    const int q = blockIdx.x * 256 + threadIdx.x, mrow = blockIdx.y, b = blockIdx.z;
+    if (q >= a.Tq) return;
+    float v = 0.f;
+    for (int p = 0; p < a.ksplit; ++p) v += a.part[(((size_t)p * d.B + b) * d.Cout + mrow) * (size_t)tqp + q];
+    if (d.shuffle <= 1) {
+        if (q < d.Tout) {
+            const size_t oi = ((size_t)b * d.Cout + mrow) * d.Tout + q;
+            if (a.bias) v += a.bias[mrow];
+            if (a.res) v += a.res[oi];
+            a.y[oi] = v;
+        }
+    } else {
+        const int co = mrow / d.shuffle, ph = mrow - co * d.shuffle;
+        const long long o = (long long)q * d.shuffle + ph - d.trim_left;
+        if (o >= 0 && o < d.Tout) {
+            const size_t oi = ((size_t)b * (d.Cout / d.shuffle) + co) * d.Tout + (size_t)o;
+            if (a.bias) v += a.bias[co];
+            if (a.res) v += a.res[oi];
+            a.y[oi] = v;
         }
     }
 }
@@ -392,6 +443,7 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     a.d = d; a.x = x; a.w = wt; a.bias = bias; a.res = residual; a.y = y;
     a.Tq = g.Tq; a.CIC = g.cic; a.KCE = g.KCE; a.KCP = g.KCP; a.LP = g.LP; a.XSZ = g.XSZ;
     a.nchunks = g.nchunks; a.cin_pad = g.nchunks * g.cic; a.Qp = g.Qp; a.lp4_magic = 0;
+    a.ksplit = 1; a.cps = g.nchunks; a.part = nullptr;
     if (g.fewout) {
         dim3 grid((d.Tout + 1023) / 1024, 1, d.B), block(256);
         if (d.Cout == 1) hipLaunchKernelGGL((conv_fewout_kernel<1, 7>), grid, block, 0, (hipStream_t)stream, a);
@@ -413,15 +465,26 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     // column tiles per workgroup: as many as keep >= 2 workgroups per CU in flight (4, 2 or 1); ACMI_CONV_NTQ forces one
     static const int want = getenv("ACMI_CONV_NTQ") ? atoi(getenv("ACMI_CONV_NTQ")) : 0;
     const long wgs = (long)g.tq * g.my * d.B;
-    const int ntq = want == 1 || want == 2 || want == 4 ? want : (wgs >= 4 * 512 ? 4 : (wgs >= 2 * 512 ? 2 : 1));
+    int ntq = want == 1 || want == 2 || want == 4 ? want : (wgs >= 4 * 512 ? 4 : (wgs >= 2 * 512 ? 2 : 1));
+    if (g.ksplit > 1) {
+        ntq = 1;
+        a.ksplit = g.ksplit; a.cps = (g.nchunks + g.ksplit - 1) / g.ksplit; a.part = work + g.pack_floats;
+        ACMI_REQUIRE((long)d.B * g.ksplit <= 65535 && d.Cout <= 65535, "acmi_conv1d: split-K grid too large");
+    }
     const int xv = (g.XSZ / 4 + 255) / 256;   // <= 6 by the 24 KB span budget
-    dim3 grid((g.tq + ntq - 1) / ntq, g.my, d.B), block(256);
+    dim3 grid((g.tq + ntq - 1) / ntq, g.my, d.B * a.ksplit), block(256);
 #define ACMI_CONV_LAUNCH(N, X) hipLaunchKernelGGL((conv_mfma_kernel<N, X>), grid, block, g.lds, (hipStream_t)stream, a)
 #define ACMI_CONV_LAUNCH_X(N)                                     \
     if (xv <= 2) ACMI_CONV_LAUNCH(N, 2); else if (xv <= 4) ACMI_CONV_LAUNCH(N, 4); else ACMI_CONV_LAUNCH(N, 6)
     if (ntq == 4) { ACMI_CONV_LAUNCH_X(4); } else if (ntq == 2) { ACMI_CONV_LAUNCH_X(2); } else { ACMI_CONV_LAUNCH_X(1); }
 #undef ACMI_CONV_LAUNCH_X
 #undef ACMI_CONV_LAUNCH
+    if (a.ksplit > 1) {
+        if (int rc = acmi_check_launch("conv_mfma_kernel")) return rc;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((g.Tq + 255) / 256, d.Cout, d.B), dim3(256), 0, (hipStream_t)stream, a,
+                           g.tq * 64);
+        return acmi_check_launch("conv_splitk_reduce_kernel");
+    }
     return acmi_check_launch("conv_mfma_kernel");
 }
 

@@ -43,6 +43,7 @@ log "attention microbench"
 python scripts/attn_bench.py > $O/attn_microbench.log 2>&1; tail -1 $O/attn_microbench.log | tee -a $O/progress.log
 log "codec bench + per-layer breakdown"
 python scripts/codec_bench.py > $O/codec_bench.jsonl 2> $O/codec_bench.err
+ACMI_CONV_KSPLIT=1 python scripts/codec_bench.py > $O/codec_bench_KSPLIT1.jsonl 2> /dev/null
 python scripts/codec_layers.py decode > $O/codec_layers_decode.log 2>&1
 python scripts/codec_layers.py encode > $O/codec_layers_encode.log 2>&1
 tail -1 $O/codec_layers_decode.log | tee -a $O/progress.log
@@ -67,6 +68,8 @@ done
 log "MultiBandDiffusion: cost + kernel stats"
 python scripts/mbd_bench.py --seconds 10 --cpu > $O/mbd_bench_10s.json 2> /dev/null; cat $O/mbd_bench_10s.json | tee -a $O/progress.log
 python scripts/mbd_bench.py --seconds 30 --batch 2 > $O/mbd_bench_30s_b2.json 2> /dev/null; cat $O/mbd_bench_30s_b2.json | tee -a $O/progress.log
+for sec in 1 3; do python scripts/mbd_bench.py --seconds $sec > $O/mbd_bench_${sec}s.json 2> /dev/null; ACMI_CONV_KSPLIT=1 python scripts/mbd_bench.py --seconds $sec > $O/mbd_bench_${sec}s_KSPLIT1.json 2> /dev/null; done
+cat $O/mbd_bench_1s.json $O/mbd_bench_1s_KSPLIT1.json | tee -a $O/progress.log
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt3 -- python $R/scripts/mbd_bench.py --seconds 10 --reps 3 > /dev/null 2>&1)
 cp $(find /tmp/kt3 -name "*kernel_stats.csv" | head -1) $O/mbd_kernel_stats.csv
 python scripts/short_names.py $O/mbd_kernel_stats.csv | head -10 | tee -a $O/progress.log
