@@ -48,6 +48,10 @@ def test_argument_validation_without_gpu():
     d.B, d.Cin, d.Tin, d.Cout, d.Tout, d.ksize = 2, 100, 1000, 70, 1000, 3
     assert lib.acmi_conv1d_weight_floats(ctypes.byref(d)) == 2 * 3 * 2 * 64 * 68      # 2 row tiles x 3 chunks x 2 parities x 64 x KCP
     assert lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 2 * 126 * (1024 + 68)       # B x Cin padded to whole chunks x (tiles + halo)
+    # few output tiles, long K: K split over 8 workgroups per tile, partial sums behind the packed input
+    d.B, d.Cin, d.Tin, d.Cout, d.Tout, d.ksize = 1, 3072, 125, 3072, 125, 3
+    assert lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 74 * 42 * (4 * 64 + 68) + 8 * 3072 * 2 * 64
+    d.B, d.Tin, d.Tout = 2, 1000, 1000
     d.Cout, d.Cin, d.ksize = 1, 64, 7      # the few-output kernel: raw weights, no scratch
     assert lib.acmi_conv1d_weight_floats(ctypes.byref(d)) == 64 * 7 and lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 0
     assert lib.acmi_lm_step(None, None, 0, None) == -1
