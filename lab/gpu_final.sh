@@ -66,7 +66,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python scripts/summarize_pmc.py $(find /tmp/pmcc_$c -name "*counter_collection.csv" | head -1) | grep -E "kernel,|conv_|lstm" > $O/conv_pmc_$c.csv
 done
 log "MultiBandDiffusion: cost + kernel stats"
-python scripts/mbd_bench.py --seconds 10 --cpu > $O/mbd_bench_10s.json 2> /dev/null; cat $O/mbd_bench_10s.json | tee -a $O/progress.log
+python scripts/mbd_bench.py --seconds 10 > $O/mbd_bench_10s.json 2> /dev/null; cat $O/mbd_bench_10s.json | tee -a $O/progress.log
 python scripts/mbd_bench.py --seconds 30 --batch 2 > $O/mbd_bench_30s_b2.json 2> /dev/null; cat $O/mbd_bench_30s_b2.json | tee -a $O/progress.log
 for sec in 1 3; do python scripts/mbd_bench.py --seconds $sec > $O/mbd_bench_${sec}s.json 2> /dev/null; ACMI_CONV_KSPLIT=1 python scripts/mbd_bench.py --seconds $sec > $O/mbd_bench_${sec}s_KSPLIT1.json 2> /dev/null; done
 cat $O/mbd_bench_1s.json $O/mbd_bench_1s_KSPLIT1.json | tee -a $O/progress.log

@@ -28,7 +28,7 @@ python scripts/codec_layers.py decode > $O/codec_layers_decode.log 2>&1
 python scripts/codec_layers.py encode > $O/codec_layers_encode.log 2>&1
 tail -1 $O/codec_layers_decode.log | tee -a $O/progress.log
 log "MultiBandDiffusion"
-python scripts/mbd_bench.py --seconds 10 --cpu > $O/mbd_bench_10s.json 2> /dev/null; cut -c1-330 $O/mbd_bench_10s.json | tee -a $O/progress.log
+python scripts/mbd_bench.py --seconds 10 > $O/mbd_bench_10s.json 2> /dev/null; cut -c1-330 $O/mbd_bench_10s.json | tee -a $O/progress.log
 for sec in 1 3; do python scripts/mbd_bench.py --seconds $sec > $O/mbd_bench_${sec}s.json 2> /dev/null; ACMI_CONV_KSPLIT=1 python scripts/mbd_bench.py --seconds $sec > $O/mbd_bench_${sec}s_KSPLIT1.json 2> /dev/null; done
 cut -c1-220 $O/mbd_bench_1s.json $O/mbd_bench_1s_KSPLIT1.json $O/mbd_bench_3s.json $O/mbd_bench_3s_KSPLIT1.json | tee -a $O/progress.log
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt3 -- python $R/scripts/mbd_bench.py --seconds 1 --reps 3 > /dev/null 2>&1)

@@ -1,8 +1,9 @@
 """MultiBandDiffusion cost at the released geometry (config/model/score/basic.yaml: hidden 48, depth 4, kernel 8, stride 4,
 growth 4; 128-d EnCodec condition at 50 Hz; 32 kHz): one U-Net forward, one reverse process of 20 steps, the 32-band EQ
-matching, and the oracle's U-Net forward on the host cores beside it.  Random weights, synthetic inputs.
+matching.  Random weights, synthetic inputs.  (The CPU side of the comparison -- the oracle's U-Net forward on the host cores --
+is timed by `python -m oracle.time_mbd`: test infrastructure, not imported here.)
 
-    python scripts/mbd_bench.py [--seconds 10] [--batch 1] [--cpu]     -> one JSON line
+    python scripts/mbd_bench.py [--seconds 10] [--batch 1]     -> one JSON line
 """
 import argparse
 import json
@@ -20,7 +21,6 @@ def main():
     ap.add_argument('--seconds', type=float, default=10.)
     ap.add_argument('--batch', type=int, default=1)
     ap.add_argument('--reps', type=int, default=5)
-    ap.add_argument('--cpu', action='store_true', help="also time the oracle's U-Net forward on the host (1 s of audio)")
     a = ap.parse_args()
     from audiocraft_amd.models.unet import DiffusionUnet
     from audiocraft_amd.modules.diffusion_schedule import MultiBandProcessor, NoiseSchedule, SplitBands
@@ -60,20 +60,6 @@ def main():
     out = {'workload': f'MBD U-Net (hidden 48, depth 4, growth 4) B={a.batch} {a.seconds:g} s @ 32 kHz', 'unet_forward_ms': t_fwd * 1e3,
            'reverse_process_20_steps_ms': t_proc * 1e3, 're_eq_32_bands_ms': t_eq * 1e3,
            'four_band_decode_rtf': a.batch * a.seconds / (4 * t_proc + t_eq)}
-    if a.cpu:
-        from oracle import mbd as ombd
-        uc = ombd.UnetConfig(**kw)
-        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-        xs, cs = x[:1, :, :32000].cpu(), cond[:1, :, :50].cpu()
-        xg, cg = x[:1, :, :32000].contiguous(), cond[:1, :, :50].contiguous()
-        t_gpu1 = timed(lambda: m(xg, 500, cg), a.reps)      # before the host cores get busy (the launches are issued from Python)
-        ombd.unet_forward(sd, uc, xs[..., :3200], 500, cs[..., :5])
-        t0 = time.perf_counter()
-        ombd.unet_forward(sd, uc, xs, 500, cs)
-        t_cpu = time.perf_counter() - t0
-        out['cpu_oracle_forward_1s_ms'] = t_cpu * 1e3
-        out['gpu_forward_1s_ms'] = t_gpu1 * 1e3
-        out['cpu_threads'] = torch.get_num_threads()
     print(json.dumps(out))
 
 
