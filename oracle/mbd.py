@@ -11,11 +11,12 @@
                         requirements.txt; absent here, restated from its published algorithm: windowed-sinc low-pass filters at
                         mel-spaced cut-offs, replicate padding, bands = differences of successive low-passes) -- PARITY UNPINNED
                         against the julius binary, checked against closed forms only (bands sum to the input)
-  multiband_generate, re_eq, tokens_to_wav
-                        audiocraft/models/multibanddiffusion.py:120-191
+  re_eq                 audiocraft/models/multibanddiffusion.py:150-164; MultiBandDiffusion.generate (:120-139) is the sum of
+                        generate_subsampled over the bands (composed in the tests)
 
-The reference's own modules (unet, diffusion_schedule with julius stubbed by this module's split_bands) generate the golden
-fixtures of tests/golden/mbd_*.npz (make_mbd_golden.py); oracle/validate_against_reference.py `mbd` re-checks at a larger size.
+The reference's own modules (unet, diffusion_schedule, and multibanddiffusion.py executed from its source text, with julius
+stubbed by this module's split_bands) generate the golden fixtures of tests/golden/mbd_*.npz (make_mbd_golden.py);
+oracle/validate_against_reference.py `mbd` re-checks at a larger size.
 """
 import math
 import typing as tp

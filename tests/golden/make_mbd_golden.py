@@ -9,6 +9,11 @@ reference (audiocraft/models/unet.py, audiocraft/modules/diffusion_schedule.py) 
                      MultiBandProcessor (4 bands) whose statistics are fixed, the reference's `torch.randn_like` draws
                      recorded (a device cannot share the CPU generator stream)
 
+  mbd_model.npz      MultiBandDiffusion.generate (two bands: two U-Nets, schedules and processors; initial noise and step noise
+                     draws recorded) and MultiBandDiffusion.re_eq (8 bands), run from the reference's own source file
+                     (audiocraft/models/multibanddiffusion.py; its imports of the solver / loader packages, which need
+                     third-party modules that are absent here and are not used by these two methods, replaced by placeholders)
+
 `julius` is absent here: the reference's MultiBandProcessor is given oracle.mbd.split_bands in its
 place, so these fixtures pin everything AROUND the band splitting (the processor's rescaling, the schedule, the U-Net) to
 the reference, and the band splitting itself stays parity-unpinned (oracle/mbd.py header).
@@ -101,7 +106,81 @@ def make_process():
             projected=proc.project_sample(out))
 
 
+def reference_mbd_classes():
+    """MultiBandDiffusion / DiffusionProcess executed from the reference's own source text.  Importing the module pulls
+    audiocraft.solvers (flashy, ...) and the hub loaders; neither is touched by `generate` / `re_eq`."""
+    from oracle import refstubs
+    src = open(os.path.join(refstubs.REF_ROOT, 'audiocraft', 'models', 'multibanddiffusion.py')).read()
+    lines = []
+    for line in src.splitlines():
+        if line.startswith('from .unet'):
+            line = 'from audiocraft.models.unet import DiffusionUnet'
+        elif line.startswith('from ..modules.diffusion_schedule'):
+            line = 'from audiocraft.modules.diffusion_schedule import NoiseSchedule'
+        elif line.startswith('from .encodec'):
+            line = 'CompressionModel = object'
+        elif line.startswith('from ..solvers.compression'):
+            line = 'CompressionSolver = None'
+        elif line.startswith('from .loaders'):
+            line = 'load_compression_model = load_diffusion_models = None'
+        lines.append(line)
+    ns: dict = {}
+    exec(compile('\n'.join(lines), 'reference:audiocraft/models/multibanddiffusion.py', 'exec'), ns)
+    return ns['MultiBandDiffusion'], ns['DiffusionProcess']
+
+
+class _Codec:
+    """what MultiBandDiffusion.__init__ / generate / re_eq read from the compression model"""
+    sample_rate, frame_rate, channels = 16000, 50, 1
+
+    def parameters(self):
+        return iter([torch.zeros(1)])
+
+
+def make_model():
+    MultiBandDiffusion, DiffusionProcess = reference_mbd_classes()
+    cfg = dict(UNET, res_blocks=1)
+    sched = dict(beta_t0=1e-4, beta_t1=0.1, beta_exp=1., num_steps=100, variance='beta', clip=5., rescale=1., noise_scale=1.0)
+    g = torch.Generator().manual_seed(17)
+    DPs, sds, pstates = [], {}, {}
+    for i in range(2):
+        m = build_unet(cfg, 20 + i)
+        proc = MultiBandProcessor(n_bands=2, sample_rate=16000, num_samples=1, power_std=1.0)
+        with torch.no_grad():
+            proc.counts.fill_(5.)
+            proc.sum_x.copy_(5 * 0.01 * torch.randn(2, generator=g))
+            proc.sum_x2.copy_(5 * (0.5 + torch.rand(2, generator=g)))
+            proc.sum_target_x2.copy_(5 * (0.5 + torch.rand(2, generator=g)))
+        DPs.append(DiffusionProcess(model=m, noise_schedule=NoiseSchedule(**sched, sample_processor=proc, device='cpu')))
+        sds.update({f'dp{i}.{k}': v for k, v in m.state_dict().items()})
+        pstates.update({f'proc{i}_{k}': getattr(proc, k) for k in ('counts', 'sum_x', 'sum_x2', 'sum_target_x2')})
+    mbd = MultiBandDiffusion(DPs=DPs, codec_model=_Codec())
+    emb = torch.randn(2, cfg['codec_dim'], 6, generator=g)
+    step_list = [99, 66, 33, 0]
+    draws = []
+    real_randn_like = torch.randn_like
+
+    def recorded(t, *a, **k):
+        draws.append(torch.randn(t.shape, generator=g))
+        return draws[-1]
+    torch.randn_like = recorded
+    try:
+        with torch.no_grad():
+            wav = mbd.generate(emb, step_list=step_list)
+    finally:
+        torch.randn_like = real_randn_like
+    ref = 0.3 * torch.randn(wav.shape, generator=g)
+    with torch.no_grad():
+        eq = mbd.re_eq(wav, ref, n_bands=8)
+        eq_half = mbd.re_eq(wav, ref, n_bands=8, strictness=0.5)
+    full = dict(cfg, schedule=sched, processor=dict(n_bands=2, sample_rate=16000, power_std=1.0), step_list=step_list,
+                draws_per_band=len(draws) // 2)
+    mg.save('mbd_model', full, sds, emb=emb, draws=torch.stack(draws), generated=wav, reference_wav=ref, re_eq=eq, re_eq_half=eq_half,
+            **pstates)
+
+
 if __name__ == '__main__':
+    make_model()
     make_unet('mbd_unet', UNET, 3)
     make_unet('mbd_unet_bilstm', dict(UNET, bilstm=True, res_blocks=1), 4)
     make_process()

@@ -331,6 +331,42 @@ def test_multibanddiffusion_tokens_to_wav_vs_oracle(C):
     assert out.shape[0] == 1 and out.shape[-1] == cond.shape[-1] * int(codec.sample_rate / codec.frame_rate) and torch.isfinite(out).all()
 
 
+def test_multibanddiffusion_vs_reference_golden(C):
+    """MultiBandDiffusion.generate + re_eq against the fixture made by the reference's own multibanddiffusion.py
+    (tests/golden/mbd_model.npz): two bands, initial and step noise replayed through the `noise_source` hooks."""
+    from audiocraft_amd.models.multibanddiffusion import DiffusionProcess, MultiBandDiffusion
+    from audiocraft_amd.modules.diffusion_schedule import MultiBandProcessor, NoiseSchedule
+    cfg, sd, a = load_golden('mbd_model')
+    n, pc = cfg['draws_per_band'], cfg['processor']
+
+    class Codec(torch.nn.Module):   # what MultiBandDiffusion reads from the compression model
+        sample_rate, frame_rate, channels = 16000, 50, 1
+
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+    DPs, inits = [], []
+    for i in range(2):
+        m = _unet(cfg, {k[len(f'dp{i}.'):]: v for k, v in sd.items() if k.startswith(f'dp{i}.')})
+        proc = MultiBandProcessor(n_bands=pc['n_bands'], sample_rate=pc['sample_rate'], num_samples=1, power_std=pc['power_std'])
+        proc.load_state_dict({k: a[f'proc{i}_{k}'] for k in ('counts', 'sum_x', 'sum_x2', 'sum_target_x2')})
+        sched = NoiseSchedule(**cfg['schedule'], sample_processor=proc.cuda())
+        d = [t.cuda() for t in a['draws'][i * n:(i + 1) * n]]
+        inits.append(d[0])
+        sched.noise_source = (lambda p: (lambda like: p.pop(0)))(d[1:])
+        DPs.append(DiffusionProcess(m, sched))
+    mbd = MultiBandDiffusion(DPs, Codec().cuda())
+    mbd.noise_source = lambda like: inits.pop(0)
+    wav = mbd.generate(a['emb'].cuda(), step_list=cfg['step_list'])
+    assert wav.shape == a['generated'].shape
+    assert torch.allclose(wav.cpu(), a['generated'], atol=5e-5, rtol=1e-4), (wav.cpu() - a['generated']).abs().max()
+    eq = mbd.re_eq(a['generated'].cuda(), a['reference_wav'].cuda(), n_bands=8).cpu()
+    assert rel(eq, a['re_eq']) < 1e-5, rel(eq, a['re_eq'])
+    eq_half = mbd.re_eq(a['generated'].cuda(), a['reference_wav'].cuda(), n_bands=8, strictness=0.5).cpu()
+    assert rel(eq_half, a['re_eq_half']) < 1e-5
+
+
 def test_load_diffusion_models_roundtrip(C, tmp_path):
     """loaders.load_diffusion_models on a package in the release layout ({'sample_rate', 'n_bands', i: {cfg, model_state,
     processor_state}}) written from reference-format state dicts."""

@@ -260,6 +260,36 @@ def test_oracle_mbd_process_vs_reference_golden():
     assert torch.allclose(ombd.project_sample(ps, a['sample']), a['projected'], atol=2e-5, rtol=1e-4)
 
 
+def _mbd_model_parts(cfg, sd, a):
+    from oracle import mbd as ombd
+    uc, sc = _mbd_cfg(cfg), ombd.ScheduleConfig(**cfg['schedule'])
+    n = cfg['draws_per_band']
+    parts = []
+    for i in range(2):
+        sdi = {k[len(f'dp{i}.'):]: v for k, v in sd.items() if k.startswith(f'dp{i}.')}
+        ps = ombd.ProcessorState(n_bands=cfg['processor']['n_bands'], sample_rate=cfg['processor']['sample_rate'],
+                                 power_std=cfg['processor']['power_std'], counts=a[f'proc{i}_counts'], sum_x=a[f'proc{i}_sum_x'],
+                                 sum_x2=a[f'proc{i}_sum_x2'], sum_target_x2=a[f'proc{i}_sum_target_x2'])
+        parts.append((sdi, uc, sc, ps, a['draws'][i * n:(i + 1) * n]))
+    return parts
+
+
+def test_oracle_mbd_model_vs_reference_golden():
+    """MultiBandDiffusion.generate (sum over two bands' reverse processes, initial and step noise replayed) and re_eq == the
+    reference's own multibanddiffusion.py (tests/golden/make_mbd_golden.py: make_model)."""
+    from oracle import mbd as ombd
+    cfg, sd, a = load_golden('mbd_model')
+    total = torch.zeros_like(a['generated'])
+    for sdi, uc, sc, ps, d in _mbd_model_parts(cfg, sd, a):
+        model = (lambda sdi, uc: (lambda x, step, cond: ombd.unet_forward(sdi, uc, x, step, cond)))(sdi, uc)
+        total = total + ombd.generate_subsampled(model, sc, d[0], cfg['step_list'], a['emb'], list(d[1:]), ps)
+    assert torch.allclose(total, a['generated'], atol=2e-5, rtol=1e-4), (total - a['generated']).abs().max()
+    eq = ombd.re_eq(a['generated'], a['reference_wav'], 16000, n_bands=8)
+    assert torch.allclose(eq, a['re_eq'], atol=2e-5, rtol=1e-4), (eq - a['re_eq']).abs().max()
+    eq_half = ombd.re_eq(a['generated'], a['reference_wav'], 16000, n_bands=8, strictness=0.5)
+    assert torch.allclose(eq_half, a['re_eq_half'], atol=2e-5, rtol=1e-4)
+
+
 def test_oracle_split_bands_closed_forms():
     """julius.SplitBands restated (parity-unpinned against the binary): the bands sum to the input exactly, a constant
     signal lives in band 0 only, a tone near Nyquist lives in the last band."""
