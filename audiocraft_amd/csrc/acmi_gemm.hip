@@ -336,6 +336,13 @@ struct TlLate {
     const float* psh; const float* posh;
 };
 
+// stamps of the in-kernel timeline (acmi_lm_internal.h); empty in the production build
+struct TlTrace {
+#ifdef ACMI_TRACE
+    unsigned long long t[ACMI_TRACE_NSTAMP];
+#endif
+};
+
 // LDS-DMA form of the weight stream (A/B variant, ACMI_LIN_DMA=1): the fragment goes global -> LDS without passing through
 // VGPRs (global_load_lds_dwordx4, 1 KB per wave instruction, non-temporal), into the workgroup's LDS image of its weight
 // slice at the fragment's own slot; the wave that requested it reads it back (ds_read_b128, lane linear) once its vmcnt
@@ -347,7 +354,7 @@ __device__ __forceinline__ void glds_frag_nt(const u32x4* gsrc_lane, unsigned ch
 
 template <typename WT, int MT, int LN, int NT, int NS, int C, bool DMA, typename LateFn>
 __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, int kc0, int ks, int np,
-                                         const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex,
+                                         const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex, TlTrace& tr,
                                          unsigned char* wl = nullptr, int kloc0 = 0, int kcs = 0) {
     constexpr bool HL = LN == 2 || LN == 3;
     const int lane = threadIdx.x & 63;
@@ -410,6 +417,17 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
     ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos; ex.sh = *L.psh; ex.osh = *L.posh;
     __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA writes (and everything else) have landed
+#ifdef ACMI_TRACE
+    {   // requests in flight, oldest first: NT C weight fragments, then MT C (x 2 with a lo term) activation fragments, the
+        // statistics partials and the six epilogue operands
+        constexpr int NWQ = DMA ? 0 : NT * C, NREST = MT * C * (HL ? 2 : 1) + ((LN == 1 || LN == 2) ? NS : 0) + 6;
+        constexpr int ALL1 = NWQ + NREST - 1 > 63 ? 63 : NWQ + NREST - 1, REST = NREST > 63 ? 63 : NREST;
+        ACMI_TR(tr.t, 1);
+        ACMI_TR_WAIT_VM(ALL1); ACMI_TR(tr.t, 2);
+        ACMI_TR_WAIT_VM(REST); ACMI_TR(tr.t, 3);
+        ACMI_TR_WAIT_VM(0); ACMI_TR(tr.t, 4);
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < C; ++i)
 #pragma unroll
@@ -435,7 +453,8 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 // row block, merged at the end by a rotation of 8 lanes.  No LayerNorm variants: the producers of x are plain GEMMs.
 template <typename WT, int MT, int C, bool DMA, typename LateFn>
 __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __restrict__ wt, int ku0, const LateFn& late_fn,
-                                            f32x4 (&acc)[2 * MT], TlExtras& ex, unsigned char* wl = nullptr, int kloc0 = 0) {
+                                            f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr, unsigned char* wl = nullptr,
+                                            int kloc0 = 0) {
     const int lane = threadIdx.x & 63;
     u32x4 bv[DMA ? 1 : C], av[MT][2 * C];
 #pragma unroll
@@ -459,6 +478,16 @@ __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __res
     ex.bias = *pb; ex.res = *pr; ex.osh = *L.posh;
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ACMI_TRACE
+    {
+        constexpr int NWQ = DMA ? 0 : C, NREST = MT * 2 * C + 3;
+        constexpr int ALL1 = NWQ + NREST - 1 > 63 ? 63 : NWQ + NREST - 1, REST = NREST > 63 ? 63 : NREST;
+        ACMI_TR(tr.t, 1);
+        ACMI_TR_WAIT_VM(ALL1); ACMI_TR(tr.t, 2);
+        ACMI_TR_WAIT_VM(REST); ACMI_TR(tr.t, 3);
+        ACMI_TR_WAIT_VM(0); ACMI_TR(tr.t, 4);
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         u32x4 b;
@@ -489,6 +518,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
                            : (HT ? 52 / (1 + 2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (NT + MT * D)));
     constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TlTrace tr{};
+    ACMI_TR(tr.t, 0);
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
     float* red = reinterpret_cast<float*>(smem);        // [NT MT][nw][256] partial accumulators
@@ -540,8 +571,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         int kc = kbeg + wave * p.fpw, rem = p.fpw;
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            if constexpr (HT) tl_chunk_ht<WT, MT, Cn, DMA>(p, wt, kc, late, accs, ex, wl, kc - kbeg);                   \
-            else tl_chunk<WT, MT, LN, NT, NS, Cn, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, wl, kc - kbeg, kcs);      \
+            if constexpr (HT) tl_chunk_ht<WT, MT, Cn, DMA>(p, wt, kc, late, accs, ex, tr, wl, kc - kbeg);               \
+            else tl_chunk<WT, MT, LN, NT, NS, Cn, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, tr, wl, kc - kbeg, kcs);  \
             kc += Cn * ks; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -555,8 +586,8 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
 #undef ACMI_TL_RUN
         kc = kbeg + nw * p.fpw + wave;
         if (kc < kbeg + kcs) {  // ragged tail: the first kcs % nw waves own one more fragment
-            if constexpr (HT) tl_chunk_ht<WT, MT, 1, DMA>(p, wt, kc, late, accs, ex, wl, kc - kbeg);
-            else tl_chunk<WT, MT, LN, NT, NS, 1, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, wl, kc - kbeg, kcs);
+            if constexpr (HT) tl_chunk_ht<WT, MT, 1, DMA>(p, wt, kc, late, accs, ex, tr, wl, kc - kbeg);
+            else tl_chunk<WT, MT, LN, NT, NS, 1, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, tr, wl, kc - kbeg, kcs);
         }
         if constexpr (HT) {  // columns 0-7 of the even accumulators + columns 8-15 of the odd ones, rotated onto 0-7
 #pragma unroll
@@ -589,7 +620,9 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
                                    (wmean && row < p.M) ? p.mean_out + row : nullptr);
             }
         }
+        ACMI_TR(tr.t, 5);
         __syncthreads();
+        ACMI_TR(tr.t, 6);
 
         // ---- epilogue: one output element per thread and pass
         for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += (int)blockDim.x) {
@@ -666,6 +699,19 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
                 reinterpret_cast<float*>(p.out)[oi] = v;
             }
         }
+#ifdef ACMI_TRACE
+        ACMI_TR(tr.t, 7);
+        ACMI_TR_WAIT_VM(0);
+        ACMI_TR(tr.t, 8);
+        if (p.trace != nullptr && lane == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            tr.t[9] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+            unsigned long long* dst = p.trace + (wg * nw + wave) * ACMI_TRACE_NSTAMP;
+#pragma unroll
+            for (int i = 0; i < ACMI_TRACE_NSTAMP; ++i) dst[i] = tr.t[i];
+        }
+#endif
     }
 }
 
@@ -683,6 +729,39 @@ __global__ __launch_bounds__(512) void lin_pair_kernel(const LinArgs p0, const L
     if ((int)blockIdx.x < tiles0) tl_body<WT, MT, 0, 1, 8, false, DMA>(p0, (int)blockIdx.x, 0, 1);
     else tl_body<WT, MT, LNB, 1, 8, false, DMA>(p1, (int)blockIdx.x - tiles0, 0, 1);
 }
+
+#ifdef ACMI_TRACE
+// Host side of the timeline: acmi_trace_config hands over a device buffer and restarts the launch index; every GEMM launch
+// of the decode step then reserves [workgroups][waves][ACMI_TRACE_NSTAMP] words of it (in launch order) and is described
+// by acmi_trace_info.  Captured into a hipGraph, a launch keeps its region: each replay overwrites the previous one's stamps.
+struct TraceRec { long long off; int kind, wgs, waves, N, K, M; };
+static unsigned long long* g_trace_buf = nullptr;
+static long long g_trace_cap = 0, g_trace_used = 0;
+static TraceRec g_trace_rec[1024];
+static int g_trace_n = 0;
+unsigned long long* acmi_trace_reserve(int kind, int wgs, int waves, int N, int K, int M) {
+    const long long need = (long long)wgs * waves * ACMI_TRACE_NSTAMP;
+    if (g_trace_buf == nullptr || g_trace_n >= 1024 || g_trace_used + need > g_trace_cap) return nullptr;
+    g_trace_rec[g_trace_n++] = TraceRec{g_trace_used, kind, wgs, waves, N, K, M};
+    unsigned long long* r = g_trace_buf + g_trace_used;
+    g_trace_used += need;
+    return r;
+}
+extern "C" int acmi_trace_config(unsigned long long* buf, long long capacity_words) {
+    g_trace_buf = buf; g_trace_cap = capacity_words; g_trace_used = 0; g_trace_n = 0;
+    return ACMI_OK;
+}
+extern "C" int acmi_trace_count() { return g_trace_n; }
+// out[0..7] = word offset (lo, hi), kind, workgroups, waves, N, K, M.  kind: bit 0 folded LayerNorm, bit 1 QKV scatter,
+// bit 2 half-tile workgroups, bit 3 paired launch, bit 4 produces x (statistics + fragments), bits 8.. features per workgroup
+extern "C" int acmi_trace_info(int i, int* out) {
+    if (i < 0 || i >= g_trace_n) return ACMI_EINVAL;
+    const TraceRec& r = g_trace_rec[i];
+    out[0] = (int)(r.off & 0xffffffffll); out[1] = (int)(r.off >> 32); out[2] = r.kind; out[3] = r.wgs; out[4] = r.waves;
+    out[5] = r.N; out[6] = r.K; out[7] = r.M;
+    return ACMI_OK;
+}
+#endif
 
 // Workgroup size.  (1) Waves are not free: the dispatcher starts ~1.25 waves / ns (a 288-workgroup x 16-wave
 // launch with no loads at all takes 6.2 us), so a wave should own ~12 fragments or more, all of them requested
@@ -733,6 +812,10 @@ static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st
             attr_set = true;
         }
     }
+#ifdef ACMI_TRACE
+    a.trace = acmi_trace_reserve((LN == 1 || LN == 2) | (a.qkv ? 2 : 0) | (HT ? 4 : 0) | (a.xt_hi != nullptr ? 16 : 0) | ((HT ? 8 : 16 * NT) << 8),
+                                 gx * a.ksplit * ((a.M + 16 * MT - 1) / (16 * MT)), nw, a.N, a.K, a.M);
+#endif
     hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT, DMA>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
                        dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_tiled_kernel");
@@ -815,6 +898,9 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
     const int mt = p0.M > 32 ? 4 : (p0.M > 16 ? 2 : 1);
     const size_t lds = (size_t)mt * nw * 1024 + (size_t)mt * 128;
     const dim3 grid(t0 + t1, 1, (p0.M + 16 * mt - 1) / (16 * mt)), block(nw * 64);
+#ifdef ACMI_TRACE
+    p0.trace = p1.trace = acmi_trace_reserve(8 | 16 | (16 << 8), (int)(grid.x * grid.z), nw, p0.N + p1.N, p0.K, p0.M);
+#endif
     if (mt == 1 && !hl && lin_dma_wanted()) {   // LDS-DMA form (A/B): both halves keep their weight slice's image in LDS
         const size_t lds_dma = lds + (size_t)(p0.NKC > p1.NKC ? p0.NKC : p1.NKC) * 1024;
         static bool attr_set = false;

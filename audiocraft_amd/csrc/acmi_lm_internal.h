@@ -37,7 +37,28 @@ struct LinArgs {
     int rpp;      // QKV scatter: rows per position (row gm = position gm / rpp of the call, cache row gm % rpp)
     // single-term raw activations with a per-row shift (include/acmi.h, acmi_linear_desc.a_shift / xt_shift / mean_out)
     const float* a_shift; const float* xt_shift; float* mean_out;
+#ifdef ACMI_TRACE
+    unsigned long long* trace;   // this launch's stamps [workgroup][wave][ACMI_TRACE_NSTAMP] (NULL: not recorded)
+#endif
 };
+
+// ---- in-kernel timeline of the decode step's GEMM launches (libacmi_trace.so only: -DACMI_TRACE, scripts/lin_timeline.py).
+// Every wave stamps s_memrealtime (the chip-wide constant-rate clock) at fixed phases of tl_body and lane 0 stores the
+// stamps when the wave ends; the production library carries none of this.
+//   0 wave entry                      1 every request issued            2 first weight fragment landed
+//   3 all weight fragments landed     4 activation / statistics / epilogue operands landed (vmcnt 0)
+//   5 MFMAs done, partial sums and row statistics in LDS (before the barrier)        6 barrier passed
+//   7 epilogue stores issued          8 stores retired (vmcnt 0)        9 HW_ID | XCC_ID << 32
+#ifdef ACMI_TRACE
+#define ACMI_TRACE_NSTAMP 10
+#define ACMI_TR_PIN() __builtin_amdgcn_sched_barrier(0)
+#define ACMI_TR(T, i) do { ACMI_TR_PIN(); (T)[i] = __builtin_amdgcn_s_memrealtime(); ACMI_TR_PIN(); } while (0)
+#define ACMI_TR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+unsigned long long* acmi_trace_reserve(int kind, int wgs, int waves, int N, int K, int M);   // host: next launch's region or NULL
+#else
+#define ACMI_TR(T, i) do { } while (0)
+#define ACMI_TR_WAIT_VM(n) do { } while (0)
+#endif
 
 template <typename WT> struct WTr {
     static constexpr int EPL = 16 / (int)sizeof(WT);  // elements per lane of a fragment
