@@ -5,6 +5,7 @@ Build it with `python -c "import __graft_entry__ as g; g.build()"` or `python -m
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -224,18 +225,19 @@ _lstm2_ok = _sig('acmi_lstm_stack2_supported', [i32] * 3)
 
 # LSTM give-up words whose host-side check is postponed (a list while a hipGraph capture is running: reading a device word
 # synchronises, which a capture forbids; the owner of the capture checks them after each replay), else None
-_deferred_lstm_checks = None
+# (per thread: another thread running an LSTM while this one captures must keep its own immediate check)
+_lstm_tls = threading.local()
 
 
 def defer_lstm_checks(sink):
-    global _deferred_lstm_checks
-    _deferred_lstm_checks = sink
+    _lstm_tls.sink = sink
 
 
 def lstm_check(err_word: torch.Tensor, what: str):
     """err_word: the [1+] int32/f32 view whose first word counts the persistent kernels' bounded-spin give-ups."""
-    if _deferred_lstm_checks is not None:
-        _deferred_lstm_checks.append((err_word, what))
+    sink = getattr(_lstm_tls, 'sink', None)
+    if sink is not None:
+        sink.append((err_word, what))
         return
     if int(err_word.view(torch.int32)[0]) != 0:
         raise AcmiError(f"{what}: the persistent LSTM kernel gave up waiting for a workgroup (set ACMI_LSTM_WAVE=0 for one launch "

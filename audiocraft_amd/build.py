@@ -26,6 +26,11 @@ def _hipcc() -> str:
 
 
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', '-ffp-contract=off']
+# Kernarg preload (gfx950): the leading scalar / pointer arguments of a kernel arrive in SGPRs at wave start (up to 14
+# dwords) instead of through scalar loads of a kernarg block that is cold on every launch of the decode chain; the
+# kernels of these files are written for it (acmi_gemm.hip: TlHot).  Firmware without the feature runs the compiler's
+# compatibility prologue, which loads the same registers.
+FILE_FLAGS = {'acmi_gemm.hip': ['-mllvm', '-amdgpu-kernarg-preload-count=14']}
 OBJDIR = os.path.join(CSRC, 'build')
 
 
@@ -54,7 +59,7 @@ def build(force: bool = False, verbose: bool = True, out: str = OUT, defines=())
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + tag + '.o')
         path = os.path.join(CSRC, src)
         if force or _stale(obj, [path] + HEADERS):
-            cmd = [_hipcc()] + FLAGS + inc + ['-c', path, '-o', obj]
+            cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + inc + ['-c', path, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -329,12 +329,57 @@ struct TlExtras {
     float sh, osh;            // shift of this lane's statistics row (consumer) / of this thread's first output row (producer)
 };
 
-// everything a chunk needs besides the weight stream; evaluated AFTER the weight requests are out (see tl_chunk)
+// What a wave needs to put its weight, activation and statistics requests on their way: the kernels' leading scalar
+// arguments.  With -mllvm -amdgpu-kernarg-preload-count=14 (audiocraft_amd/build.py) the command processor hands them
+// over in SGPRs at wave start, so a wave's first HBM request is ~30 instructions from its entry.  Everything else -- the
+// LinArgs block, by value BEHIND them in the kernarg segment -- is read with scalar loads issued after the weight
+// requests (tl_load_args): a decode position is ~340 launches whose kernarg blocks are each read once per replay,
+// ~3 GB of traffic after their previous use, i.e. cold in the scalar cache and in L2, and hipcc's own prologue fetched
+// the 320-byte block in three DEPENDENT s_load rounds (SGPR pressure) in front of the first weight request of every
+// wave (lab/kernarg_lab.hip prices a round).
+struct TlHot {
+    const u32x4* w; const u32x4* a; const float* a_stats; const float* a_shift;
+    int NKC, kcs, fpw, nw, ksp, a_rbs, M, a_np;
+};
+#define ACMI_AS4 __attribute__((address_space(4)))
+#define ACMI_TL_ARGS_OFF 48        // byte offset of the LinArgs block in the kernarg segment of lin_tiled_kernel
+#define ACMI_TL_ARGS_OFF_PAIR 56   // ... of the first of the two blocks of lin_pair_kernel
+static_assert(alignof(LinArgs) == 8 && sizeof(LinArgs) % 8 == 0, "kernarg layout of lin_tiled_kernel / lin_pair_kernel");
+
+__device__ __forceinline__ TlHot tl_unpack(const u32x4* w, const u32x4* a, const float* st, const float* sh, unsigned g0,
+                                           unsigned g1, unsigned g2, unsigned g3) {
+    TlHot h;
+    h.w = w; h.a = a; h.a_stats = st; h.a_shift = sh;
+    h.NKC = (int)(g0 & 0xffffu); h.kcs = (int)(g0 >> 16);
+    h.fpw = (int)(g1 & 0xfffu); h.nw = (int)((g1 >> 12) & 0xfu); h.ksp = (int)(g1 >> 16);
+    h.a_rbs = (int)(g2 & 0xffffu); h.M = (int)(g2 >> 16); h.a_np = (int)g3;
+    return h;
+}
+// the LinArgs block at byte `aoff` of the kernarg segment, read where this is called (`z`: an opaque zero produced behind the
+// weight requests -- the loads depend on it and cannot be hoisted in front of them)
+__device__ __forceinline__ void tl_load_args(LinArgs& p, int aoff, int z) {
+    const char ACMI_AS4* ka = (const char ACMI_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+    const void ACMI_AS4* src = (const void ACMI_AS4*)__builtin_assume_aligned((const void ACMI_AS4*)(ka + (aoff + z)), 8);
+    __builtin_memcpy(&p, src, sizeof(LinArgs));
+}
+// one word of every 64-byte line of that block: later scalar loads of its fields (the epilogue's) hit the scalar cache
+__device__ __forceinline__ void tl_touch_args(int aoff, int z) {
+    const char ACMI_AS4* ka = (const char ACMI_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int ACMI_AS4* src = (const int ACMI_AS4*)__builtin_assume_aligned((const void ACMI_AS4*)(ka + (aoff + z)), 8);
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < (int)sizeof(LinArgs) / 4; i += 16) acc |= src[i];
+    acc |= src[(int)sizeof(LinArgs) / 4 - 1];
+    asm volatile("" :: "s"(acc));
+}
+
+// addresses of a chunk's activation / statistics requests (from TlHot, or from LinArgs for the lo term) and of the
+// epilogue operands (from LinArgs); evaluated AFTER the weight requests are out (see tl_chunk)
 struct TlLate {
     const u32x4* at; const u32x4* al; int mts, mtl, mtv;
-    const float* st_ptr; const float* pb; const float* pc; const float* pr; const int* ppos;
-    const float* psh; const float* posh;
+    const float* st_ptr; const float* psh;
 };
+struct TlEpi { const float* pb; const float* pc; const float* pr; const int* ppos; const float* posh; };
 
 // stamps of the in-kernel timeline (acmi_lm_internal.h); empty in the production build
 struct TlTrace {
@@ -352,13 +397,13 @@ __device__ __forceinline__ void glds_frag_nt(const u32x4* gsrc_lane, unsigned ch
                                      (__attribute__((address_space(3))) void*)lds_slot, 16, 0, 2 /* nt */);
 }
 
-template <typename WT, int MT, int LN, int NT, int NS, int C, bool DMA, typename LateFn>
-__device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restrict__ wt, int kc0, int ks, int np,
-                                         const LateFn& late_fn, f32x4 (&acc)[NT * MT], TlExtras& ex, TlTrace& tr,
-                                         unsigned char* wl = nullptr, int kloc0 = 0, int kcs = 0) {
+template <typename WT, int MT, int LN, int NT, int NS, int C, bool DMA, typename LateFn, typename EpiFn>
+__device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int aoff, const u32x4* __restrict__ wt, int kc0, int ks,
+                                         int np, const LateFn& late_fn, const EpiFn& epi_fn, f32x4 (&acc)[NT * MT], TlExtras& ex,
+                                         TlTrace& tr, unsigned char* wl = nullptr, int kloc0 = 0, int kcs = 0) {
     constexpr bool HL = LN == 2 || LN == 3;
     const int lane = threadIdx.x & 63;
-    const int wts = p.NKC * 64;  // fragment lanes between the NT adjacent n-tiles of this workgroup
+    const int wts = h.NKC * 64;  // fragment lanes between the NT adjacent n-tiles of this workgroup
     u32x4 bv[DMA ? 1 : NT][DMA ? 1 : C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
     // Request order: all weight fragments first -- they come from HBM, the activation fragments from L2, and the HBM
     // requests should be on their way as early as possible (FFN2 10.5 -> 9.9 us; whole position 2.57 -> 2.50 ms; with
@@ -375,19 +420,20 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
                 else bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
             }
         }
-        // The weight requests need four kernel arguments and ~20 instructions of address arithmetic; the ~100
-        // instructions (and two more scalar-load round trips) that set up the activation, statistics and epilogue
-        // operand addresses used to sit in FRONT of them: ~0.5 us before the first HBM request of every launch.
+        // The weight requests need the preloaded arguments (TlHot) and ~20 instructions of address arithmetic; the ~100
+        // instructions that set up the activation, statistics and epilogue operand addresses, and every scalar load of
+        // the LinArgs block, sit BEHIND them.
         __builtin_amdgcn_sched_barrier(0);
     }
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
+    opaque0 = __builtin_amdgcn_readfirstlane(opaque0);   // (an asm result counts as divergent: keep the loads below scalar)
+    tl_load_args(p, aoff, opaque0);
     const TlLate L = late_fn(opaque0);
     const u32x4* __restrict__ at = L.at;
     const u32x4* __restrict__ al = L.al;
     const int mts = L.mts, mtl = L.mtl, mtv = L.mtv;
-    const float* st_ptr = L.st_ptr; const float* pb = L.pb; const float* pc = L.pc; const float* pr = L.pr;
-    const int* ppos = L.ppos;
+    const float* st_ptr = L.st_ptr;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         const int ko = (kc0 + i * ks) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
@@ -414,7 +460,13 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
             ex.pm[i] = t.x; ex.pq[i] = t.y;
         }
     }
-    ex.bias = *pb; ex.colsum = *pc; ex.res = *pr; ex.tpos = *ppos; ex.sh = *L.psh; ex.osh = *L.posh;
+    ex.sh = *L.psh;
+    __builtin_amdgcn_sched_barrier(0);  // the requests above need no field of LinArgs (single-term activations): no wait so far
+    {
+        const TlEpi E = epi_fn(opaque0);   // first use of the block's fields: the scalar loads are waited for here
+        ex.bias = *E.pb; ex.colsum = *E.pc; ex.res = *E.pr; ex.tpos = *E.ppos; ex.osh = *E.posh;
+        tl_touch_args(aoff, opaque0);
+    }
     __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA writes (and everything else) have landed
 #ifdef ACMI_TRACE
@@ -451,10 +503,10 @@ __device__ __forceinline__ void tl_chunk(const LinArgs& p, const u32x4* __restri
 // B operand of TWO MFMAs: with the A fragment 2u the accumulator columns 0-7 are feature sums, with A fragment 2u + 1
 // the columns 8-15 are (the other columns hold products of mismatched K ranges and are dropped).  Two accumulators per
 // row block, merged at the end by a rotation of 8 lanes.  No LayerNorm variants: the producers of x are plain GEMMs.
-template <typename WT, int MT, int C, bool DMA, typename LateFn>
-__device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __restrict__ wt, int ku0, const LateFn& late_fn,
-                                            f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr, unsigned char* wl = nullptr,
-                                            int kloc0 = 0) {
+template <typename WT, int MT, int C, bool DMA, typename LateFn, typename EpiFn>
+__device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u32x4* __restrict__ wt, int ku0, const LateFn& late_fn,
+                                            const EpiFn& epi_fn, f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr,
+                                            unsigned char* wl = nullptr, int kloc0 = 0) {
     const int lane = threadIdx.x & 63;
     u32x4 bv[DMA ? 1 : C], av[MT][2 * C];
 #pragma unroll
@@ -465,17 +517,23 @@ __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __res
     __builtin_amdgcn_sched_barrier(0);
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
+    opaque0 = __builtin_amdgcn_readfirstlane(opaque0);
+    tl_load_args(p, aoff, opaque0);
     const TlLate L = late_fn(opaque0);
     const u32x4* __restrict__ at = L.at;
     const int mts = L.mts, mtv = L.mtv;
-    const float* pb = L.pb; const float* pr = L.pr;
 #pragma unroll
     for (int i = 0; i < 2 * C; ++i) {
         const int ko = (2 * ku0 + i) * 64;
 #pragma unroll
         for (int u = 0; u < MT; ++u) av[u][i] = (at + (min(u, mtv - 1) * mts + ko))[lane];
     }
-    ex.bias = *pb; ex.res = *pr; ex.osh = *L.posh;
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const TlEpi E = epi_fn(opaque0);
+        ex.bias = *E.pb; ex.res = *E.pr; ex.osh = *E.posh;
+        tl_touch_args(aoff, opaque0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ACMI_TRACE
@@ -504,7 +562,7 @@ __device__ __forceinline__ void tl_chunk_ht(const LinArgs& p, const u32x4* __res
 // NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
 // the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs.
 template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false, bool DMA = false>
-__device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, const int kslice, const int ksp) {
+__device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const int wgtile, const int kslice) {
     static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
     static_assert(!HT || (NT == 1 && LN == 0), "half-tile workgroups: plain GEMM, one (half) n-tile");
     const int ntile = wgtile * NT;   // first n-tile of this workgroup (HT: the half-tile index)
@@ -520,21 +578,22 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TlTrace tr{};
     ACMI_TR(tr.t, 0);
-    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nw = h.nw, ksp = h.ksp;   // (blockDim / gridDim would be scalar loads of the kernarg segment)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
+    LinArgs p;   // filled by the first chunk, behind its weight requests
     float* red = reinterpret_cast<float*>(smem);        // [NT MT][nw][256] partial accumulators
     float* rowstat = red + (size_t)NT * MT * nw * 256;  // [16 MT][2] mean, rstd
     unsigned char* wl = reinterpret_cast<unsigned char*>(rowstat + 32 * MT);   // DMA: [NT][kcs] KB image of the weight slice
-    const int n0 = ntile * (HT ? 8 : 16), NKC = HT ? p.NKC >> 1 : p.NKC;   // HT: K counted in 1 KB weight units
-    const u32x4* wt = reinterpret_cast<const u32x4*>(p.w) + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
-    const int kcs = p.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
+    const int n0 = ntile * (HT ? 8 : 16), NKC = HT ? h.NKC >> 1 : h.NKC;   // HT: K counted in 1 KB weight units
+    const u32x4* wt = h.w + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
+    const int kcs = h.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
     const float* own = reinterpret_cast<const float*>(wt + (size_t)(kbeg + min(wave, kcs - 1)) * 64 + lane);
 
     // one group of MT 16-row blocks per workgroup (grid.z): no loop around the body, so that nothing of the
     // epilogue is hoisted in front of the first load
     {
         const int mg = (int)blockIdx.z * 16 * MT;
-        const int mtv = min(MT, (p.M - mg + 15) >> 4);
+        const int mtv = min(MT, (h.M - mg + 15) >> 4);
         f32x4 accs[(HT ? 2 : NT) * MT];
 #pragma unroll
         for (int u = 0; u < (HT ? 2 : NT) * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -544,35 +603,42 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         // it keeps loop-invariant code motion from hoisting the arithmetic back in front of them)
         auto late = [&](const int z) -> TlLate {
             TlLate L;
-            const int mgz = mg + z, lz = lane + z, wz = wave + z, n0z = n0 + z;
-            L.mts = p.a_rbs * 64; L.mtl = p.alo_rbs * 64;   // fragment lanes between consecutive 16-row blocks (a, a_lo)
+            const int mgz = mg + z, lz = lane + z, wz = wave + z;
+            L.mts = h.a_rbs * 64; L.mtl = D == 2 ? p.alo_rbs * 64 : 0;   // fragment lanes between consecutive 16-row blocks (a, a_lo)
             L.mtv = mtv;
-            L.at = reinterpret_cast<const u32x4*>(p.a) + (size_t)((mgz >> 4) * L.mts);
+            L.at = h.a + (size_t)((mgz >> 4) * L.mts);
             L.al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mgz >> 4) * L.mtl) : nullptr;
             L.st_ptr = own;
-            if (FOLD) L.st_ptr = p.a_stats + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), p.M - 1) * p.a_np * 2;
+            if (FOLD) L.st_ptr = h.a_stats + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), h.M - 1) * h.a_np * 2;
+            L.psh = (FOLD && h.a_shift != nullptr) ? h.a_shift + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), h.M - 1) : own;
+            return L;
+        };
+        auto epi = [&](const int z) -> TlEpi {
+            TlEpi E;
+            const int mgz = mg + z, n0z = n0 + z;
             // this thread's first epilogue element
             const int e0 = (int)threadIdx.x + z, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
             const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
             const int egn = min(n0z + (HT ? (enn & 7) : 16 * et + enn), p.N - 1), egm = min(mgz + 16 * eu + emm, p.M - 1);
-            L.pb = p.bias != nullptr ? p.bias + egn : own;
-            L.pc = p.colsum != nullptr ? p.colsum + egn : own;
-            L.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
-            L.ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
-            L.psh = (FOLD && p.a_shift != nullptr) ? p.a_shift + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), p.M - 1) : own;
-            L.posh = p.xt_shift != nullptr ? p.xt_shift + egm : own;
-            return L;
+            E.pb = p.bias != nullptr ? p.bias + egn : own;
+            E.pc = p.colsum != nullptr ? p.colsum + egn : own;
+            E.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
+            E.ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+            E.posh = p.xt_shift != nullptr ? p.xt_shift + egm : own;
+            return E;
         };
         TlExtras ex;
 
         // wave w owns the CONTIGUOUS run of K fragments [w fpw, (w + 1) fpw) (+ a ragged tail): its requests walk
         // 1 KB, 2 KB, ... through one DRAM page instead of striding by nw KB (out-proj 4.81 -> 4.57, FFN2 9.93 -> 9.37 us)
         const int ks = 1;
-        int kc = kbeg + wave * p.fpw, rem = p.fpw;
+        int kc = kbeg + wave * h.fpw, rem = h.fpw;
+        if (rem == 0 && nw * h.fpw + wave >= kcs) tl_load_args(p, aoff, 0);   // a wave without fragments: no chunk fills p
 #define ACMI_TL_RUN(Cn)                                                                                                 \
         while (rem >= Cn) {                                                                                            \
-            if constexpr (HT) tl_chunk_ht<WT, MT, Cn, DMA>(p, wt, kc, late, accs, ex, tr, wl, kc - kbeg);               \
-            else tl_chunk<WT, MT, LN, NT, NS, Cn, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, tr, wl, kc - kbeg, kcs);  \
+            if constexpr (HT) tl_chunk_ht<WT, MT, Cn, DMA>(p, aoff, wt, kc, late, epi, accs, ex, tr, wl, kc - kbeg);   \
+            else tl_chunk<WT, MT, LN, NT, NS, Cn, DMA>(h, p, aoff, wt, kc, ks, h.a_np, late, epi, accs, ex, tr, wl,    \
+                                                       kc - kbeg, kcs);                                                \
             kc += Cn * ks; rem -= Cn;                                                                                  \
         }
         if (CMAX >= 24) { ACMI_TL_RUN(24) }
@@ -584,10 +650,10 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         ACMI_TL_RUN(2)
         ACMI_TL_RUN(1)
 #undef ACMI_TL_RUN
-        kc = kbeg + nw * p.fpw + wave;
+        kc = kbeg + nw * h.fpw + wave;
         if (kc < kbeg + kcs) {  // ragged tail: the first kcs % nw waves own one more fragment
-            if constexpr (HT) tl_chunk_ht<WT, MT, 1, DMA>(p, wt, kc, late, accs, ex, tr, wl, kc - kbeg);
-            else tl_chunk<WT, MT, LN, NT, NS, 1, DMA>(p, wt, kc, ks, p.a_np, late, accs, ex, tr, wl, kc - kbeg, kcs);
+            if constexpr (HT) tl_chunk_ht<WT, MT, 1, DMA>(p, aoff, wt, kc, late, epi, accs, ex, tr, wl, kc - kbeg);
+            else tl_chunk<WT, MT, LN, NT, NS, 1, DMA>(h, p, aoff, wt, kc, ks, h.a_np, late, epi, accs, ex, tr, wl, kc - kbeg, kcs);
         }
         if constexpr (HT) {  // columns 0-7 of the even accumulators + columns 8-15 of the odd ones, rotated onto 0-7
 #pragma unroll
@@ -625,7 +691,7 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
         ACMI_TR(tr.t, 6);
 
         // ---- epilogue: one output element per thread and pass
-        for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += (int)blockDim.x) {
+        for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += nw * 64) {
             const int t = (e >> 8) % NT, u = (e >> 8) / NT, mm = (e >> 4) & 15, nn = e & 15;
             const bool first = e == (int)threadIdx.x;
             const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
@@ -715,19 +781,33 @@ __device__ __forceinline__ void tl_body(const LinArgs& p, const int wgtile, cons
     }
 }
 
+// Kernarg layout (both kernels): the TlHot words first (<= 14 dwords: preloaded into SGPRs), the LinArgs block(s) at byte
+// ACMI_TL_ARGS_OFF -- never touched through the parameter, only through tl_load_args.
+//   g0 = K tiles | K tiles per slice << 16     g1 = fragments per wave | waves << 12 | split-K slices << 16
+//   g2 = a_rbs | M << 16                       g3 = statistics partials per row
 template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false, bool DMA = false>
-__global__ __launch_bounds__(512) void lin_tiled_kernel(const LinArgs p) {
-    tl_body<WT, MT, LN, NT, NS, HT, DMA>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+__global__ __launch_bounds__(512) void lin_tiled_kernel(const u32x4* hw, const u32x4* ha, const float* hst, const float* hsh,
+                                                        unsigned g0, unsigned g1, unsigned g2, unsigned g3, const LinArgs) {
+    const TlHot h = tl_unpack(hw, ha, hst, hsh, g0, g1, g2, g3);
+    tl_body<WT, MT, LN, NT, NS, HT, DMA>(h, ACMI_TL_ARGS_OFF, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
 // (plain), the rest run p1 (LN 3: x | a concatenated along K, no LayerNorm).  Used for
 //   x1 = x0 + att W_out^T   and   r = [x0 | att] [W_cq' | W_cq' W_out]^T  (= x1 W_cq'^T, the cross-attention
 // query before its LayerNorm statistics are applied), see acmi_lm_step.
+//   g00 / g01 = K tiles | K tiles per slice << 16 of p0 / p1     g1 = fragments per wave of p0 | of p1 << 12 | waves << 24
+//   g2 = a_rbs | M << 16 (shared)
 template <typename WT, int MT, int LNB, bool DMA = false>
-__global__ __launch_bounds__(512) void lin_pair_kernel(const LinArgs p0, const LinArgs p1, const int tiles0) {
-    if ((int)blockIdx.x < tiles0) tl_body<WT, MT, 0, 1, 8, false, DMA>(p0, (int)blockIdx.x, 0, 1);
-    else tl_body<WT, MT, LNB, 1, 8, false, DMA>(p1, (int)blockIdx.x - tiles0, 0, 1);
+__global__ __launch_bounds__(512) void lin_pair_kernel(const u32x4* hw0, const u32x4* hw1, const u32x4* ha0, const u32x4* ha1,
+                                                       unsigned g00, unsigned g01, unsigned g1, unsigned g2, int tiles0, int,
+                                                       const LinArgs, const LinArgs) {
+    const bool first = (int)blockIdx.x < tiles0;
+    const unsigned nw = g1 >> 24;
+    const TlHot h = tl_unpack(first ? hw0 : hw1, first ? ha0 : ha1, nullptr, nullptr, first ? g00 : g01,
+                              ((first ? g1 : g1 >> 12) & 0xfffu) | (nw << 12) | (1u << 16), g2, 0u);
+    if (first) tl_body<WT, MT, 0, 1, 8, false, DMA>(h, ACMI_TL_ARGS_OFF_PAIR, (int)blockIdx.x, 0);
+    else tl_body<WT, MT, LNB, 1, 8, false, DMA>(h, ACMI_TL_ARGS_OFF_PAIR + (int)sizeof(LinArgs), (int)blockIdx.x - tiles0, 0);
 }
 
 #ifdef ACMI_TRACE
@@ -816,8 +896,13 @@ static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st
     a.trace = acmi_trace_reserve((LN == 1 || LN == 2) | (a.qkv ? 2 : 0) | (HT ? 4 : 0) | (a.xt_hi != nullptr ? 16 : 0) | ((HT ? 8 : 16 * NT) << 8),
                                  gx * a.ksplit * ((a.M + 16 * MT - 1) / (16 * MT)), nw, a.N, a.K, a.M);
 #endif
+    ACMI_REQUIRE(a.NKC <= 0xffff && a.kcs <= 0xffff && a.fpw <= 0xfff && a.ksplit <= 0xffff && a.a_rbs <= 0xffff && a.M <= 0xffff,
+                 "acmi_linear: geometry beyond the packed launch words (K tiles %d, fragments per wave %d, M %d)", a.NKC, a.fpw, a.M);
+    const unsigned g0 = (unsigned)a.NKC | ((unsigned)a.kcs << 16), g1 = (unsigned)a.fpw | ((unsigned)nw << 12) | ((unsigned)a.ksplit << 16);
+    const unsigned g2 = (unsigned)a.a_rbs | ((unsigned)a.M << 16), g3 = (unsigned)a.a_np;
     hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT, DMA>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
-                       dim3(nw * 64), lds, st, a);
+                       dim3(nw * 64), lds, st, reinterpret_cast<const u32x4*>(a.w), reinterpret_cast<const u32x4*>(a.a),
+                       LN == 1 || LN == 2 ? a.a_stats : nullptr, LN == 1 || LN == 2 ? a.a_shift : nullptr, g0, g1, g2, g3, a);
     return acmi_check_launch("lin_tiled_kernel");
 }
 
@@ -898,6 +983,13 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
     const int mt = p0.M > 32 ? 4 : (p0.M > 16 ? 2 : 1);
     const size_t lds = (size_t)mt * nw * 1024 + (size_t)mt * 128;
     const dim3 grid(t0 + t1, 1, (p0.M + 16 * mt - 1) / (16 * mt)), block(nw * 64);
+    ACMI_REQUIRE(p0.a_rbs == p1.a_rbs, "acmi_linear_pair: the two activations must share a_rbs (%d vs %d)", p0.a_rbs, p1.a_rbs);
+    ACMI_REQUIRE(p0.NKC <= 0xffff && p1.NKC <= 0xffff && p0.fpw <= 0xfff && p1.fpw <= 0xfff && p0.a_rbs <= 0xffff && p0.M <= 0xffff,
+                 "acmi_linear_pair: geometry beyond the packed launch words");
+    const u32x4* hw0 = reinterpret_cast<const u32x4*>(p0.w); const u32x4* hw1 = reinterpret_cast<const u32x4*>(p1.w);
+    const u32x4* ha0 = reinterpret_cast<const u32x4*>(p0.a); const u32x4* ha1 = reinterpret_cast<const u32x4*>(p1.a);
+    const unsigned g00 = (unsigned)p0.NKC | ((unsigned)p0.kcs << 16), g01 = (unsigned)p1.NKC | ((unsigned)p1.kcs << 16);
+    const unsigned g1 = (unsigned)p0.fpw | ((unsigned)p1.fpw << 12) | ((unsigned)nw << 24), g2 = (unsigned)p0.a_rbs | ((unsigned)p0.M << 16);
 #ifdef ACMI_TRACE
     p0.trace = p1.trace = acmi_trace_reserve(8 | 16 | (16 << 8), (int)(grid.x * grid.z), nw, p0.N + p1.N, p0.K, p0.M);
 #endif
@@ -913,14 +1005,14 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
             attr_set = true;
         }
         if (lds_dma <= 160 * 1024) {
-            hipLaunchKernelGGL((lin_pair_kernel<WT, 1, 0, true>), grid, block, lds_dma, st, p0, p1, t0);
+            hipLaunchKernelGGL((lin_pair_kernel<WT, 1, 0, true>), grid, block, lds_dma, st, hw0, hw1, ha0, ha1, g00, g01, g1, g2, t0, 0, p0, p1);
             return acmi_check_launch("lin_pair_kernel");
         }
     }
 #define ACMI_PAIR_CASE(MTv)                                                                              \
     if (mt == MTv) {                                                                                     \
-        if (hl) hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 3>), grid, block, lds, st, p0, p1, t0);      \
-        else hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 0>), grid, block, lds, st, p0, p1, t0);         \
+        if (hl) hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 3>), grid, block, lds, st, hw0, hw1, ha0, ha1, g00, g01, g1, g2, t0, 0, p0, p1); \
+        else hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 0>), grid, block, lds, st, hw0, hw1, ha0, ha1, g00, g01, g1, g2, t0, 0, p0, p1);    \
     }
     ACMI_PAIR_CASE(1) ACMI_PAIR_CASE(2) ACMI_PAIR_CASE(4)
 #undef ACMI_PAIR_CASE

@@ -539,6 +539,8 @@ static int gemm_produce_x(StepCtx& c, const void* a, const void* w, int K, bool 
 // standardised into the weight's element type; the affine part lives in the folded matrices) -> QKV GEMM whose epilogue
 // appends K / V to the caches -> causal attention over [0, position] -> out projection accumulating onto x -> cross
 // attention (the decode kernel on every row: the source is short) -> FFN.  Rows are position-minor (include/acmi.h).
+// CONTRACT: the stream is empty (pos[0] == 0, a device word this host code cannot read without a sync): pf_vt / pf_tcap
+// hold positions [0, npos_pad) only.  LMModel._prefill(start) routes a non-empty stream to the chunked path.
 static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStream_t st) {
     const int npos = s->n_pos, npp = (npos + 15) / 16 * 16, M = s->Beff * npp;
     const int d = m->dim, H = m->num_heads, hd = d / H, F = m->ffn_dim;

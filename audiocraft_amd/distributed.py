@@ -22,8 +22,28 @@ import torch.distributed as dist
 ConditionTensors = tp.Dict[str, tp.Tuple[torch.Tensor, torch.Tensor]]
 
 
+def shared_device_allowed() -> bool:
+    """ACMI_ALLOW_SHARED_DEVICE=1: several ranks may drive ONE device (rank r -> device r % device_count).  A test switch:
+    it lets a 1-GPU box execute the whole multi-process path (spawn, rendezvous, broadcast, sharded generate with the real
+    kernels, all-gather, the max-over-ranks clock).  RCCL refuses two ranks on one device, so it goes with
+    ACMI_DIST_BACKEND=gloo; production stays one process per GPU over RCCL."""
+    return os.environ.get('ACMI_ALLOW_SHARED_DEVICE', '') == '1'
+
+
+def device_index(local_rank: int) -> int:
+    """HIP device of this rank: LOCAL_RANK (one process per GPU), or LOCAL_RANK % device_count with the shared-device switch."""
+    n_dev = torch.cuda.device_count()
+    if shared_device_allowed() and n_dev > 0:
+        return local_rank % n_dev
+    if local_rank >= n_dev:   # one process per GPU: LOCAL_RANK r drives HIP device r of this node
+        raise RuntimeError(f"LOCAL_RANK={local_rank} but this node shows {n_dev} device(s) "
+                           f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})")
+    return local_rank
+
+
 def init_from_env(backend: tp.Optional[str] = None) -> tp.Tuple[int, int, int]:
-    """-> (rank, world_size, local_rank); initialises the default process group when WORLD_SIZE > 1."""
+    """-> (rank, world_size, local_rank); initialises the default process group when WORLD_SIZE > 1.
+    Backend: the argument, else ACMI_DIST_BACKEND, else "nccl" (= RCCL) with a GPU and "gloo" without."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -31,17 +51,30 @@ def init_from_env(backend: tp.Optional[str] = None) -> tp.Tuple[int, int, int]:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('ACMI_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
-            n_dev = torch.cuda.device_count()
-            if local_rank >= n_dev:   # one process per GPU: LOCAL_RANK r drives HIP device r of this node
-                raise RuntimeError(f"rank {rank}: LOCAL_RANK={local_rank} but this node shows {n_dev} device(s) "
-                                   f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')})")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            if shared_device_allowed() and world > torch.cuda.device_count():
+                raise RuntimeError("ACMI_ALLOW_SHARED_DEVICE=1 needs ACMI_DIST_BACKEND=gloo: RCCL refuses two ranks on one device")
+            idx = device_index(local_rank)
+            torch.cuda.set_device(idx)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', idx))
         else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device_index(local_rank))
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def _staged(t: torch.Tensor) -> torch.Tensor:
+    """The tensor a collective runs on: gloo moves host memory only (its device support covers broadcast / all_reduce, not
+    all_gather), so with that backend device tensors are staged through the host; RCCL takes them as they are."""
+    if not t.is_cuda:
+        return t
+    try:
+        gloo = dist.get_backend() == 'gloo'
+    except (ValueError, RuntimeError):   # no default group (a caller-provided transport): nothing to stage for
+        gloo = False
+    return t.cpu() if gloo else t
 
 
 def world_size() -> int:
@@ -97,7 +130,9 @@ def broadcast_condition_tensors(ct: tp.Optional[ConditionTensors], device, src: 
         header = _pack_header(ct).to(device)
     else:
         header = torch.zeros(_MAX_CONDS, _NAME_BYTES // 8 + 3, dtype=torch.int64, device=device)
-    dist.broadcast(header, src=src)
+    hs = _staged(header)
+    dist.broadcast(hs, src=src)
+    header = hs.to(header.device)
     layout = _unpack_header(header)
     total = sum(rows * L * d + rows * L for _, (rows, L, d) in layout)
     if rank() == src:
@@ -107,7 +142,9 @@ def broadcast_condition_tensors(ct: tp.Optional[ConditionTensors], device, src: 
         assert payload.numel() == total
     else:
         payload = torch.empty(total, device=device, dtype=torch.float32)
-    dist.broadcast(payload, src=src)
+    ps = _staged(payload)
+    dist.broadcast(ps, src=src)
+    payload = ps.to(payload.device)
     out: ConditionTensors = {}
     off = 0
     for name, (rows, L, d) in layout:
@@ -139,12 +176,13 @@ def gather_rows(local: torch.Tensor, B_global: int) -> torch.Tensor:
     max_rows = -(-B_global // world)
     pad = torch.zeros((max_rows,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
     pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous())
+    send = _staged(pad.contiguous())
+    bufs = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(bufs, send)
     parts = []
     for r in range(world):
         lo, hi = shard_range(B_global, r, world)
-        parts.append(bufs[r][:hi - lo])
+        parts.append(bufs[r][:hi - lo].to(local.device))
     del rk
     return torch.cat(parts, dim=0)
 

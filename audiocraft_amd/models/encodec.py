@@ -116,8 +116,8 @@ class EncodecModel(CompressionModel):
     def _seanet(self, which: str, net: nn.Module, x: torch.Tensor) -> torch.Tensor:
         x = x.float().contiguous()
         samples = x.shape[0] * x.shape[-1] * (self.decoder.hop_length if which == 'dec' else 1)
-        if not x.is_cuda or samples == 0 or samples > self.GRAPH_MAX_SAMPLES:
-            return net(x)
+        if not x.is_cuda or samples == 0 or samples > self.GRAPH_MAX_SAMPLES or torch.cuda.is_current_stream_capturing():
+            return net(x)   # (inside somebody else's capture: plain launches, which that capture records)
         graphs = self.__dict__.setdefault('_graphs', {})
         key = (which, tuple(x.shape))
         entry = graphs.get(key)

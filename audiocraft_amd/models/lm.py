@@ -816,12 +816,13 @@ class LMModel(nn.Module):
             state.pf_xn, state.pf_vt, state.pf_tcap = None, None, 0
             state.n_pos = 1
 
-    def _prefill(self, desc, state, n_positions: int):
-        """Run `n_positions` input-only positions (prepended conditions, prompt tokens) from the start of an empty stream
-        (every caller has just zeroed the position counter): one MFMA-tiled forward over all of them when the geometry
-        allows (`_big_prefill_ok`), else the same kernels as a decode position, several consecutive positions per call as
-        extra rows (acmi_lm_state.n_pos)."""
-        if n_positions > 0 and self._big_prefill_ok(n_positions):
+    def _prefill(self, desc, state, n_positions: int, start: int = 0):
+        """Run `n_positions` input-only positions (prepended conditions, prompt tokens) beginning at stream position `start`
+        (= what the device position counter holds; every caller today has just zeroed it): one MFMA-tiled forward over all
+        of them when the stream is EMPTY and the geometry allows (`_big_prefill_ok`) -- lm_prefill_big sizes its time-minor V
+        scratch for positions [0, n_positions) only, so a non-empty stream must take the other path -- else the same kernels
+        as a decode position, several consecutive positions per call as extra rows (acmi_lm_state.n_pos)."""
+        if n_positions > 0 and start == 0 and self._big_prefill_ok(n_positions):
             return self._prefill_big(desc, state, self._run, n_positions)
         done = 0
         while done < n_positions:

@@ -188,6 +188,19 @@ def load_mbd_ckpt(file_or_id: str, filename: tp.Optional[str] = None):
     return _get_state_dict(file_or_id, filename or 'mbd.pt')
 
 
+def _pick_mbd_cfg(cfg, is_config, to_container) -> dict:
+    """The saved `cfg` of a released MultiBandDiffusion band is an OmegaConf node of the WHOLE training xp.  Only the
+    sub-trees the reference reads (loaders.py:188-199, builders.py:291-306: channels, schedule, diffusion_unet, processor)
+    are resolved: a full resolve would also evaluate unrelated interpolations (`${oc.env:USER}` in dora.dir, hydra / dora
+    resolvers, `???` nodes) and fail on nodes nobody uses."""
+    picked = {}
+    for k in ('channels', 'schedule', 'diffusion_unet', 'processor', 'sample_rate'):
+        if k in cfg:
+            node = cfg[k]
+            picked[k] = to_container(node) if is_config(node) else node
+    return picked
+
+
 def load_diffusion_models(file_or_id: str, device='cuda', filename: tp.Optional[str] = None):
     """reference loaders.py:181-203: one (DiffusionUnet, sample processor, cfg) per band from a MultiBandDiffusion package
     {'sample_rate', 'n_bands', i: {'cfg', 'model_state', 'processor_state'}}.  `cfg` may be an OmegaConf node (released
@@ -199,7 +212,7 @@ def load_diffusion_models(file_or_id: str, device='cuda', filename: tp.Optional[
         cfg = pkg[i]['cfg']
         if not isinstance(cfg, (dict, str)):
             from omegaconf import OmegaConf   # only reachable when the pickle itself needed it
-            cfg = OmegaConf.to_container(cfg, resolve=True)
+            cfg = _pick_mbd_cfg(cfg, OmegaConf.is_config, lambda node: OmegaConf.to_container(node, resolve=True))
         cfg = parse_cfg(cfg)
         model = builders.get_diffusion_model(cfg)
         model.load_state_dict(pkg[i]['model_state'])

@@ -117,6 +117,32 @@ class MultiBandProcessor(SampleProcessor):
         self.register_buffer('sum_x2', torch.zeros(n_bands))
         self.register_buffer('sum_target_x2', torch.zeros(n_bands))
 
+    # The reference's processor holds julius.SplitBands, an nn.Module whose low-pass bank is a persistent buffer: released
+    # `processor_state` dicts carry `split_bands.lowpass.filters` [n_bands - 1, 1, 2 half + 1] next to the four statistics
+    # (julius/lowpass.py registers it; the reference strict-loads these files, diffusion_schedule.py:35-60).  Same key
+    # here, both ways: written by state_dict(), and on load the checkpoint's bank REPLACES the computed one, as
+    # load_state_dict does for a buffer in the reference.
+    _FILTERS_KEY = 'split_bands.lowpass.filters'
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.n_bands > 1:
+            destination[prefix + self._FILTERS_KEY] = self.split_bands._host[0][:, None, :].clone()
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        key = prefix + self._FILTERS_KEY
+        if key in state_dict:
+            f = state_dict.pop(key)   # (the caller's dict is a shallow copy made by load_state_dict)
+            want = self.split_bands._host[0]
+            if self.n_bands == 1 or f.dim() != 3 or f.shape[0] != self.n_bands - 1 or f.shape[1] != 1 or f.shape[2] % 2 != 1:
+                error_msgs.append(f'{key}: shape {tuple(f.shape)} is not a bank of {self.n_bands - 1} odd-length low-pass filters')
+            else:
+                bank = f[:, 0, :].detach().to('cpu', torch.float32).contiguous()
+                self.split_bands._host = (bank, (bank.shape[1] - 1) // 2)
+                self.split_bands._dev = {}
+                self.filters_max_abs_diff = float((bank - want).abs().max()) if bank.shape == want.shape else float('inf')
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     @property
     def mean(self):
         return self.sum_x / self.counts

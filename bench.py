@@ -305,7 +305,8 @@ def _spawn_ranks(n: int) -> int:
     import socket
     import subprocess
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < n:
+    shared = os.environ.get('ACMI_ALLOW_SHARED_DEVICE', '') == '1' and have > 0   # test switch: ranks share devices (gloo)
+    if have < n and not shared:
         print(f"bench.py: --gpus {n} needs {n} visible MI355X devices, this node shows {have} "
               f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}); nothing was run", file=sys.stderr)
         return 2
@@ -348,6 +349,7 @@ def main():
     ap.add_argument('--greedy', action='store_true', help='argmax decoding (BASELINE.json configs[1])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dump-tokens', default='', help='rank 0 saves the gathered tokens of the last step here (tests)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:   # no external launcher: spawn the ranks here
@@ -360,12 +362,13 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (there is no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():   # one process per GPU: LOCAL_RANK r drives HIP device r
-        sys.exit(f"bench.py: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} device(s) are visible to this rank; "
-                 f"--gpus {args.gpus} needs {args.gpus} MI355X on this node")
-    torch.cuda.set_device(local_rank)
-    assert torch.cuda.current_device() == local_rank
-    dev = torch.device('cuda', local_rank)
+    try:   # one process per GPU: LOCAL_RANK r drives HIP device r (ACMI_ALLOW_SHARED_DEVICE=1, tests: r % device_count)
+        dev_idx = adist.device_index(local_rank)
+    except RuntimeError as e:
+        sys.exit(f"bench.py: {e}; --gpus {args.gpus} needs {args.gpus} MI355X on this node")
+    torch.cuda.set_device(dev_idx)
+    assert torch.cuda.current_device() == dev_idx
+    dev = torch.device('cuda', dev_idx)
 
     model = MusicGen.get_random_init(args.model, dev, torch.bfloat16, text_len=args.text_len, seed=0)
     model.set_generation_params(use_sampling=not args.greedy, top_k=args.top_k, duration=args.duration)
@@ -398,7 +401,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if torch.distributed.get_backend() != 'gloo' else 'cpu', dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert tokens.shape == (B_global, 4, T) and wav.shape == (B, 1, T * 640)
@@ -416,6 +419,8 @@ def main():
                                f"({config_tag(args)})",
                    "global_batch": B_global, "seq_len": T, "parallelism": f"dp{world} (prompt sharding)"},
     }
+    if rank == 0 and args.dump_tokens:
+        torch.save(tokens.cpu(), args.dump_tokens)
     if rank == 0:
         lm = model.lm
         n_pos = T + 3

@@ -171,3 +171,43 @@ def test_sharded_path_fake_two_ranks_real_kernels(monkeypatch):
         assert tokens.shape == (B_global, 4, T)
         assert torch.equal(tokens, ref_t.cpu()), f"rank {rk}: gathered tokens differ from the unsharded result"
         assert torch.allclose(wav, ref_w.cpu(), atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The whole multi-PROCESS path on a 1-GPU box: `python bench.py --gpus 2` exactly as the driver's scaling run starts it
+# (no launcher -> bench.py spawns its ranks, rendezvous on 127.0.0.1), with the two test switches of
+# audiocraft_amd/distributed.py -- ACMI_DIST_BACKEND=gloo (RCCL refuses two ranks on one device) and
+# ACMI_ALLOW_SHARED_DEVICE=1 (rank r -> device r % device_count).  Executes _spawn_ranks, init_from_env, the two
+# broadcasts of the conditioning, the sharded generate + decode with the real kernels in two processes, gather_rows, the
+# all_reduce(MAX) of the clock and rank 0's JSON line.
+# ----------------------------------------------------------------------------------------------------------------------
+def _run_bench(tmp_path, gpus, batch, tag):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tok = tmp_path / f'tokens_{tag}.pt'
+    env = dict(os.environ, ACMI_DIST_BACKEND='gloo', ACMI_ALLOW_SHARED_DEVICE='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '1', '--warmup', '0', '--duration', '2',
+           '--model', 'facebook/musicgen-small', '--batch', str(batch), '--greedy', '--no-cpu-baseline', '--no-roofline',
+           '--dump-tokens', str(tok)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), torch.load(tok)
+
+
+def test_bench_two_processes_on_one_device(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    line2, tok2 = _run_bench(tmp_path, 2, 4, 'w2')     # 2 ranks x 4 prompts
+    assert line2['n_gpus'] == 2 and line2['config']['global_batch'] == 8 and line2['scaling'] == 'weak'
+    assert line2['config']['parallelism'].startswith('dp2') and line2['value'] > 0 and line2['ms_per_step'] > 0
+    assert line2['step_roofline']['peak'] == 2 * 8000.0
+    line1, tok1 = _run_bench(tmp_path, 1, 8, 'w1')     # the same 8 prompts on one rank
+    assert line1['n_gpus'] == 1 and line1['config']['global_batch'] == 8
+    assert tok2.shape == tok1.shape == (8, 4, 100)
+    assert torch.equal(tok2, tok1), "gathered greedy tokens of the 2-rank run differ from the unsharded run"

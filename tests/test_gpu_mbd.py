@@ -379,6 +379,9 @@ def test_load_diffusion_models_roundtrip(C, tmp_path):
           'processor': {'use': True, 'name': 'multi_band_processor', 'n_bands': pc['n_bands'], 'num_samples': pc.get('num_samples', 10),
                         'power_std': pc['power_std']}}
     pstate = {'counts': a['proc_counts'], 'sum_x': a['proc_sum_x'], 'sum_x2': a['proc_sum_x2'], 'sum_target_x2': a['proc_sum_target_x2']}
+    # the release layout also carries julius' low-pass bank (a buffer of the reference's SplitBands)
+    from audiocraft_amd.modules.diffusion_schedule import band_filters
+    pstate['split_bands.lowpass.filters'] = band_filters(pc['sample_rate'], pc['n_bands'])[0][:, None, :]
     pkg = {'sample_rate': pc['sample_rate'], 'n_bands': 2,
            0: {'cfg': xp, 'model_state': sd, 'processor_state': pstate}, 1: {'cfg': json.dumps(xp), 'model_state': sd, 'processor_state': pstate}}
     path = tmp_path / 'mbd_test.th'

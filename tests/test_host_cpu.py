@@ -585,3 +585,46 @@ def test_band_filters_and_schedule_host_side():
     assert torch.equal(s.get_alpha_bar(41), ombd.alpha_bar_at(sc, 41))
     ab = s.get_alpha_bar()[[0, 20, 40, 99]]
     assert torch.allclose(1 - betas_from_alpha_bar(ab), torch.cat([ab[:1], ab[1:] / ab[:-1]]))
+
+
+def test_multiband_processor_state_dict_has_the_release_layout():
+    """Released `processor_state` dicts carry julius' low-pass bank as `split_bands.lowpass.filters` (a persistent buffer of
+    the reference's julius.SplitBands; the reference strict-loads those files): the key is written, accepted by a strict load,
+    and the checkpoint's bank replaces the computed one like a loaded buffer does in the reference."""
+    from audiocraft_amd.modules.diffusion_schedule import MultiBandProcessor, band_filters
+    p = MultiBandProcessor(n_bands=4, sample_rate=16000, num_samples=10, power_std=[1., 1., .5, .5])
+    sd = p.state_dict()
+    assert set(sd) == {'counts', 'sum_x', 'sum_x2', 'sum_target_x2', 'split_bands.lowpass.filters'}
+    bank, half = band_filters(16000, 4)
+    assert sd['split_bands.lowpass.filters'].shape == (3, 1, 2 * half + 1)
+    assert torch.equal(sd['split_bands.lowpass.filters'][:, 0], bank)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd['counts'] += 7
+    sd['split_bands.lowpass.filters'] = sd['split_bands.lowpass.filters'] * 1.5      # "the checkpoint's" bank
+    q = MultiBandProcessor(n_bands=4, sample_rate=16000, num_samples=10, power_std=[1., 1., .5, .5])
+    q.load_state_dict(sd, strict=True)
+    assert float(q.counts) == 7 and torch.equal(q.split_bands._host[0], bank * 1.5) and q.split_bands._host[1] == half
+    assert q.filters_max_abs_diff > 0
+    q.load_state_dict({k: v for k, v in sd.items() if not k.startswith('split_bands')}, strict=True)   # hand-built dicts still load
+    bad = dict(sd)
+    bad['split_bands.lowpass.filters'] = torch.zeros(2, 1, 5)
+    with pytest.raises(RuntimeError, match='low-pass'):
+        MultiBandProcessor(n_bands=4, sample_rate=16000).load_state_dict(bad)
+
+
+def test_mbd_cfg_resolves_only_what_the_loader_reads():
+    """An xp config whose unrelated nodes cannot be resolved (dora.dir = ${oc.env:USER} with USER unset, `???`) must load."""
+    from audiocraft_amd.models.loaders import _pick_mbd_cfg
+
+    class Node(dict):   # stands in for an OmegaConf DictConfig: resolving the poisoned sub-tree raises
+        pass
+
+    def to_container(node):
+        if node.get('_poison'):
+            raise RuntimeError('InterpolationResolutionError')
+        return {k: v for k, v in node.items()}
+
+    cfg = Node(channels=1, schedule=Node(num_steps=10), diffusion_unet=Node(hidden=8), processor=Node(use=False),
+               dora=Node(_poison=True, dir='${oc.env:USER}'), datasource=Node(_poison=True))
+    out = _pick_mbd_cfg(cfg, lambda n: isinstance(n, Node), to_container)
+    assert out == {'channels': 1, 'schedule': {'num_steps': 10}, 'diffusion_unet': {'hidden': 8}, 'processor': {'use': False}}
