@@ -310,20 +310,25 @@ static int launch_rowmajor(LinArgs& a, hipStream_t st) {
 // =====================================================================================================
 // lin_tiled_kernel: the decode step's GEMM  (tiled activation x tiled weight)
 // =====================================================================================================
-// One workgroup = 16 output features (x one K slice with split-K); its nw <= 8 waves own the K fragments
-// kc = wave, wave + nw, ...  Every wave requests everything it will ever need up front, in the order in which
-// it is consumed -- (weight fragment, activation fragments) pairs, then the LayerNorm row statistics, then the
-// epilogue operands of its thread -- because vmcnt retires in order and anything requested later (a cold bias
-// vector in the epilogue, say) is a full HBM round trip on the tail of the launch.  Absent operands are
-// replaced by the address of the wave's own first weight fragment (already in flight: no extra line, page or
-// hot spot), so the prologue is branch free.
-//   LN 0: plain   1: folded LayerNorm, single-term activation   2: folded LayerNorm, hi + lo activation
-//      3: no LayerNorm, hi + lo activation for the first lo_split K fragments (x | a concatenated along K)
-#ifndef ACMI_TL_WFIRST
-#define ACMI_TL_WFIRST(LN) true
-#endif
+// One workgroup = 16 output features (x one K slice with split-K); its nw <= 8 waves own contiguous runs of K
+// fragments.  Every wave requests everything it will ever need up front -- weight fragments, then activation
+// fragments, then the LayerNorm row statistics, then the epilogue operands of its thread -- because vmcnt retires
+// in order and anything requested later (a cold bias vector in the epilogue, say) is a full HBM round trip on the
+// tail of the launch.  Absent operands are replaced by the address of the wave's own first weight fragment
+// (already in flight: no extra line, page or hot spot), so the prologue is branch free.
+//   LN 0: plain   1: folded LayerNorm, single-term activation, statistics from the producer's partials
+//      2: folded LayerNorm, hi + lo activation   3: no LayerNorm, hi + lo activation for the first lo_split K
+//      fragments (x | a concatenated along K)
+//      4: folded LayerNorm, single-term activation, statistics FROM THE FRAGMENTS (round 4): two more MFMAs per
+//         activation fragment a -- a x ones (row sums) and a x a^T (Gram matrix: its diagonal holds the rows' sums of
+//         squares; the A and B operands of the 16x16 MFMA share one register layout, so `a` serves as both) -- give
+//         mean and variance of exactly the values the GEMM multiplies, and the consumer loads no partials at all.
+//         The in-kernel timeline (profiles/r04_lin_timeline*.csv) priced the partials: 16 dwordx2 requests per lane
+//         (24 KB per workgroup, freshly written by the previous launch) through the same per-CU address pipe as the
+//         weight stream, plus Chan's combination in front of the barrier.  The fragments are bf16(x - shift) with the
+//         shift near the row mean, so the one-pass variance sum(a^2) / K - mean^2 does not cancel.
 struct TlExtras {
-    float pm[16], pq[16];   // LN > 0: (mean, M2) partials of this lane's statistics row (the first NS of them)
+    float pm[16], pq[16];   // LN 1 / 2: (mean, M2) partials of this lane's statistics row (the first NS of them)
     float bias, colsum, res;  // epilogue operands of this thread's first output element
     int tpos;                 // QKV: the position the new K / V rows are stored at
     float sh, osh;            // shift of this lane's statistics row (consumer) / of this thread's first output row (producer)
@@ -336,7 +341,7 @@ struct TlExtras {
 // requests (tl_load_args): a decode position is ~340 launches whose kernarg blocks are each read once per replay,
 // ~3 GB of traffic after their previous use, i.e. cold in the scalar cache and in L2, and hipcc's own prologue fetched
 // the 320-byte block in three DEPENDENT s_load rounds (SGPR pressure) in front of the first weight request of every
-// wave (lab/kernarg_lab.hip prices a round).
+// wave (lab/kernarg_lab.hip prices a round; same-box A/B of the two forms: 6.98 -> 6.21 us per launch).
 struct TlHot {
     const u32x4* w; const u32x4* a; const float* a_stats; const float* a_shift;
     int NKC, kcs, fpw, nw, ksp, a_rbs, M, a_np;
@@ -355,8 +360,8 @@ __device__ __forceinline__ TlHot tl_unpack(const u32x4* w, const u32x4* a, const
     h.a_rbs = (int)(g2 & 0xffffu); h.M = (int)(g2 >> 16); h.a_np = (int)g3;
     return h;
 }
-// the LinArgs block at byte `aoff` of the kernarg segment, read where this is called (`z`: an opaque zero produced behind the
-// weight requests -- the loads depend on it and cannot be hoisted in front of them)
+// the LinArgs block at byte `aoff` of the kernarg segment, read where this is called (`z`: an opaque zero produced behind
+// the weight requests -- the loads depend on it and cannot be hoisted in front of them)
 __device__ __forceinline__ void tl_load_args(LinArgs& p, int aoff, int z) {
     const char ACMI_AS4* ka = (const char ACMI_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
     const void ACMI_AS4* src = (const void ACMI_AS4*)__builtin_assume_aligned((const void ACMI_AS4*)(ka + (aoff + z)), 8);
@@ -388,43 +393,32 @@ struct TlTrace {
 #endif
 };
 
-// LDS-DMA form of the weight stream (A/B variant, ACMI_LIN_DMA=1): the fragment goes global -> LDS without passing through
-// VGPRs (global_load_lds_dwordx4, 1 KB per wave instruction, non-temporal), into the workgroup's LDS image of its weight
-// slice at the fragment's own slot; the wave that requested it reads it back (ds_read_b128, lane linear) once its vmcnt
-// has covered the request -- no barrier: a wave only ever reads what it requested itself.
-__device__ __forceinline__ void glds_frag_nt(const u32x4* gsrc_lane, unsigned char* lds_slot) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
-                                     (__attribute__((address_space(3))) void*)lds_slot, 16, 0, 2 /* nt */);
-}
+template <typename WT> __device__ __forceinline__ u32x4 ones_frag();
+template <> __device__ __forceinline__ u32x4 ones_frag<bf16_t>() { return u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; }
+template <> __device__ __forceinline__ u32x4 ones_frag<float>() { return u32x4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u}; }
 
-template <typename WT, int MT, int LN, int NT, int NS, int C, bool DMA, typename LateFn, typename EpiFn>
-__device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int aoff, const u32x4* __restrict__ wt, int kc0, int ks,
-                                         int np, const LateFn& late_fn, const EpiFn& epi_fn, f32x4 (&acc)[NT * MT], TlExtras& ex,
-                                         TlTrace& tr, unsigned char* wl = nullptr, int kloc0 = 0, int kcs = 0) {
+template <typename WT, int MT, int LN, int NT, int NS, int C, typename LateFn, typename EpiFn>
+__device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int aoff, const u32x4* __restrict__ wt, int kc0,
+                                         int np, const LateFn& late_fn, const EpiFn& epi_fn, f32x4 (&acc)[NT * MT],
+                                         f32x4 (&accx)[2 * MT], TlExtras& ex, TlTrace& tr) {
     constexpr bool HL = LN == 2 || LN == 3;
+    constexpr bool PART = LN == 1 || LN == 2;   // statistics from the producer's partials
     const int lane = threadIdx.x & 63;
     const int wts = h.NKC * 64;  // fragment lanes between the NT adjacent n-tiles of this workgroup
-    u32x4 bv[DMA ? 1 : NT][DMA ? 1 : C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
+    u32x4 bv[NT][C], av[MT][C], lv[HL ? MT : 1][HL ? C : 1];
     // Request order: all weight fragments first -- they come from HBM, the activation fragments from L2, and the HBM
     // requests should be on their way as early as possible (FFN2 10.5 -> 9.9 us; whole position 2.57 -> 2.50 ms; with
     // (weight, activations) pairs in consumption order only the hi / lo variants in isolation were 0.1-0.2 us faster).
-    constexpr bool WFIRST = ACMI_TL_WFIRST(LN);
-    static_assert(!DMA || ACMI_TL_WFIRST(LN), "the LDS-DMA form issues the whole weight run first");
-    if (WFIRST) {
 #pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const int ko = (kc0 + i * ks) * 64;
+    for (int i = 0; i < C; ++i) {
+        const int ko = (kc0 + i) * 64;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if constexpr (DMA) glds_frag_nt(wt + (t * wts + ko) + lane, wl + (size_t)(t * kcs + kloc0 + i) * 1024);
-                else bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
-            }
-        }
-        // The weight requests need the preloaded arguments (TlHot) and ~20 instructions of address arithmetic; the ~100
-        // instructions that set up the activation, statistics and epilogue operand addresses, and every scalar load of
-        // the LinArgs block, sit BEHIND them.
-        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
     }
+    // The weight requests need the preloaded arguments (TlHot) and ~20 instructions of address arithmetic; the ~100
+    // instructions that set up the activation, statistics and epilogue operand addresses, and every scalar load of
+    // the LinArgs block, sit BEHIND them.
+    __builtin_amdgcn_sched_barrier(0);
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
     opaque0 = __builtin_amdgcn_readfirstlane(opaque0);   // (an asm result counts as divergent: keep the loads below scalar)
@@ -436,23 +430,17 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
     const float* st_ptr = L.st_ptr;
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        const int ko = (kc0 + i * ks) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
-        if constexpr (!DMA) {
-            if (!WFIRST) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
-            }
-        }
+        const int ko = (kc0 + i) * 64;  // wave-uniform; 32-bit index math (a matrix has < 2^31 fragments' lanes)
 #pragma unroll
         for (int u = 0; u < MT; ++u) {  // row blocks beyond M re-read the last valid one (their results are dropped)
             const int ub = min(u, mtv - 1);
             av[u][i] = (at + (ub * mts + ko))[lane];
             if (LN == 2) lv[u][i] = (al + (ub * mtl + ko))[lane];
             if (LN == 3)  // fragments past lo_split have no lo term: re-read the last one (L1 hit), zeroed below
-                lv[u][i] = (al + (ub * mtl + min(kc0 + i * ks, p.lo_split - 1) * 64))[lane];
+                lv[u][i] = (al + (ub * mtl + min(kc0 + i, p.lo_split - 1) * 64))[lane];
         }
     }
-    if (LN == 1 || LN == 2) {
+    if (PART) {
         const int jj = (int)(threadIdx.x & 15);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -468,11 +456,10 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
         tl_touch_args(aoff, opaque0);
     }
     __builtin_amdgcn_sched_barrier(0);  // keep every request in front of the first wait
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA writes (and everything else) have landed
 #ifdef ACMI_TRACE
     {   // requests in flight, oldest first: NT C weight fragments, then MT C (x 2 with a lo term) activation fragments, the
         // statistics partials and the six epilogue operands
-        constexpr int NWQ = DMA ? 0 : NT * C, NREST = MT * C * (HL ? 2 : 1) + ((LN == 1 || LN == 2) ? NS : 0) + 6;
+        constexpr int NWQ = NT * C, NREST = MT * C * (HL ? 2 : 1) + (PART ? NS : 0) + 6;
         constexpr int ALL1 = NWQ + NREST - 1 > 63 ? 63 : NWQ + NREST - 1, REST = NREST > 63 ? 63 : NREST;
         ACMI_TR(tr.t, 1);
         ACMI_TR_WAIT_VM(ALL1); ACMI_TR(tr.t, 2);
@@ -480,18 +467,20 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
         ACMI_TR_WAIT_VM(0); ACMI_TR(tr.t, 4);
     }
 #endif
+    const u32x4 ones = ones_frag<WT>();
 #pragma unroll
     for (int i = 0; i < C; ++i)
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            if (LN == 3 && kc0 + i * ks >= p.lo_split) lv[u][i] = u32x4{0u, 0u, 0u, 0u};
+            if (LN == 3 && kc0 + i >= p.lo_split) lv[u][i] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                u32x4 b;
-                if constexpr (DMA) b = *reinterpret_cast<const u32x4*>(wl + (size_t)(t * kcs + kloc0 + i) * 1024 + lane * 16);
-                else b = bv[t][i];
-                mma_frag(av[u][i], b, acc[t * MT + u], WT());
-                if (HL) mma_frag(lv[u][i], b, acc[t * MT + u], WT());
+                mma_frag(av[u][i], bv[t][i], acc[t * MT + u], WT());
+                if (HL) mma_frag(lv[u][i], bv[t][i], acc[t * MT + u], WT());
+            }
+            if (LN == 4) {   // row sums and the Gram matrix of the fragment (its diagonal: the rows' sums of squares)
+                mma_frag(av[u][i], ones, accx[2 * u], WT());
+                mma_frag(av[u][i], av[u][i], accx[2 * u + 1], WT());
             }
         }
 }
@@ -503,17 +492,13 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
 // B operand of TWO MFMAs: with the A fragment 2u the accumulator columns 0-7 are feature sums, with A fragment 2u + 1
 // the columns 8-15 are (the other columns hold products of mismatched K ranges and are dropped).  Two accumulators per
 // row block, merged at the end by a rotation of 8 lanes.  No LayerNorm variants: the producers of x are plain GEMMs.
-template <typename WT, int MT, int C, bool DMA, typename LateFn, typename EpiFn>
+template <typename WT, int MT, int C, typename LateFn, typename EpiFn>
 __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u32x4* __restrict__ wt, int ku0, const LateFn& late_fn,
-                                            const EpiFn& epi_fn, f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr,
-                                            unsigned char* wl = nullptr, int kloc0 = 0) {
+                                            const EpiFn& epi_fn, f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr) {
     const int lane = threadIdx.x & 63;
-    u32x4 bv[DMA ? 1 : C], av[MT][2 * C];
+    u32x4 bv[C], av[MT][2 * C];
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
-        if constexpr (DMA) glds_frag_nt(wt + (ku0 + i) * 64 + lane, wl + (size_t)(kloc0 + i) * 1024);
-        else bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
-    }
+    for (int i = 0; i < C; ++i) bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
     __builtin_amdgcn_sched_barrier(0);
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
@@ -535,10 +520,9 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
         tl_touch_args(aoff, opaque0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ACMI_TRACE
     {
-        constexpr int NWQ = DMA ? 0 : C, NREST = MT * 2 * C + 3;
+        constexpr int NWQ = C, NREST = MT * 2 * C + 3;
         constexpr int ALL1 = NWQ + NREST - 1 > 63 ? 63 : NWQ + NREST - 1, REST = NREST > 63 ? 63 : NREST;
         ACMI_TR(tr.t, 1);
         ACMI_TR_WAIT_VM(ALL1); ACMI_TR(tr.t, 2);
@@ -548,32 +532,170 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
 #endif
 #pragma unroll
     for (int i = 0; i < C; ++i) {
-        u32x4 b;
-        if constexpr (DMA) b = *reinterpret_cast<const u32x4*>(wl + (size_t)(kloc0 + i) * 1024 + lane * 16);
-        else b = bv[i];
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
-            mma_frag(av[u][2 * i], b, acc[2 * u], WT());
-            mma_frag(av[u][2 * i + 1], b, acc[2 * u + 1], WT());
+            mma_frag(av[u][2 * i], bv[i], acc[2 * u], WT());
+            mma_frag(av[u][2 * i + 1], bv[i], acc[2 * u + 1], WT());
+        }
+    }
+}
+
+// ---- the epilogue: one output element per thread and pass.
+// EPI fixes, at compile time, what the flags of LinArgs would otherwise decide at run time; the launcher picks the
+// specialisation the call's flags allow (tiled_epi) and the kernel jumps to it with ONE uniform branch.  The generic
+// form (EPI_GEN) keeps every flag a run-time test; all forms are the same source, so their arithmetic is the same.
+// Why: the timeline showed ~1.1-1.3 us between the barrier and the last store of EVERY launch -- ~200 executed
+// instructions, but spread over ~30 taken branches of cold code, each a new instruction-cache line fetched from L2.
+enum { EPI_GEN = 0, EPI_PRODX = 1, EPI_TILED = 2, EPI_F32 = 3, EPI_QKV = 4 };
+//   EPI_PRODX  x <- x + a W^T (+ bias): f32 in place, the raw fragments of the new x (single term, optional shift),
+//              optional statistics partials.  No activation, no LayerNorm, no split-K.
+//   EPI_TILED  out = act(LN?(a) W^T + bias) in A-fragment order (FFN1)
+//   EPI_F32    out = LN?(a) W^T + bias (+ residual), row-major f32 (heads, the paired cross-query GEMM)
+//   EPI_QKV    the QKV scatter of a decode step (one position per call, head size and model width multiples of 16, so
+//              that a 16-feature tile lies in ONE of q / k / v / r and in ONE head: all index divisions are per tile)
+
+// NW: the workgroup's wave count as a compile-time constant (8 / 4: the decode step's launches), or 0 = run time.  With it the
+// cross-wave sums are straight-line LDS reads, and a launch whose outputs fit one pass (MT = 1, 256 NT <= 64 NW) has no loop.
+template <typename WT, int MT, int LN, int NT, bool HT, int EPI, int NW>
+__device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex, const float* __restrict__ red,
+                                            const float* __restrict__ rowstat, const int nw_rt, const int ksp, const int kslice,
+                                            const int mg, const int mtv, const int n0, const int ntile, const int wgtile) {
+    const int nw = NW > 0 ? NW : nw_rt;
+    constexpr bool ONE = NW > 0 && MT == 1 && 256 * NT <= 64 * NW;   // every thread owns at most one output element
+    constexpr bool FOLD = LN == 1 || LN == 2 || LN == 4;
+    constexpr bool GRAM = LN == 4;
+    constexpr bool G = EPI == EPI_GEN;
+    constexpr int XT = (HT ? 1 : NT) * MT;   // first extra tile (row sums / Gram) of the reduction buffer
+    const bool split = G ? ksp > 1 : false;
+    const bool qkv = G ? p.qkv != 0 : EPI == EPI_QKV;
+    const bool has_res = G || EPI == EPI_F32 ? p.residual != nullptr : EPI == EPI_PRODX;
+    const bool has_stats = G || EPI == EPI_PRODX ? p.stats_out != nullptr : false;
+    const bool has_xt = G ? p.xt_hi != nullptr : EPI == EPI_PRODX;
+    const bool has_xlo = G ? p.xt_lo != nullptr : false;
+    const bool gelu = G || EPI == EPI_TILED ? p.act == 1 : false;
+    const int out_mode = G ? p.out_mode : (EPI == EPI_TILED ? ACMI_OUT_TILED : ACMI_OUT_F32);
+    for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += ONE ? 256 * MT * NT : nw * 64) {
+        const int t = (e >> 8) % NT, u = (e >> 8) / NT, mm = (e >> 4) & 15, nn = e & 15;
+        const bool first = ONE ? true : e == (int)threadIdx.x;
+        const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < nw; ++w) v += red[((size_t)(t * MT + u) * nw + w) * 256 + idx];
+        const int gm = mg + 16 * u + mm, gn = n0 + 16 * t + nn;
+        const bool valid = gm < p.M && gn < p.N && (!HT || nn < 8);
+        if (split) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
+            if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
+            continue;
+        }
+        size_t oi = 0;
+        // QKV launch carrying the x0 part of the cross-attention query: features >= 3d are stored raw
+        const bool rawcol = qkv && gn >= 3 * p.d;
+        if (FOLD) {   // folded LayerNorm: rstd * (x W'^T - mean * colsum)
+            float mean_s, rstd;
+            if (GRAM) {
+                // row sum (any column of the row's sums tile) and sum of squares (the diagonal of the Gram tile), summed over
+                // the waves' K slices in wave order like the products
+                const int idg = (((mm >> 2) * 16 + mm) << 2) + (mm & 3);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < nw; ++w) {
+                    s1 += red[((size_t)(XT + 2 * u) * nw + w) * 256 + idx];
+                    s2 += red[((size_t)(XT + 2 * u + 1) * nw + w) * 256 + idg];
+                }
+                const float rk = p.inv_K;   // 1 / K, rounded on the host
+                mean_s = s1 * rk;   // = mean - shift: the fragments are x - shift
+                rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * rk - mean_s * mean_s, 0.f) + p.eps);   // v_rsq_f32: 1 ulp
+                // the row means also go to mean_out (the shift of the next producers of x): first n-tile's workgroup only
+                if (p.mean_out != nullptr && wgtile == 0 && t == 0 && nn == 0 && gm < p.M)
+                    p.mean_out[gm] = mean_s + (p.a_shift != nullptr ? (first ? ex.sh : p.a_shift[gm]) : 0.f);
+            } else {
+                const float* rs = rowstat + (u * 16 + mm) * 2;
+                mean_s = rs[0]; rstd = rs[1];
+            }
+            if (valid && !rawcol) v = rstd * (v - mean_s * (first ? ex.colsum : p.colsum[gn]));
+        }
+        if (valid) {
+            if (p.bias) v += first ? ex.bias : p.bias[gn];
+            if (!qkv) {
+                if (gelu) v = gelu_exact(v);
+                oi = (size_t)gm * p.N + gn;
+                if (has_res) v += first ? ex.res : p.residual[oi];
+            }
+        }
+        if (has_stats) {
+            // (mean, M2) of this workgroup's 16 output features per row, for the LayerNorm of the consumer
+            // (HT: of its 8 features; lanes 8-15 of a row hold nothing and stay out of lanes 0-7's sums)
+            float sm = valid ? v : 0.f;
+            sm = HT ? row8_sum(sm) : row16_sum(sm);
+            const float mb = sm * (HT ? 0.125f : 0.0625f);
+            float dq = valid ? (v - mb) * (v - mb) : 0.f;
+            dq = HT ? row8_sum(dq) : row16_sum(dq);
+            if (nn == 0 && gm < p.M)
+                *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> (HT ? 3 : 4)) + ntile + t) * 2) = make_float2(mb, dq);
+        }
+        if (!valid) continue;
+        if (has_xt) {  // the residual stream also raw in A-fragment order for the next GEMM
+            const size_t ti = tiled_index<WT>(gm, gn, p.xt_nkc);
+            // single-term form: relative to the row's shift (include/acmi.h, acmi_linear_desc.xt_shift)
+            const float vs = p.xt_shift != nullptr ? v - (first ? ex.osh : p.xt_shift[gm]) : v;
+            if (sizeof(WT) == 2) {
+                const bf16_t hi = f32_to_bf16(vs);
+                reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
+                if (has_xlo)
+                    reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<WT>(gm, gn, p.xt_lo_nkc)] = f32_to_bf16(vs - bf16_to_f32(hi));
+            } else {
+                reinterpret_cast<float*>(p.xt_hi)[ti] = vs;
+            }
+        }
+        if (qkv) {
+            int part, f, h, dd, pidx, brow;
+            if (EPI == EPI_QKV) {
+                // per 16-feature tile (wave-uniform values: scalar arithmetic): the tile lies in one part and one head
+                const int fb = __builtin_amdgcn_readfirstlane(n0 + 16 * t);
+                part = fb / p.d;
+                const int f0 = fb - part * p.d;
+                h = f0 / p.hd;
+                f = f0 + nn; dd = f0 - h * p.hd + nn;
+                pidx = 0; brow = gm;
+            } else {
+                part = gn / p.d; f = gn - part * p.d;
+                h = f / p.hd; dd = f - h * p.hd;
+                pidx = gm / p.rpp; brow = gm - pidx * p.rpp;  // several positions per call (prefill)
+            }
+            if (part == 0) {
+                p.q_out[(size_t)gm * p.d + f] = v;
+            } else if (part == 3) {
+                p.r_out[(size_t)gm * p.d + f] = v;
+            } else {
+                const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + ex.tpos + pidx) * p.hd + dd;
+                void* cache = part == 1 ? p.k_cache : p.v_cache;
+                if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v);
+                else reinterpret_cast<float*>(cache)[ci] = v;
+            }
+        } else if (out_mode == ACMI_OUT_TILED) {
+            st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
+        } else if (out_mode == ACMI_OUT_BF16) {
+            reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
+        } else {
+            reinterpret_cast<float*>(p.out)[oi] = v;
         }
     }
 }
 
 // NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
 // the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs.
-template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false, bool DMA = false>
+template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false>
 __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const int wgtile, const int kslice) {
     static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
     static_assert(!HT || (NT == 1 && LN == 0), "half-tile workgroups: plain GEMM, one (half) n-tile");
     const int ntile = wgtile * NT;   // first n-tile of this workgroup (HT: the half-tile index)
     constexpr int D = (LN == 2 || LN == 3) ? 2 : 1;
-    constexpr bool FOLD = LN == 1 || LN == 2;
+    constexpr bool PART = LN == 1 || LN == 2;
+    constexpr bool GRAM = LN == 4;
     // fragments per straight-line chunk: (1 + MT D) C fragment registers (4 VGPRs each) must leave the kernel
     // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
     // VGPRs of a 2-waves-per-SIMD launch
-    // (LDS-DMA form: the weight fragments hold no registers, the budget is the activation's alone)
-    constexpr int CQ = DMA ? (HT ? 52 / (2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (MT * D)))
-                           : (HT ? 52 / (1 + 2 * MT) : ((LN > 0 ? (NS > 8 ? 36 : 44) : 52) / (NT + MT * D)));
+    constexpr int CQ = HT ? 52 / (1 + 2 * MT) : ((PART ? (NS > 8 ? 36 : 44) : (GRAM ? 48 : 52)) / (NT + MT * D));
     constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TlTrace tr{};
@@ -581,9 +703,9 @@ __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const in
     const int lane = threadIdx.x & 63, nw = h.nw, ksp = h.ksp;   // (blockDim / gridDim would be scalar loads of the kernarg segment)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: fragment addresses stay in SGPRs
     LinArgs p;   // filled by the first chunk, behind its weight requests
-    float* red = reinterpret_cast<float*>(smem);        // [NT MT][nw][256] partial accumulators
-    float* rowstat = red + (size_t)NT * MT * nw * 256;  // [16 MT][2] mean, rstd
-    unsigned char* wl = reinterpret_cast<unsigned char*>(rowstat + 32 * MT);   // DMA: [NT][kcs] KB image of the weight slice
+    constexpr int NRED = (HT ? 1 : NT) * MT + (GRAM ? 2 * MT : 0);   // tiles of the cross-wave reduction
+    float* red = reinterpret_cast<float*>(smem);        // [NRED][nw][256] partial accumulators (+ row sums / Gram tiles)
+    float* rowstat = red + (size_t)NRED * nw * 256;     // [16 MT][2] mean, rstd (LN 1 / 2)
     const int n0 = ntile * (HT ? 8 : 16), NKC = HT ? h.NKC >> 1 : h.NKC;   // HT: K counted in 1 KB weight units
     const u32x4* wt = h.w + (size_t)ntile * NKC * 64;  // + fragment * 64 + lane
     const int kcs = h.kcs, kbeg = kslice * kcs;         // this workgroup's K slice
@@ -591,205 +713,147 @@ __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const in
 
     // one group of MT 16-row blocks per workgroup (grid.z): no loop around the body, so that nothing of the
     // epilogue is hoisted in front of the first load
-    {
-        const int mg = (int)blockIdx.z * 16 * MT;
-        const int mtv = min(MT, (h.M - mg + 15) >> 4);
-        f32x4 accs[(HT ? 2 : NT) * MT];
+    const int mg = (int)blockIdx.z * 16 * MT;
+    const int mtv = min(MT, (h.M - mg + 15) >> 4);
+    f32x4 accs[(HT ? 2 : NT) * MT], accx[2 * MT];
 #pragma unroll
-        for (int u = 0; u < (HT ? 2 : NT) * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ngroups = 4 * mtv;   // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
-        // addresses of everything but the weights: evaluated by tl_chunk once its weight requests are out
-        // (`z` is an opaque zero produced behind the weight requests: added to every index these addresses derive from,
-        // it keeps loop-invariant code motion from hoisting the arithmetic back in front of them)
-        auto late = [&](const int z) -> TlLate {
-            TlLate L;
-            const int mgz = mg + z, lz = lane + z, wz = wave + z;
-            L.mts = h.a_rbs * 64; L.mtl = D == 2 ? p.alo_rbs * 64 : 0;   // fragment lanes between consecutive 16-row blocks (a, a_lo)
-            L.mtv = mtv;
-            L.at = h.a + (size_t)((mgz >> 4) * L.mts);
-            L.al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mgz >> 4) * L.mtl) : nullptr;
-            L.st_ptr = own;
-            if (FOLD) L.st_ptr = h.a_stats + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), h.M - 1) * h.a_np * 2;
-            L.psh = (FOLD && h.a_shift != nullptr) ? h.a_shift + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), h.M - 1) : own;
-            return L;
-        };
-        auto epi = [&](const int z) -> TlEpi {
-            TlEpi E;
-            const int mgz = mg + z, n0z = n0 + z;
-            // this thread's first epilogue element
-            const int e0 = (int)threadIdx.x + z, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
-            const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
-            const int egn = min(n0z + (HT ? (enn & 7) : 16 * et + enn), p.N - 1), egm = min(mgz + 16 * eu + emm, p.M - 1);
-            E.pb = p.bias != nullptr ? p.bias + egn : own;
-            E.pc = p.colsum != nullptr ? p.colsum + egn : own;
-            E.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
-            E.ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
-            E.posh = p.xt_shift != nullptr ? p.xt_shift + egm : own;
-            return E;
-        };
-        TlExtras ex;
+    for (int u = 0; u < (HT ? 2 : NT) * MT; ++u) accs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2 * MT; ++u) accx[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = 4 * mtv;   // statistics: groups of 4 rows (16 lanes each), group g of this wave first = wave
+    // addresses of everything but the weights: evaluated by tl_chunk once its weight requests are out
+    // (`z` is an opaque zero produced behind the weight requests: added to every index these addresses derive from,
+    // it keeps loop-invariant code motion from hoisting the arithmetic back in front of them)
+    auto late = [&](const int z) -> TlLate {
+        TlLate L;
+        const int mgz = mg + z, lz = lane + z, wz = wave + z;
+        L.mts = h.a_rbs * 64; L.mtl = D == 2 ? p.alo_rbs * 64 : 0;   // fragment lanes between consecutive 16-row blocks (a, a_lo)
+        L.mtv = mtv;
+        L.at = h.a + (size_t)((mgz >> 4) * L.mts);
+        L.al = D == 2 ? reinterpret_cast<const u32x4*>(p.a_lo) + (size_t)((mgz >> 4) * L.mtl) : nullptr;
+        L.st_ptr = own;
+        if (PART) L.st_ptr = h.a_stats + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), h.M - 1) * h.a_np * 2;
+        L.psh = own;
+        if (PART && h.a_shift != nullptr) L.psh = h.a_shift + min(mgz + min(wz, ngroups - 1) * 4 + (lz >> 4), h.M - 1);
+        // LN 4: the shift of this thread's first epilogue row (only the workgroup that publishes mean_out adds it back)
+        if (GRAM && h.a_shift != nullptr) L.psh = h.a_shift + min(mgz + 16 * ((((int)threadIdx.x + z) >> 8) / NT) + ((lz >> 4) & 3) + 4 * (wz & 3), h.M - 1);
+        return L;
+    };
+    auto epi = [&](const int z) -> TlEpi {
+        TlEpi E;
+        const int mgz = mg + z, n0z = n0 + z;
+        // this thread's first epilogue element
+        const int e0 = (int)threadIdx.x + z, eq = e0 >> 8, emm = (e0 >> 4) & 15, enn = e0 & 15;
+        const int et = eq % NT, eu = eq / NT;   // (n-tile, row block) of that element: e >> 8 = row block * NT + n-tile
+        const int egn = min(n0z + (HT ? (enn & 7) : 16 * et + enn), p.N - 1), egm = min(mgz + 16 * eu + emm, p.M - 1);
+        E.pb = p.bias != nullptr ? p.bias + egn : own;
+        E.pc = p.colsum != nullptr ? p.colsum + egn : own;
+        E.pr = p.residual != nullptr ? p.residual + (egm * p.N + egn) : own;
+        E.ppos = p.qkv ? p.pos : reinterpret_cast<const int*>(own);
+        E.posh = p.xt_shift != nullptr ? p.xt_shift + egm : own;
+        return E;
+    };
+    TlExtras ex;
 
-        // wave w owns the CONTIGUOUS run of K fragments [w fpw, (w + 1) fpw) (+ a ragged tail): its requests walk
-        // 1 KB, 2 KB, ... through one DRAM page instead of striding by nw KB (out-proj 4.81 -> 4.57, FFN2 9.93 -> 9.37 us)
-        const int ks = 1;
-        int kc = kbeg + wave * h.fpw, rem = h.fpw;
-        if (rem == 0 && nw * h.fpw + wave >= kcs) tl_load_args(p, aoff, 0);   // a wave without fragments: no chunk fills p
+    // wave w owns the CONTIGUOUS run of K fragments [w fpw, (w + 1) fpw) (+ a ragged tail): its requests walk
+    // 1 KB, 2 KB, ... through one DRAM page instead of striding by nw KB (out-proj 4.81 -> 4.57, FFN2 9.93 -> 9.37 us)
+    int kc = kbeg + wave * h.fpw, rem = h.fpw;
+    if (rem == 0 && nw * h.fpw + wave >= kcs) tl_load_args(p, aoff, 0);   // a wave without fragments: no chunk fills p
 #define ACMI_TL_RUN(Cn)                                                                                                 \
-        while (rem >= Cn) {                                                                                            \
-            if constexpr (HT) tl_chunk_ht<WT, MT, Cn, DMA>(p, aoff, wt, kc, late, epi, accs, ex, tr, wl, kc - kbeg);   \
-            else tl_chunk<WT, MT, LN, NT, NS, Cn, DMA>(h, p, aoff, wt, kc, ks, h.a_np, late, epi, accs, ex, tr, wl,    \
-                                                       kc - kbeg, kcs);                                                \
-            kc += Cn * ks; rem -= Cn;                                                                                  \
-        }
-        if (CMAX >= 24) { ACMI_TL_RUN(24) }
-        if (CMAX >= 16) { ACMI_TL_RUN(16) }
-        if (CMAX >= 12) { ACMI_TL_RUN(12) }
-        if (CMAX >= 8) { ACMI_TL_RUN(8) }
-        if (CMAX >= 6) { ACMI_TL_RUN(6) }
-        if (CMAX >= 4) { ACMI_TL_RUN(4) }
-        ACMI_TL_RUN(2)
-        ACMI_TL_RUN(1)
-#undef ACMI_TL_RUN
-        kc = kbeg + nw * h.fpw + wave;
-        if (kc < kbeg + kcs) {  // ragged tail: the first kcs % nw waves own one more fragment
-            if constexpr (HT) tl_chunk_ht<WT, MT, 1, DMA>(p, aoff, wt, kc, late, epi, accs, ex, tr, wl, kc - kbeg);
-            else tl_chunk<WT, MT, LN, NT, NS, 1, DMA>(h, p, aoff, wt, kc, ks, h.a_np, late, epi, accs, ex, tr, wl, kc - kbeg, kcs);
-        }
-        if constexpr (HT) {  // columns 0-7 of the even accumulators + columns 8-15 of the odd ones, rotated onto 0-7
-#pragma unroll
-            for (int u = 0; u < MT; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) accs[u][r] = accs[2 * u][r] + dpp_f32<0x128>(accs[2 * u + 1][r]);
-        }
-
-        // ---- deterministic cross-wave reduction through LDS
-#pragma unroll
-        for (int u = 0; u < NT * MT; ++u)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[((size_t)u * nw + wave) * 256 + lane * 4 + r] = accs[u][r];
-        if (FOLD) {
-            // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
-#pragma unroll
-            for (int i = 0; i < NS; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
-            // the row means also go to mean_out (the shift of the next producers of x): first n-tile's workgroup only
-            const bool wmean = p.mean_out != nullptr && wgtile == 0;
-            if (wave < ngroups) {
-                const int row = mg + wave * 4 + (lane >> 4);
-                rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8,
-                                   p.a_shift != nullptr ? ex.sh : 0.f, (wmean && row < p.M) ? p.mean_out + row : nullptr);
-            }
-            for (int g = wave + nw; g < ngroups; g += nw) {
-                const int row = mg + g * 4 + (lane >> 4);
-                rowstat_load<NS>(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
-                rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8,
-                                   p.a_shift != nullptr ? p.a_shift[min(row, p.M - 1)] : 0.f,
-                                   (wmean && row < p.M) ? p.mean_out + row : nullptr);
-            }
-        }
-        ACMI_TR(tr.t, 5);
-        __syncthreads();
-        ACMI_TR(tr.t, 6);
-
-        // ---- epilogue: one output element per thread and pass
-        for (int e = (int)threadIdx.x; e < 256 * mtv * NT; e += nw * 64) {
-            const int t = (e >> 8) % NT, u = (e >> 8) / NT, mm = (e >> 4) & 15, nn = e & 15;
-            const bool first = e == (int)threadIdx.x;
-            const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
-            float v = 0.f;
-            for (int w = 0; w < nw; ++w) v += red[((size_t)(t * MT + u) * nw + w) * 256 + idx];
-            const int gm = mg + 16 * u + mm, gn = n0 + 16 * t + nn;
-            const bool valid = gm < p.M && gn < p.N && (!HT || nn < 8);
-            if (ksp > 1) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
-                if (valid) reinterpret_cast<float*>(p.out)[((size_t)kslice * p.M + gm) * p.N + gn] = v;
-                continue;
-            }
-            size_t oi = 0;
-            // QKV launch carrying the x0 part of the cross-attention query: features >= 3d are stored raw
-            const bool rawcol = p.qkv && gn >= 3 * p.d;
-            if (valid) {
-                if (FOLD && !rawcol) {  // folded LayerNorm: rstd * (x W'^T - mean * colsum)
-                    const float* rs = rowstat + (u * 16 + mm) * 2;
-                    v = rs[1] * (v - rs[0] * (first ? ex.colsum : p.colsum[gn]));
-                }
-                if (p.bias) v += first ? ex.bias : p.bias[gn];
-                if (!p.qkv) {
-                    if (p.act == 1) v = gelu_exact(v);
-                    oi = (size_t)gm * p.N + gn;
-                    if (p.residual) v += first ? ex.res : p.residual[oi];
-                }
-            }
-            if (p.stats_out != nullptr) {
-                // (mean, M2) of this workgroup's 16 output features per row, for the LayerNorm of the consumer
-                // (HT: of its 8 features; lanes 8-15 of a row hold nothing and stay out of lanes 0-7's sums)
-                float sm = valid ? v : 0.f;
-                sm = HT ? row8_sum(sm) : row16_sum(sm);
-                const float mb = sm * (HT ? 0.125f : 0.0625f);
-                float dq = valid ? (v - mb) * (v - mb) : 0.f;
-                dq = HT ? row8_sum(dq) : row16_sum(dq);
-                if (nn == 0 && gm < p.M)
-                    *reinterpret_cast<float2*>(p.stats_out + ((size_t)gm * (p.N >> (HT ? 3 : 4)) + ntile + t) * 2) = make_float2(mb, dq);
-            }
-            if (!valid) continue;
-            if (p.xt_hi != nullptr) {  // the residual stream also raw in A-fragment order for the next GEMM
-                const size_t ti = tiled_index<WT>(gm, gn, p.xt_nkc);
-                // single-term form: relative to the row's shift (include/acmi.h, acmi_linear_desc.xt_shift)
-                const float vs = p.xt_shift != nullptr ? v - (first ? ex.osh : p.xt_shift[gm]) : v;
-                if (sizeof(WT) == 2) {
-                    const bf16_t hi = f32_to_bf16(vs);
-                    reinterpret_cast<bf16_t*>(p.xt_hi)[ti] = hi;
-                    if (p.xt_lo != nullptr)
-                        reinterpret_cast<bf16_t*>(p.xt_lo)[tiled_index<WT>(gm, gn, p.xt_lo_nkc)] = f32_to_bf16(vs - bf16_to_f32(hi));
-                } else {
-                    reinterpret_cast<float*>(p.xt_hi)[ti] = vs;
-                }
-            }
-            if (p.qkv) {
-                const int part = gn / p.d, f = gn - part * p.d;
-                if (part == 0) {
-                    p.q_out[(size_t)gm * p.d + f] = v;
-                } else if (part == 3) {
-                    p.r_out[(size_t)gm * p.d + f] = v;
-                } else {
-                    const int h = f / p.hd, dd = f - h * p.hd;
-                    const int pidx = gm / p.rpp, brow = gm - pidx * p.rpp;  // several positions per call (prefill)
-                    const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + ex.tpos + pidx) * p.hd + dd;
-                    void* cache = part == 1 ? p.k_cache : p.v_cache;
-                    if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v);
-                    else reinterpret_cast<float*>(cache)[ci] = v;
-                }
-            } else if (p.out_mode == ACMI_OUT_TILED) {
-                st_f32(reinterpret_cast<WT*>(p.out) + tiled_index<WT>(gm, gn, p.NKC_out), v);
-            } else if (p.out_mode == ACMI_OUT_BF16) {
-                reinterpret_cast<bf16_t*>(p.out)[oi] = f32_to_bf16(v);
-            } else {
-                reinterpret_cast<float*>(p.out)[oi] = v;
-            }
-        }
-#ifdef ACMI_TRACE
-        ACMI_TR(tr.t, 7);
-        ACMI_TR_WAIT_VM(0);
-        ACMI_TR(tr.t, 8);
-        if (p.trace != nullptr && lane == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            tr.t[9] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
-            const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-            unsigned long long* dst = p.trace + (wg * nw + wave) * ACMI_TRACE_NSTAMP;
-#pragma unroll
-            for (int i = 0; i < ACMI_TRACE_NSTAMP; ++i) dst[i] = tr.t[i];
-        }
-#endif
+    while (rem >= Cn) {                                                                                                \
+        if constexpr (HT) tl_chunk_ht<WT, MT, Cn>(p, aoff, wt, kc, late, epi, accs, ex, tr);                           \
+        else tl_chunk<WT, MT, LN, NT, NS, Cn>(h, p, aoff, wt, kc, h.a_np, late, epi, accs, accx, ex, tr);              \
+        kc += Cn; rem -= Cn;                                                                                           \
     }
+    if (CMAX >= 24) { ACMI_TL_RUN(24) }
+    if (CMAX >= 16) { ACMI_TL_RUN(16) }
+    if (CMAX >= 12) { ACMI_TL_RUN(12) }
+    if (CMAX >= 8) { ACMI_TL_RUN(8) }
+    if (CMAX >= 6) { ACMI_TL_RUN(6) }
+    if (CMAX >= 4) { ACMI_TL_RUN(4) }
+    ACMI_TL_RUN(2)
+    ACMI_TL_RUN(1)
+#undef ACMI_TL_RUN
+    kc = kbeg + nw * h.fpw + wave;
+    if (kc < kbeg + kcs) {  // ragged tail: the first kcs % nw waves own one more fragment
+        if constexpr (HT) tl_chunk_ht<WT, MT, 1>(p, aoff, wt, kc, late, epi, accs, ex, tr);
+        else tl_chunk<WT, MT, LN, NT, NS, 1>(h, p, aoff, wt, kc, h.a_np, late, epi, accs, accx, ex, tr);
+    }
+    if constexpr (HT) {  // columns 0-7 of the even accumulators + columns 8-15 of the odd ones, rotated onto 0-7
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accs[u][r] = accs[2 * u][r] + dpp_f32<0x128>(accs[2 * u + 1][r]);
+    }
+
+    // ---- deterministic cross-wave reduction through LDS
+#pragma unroll
+    for (int u = 0; u < (HT ? 1 : NT) * MT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((size_t)u * nw + wave) * 256 + lane * 4 + r] = accs[u][r];
+    if (GRAM) {
+#pragma unroll
+        for (int u = 0; u < 2 * MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)((HT ? 1 : NT) * MT + u) * nw + wave) * 256 + lane * 4 + r] = accx[u][r];
+    }
+    if (PART) {
+        // mean / rstd of rows mg .. mg + 16 mtv - 1 from the producer's equal-count partials (Chan)
+#pragma unroll
+        for (int i = 0; i < NS; ++i) asm volatile("" : "+v"(ex.pm[i]), "+v"(ex.pq[i]));  // stays behind the K loop
+        // the row means also go to mean_out (the shift of the next producers of x): first n-tile's workgroup only
+        const bool wmean = p.mean_out != nullptr && wgtile == 0;
+        if (wave < ngroups) {
+            const int row = mg + wave * 4 + (lane >> 4);
+            rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + wave * 8,
+                               p.a_shift != nullptr ? ex.sh : 0.f, (wmean && row < p.M) ? p.mean_out + row : nullptr);
+        }
+        for (int g = wave + nw; g < ngroups; g += nw) {
+            const int row = mg + g * 4 + (lane >> 4);
+            rowstat_load<NS>(p.a_stats, p.a_np, p.M, mg + g * 4, lane, ex.pm, ex.pq);
+            rowstat_finish<NS>(ex.pm, ex.pq, p.a_np, p.a_cnt, p.K, p.eps, lane, rowstat + g * 8,
+                               p.a_shift != nullptr ? p.a_shift[min(row, p.M - 1)] : 0.f,
+                               (wmean && row < p.M) ? p.mean_out + row : nullptr);
+        }
+    }
+    ACMI_TR(tr.t, 5);
+    __syncthreads();
+    ACMI_TR(tr.t, 6);
+
+    // the specialised forms exist for the wave count the decode step launches them with (the launcher sets p.epi accordingly:
+    // 8 waves, or 4 for the GEMMs with N = d); everything else takes the generic form
+#define ACMI_TL_EPI(E, W) tl_epilogue<WT, MT, LN, NT, HT, E, W>(p, ex, red, rowstat, nw, ksp, kslice, mg, mtv, n0, ntile, wgtile)
+    const int epi_kind = __builtin_amdgcn_readfirstlane(p.epi);
+    if (LN == 0 && NT == 1 && epi_kind == EPI_PRODX) { if (nw == 8) ACMI_TL_EPI(EPI_PRODX, 8); else ACMI_TL_EPI(EPI_PRODX, 4); }
+    else if (!HT && LN != 3 && epi_kind == EPI_TILED) ACMI_TL_EPI(EPI_TILED, 8);
+    else if (!HT && epi_kind == EPI_F32) { if (nw == 8) ACMI_TL_EPI(EPI_F32, 8); else ACMI_TL_EPI(EPI_F32, 4); }
+    else if (!HT && (LN == 1 || LN == 2 || LN == 4) && epi_kind == EPI_QKV) ACMI_TL_EPI(EPI_QKV, 8);
+    else ACMI_TL_EPI(EPI_GEN, 0);
+#undef ACMI_TL_EPI
+#ifdef ACMI_TRACE
+    ACMI_TR(tr.t, 7);
+    ACMI_TR_WAIT_VM(0);
+    ACMI_TR(tr.t, 8);
+    if (p.trace != nullptr && lane == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tr.t[9] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        const size_t wg = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        unsigned long long* dst = p.trace + (wg * nw + wave) * ACMI_TRACE_NSTAMP;
+#pragma unroll
+        for (int i = 0; i < ACMI_TRACE_NSTAMP; ++i) dst[i] = tr.t[i];
+    }
+#endif
 }
 
 // Kernarg layout (both kernels): the TlHot words first (<= 14 dwords: preloaded into SGPRs), the LinArgs block(s) at byte
-// ACMI_TL_ARGS_OFF -- never touched through the parameter, only through tl_load_args.
+// ACMI_TL_ARGS_OFF(_PAIR) -- never touched through the parameter, only through tl_load_args.
 //   g0 = K tiles | K tiles per slice << 16     g1 = fragments per wave | waves << 12 | split-K slices << 16
 //   g2 = a_rbs | M << 16                       g3 = statistics partials per row
-template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false, bool DMA = false>
+template <typename WT, int MT, int LN, int NT, int NS = 8, bool HT = false>
 __global__ __launch_bounds__(512) void lin_tiled_kernel(const u32x4* hw, const u32x4* ha, const float* hst, const float* hsh,
                                                         unsigned g0, unsigned g1, unsigned g2, unsigned g3, const LinArgs) {
     const TlHot h = tl_unpack(hw, ha, hst, hsh, g0, g1, g2, g3);
-    tl_body<WT, MT, LN, NT, NS, HT, DMA>(h, ACMI_TL_ARGS_OFF, (int)blockIdx.x, (int)blockIdx.y);
+    tl_body<WT, MT, LN, NT, NS, HT>(h, ACMI_TL_ARGS_OFF, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Two independent GEMMs of the chain in ONE launch (one dependency edge less): workgroups [0, tiles0) run p0
@@ -798,7 +862,7 @@ __global__ __launch_bounds__(512) void lin_tiled_kernel(const u32x4* hw, const u
 // query before its LayerNorm statistics are applied), see acmi_lm_step.
 //   g00 / g01 = K tiles | K tiles per slice << 16 of p0 / p1     g1 = fragments per wave of p0 | of p1 << 12 | waves << 24
 //   g2 = a_rbs | M << 16 (shared)
-template <typename WT, int MT, int LNB, bool DMA = false>
+template <typename WT, int MT, int LNB>
 __global__ __launch_bounds__(512) void lin_pair_kernel(const u32x4* hw0, const u32x4* hw1, const u32x4* ha0, const u32x4* ha1,
                                                        unsigned g00, unsigned g01, unsigned g1, unsigned g2, int tiles0, int,
                                                        const LinArgs, const LinArgs) {
@@ -806,8 +870,8 @@ __global__ __launch_bounds__(512) void lin_pair_kernel(const u32x4* hw0, const u
     const unsigned nw = g1 >> 24;
     const TlHot h = tl_unpack(first ? hw0 : hw1, first ? ha0 : ha1, nullptr, nullptr, first ? g00 : g01,
                               ((first ? g1 : g1 >> 12) & 0xfffu) | (nw << 12) | (1u << 16), g2, 0u);
-    if (first) tl_body<WT, MT, 0, 1, 8, false, DMA>(h, ACMI_TL_ARGS_OFF_PAIR, (int)blockIdx.x, 0);
-    else tl_body<WT, MT, LNB, 1, 8, false, DMA>(h, ACMI_TL_ARGS_OFF_PAIR + (int)sizeof(LinArgs), (int)blockIdx.x - tiles0, 0);
+    if (first) tl_body<WT, MT, 0, 1, 8, false>(h, ACMI_TL_ARGS_OFF_PAIR, (int)blockIdx.x, 0);
+    else tl_body<WT, MT, LNB, 1, 8, false>(h, ACMI_TL_ARGS_OFF_PAIR + (int)sizeof(LinArgs), (int)blockIdx.x - tiles0, 0);
 }
 
 #ifdef ACMI_TRACE
@@ -873,18 +937,27 @@ static int tiled_prepare(LinArgs& a) {
     return ACMI_OK;
 }
 
-// A/B switch: ACMI_LIN_DMA=1 streams the weights through LDS-DMA (calls of <= 16 rows, whose weight slice fits the LDS)
-static bool lin_dma_wanted() {
-    static const bool v = getenv("ACMI_LIN_DMA") != nullptr && getenv("ACMI_LIN_DMA")[0] == '1';
-    return v;
+// which specialised epilogue the call's flags allow (tl_epilogue); HT / LayerNorm mode are checked in the kernel
+static int tiled_epi(const LinArgs& a, int nw) {
+    if (a.ksplit > 1 || (nw != 8 && nw != 4)) return EPI_GEN;
+    const bool w8 = nw == 8;   // QKV / tiled-output launches are specialised for 8 waves only
+    if (a.qkv)
+        return (w8 && a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && a.N % 16 == 0 && a.stats_out == nullptr && a.xt_hi == nullptr)
+                   ? EPI_QKV : EPI_GEN;
+    if (a.xt_hi != nullptr)
+        return (a.out_mode == ACMI_OUT_F32 && a.residual != nullptr && a.xt_lo == nullptr && a.act == 0) ? EPI_PRODX : EPI_GEN;
+    if (a.stats_out != nullptr) return EPI_GEN;
+    if (a.out_mode == ACMI_OUT_TILED) return (w8 && a.residual == nullptr) ? EPI_TILED : EPI_GEN;
+    if (a.out_mode == ACMI_OUT_F32) return a.act == 0 ? EPI_F32 : EPI_GEN;
+    return EPI_GEN;
 }
 
-template <typename WT, int MT, int LN, int NT, int NS, bool HT, bool DMA>
+template <typename WT, int MT, int LN, int NT, int NS, bool HT>
 static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {  // 2 n-tiles x 4 row blocks x 8 waves: just above the default dynamic LDS limit
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT, DMA>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
                 return ACMI_ELAUNCH;
@@ -892,17 +965,20 @@ static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st
             attr_set = true;
         }
     }
+    a.epi = tiled_epi(a, nw);
+    a.inv_K = 1.0f / (float)a.K;
 #ifdef ACMI_TRACE
-    a.trace = acmi_trace_reserve((LN == 1 || LN == 2) | (a.qkv ? 2 : 0) | (HT ? 4 : 0) | (a.xt_hi != nullptr ? 16 : 0) | ((HT ? 8 : 16 * NT) << 8),
+    a.trace = acmi_trace_reserve((LN == 1 || LN == 2 || LN == 4) | (a.qkv ? 2 : 0) | (HT ? 4 : 0) | (a.xt_hi != nullptr ? 16 : 0) | ((HT ? 8 : 16 * NT) << 8),
                                  gx * a.ksplit * ((a.M + 16 * MT - 1) / (16 * MT)), nw, a.N, a.K, a.M);
 #endif
     ACMI_REQUIRE(a.NKC <= 0xffff && a.kcs <= 0xffff && a.fpw <= 0xfff && a.ksplit <= 0xffff && a.a_rbs <= 0xffff && a.M <= 0xffff,
                  "acmi_linear: geometry beyond the packed launch words (K tiles %d, fragments per wave %d, M %d)", a.NKC, a.fpw, a.M);
     const unsigned g0 = (unsigned)a.NKC | ((unsigned)a.kcs << 16), g1 = (unsigned)a.fpw | ((unsigned)nw << 12) | ((unsigned)a.ksplit << 16);
     const unsigned g2 = (unsigned)a.a_rbs | ((unsigned)a.M << 16), g3 = (unsigned)a.a_np;
-    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT, DMA>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
+    constexpr bool PART = LN == 1 || LN == 2;
+    hipLaunchKernelGGL((lin_tiled_kernel<WT, MT, LN, NT, NS, HT>), dim3(gx, a.ksplit, (a.M + 16 * MT - 1) / (16 * MT)),
                        dim3(nw * 64), lds, st, reinterpret_cast<const u32x4*>(a.w), reinterpret_cast<const u32x4*>(a.a),
-                       LN == 1 || LN == 2 ? a.a_stats : nullptr, LN == 1 || LN == 2 ? a.a_shift : nullptr, g0, g1, g2, g3, a);
+                       PART ? a.a_stats : nullptr, PART || LN == 4 ? a.a_shift : nullptr, g0, g1, g2, g3, a);
     return acmi_check_launch("lin_tiled_kernel");
 }
 
@@ -912,12 +988,8 @@ static int launch_tiled_t(LinArgs& a, hipStream_t st) {
     const int wgs = gx * a.ksplit, frags = (HT ? a.NKC / 2 : a.NKC) / a.ksplit;
     const int nw = tiled_waves(wgs, frags * NT);
     a.kcs = frags; a.fpw = frags / nw;
-    const size_t lds = (size_t)NT * MT * nw * 1024 + (size_t)MT * 128;
-    if constexpr (MT == 1 && LN != 3) {
-        const size_t lds_dma = lds + (size_t)NT * frags * 1024;
-        if (lin_dma_wanted() && lds_dma <= 160 * 1024) return launch_tiled_k<WT, MT, LN, NT, NS, HT, true>(a, gx, nw, lds_dma, st);
-    }
-    return launch_tiled_k<WT, MT, LN, NT, NS, HT, false>(a, gx, nw, lds, st);
+    const size_t lds = (size_t)(NT * MT + (LN == 4 ? 2 * MT : 0)) * nw * 1024 + (size_t)MT * 128;
+    return launch_tiled_k<WT, MT, LN, NT, NS, HT>(a, gx, nw, lds, st);
 }
 
 template <typename WT>
@@ -925,7 +997,8 @@ static int launch_tiled(LinArgs& a, hipStream_t st) {
     int rc = tiled_prepare<WT>(a);
     if (rc) return rc;
     const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);  // 1, 2 or 4 16-row blocks share each weight fragment
-    const int ln = a.colsum == nullptr ? (a.lo_split > 0 ? 3 : 0) : (a.a_lo != nullptr ? 2 : 1);
+    // folded LayerNorm: statistics from the producer's partials (a_stats; with a lo term: LN 2), or from the fragments (LN 4)
+    const int ln = a.colsum == nullptr ? (a.lo_split > 0 ? 3 : 0) : (a.a_stats == nullptr ? 4 : (a.a_lo != nullptr ? 2 : 1));
     // wide (32-feature) workgroups when the 16-feature grid would not fit the 256 CUs in one workgroup each:
     // the activation fragments, re-read by every workgroup, are then shared by two n-tiles
     static const bool wide_ok = !(getenv("ACMI_LIN_WIDE") != nullptr && getenv("ACMI_LIN_WIDE")[0] == '0');
@@ -937,7 +1010,7 @@ static int launch_tiled(LinArgs& a, hipStream_t st) {
         if (mt == 1) return launch_tiled_t<WT, 1, 0, 1, 8, true>(a, st);
         return launch_tiled_t<WT, 2, 0, 1, 8, true>(a, st);
     }
-    if (a.colsum != nullptr && a.a_np > 128) {   // statistics of a half-tile producer: up to 256 partials per row
+    if (a.colsum != nullptr && a.a_stats != nullptr && a.a_np > 128) {   // statistics of a half-tile producer: up to 256 partials per row
         ACMI_REQUIRE(a.a_np <= 256 && mt <= 2, "acmi_linear: %d statistics partials per row unsupported (<= 256, and <= 128 "
                      "for M > 32; M=%d)", a.a_np, a.M);
         const bool wide = wide_ok && a.ksplit == 1 && tiles > 256 && tiles % 2 == 0 && a.N % 16 == 0 &&
@@ -955,12 +1028,14 @@ static int launch_tiled(LinArgs& a, hipStream_t st) {
         a.stats_out == nullptr && a.xt_hi == nullptr) {
 #define ACMI_TLW_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv, 2>(a, st);
         ACMI_TLW_CASE(1, 0) ACMI_TLW_CASE(1, 1) ACMI_TLW_CASE(1, 2)
+        ACMI_TLW_CASE(1, 4) ACMI_TLW_CASE(2, 4)
         ACMI_TLW_CASE(2, 0) ACMI_TLW_CASE(2, 1) ACMI_TLW_CASE(2, 2)
         ACMI_TLW_CASE(4, 0) ACMI_TLW_CASE(4, 1) ACMI_TLW_CASE(4, 2)
 #undef ACMI_TLW_CASE
     }
 #define ACMI_TL_CASE(MTv, LNv) if (mt == MTv && ln == LNv) return launch_tiled_t<WT, MTv, LNv, 1>(a, st);
     ACMI_TL_CASE(1, 0) ACMI_TL_CASE(1, 1) ACMI_TL_CASE(1, 2) ACMI_TL_CASE(1, 3)
+    ACMI_TL_CASE(1, 4) ACMI_TL_CASE(2, 4)
     ACMI_TL_CASE(2, 0) ACMI_TL_CASE(2, 1) ACMI_TL_CASE(2, 2) ACMI_TL_CASE(2, 3)
     ACMI_TL_CASE(4, 0) ACMI_TL_CASE(4, 1) ACMI_TL_CASE(4, 2) ACMI_TL_CASE(4, 3)
 #undef ACMI_TL_CASE
@@ -993,22 +1068,8 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
 #ifdef ACMI_TRACE
     p0.trace = p1.trace = acmi_trace_reserve(8 | 16 | (16 << 8), (int)(grid.x * grid.z), nw, p0.N + p1.N, p0.K, p0.M);
 #endif
-    if (mt == 1 && !hl && lin_dma_wanted()) {   // LDS-DMA form (A/B): both halves keep their weight slice's image in LDS
-        const size_t lds_dma = lds + (size_t)(p0.NKC > p1.NKC ? p0.NKC : p1.NKC) * 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_pair_kernel<WT, 1, 0, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                acmi_set_error("acmi_linear_pair: cannot raise the dynamic LDS limit");
-                return ACMI_ELAUNCH;
-            }
-            attr_set = true;
-        }
-        if (lds_dma <= 160 * 1024) {
-            hipLaunchKernelGGL((lin_pair_kernel<WT, 1, 0, true>), grid, block, lds_dma, st, hw0, hw1, ha0, ha1, g00, g01, g1, g2, t0, 0, p0, p1);
-            return acmi_check_launch("lin_pair_kernel");
-        }
-    }
+    p0.epi = tiled_epi(p0, nw); p1.epi = tiled_epi(p1, nw);
+    p0.inv_K = 1.0f / (float)p0.K; p1.inv_K = 1.0f / (float)p1.K;
 #define ACMI_PAIR_CASE(MTv)                                                                              \
     if (mt == MTv) {                                                                                     \
         if (hl) hipLaunchKernelGGL((lin_pair_kernel<WT, MTv, 3>), grid, block, lds, st, hw0, hw1, ha0, ha1, g00, g01, g1, g2, t0, 0, p0, p1); \
@@ -1024,8 +1085,10 @@ int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     if (a.ksplit < 1) a.ksplit = 1;
     if (a.rpp <= 0) a.rpp = a.M;
     ACMI_REQUIRE(!(a.a_tiled && a.ln_mode), "acmi_linear: LayerNorm needs a row-major activation");
-    ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && a.a_stats != nullptr && a.a_np >= 1 && a.a_np <= 256 && a.a_np * a.a_cnt == a.K),
-                 "acmi_linear: folded LayerNorm needs a tiled activation and row statistics (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
+    ACMI_REQUIRE(a.colsum == nullptr || (a.a_tiled && (a.a_stats == nullptr || (a.a_np >= 1 && a.a_np <= 256 && a.a_np * a.a_cnt == a.K))),
+                 "acmi_linear: folded LayerNorm needs a tiled activation and consistent row statistics (np=%d cnt=%d K=%d)", a.a_np, a.a_cnt, a.K);
+    ACMI_REQUIRE(a.colsum == nullptr || a.a_stats != nullptr || (a.a_lo == nullptr && a.M <= 32),
+                 "acmi_linear: LayerNorm statistics from the fragments (a_stats NULL) need a single-term activation and M <= 32 (M=%d)", a.M);
     ACMI_REQUIRE(a.colsum == nullptr || a.ksplit == 1, "acmi_linear: folded LayerNorm cannot be combined with split-K");
     if (a.a_tiled) return wdtype == ACMI_BF16 ? launch_tiled<bf16_t>(a, st) : launch_tiled<float>(a, st);
     return wdtype == ACMI_BF16 ? launch_rowmajor<bf16_t>(a, st) : launch_rowmajor<float>(a, st);
@@ -1057,7 +1120,7 @@ static int desc_to_args(const acmi_linear_desc& c, LinArgs& p) {
     p.ln_mode = c.ln_g ? 2 : (c.a_mode == ACMI_A_ROWMAJOR_F32_NORM ? 1 : 0);
     p.ln_g = c.ln_g; p.ln_b = c.ln_b; p.eps = c.eps;
     if (c.colsum != nullptr) {
-        ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.a_stats != nullptr, "acmi_linear: colsum needs a tiled activation and a_stats");
+        ACMI_REQUIRE(c.a_mode == ACMI_A_TILED, "acmi_linear: colsum needs a tiled activation");
         p.a_stats = c.a_stats; p.a_np = c.a_stats_np; p.a_cnt = c.a_stats_cnt; p.colsum = c.colsum; p.a_lo = c.a_lo;
     } else if (c.a_lo != nullptr) {  // hi + lo activation without LayerNorm (first lo_K columns)
         ACMI_REQUIRE(c.a_mode == ACMI_A_TILED && c.lo_K > 0 && c.lo_K <= c.K && c.lo_K % kt == 0,

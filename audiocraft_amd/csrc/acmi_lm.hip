@@ -493,6 +493,10 @@ struct StepCtx {
     // this layer's producers store with (the means the layer's QKV launch wrote); both NULL in hi / lo mode
     const float* xsh; float* nsh;
     bool use_lo;               // bf16 hi / lo pair
+    // round 4: in single-term + shift mode with <= 32 rows the LayerNorm-consuming GEMMs take their row statistics from the
+    // fragments themselves (acmi_linear_desc: colsum without a_stats), so the producers of x write partials only for the
+    // one consumer that is not a GEMM: the cross-attention kernel's query hook (the paired out-projection's x1)
+    bool gram;
 };
 
 // out = act(LayerNorm(x) W'^T + bias): folded into the GEMM, or standardisation kernel + plain GEMM
@@ -501,7 +505,7 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
     p.a_tiled = 1; p.w = w; p.bias = bias; p.M = c.rows; p.N = N; p.K = m->dim;
     if (c.lnm == LN_FOLD) {
         p.a = c.xh; p.a_rbs = c.rbs; p.a_lo = c.use_lo ? c.xl : nullptr;
-        p.a_stats = s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
+        p.a_stats = c.gram ? nullptr : s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
         p.a_shift = c.xsh;
     } else {
         int rc = acmi_launch_ln_tile(s->x, c.xh, m->wdtype, c.rows, m->dim, m->eps, nullptr, 0, c.st);
@@ -513,13 +517,13 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
 
 // describes x <- x + a W^T (in place on the f32 copy), also emitted as fragments into (xh, xl) + statistics
 static void gemm_produce_x_args(StepCtx& c, LinArgs& p, const void* a, int a_rbs, const void* w, int K, void* xh, void* xl,
-                                const float* bias = nullptr) {
+                                const float* bias = nullptr, bool stats_needed = false) {
     const acmi_lm_model* m = c.m; const acmi_lm_state* s = c.s;
     p.bias = bias;
     p.a = a; p.a_tiled = 1; p.a_rbs = a_rbs; p.w = w; p.residual = s->x; p.out = s->x; p.out_mode = ACMI_OUT_F32;
     p.M = c.rows; p.N = m->dim; p.K = K;
     if (c.lnm == LN_FOLD) {
-        p.stats_out = s->stats;
+        p.stats_out = (c.gram && !stats_needed) ? nullptr : s->stats;
         p.xt_hi = xh; p.xt_lo = c.use_lo ? xl : nullptr; p.xt_nkc = c.rbs; p.xt_lo_nkc = c.nkc_d;
         p.xt_shift = c.nsh;
     }
@@ -674,6 +678,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     const bool foldbf = c.lnm == LN_FOLD && wbf;
     const bool shifted = foldbf && s->xshift != nullptr && fold_lo_env() != 1 && !shift_off;
     c.use_lo = foldbf && !shifted && s->xlo != nullptr && (fold_lo_env() == 1 || (fold_lo_env() == -1 && !shift_off));
+    static const bool gram_off = getenv("ACMI_LN_GRAM") != nullptr && getenv("ACMI_LN_GRAM")[0] == '0';   // A/B: partials
+    c.gram = shifted && M <= 32 && !gram_off;
     float* const shbuf[2] = {s->xshift, s->xshift != nullptr ? s->xshift + M : nullptr};
     c.xsh = nullptr; c.nsh = nullptr;
     // Cross-attention query without a launch of its own (include/acmi.h, acmi_linear_pair): needs the folded
@@ -749,7 +755,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 // r += att (W_cq' W_out)^T, which completes r = x1 W_cq'^T (its x0 part came out of the QKV launch)
                 LinArgs p0 = {}, p1 = {};
                 const void* att_half = reinterpret_cast<const unsigned char*>(c.xh) + (size_t)c.nkc_d * 1024;  // K tile nkc_d
-                gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1], L.b_out);
+                gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1], L.b_out, true);
                 p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs; p1.bias = L.b_mq;
                 p1.w = L.w_mq; p1.residual = s->r; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = d;
                 if ((rc = acmi_launch_pair(p0, p1, m->wdtype, st))) return rc;

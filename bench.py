@@ -76,6 +76,9 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     hilo = wd == torch.bfloat16 and os.environ.get('ACMI_LN_LO', '') == '1'
     xl = [_C.tile_matrix(rnd(d) * 2.0 ** -9, wd) if hilo else None for _ in range(2)]
     shifts = [torch.zeros(B_eff, device=dev), torch.zeros(B_eff, device=dev)] if (wd == torch.bfloat16 and not hilo) else None
+    # single-term + shift mode, <= 32 rows: the LayerNorm-consuming GEMMs take their row statistics from the fragments
+    # (no a_stats) and only the paired out projection still writes partials (for the cross-attention query hook)
+    gram = shifts is not None and B_eff <= 32 and os.environ.get('ACMI_LN_GRAM', '') != '0'
     layer_no = 0
     np_ = max(1, d // 16)                                     # statistics partials of the current x (cnt elements each)
     stats = torch.zeros(B_eff, max(1, d // 8), 2, device=dev)
@@ -100,14 +103,15 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     def consume(w, out, out_mode, colsum, bias, act=0, first_of_layer=False, produced=True, publish=True):
         # LayerNorm(x) @ W'^T: raw fragments + statistics + column sums; the QKV launch also publishes the row means
         nonlocal launches, nbytes
-        _C.linear_ex(xh[cur], w, out, B_eff, _C.A_TILED, out_mode, a_stats=stats, np_=np_, cnt=d // np_, bias=bias, act=act,
+        _C.linear_ex(xh[cur], w, out, B_eff, _C.A_TILED, out_mode, a_stats=None if gram else stats, np_=np_, cnt=d // np_, bias=bias, act=act,
                      a_lo=xl[cur], colsum=colsum, a_rbs=rbs, a_shift=sh_out() if produced and not first_of_layer else sh_in(),
                      mean_out=sh_out() if (first_of_layer and publish) else None)
         launches += 1
         nbytes += wbytes(w)
 
-    def produce_desc(a, w, a_rbs, dst):
-        return _C.linear_desc(a, w, x, B_eff, _C.A_TILED, _C.OUT_F32, residual=x0, stats_out=stats, xt_hi=xh[dst],
+    def produce_desc(a, w, a_rbs, dst, stats_needed=False):
+        return _C.linear_desc(a, w, x, B_eff, _C.A_TILED, _C.OUT_F32, residual=x0,
+                              stats_out=None if (gram and not stats_needed) else stats, xt_hi=xh[dst],
                               xt_lo=xl[dst], a_rbs=a_rbs, xt_rbs=rbs, xt_shift=sh_out())
 
     def produce(a, w):
@@ -128,7 +132,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
                 # and the att part of that query in one launch (acmi_linear_pair); acmi_lm_layer.w_qkvx / w_mq
                 consume(ent['w_qkvx'], qkv, _C.OUT_F32, ent['cs_qkvx'], ent['b_qkvx'], first_of_layer=True)
                 att_half = xh[cur].view(-1)[(dp // kt) * 64 * (16 // xh[cur].element_size()):]
-                p0 = produce_desc(att_half, ent['w_out'], rbs, cur ^ 1)
+                p0 = produce_desc(att_half, ent['w_out'], rbs, cur ^ 1, stats_needed=True)
                 p1 = _C.linear_desc(att_half, ent['w_mq'], q, B_eff, _C.A_TILED, _C.OUT_F32, residual=q, a_rbs=rbs)
                 _C.linear_pair(p0, p1)
                 launches += 1

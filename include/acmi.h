@@ -352,7 +352,12 @@ typedef struct {
     /* folded LayerNorm (a_mode ACMI_A_TILED, a_stats and colsum given): `a` holds the RAW rows in fragment
      * order (bf16 weights: a = bf16(x), a_lo = bf16(x - a) or NULL for a single-term activation; f32: a = x),
      * colsum[n] = sum_k W[n, k]; the kernel returns act(rstd * (a W^T - mean * colsum) + bias) (+ residual)
-     * with mean / rstd per row from the a_stats partials (K elements per row in total). */
+     * with mean / rstd per row from the a_stats partials (K elements per row in total).
+     * colsum WITHOUT a_stats (a_stats NULL; single-term activation, M <= 32): the row statistics come FROM THE FRAGMENTS --
+     * two more MFMAs per activation fragment accumulate the rows' sums and sums of squares (a x ones, a x a^T), so that
+     * mean / variance are those of exactly the values the GEMM multiplies (one-pass variance: meant for fragments stored
+     * relative to a shift near the row mean, a_shift below; then mean = fragment mean + a_shift).  The consumer loads no
+     * partials and the producers of such an activation need no stats_out. */
     const void* a_lo; const float* colsum;
     /* xt_hi (or NULL): the final outputs are ALSO written as a raw tiled activation [., N] in wdtype
      * (bf16: xt_hi = bf16(v), xt_lo = bf16(v - xt_hi); f32: xt_hi = v, xt_lo unused) for such a consumer. */

@@ -677,6 +677,57 @@ def test_linear_single_term_with_row_shift(C, M, d, N2, half):
     assert r0 > 5 * r
 
 
+@pytest.mark.parametrize('M,d,N2,act', [(16, 1536, 6144, 0), (16, 1536, 4608, 1), (5, 512, 96, 0), (32, 2048, 512, 0), (17, 1536, 8192, 0),
+                                        (2, 1024, 3072, 1)])
+@pytest.mark.parametrize('out_tiled', [False, True])
+def test_linear_layernorm_statistics_from_fragments(C, M, d, N2, act, out_tiled):
+    """Folded LayerNorm WITHOUT statistics partials (acmi_linear_desc: colsum given, a_stats NULL): mean / variance of the
+    rows come out of the activation fragments themselves (a x ones, a x a^T on the matrix cores).  Checked (1) tightly
+    against the LayerNorm of the values the fragments actually hold (the kernel's arithmetic model), (2) against the
+    LayerNorm of the exact rows at the accuracy of the partials-based form, (3) mean_out = the exact row means to the
+    rounding of the fragments, (4) against the partials-based launch of the same operands."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(M * 7 + d + N2)
+    x = torch.randn(M, d, generator=g) * 1.7 + 40.0 * (1 + torch.arange(M).float()[:, None] / M)   # mean / std ~ 25-50
+    shift = x.mean(1) + 0.3 * torch.randn(M, generator=g)
+    w2 = torch.randn(N2, d, generator=g) / math.sqrt(d)
+    b2 = 0.1 * torch.randn(N2, generator=g)
+    frag = (x - shift[:, None]).to(dt)                       # what a producer stores (xt_hi with xt_shift)
+    hi = C.tile_matrix(frag.float().cuda(), dt)
+    w2t = C.TiledWeight(w2.cuda(), dt)
+    colsum = w2.to(dt).double().sum(1).float().cuda()
+    post = (lambda t: F.gelu(t)) if act else (lambda t: t)
+
+    def run(**kw):
+        means = torch.full((M,), float('nan'), device='cuda')
+        if out_tiled:
+            buf = C.tiled_activation_buffer(M, N2, dt, 'cuda')
+            C.linear_ex(hi, w2t, buf, M, C.A_TILED, C.OUT_TILED, bias=b2.cuda(), colsum=colsum, a_shift=shift.cuda(), mean_out=means,
+                        act=act, **kw)
+            return C.untile_matrix(buf, M, N2).float().cpu(), means.cpu()
+        out = torch.empty(M, N2, device='cuda')
+        C.linear_ex(hi, w2t, out, M, C.A_TILED, C.OUT_F32, bias=b2.cuda(), colsum=colsum, a_shift=shift.cuda(), mean_out=means, act=act,
+                    **kw)
+        return out.cpu(), means.cpu()
+
+    out, means = run()
+    model = post(F.layer_norm(frag.double(), (d,), None, None, 1e-5) @ w2.to(dt).double().t() + b2.double()).float()
+    exact = post(F.layer_norm(x.double(), (d,), None, None, 1e-5) @ w2.to(dt).double().t() + b2.double()).float()
+    tol_store = 5e-3 if out_tiled else 0.0    # a tiled output is rounded to bf16
+    r_model, r_exact = rel(out, model), rel(out, exact)
+    assert r_model < 2e-5 + tol_store, f"vs the LayerNorm of the stored fragments: rel-L2 {r_model}"
+    assert r_exact < 6e-3, f"vs the LayerNorm of the exact rows: rel-L2 {r_exact}"
+    assert torch.allclose(means, x.mean(1), rtol=0, atol=2e-3), (means - x.mean(1)).abs().max()
+    # the partials-based form on the same fragments (exact statistics of x in 16-element partials)
+    xb = x.view(M, d // 16, 16)
+    mb = xb.mean(-1)
+    stats = torch.stack([mb, ((xb - mb[..., None]) ** 2).sum(-1)], dim=-1).contiguous().cuda()
+    out_p, means_p = run(a_stats=stats, np_=d // 16, cnt=16)
+    assert rel(out, out_p) < 3e-3 + tol_store
+    print(f"[fragment statistics] M={M} d={d} N={N2}: rel-L2 vs model {r_model:.1e}, vs exact {r_exact:.1e} "
+          f"(partials form vs exact {rel(out_p, exact):.1e})")
+
+
 def test_attention_query_shift_and_active_rows(C):
     """acmi_attn_desc.q_shift: q built on the row minus its shift, q <- rstd (q - (mean - shift) colsum) + bias;
     active_rows: query rows past it are neither launched nor written."""

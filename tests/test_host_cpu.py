@@ -527,6 +527,16 @@ def test_audio_write_and_normalisation(tmp_path):
     loud = normalize_audio(wav.clone(), strategy='loudness', sample_rate=sr)
     assert abs(loudness(loud, sr) - (-14.0)) < 0.05
     assert normalize_audio(1e-4 * tone, strategy='loudness', sample_rate=sr).abs().max() < 2e-4    # below the energy floor
+    # against the oracle's independent restatement of torchaudio's meter (oracle/loudness.py), on noise: white, coloured,
+    # multi-channel, with near-silent stretches (both gates active), loud enough for the biquads' clamp, other sample rates
+    from oracle import loudness as ol
+    rng = np.random.default_rng(0)
+    for C, amp, rate in ((1, 0.1, 32000), (2, 0.3, 32000), (3, 0.05, 16000), (1, 1.5, 24000), (5, 0.2, 44100)):
+        x = rng.standard_normal((C, int(1.7 * rate))) * amp
+        x = np.cumsum(x, axis=-1) * 0.05 + x if C == 2 else x       # a coloured case
+        x[:, rate // 2:rate] *= 1e-4
+        assert abs(loudness(torch.tensor(x), rate) - ol.loudness(x, rate)) < 1e-6
+    assert loudness(torch.zeros(1, sr), sr) == -float('inf') == ol.loudness(np.zeros((1, sr)), sr)
     p = audio_write(tmp_path / 'sub' / 'clip', torch.cat([wav, -wav]), sr, strategy='peak')
     assert p.name == 'clip.wav' and p.exists()
     with wave.open(str(p)) as f:

@@ -308,3 +308,48 @@ def test_oracle_split_bands_closed_forms():
     assert energy.argmax() == 5 and energy[5] > 0.9 * energy.sum()
     cut = ombd.mel_frequencies(7, 0, 8000.)
     assert cut[0] == 0 and abs(float(cut[-1]) - 8000.) < 1e-2 and (cut[1:] > cut[:-1]).all()
+
+
+def test_loudness_oracle_pinned_to_bs1770():
+    """oracle/loudness.py (torchaudio's BS.1770-4 meter restated; parity unpinned against the torchaudio binary): what the
+    recommendation itself fixes -- the K-weighting coefficients it tabulates at 48 kHz, the 997 Hz calibration tone, the
+    channel sum, the gates."""
+    import math
+    import numpy as np
+    from oracle import loudness as ol
+    b, a = ol.treble_coefficients(48000)
+    assert np.allclose(b, [1.53512485958697, -2.69169618940638, 1.19839281085285], atol=2e-4)
+    assert np.allclose(a, [1.0, -1.69065929318241, 0.73248077421585], atol=2e-4)
+    b, a = ol.highpass_coefficients(48000)   # (the table normalises b to [1, -2, 1]; the cookbook form carries the gain 0.995)
+    assert np.allclose(np.asarray(b) / b[0], [1.0, -2.0, 1.0], atol=1e-12) and abs(b[0] - 1.0) < 6e-3
+    assert np.allclose(a, [1.0, -1.99004745483398, 0.99007225036621], atol=1e-4)
+    sr = 48000
+    t = np.arange(2 * sr) / sr
+    tone = np.sin(2 * math.pi * 997.0 * t)
+    for amp in (0.5, 0.1, 0.01):
+        assert abs(ol.loudness(amp * tone, sr) - (-3.01 + 20 * math.log10(amp))) < 0.06
+    assert abs(ol.loudness(np.stack([0.1 * tone, 0.1 * tone]), sr) - ol.loudness(0.1 * tone, sr) - 3.01) < 0.01
+    # gates.  A stretch of silence: blocks lying wholly inside it fall below the absolute gate; the blocks that straddle an
+    # edge hold a fraction f of the tone's power, stay within 10 LU of the gated mean and count with that fraction.
+    gate, step = int(round(0.4 * sr)), int(round(0.1 * sr))
+    loud = np.ones(2 * sr)
+    loud[sr // 2:sr + sr // 2] = 0.0
+
+    def expected_offset(mask, floor_db):
+        f = np.array([mask[k:k + gate].mean() for k in range(0, len(mask) - gate + 1, step)])
+        keep = 10 * np.log10(np.maximum(f, 1e-30)) > floor_db            # absolute gate (relative to the tone's level)
+        rel = 10 * math.log10(f[keep].mean()) - 10.0
+        keep &= 10 * np.log10(np.maximum(f, 1e-30)) > rel
+        return 10 * math.log10(f[keep].mean())
+
+    full = ol.loudness(0.1 * tone, sr)
+    assert abs(ol.loudness(0.1 * tone * loud, sr) - (full + expected_offset(loud, -70.0 - full))) < 0.05
+    # a -40 dB tail: its blocks pass the absolute gate and fall to the relative one
+    mask2 = np.concatenate([np.ones(2 * sr), np.full(2 * sr, 1e-4)])       # power ratio of the two halves
+    y = np.concatenate([0.1 * tone, 0.001 * tone])
+    assert ol.loudness(0.001 * tone, sr) > -70.0
+    assert abs(ol.loudness(y, sr) - (full + expected_offset(mask2, -70.0 - full))) < 0.05
+    assert ol.loudness(y, sr) > full - 0.7                                   # (an ungated mean would read 3 dB lower)
+    assert ol.loudness(1e-5 * tone, sr) == -math.inf           # everything below the absolute gate
+    # the clamp of torchaudio's biquads: a full-scale tone, boosted by the shelf, is clipped and reads lower than -3.01
+    assert ol.loudness(tone, sr) < -3.01
