@@ -28,9 +28,10 @@ def _hipcc() -> str:
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', '-ffp-contract=off']
 # Kernarg preload (gfx950): the leading scalar / pointer arguments of a kernel arrive in SGPRs at wave start (up to 14
 # dwords) instead of through scalar loads of a kernarg block that is cold on every launch of the decode chain; the
-# kernels of these files are written for it (acmi_gemm.hip: TlHot).  Firmware without the feature runs the compiler's
+# kernels of these files are written for it (acmi_gemm.hip: TlHot; acmi_attn.hip: attn_decode_kernel).  Firmware without the feature runs the compiler's
 # compatibility prologue, which loads the same registers.
-FILE_FLAGS = {'acmi_gemm.hip': ['-mllvm', '-amdgpu-kernarg-preload-count=14']}
+_PRELOAD = ['-mllvm', '-amdgpu-kernarg-preload-count=14']
+FILE_FLAGS = {'acmi_gemm.hip': _PRELOAD, 'acmi_attn.hip': _PRELOAD}
 OBJDIR = os.path.join(CSRC, 'build')
 
 

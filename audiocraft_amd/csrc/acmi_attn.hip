@@ -38,13 +38,30 @@ struct AttnArgs {
     int pm_n;              // > 0: position-minor query rows (row = cache row * pm_n + position), else row = position * rpp + cache row
 };
 
+// Leading arguments = what the first K / V requests need; with kernarg preload (audiocraft_amd/build.py) they arrive in
+// SGPRs at wave start.  The AttnArgs block behind them (byte ACMI_ATTN_ARGS_OFF of the kernarg segment) is read with scalar
+// loads issued AFTER those requests, and so is the device-side length word: a decode position runs 96 of these launches,
+// every one of which used to spend two dependent scalar round trips (kernarg block, then *len_dev -- a word the previous
+// position's sampler wrote, cold in this CU's scalar cache) in front of its first HBM request.  The first chunk is now
+// requested SPECULATIVELY, clamped to the cache capacity instead of the length (any address below Tcap is readable), and
+// masked once the length is known.
+//   g0 = H | Tcap << 16   g1 = rpp | pm_n << 16   g2 = len (host value / bound)   g3 = active_rows | speculate << 16 | waves << 24
+#define ACMI_ATTN_ARGS_OFF 48
+#define ACMI_AS4 __attribute__((address_space(4)))
+__device__ __forceinline__ void attn_load_args(AttnArgs& p, int z) {   // z: an opaque zero produced behind the first requests
+    const char ACMI_AS4* ka = (const char ACMI_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+    __builtin_memcpy(&p, (const void ACMI_AS4*)__builtin_assume_aligned((const void ACMI_AS4*)(ka + (ACMI_ATTN_ARGS_OFF + z)), 8),
+                     sizeof(AttnArgs));
+}
 template <typename KT, int HD, bool QN>  // QN: LayerNorm hook on q (separate instantiation: no branch around its loads)
-__global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
-    const float* __restrict__ q = p.q;
-    const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.kc);
-    const KT* __restrict__ vc = reinterpret_cast<const KT*>(p.vc);
-    const int H = p.H, Tcap = p.Tcap;
-    const float scale = p.scale;
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float* hq, const void* hkc, const void* hvc, const int* hlen_dev,
+                                                          unsigned g0, unsigned g1, unsigned g2, unsigned g3, const AttnArgs) {
+    const float* __restrict__ q = hq;
+    const KT* __restrict__ kc = reinterpret_cast<const KT*>(hkc);
+    const KT* __restrict__ vc = reinterpret_cast<const KT*>(hvc);
+    const int H = (int)(g0 & 0xffffu), Tcap = (int)(g0 >> 16);
+    const int h_rpp = (int)(g1 & 0xffffu), h_pm_n = (int)(g1 >> 16), h_len = (int)g2, h_active = (int)(g3 & 0xffffu);
+    const bool spec = ((g3 >> 16) & 0xffu) != 0;   // first chunk before the length is known (no window, no per-row lengths)
     constexpr int DPL = HD >= 8 ? 8 : HD;  // dims per lane
     constexpr int LPP = HD / DPL;          // lanes per position
     constexpr int PPI = 64 / LPP;          // positions covered by one load instruction of a wave
@@ -55,11 +72,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane % LPP, pp = lane / LPP;
     // several positions per call (prefill): cache row b0 and position index pidx of query row b (one division either way)
-    const int dv = p.pm_n > 0 ? p.pm_n : p.rpp, qd = b / dv, rm = b - qd * dv;
-    const int b0 = p.pm_n > 0 ? qd : rm, pidx = p.pm_n > 0 ? rm : qd;
-    if (p.active_rows > 0 && b0 >= p.active_rows) return;   // null condition: K = V = 0, the output is exactly 0 (workgroup uniform)
-    const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len)) : (p.len_dev ? (*p.len_dev + p.len_bias + pidx) : p.len);
-
+    const int dv = h_pm_n > 0 ? h_pm_n : h_rpp, qd = b / dv, rm = b - qd * dv;
+    const int b0 = h_pm_n > 0 ? qd : rm, pidx = h_pm_n > 0 ? rm : qd;
+    if (h_active > 0 && b0 >= h_active) return;   // null condition: K = V = 0, the output is exactly 0 (workgroup uniform)
+    const KT* kb = kc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
+    const KT* vb = vc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
+    const int nwv = __builtin_amdgcn_readfirstlane((int)(g3 >> 24));  // 1, 2 or 4 waves share the positions of this (row, head)
+    rawv kr[NI], vr[NI];
+    int lim = spec ? (hlen_dev != nullptr ? Tcap : h_len) : 0;   // addresses are clamped to lim - 1: the length once it is known
+    auto load_kv = [&](int t0) {
+        // branch free: lanes past the end re-read the last position (their scores are masked below); a per-lane
+        // zero fill would write the registers of loads still in flight and make every load wait for the previous
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int t = min(t0 + i * PPI + pp, lim - 1);
+            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
+            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
+    };
+    // the device-side length word goes out FIRST (vmcnt retires in order: it is back before the chunk behind it)
+    int len_word = 0;
+    if (hlen_dev != nullptr) len_word = __builtin_nontemporal_load(hlen_dev);
+    if (spec) load_kv(wave * CH);
+    // everything else comes from the AttnArgs block, read here (behind the first chunk's requests)
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    opaque0 = __builtin_amdgcn_readfirstlane(opaque0);
+    AttnArgs p;
+    attn_load_args(p, opaque0);
+    const float scale = p.scale;
     float qv[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) qv[e] = q[((size_t)b * H + h) * HD + c * DPL + e];
@@ -78,34 +120,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
             spm[i] = t.x; spq[i] = t.y;
         }
     }
-    const KT* kb = kc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
-    const KT* vb = vc + ((size_t)b0 * H + h) * Tcap * HD + c * DPL;
-
     float m = -INFINITY, l = 0.f, o[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);   // every request above is out before the length is waited for
+    const int len = p.len_rows ? max(1, min(p.len_rows[b0], p.len))
+                               : (hlen_dev != nullptr ? (__builtin_amdgcn_readfirstlane(len_word) + p.len_bias + pidx) : p.len);
 
-    const int nwv = blockDim.x >> 6;  // 1, 2 or 4 waves share the positions of this (row, head)
     // K and V of a whole chunk are requested together (2 * NI wide loads in flight per lane); the first chunk
     // goes out before anything waits on q (its LayerNorm hook needs the fresh statistics of x).
     // (Round 3 tried a second register set -- the next chunk in flight while one is multiplied, with exact vmcnt counts in
     // the steady state: 27.4 us at t = 1500 either way, +0.4 ... 0.8 us at every length from the longer prologue and the
     // 214 VGPRs.  The slope of this kernel, 0.0159 us per position = 6.2 TB/s, IS the copy bandwidth of the chip: what is
     // left is the fixed 3.6 us, 1.55 of them the kernel boundary.  profiles/r03_attn_microbench.log)
-    rawv kr[NI], vr[NI];
-    auto load_kv = [&](int t0) {
-        // branch free: lanes past the end re-read the last position (their scores are masked below); a per-lane
-        // zero fill would write the registers of loads still in flight and make every load wait for the previous
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int t = min(t0 + i * PPI + pp, len - 1);
-            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
-            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the 2 * NI requests together (the scheduler sinks them to their uses)
-    };
     const int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
-    load_kv(start + wave * CH);
+    lim = len;
+    if (!spec) load_kv(start + wave * CH);
     if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
         const bool v0 = lane < p.q_np, v1 = lane + 64 < p.q_np;
         const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)p.q_np;
@@ -117,6 +147,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const AttnArgs p) {
         for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - meff * qcs[e]) + qb[e];
     }
     for (int t0 = start + wave * CH; t0 < len; t0 += nwv * CH) {   // kr / vr hold the chunk at t0
+        if (t0 + CH > len) {   // (wave-uniform) the chunk runs past the end: whatever the clamped / speculative requests fetched
+#pragma unroll                  // there gets weight 0 below -- make it a finite 0 as well (0 x NaN would poison the sum)
+            for (int i = 0; i < NI; ++i)
+                if (t0 + i * PPI + pp >= len) {
+#pragma unroll
+                    for (int e = 0; e < DPL; ++e) vr[i][e] = (KT)0;
+                }
+        }
         float s[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -200,10 +238,17 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     // rows past active_rows do nothing: with one position per call (query row == cache row) they are not even launched
     const int rows = (a.active_rows > 0 && Beff == a.rpp) ? a.active_rows : Beff;
     dim3 grid(a.H, rows), block(64 * nwv);
+    ACMI_REQUIRE(a.H <= 0xffff && a.Tcap <= 0xffff && a.rpp <= 0xffff && a.pm_n <= 0xffff && a.active_rows <= 0xffff,
+                 "acmi_attn_decode: geometry beyond the packed launch words (H %d, Tcap %d, rows %d)", a.H, a.Tcap, a.rpp);
+    // the first chunk may be requested before the length is known unless the window start or a per-row length decides it
+    const unsigned spec = (a.past_context <= 0 && a.len_rows == nullptr) ? 1u : 0u;
+    const unsigned g0 = (unsigned)a.H | ((unsigned)a.Tcap << 16), g1 = (unsigned)a.rpp | ((unsigned)a.pm_n << 16);
+    const unsigned g2 = (unsigned)a.len, g3 = (unsigned)a.active_rows | (spec << 16) | ((unsigned)nwv << 24);
 #define ACMI_ATTN_CASE(HD)                                                                              \
     case HD:                                                                                            \
-        if (a.q_colsum != nullptr) hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false>), grid, block, 0, st, a);            \
+        if (a.q_colsum != nullptr)                                                                      \
+            hipLaunchKernelGGL((attn_decode_kernel<KT, HD, true>), grid, block, 0, st, a.q, a.kc, a.vc, a.len_dev, g0, g1, g2, g3, a);  \
+        else hipLaunchKernelGGL((attn_decode_kernel<KT, HD, false>), grid, block, 0, st, a.q, a.kc, a.vc, a.len_dev, g0, g1, g2, g3, a); \
         break;
     switch (hd) {
         ACMI_ATTN_CASE(4)

@@ -409,8 +409,17 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
     // Request order: all weight fragments first -- they come from HBM, the activation fragments from L2, and the HBM
     // requests should be on their way as early as possible (FFN2 10.5 -> 9.9 us; whole position 2.57 -> 2.50 ms; with
     // (weight, activations) pairs in consumption order only the hi / lo variants in isolation were 0.1-0.2 us faster).
+    // ACMI_TL_ORDER (experiment switch; round 4, same box: 5.61 us per launch for 0 against 5.76 / 5.77 / 5.77 for 1 / 2 / 4,
+    // RTF 65.0 against 63.3 / 63.8 -- the activation's 0.5 us behind the last weight fragment is cheaper than any delay of
+    // the HBM requests): 0 = all weight fragments, then all activation fragments; k > 0 = the first
+    // C - C / k weight fragments, then the activation fragments interleaved with the remaining weight fragments, so that
+    // the last activation request is out before the last weight request (the activation comes from L2: it is back by then)
+#ifndef ACMI_TL_ORDER
+#define ACMI_TL_ORDER 0
+#endif
+    constexpr int CW = (ACMI_TL_ORDER > 0 && LN != 2 && LN != 3) ? C - C / ACMI_TL_ORDER : C;   // weight fragments requested up front
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
+    for (int i = 0; i < CW; ++i) {
         const int ko = (kc0 + i) * 64;
 #pragma unroll
         for (int t = 0; t < NT; ++t) bv[t][i] = ld_frag_nt(wt + (t * wts + ko) + lane);
@@ -439,6 +448,15 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
             if (LN == 3)  // fragments past lo_split have no lo term: re-read the last one (L1 hit), zeroed below
                 lv[u][i] = (al + (ub * mtl + min(kc0 + i, p.lo_split - 1) * 64))[lane];
         }
+        if constexpr (CW < C) {   // the held-back weight fragments, spread evenly behind the activation fragments
+#pragma unroll
+            for (int j = CW; j < C; ++j) {
+                if ((j - CW) * C / (C - CW) == i) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bv[t][j] = ld_frag_nt(wt + (t * wts + (kc0 + j) * 64) + lane);
+                }
+            }
+        }
     }
     if (PART) {
         const int jj = (int)(threadIdx.x & 15);
@@ -459,7 +477,9 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
 #ifdef ACMI_TRACE
     {   // requests in flight, oldest first: NT C weight fragments, then MT C (x 2 with a lo term) activation fragments, the
         // statistics partials and the six epilogue operands
-        constexpr int NWQ = NT * C, NREST = MT * C * (HL ? 2 : 1) + (PART ? NS : 0) + 6;
+        // (interleaved order: the fragments of both kinds count as "weights", the trailing requests are the rest)
+        constexpr bool IL = CW < C;
+        constexpr int NWQ = NT * C + (IL ? MT * C : 0), NREST = (IL ? 0 : MT * C * (HL ? 2 : 1)) + (PART ? NS : 0) + 6;
         constexpr int ALL1 = NWQ + NREST - 1 > 63 ? 63 : NWQ + NREST - 1, REST = NREST > 63 ? 63 : NREST;
         ACMI_TR(tr.t, 1);
         ACMI_TR_WAIT_VM(ALL1); ACMI_TR(tr.t, 2);
@@ -497,8 +517,9 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
                                             const EpiFn& epi_fn, f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr) {
     const int lane = threadIdx.x & 63;
     u32x4 bv[C], av[MT][2 * C];
+    constexpr int CW = ACMI_TL_ORDER > 0 ? C - C / ACMI_TL_ORDER : C;
 #pragma unroll
-    for (int i = 0; i < C; ++i) bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
+    for (int i = 0; i < CW; ++i) bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
     __builtin_amdgcn_sched_barrier(0);
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
@@ -512,6 +533,11 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
         const int ko = (2 * ku0 + i) * 64;
 #pragma unroll
         for (int u = 0; u < MT; ++u) av[u][i] = (at + (min(u, mtv - 1) * mts + ko))[lane];
+        if constexpr (CW < C) {
+#pragma unroll
+            for (int j = CW; j < C; ++j)
+                if ((j - CW) * 2 * C / (C - CW) == i) bv[j] = ld_frag_nt(wt + (ku0 + j) * 64 + lane);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -522,7 +548,8 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
     __builtin_amdgcn_sched_barrier(0);
 #ifdef ACMI_TRACE
     {
-        constexpr int NWQ = C, NREST = MT * 2 * C + 3;
+        constexpr bool IL = CW < C;
+        constexpr int NWQ = C + (IL ? MT * 2 * C : 0), NREST = (IL ? 0 : MT * 2 * C) + 3;
         constexpr int ALL1 = NWQ + NREST - 1 > 63 ? 63 : NWQ + NREST - 1, REST = NREST > 63 ? 63 : NREST;
         ACMI_TR(tr.t, 1);
         ACMI_TR_WAIT_VM(ALL1); ACMI_TR(tr.t, 2);
@@ -651,11 +678,12 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
             int part, f, h, dd, pidx, brow;
             if (EPI == EPI_QKV) {
                 // per 16-feature tile (wave-uniform values: scalar arithmetic): the tile lies in one part and one head
+                // (no division: four parts at most, and the launcher admits power-of-two head sizes only: p.hd_shift)
                 const int fb = __builtin_amdgcn_readfirstlane(n0 + 16 * t);
-                part = fb / p.d;
+                part = (fb >= p.d) + (fb >= 2 * p.d) + (fb >= 3 * p.d);
                 const int f0 = fb - part * p.d;
-                h = f0 / p.hd;
-                f = f0 + nn; dd = f0 - h * p.hd + nn;
+                h = f0 >> p.hd_shift;
+                f = f0 + nn; dd = f0 - (h << p.hd_shift) + nn;
                 pidx = 0; brow = gm;
             } else {
                 part = gn / p.d; f = gn - part * p.d;
@@ -942,8 +970,8 @@ static int tiled_epi(const LinArgs& a, int nw) {
     if (a.ksplit > 1 || (nw != 8 && nw != 4)) return EPI_GEN;
     const bool w8 = nw == 8;   // QKV / tiled-output launches are specialised for 8 waves only
     if (a.qkv)
-        return (w8 && a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && a.N % 16 == 0 && a.stats_out == nullptr && a.xt_hi == nullptr)
-                   ? EPI_QKV : EPI_GEN;
+        return (w8 && a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && (a.hd & (a.hd - 1)) == 0 && a.N % 16 == 0 && a.N <= 4 * a.d &&
+                a.stats_out == nullptr && a.xt_hi == nullptr) ? EPI_QKV : EPI_GEN;
     if (a.xt_hi != nullptr)
         return (a.out_mode == ACMI_OUT_F32 && a.residual != nullptr && a.xt_lo == nullptr && a.act == 0) ? EPI_PRODX : EPI_GEN;
     if (a.stats_out != nullptr) return EPI_GEN;
@@ -967,6 +995,8 @@ static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st
     }
     a.epi = tiled_epi(a, nw);
     a.inv_K = 1.0f / (float)a.K;
+    a.hd_shift = 0;
+    while (a.qkv && (1 << a.hd_shift) < a.hd) ++a.hd_shift;
 #ifdef ACMI_TRACE
     a.trace = acmi_trace_reserve((LN == 1 || LN == 2 || LN == 4) | (a.qkv ? 2 : 0) | (HT ? 4 : 0) | (a.xt_hi != nullptr ? 16 : 0) | ((HT ? 8 : 16 * NT) << 8),
                                  gx * a.ksplit * ((a.M + 16 * MT - 1) / (16 * MT)), nw, a.N, a.K, a.M);

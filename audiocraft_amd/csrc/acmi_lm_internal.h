@@ -38,6 +38,7 @@ struct LinArgs {
     // single-term raw activations with a per-row shift (include/acmi.h, acmi_linear_desc.a_shift / xt_shift / mean_out)
     const float* a_shift; const float* xt_shift; float* mean_out;
     float inv_K;  // tiled path: 1 / K (set by the launcher)
+    int hd_shift; // QKV scatter: log2(hd) when the specialised epilogue runs (power-of-two head size)
     int epi;      // tiled path: the specialised epilogue this call's flags allow (acmi_gemm.hip, tl_epilogue), set by the launcher
 #ifdef ACMI_TRACE
     unsigned long long* trace;   // this launch's stamps [workgroup][wave][ACMI_TRACE_NSTAMP] (NULL: not recorded)

@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0  # what a float4 copy kernel reaches on this chip (same guide): the practical ceiling of a stream
 
 
 def lm_algorithmic_bytes(lm, B_eff: int, n_positions: int, Lc: int, prefix: int = 0):
@@ -181,27 +182,75 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     return dict(avg_us=ms * 1e3 / (launches * reps), bytes_per_launch=nbytes / launches, launches_per_position=launches)
 
 
+def measure_attn_kernel(model, B_eff: int, T: int, reps: int = 3):
+    """Average duration of the self-attention decode launch at the MEAN context of a T-frame generate: one launch per layer on
+    that layer's own KV cache (cold, as in a decode position), captured into a hipGraph, HIP events on the launch stream.
+    Algorithmic bytes: K and V rows [0, context) of every (row, head), each read once."""
+    from audiocraft_amd import _C
+    lm = model.lm
+    run = lm._run
+    k, v = run['k'], run['v']                     # [L, Beff, H, Tmax, hd], what the last generate left
+    L, _, H, Tmax, hd = k.shape
+    ctx = max(1, min(Tmax, (T + 3) // 2))
+    q = torch.randn(B_eff, H * hd, device=k.device)
+    out = _C.tiled_activation_buffer(B_eff, H * hd, lm.weight_dtype, k.device)
+    pos = torch.tensor([ctx - 1, 0, 0, 0], dtype=torch.int32, device=k.device)   # the length is a device word, as in generate()
+
+    def one_pass():
+        for li in range(L):
+            _C.attn_decode(q, k[li], v[li], out, 0, len_dev=pos, len_bias=1, out_tiled=True)
+
+    one_pass()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        try:
+            one_pass()
+        finally:
+            graph.capture_end()
+        graph.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(side)
+        side.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    nbytes = 2 * B_eff * H * ctx * hd * k.element_size()
+    return dict(avg_us=e0.elapsed_time(e1) * 1e3 / (L * reps), bytes_per_launch=nbytes, context=ctx, launches=L)
+
+
 def pmc_traffic_per_launch():
-    """HBM bytes per lin_tiled_kernel launch from the committed rocprofv3 PMC passes over the same launch chain
-    (profiles/r*_lin_chain_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, scripts/dbg_chain.py):
+    """-> (HBM bytes per lin_tiled_kernel launch, source) from the committed rocprofv3 PMC passes over the same launch
+    chain (profiles/r*_lin_chain_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, scripts/dbg_chain.py):
     FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half size
-    (MI355X_MICROARCH.md, HBM section), hence the x2.  None if no PMC summary is present."""
+    (MI355X_MICROARCH.md, HBM section), hence the x2.  (None, reason) if no PMC summary is present.  The counters cannot be
+    collected inside this process; `source` says which files the figure was read from and how old they are, so that a
+    stale figure is visible in the bench line."""
     import csv
     import glob
     vals = {}
+    used = []
     for name in ('FETCH_SIZE', 'WRITE_SIZE'):
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_lin_chain_pmc_{name}.csv')))
         if not files:
-            return None
+            return None, 'no PMC summary under profiles/'
         total = n = 0.0  # dispatch-weighted mean over the kernel's template variants (plain / folded LayerNorm)
+        used.append(files[-1])
         for row in csv.DictReader(open(files[-1])):
             if ('lin_tiled_kernel' in row['kernel'] or 'lin_pair_kernel' in row['kernel']) and row['counter'] == name:
                 total += float(row['mean_per_dispatch']) * float(row['dispatches'])
                 n += float(row['dispatches'])
         if n == 0:
-            return None
+            return None, f'no lin_tiled_kernel rows in {os.path.basename(files[-1])}'
         vals[name] = total / n
-    return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024)
+    age_days = (time.time() - min(os.path.getmtime(f) for f in used)) / 86400.0
+    src = ' + '.join(os.path.basename(f) for f in used) + f' (committed rocprofv3 --pmc passes of scripts/dbg_chain.py; file age {age_days:.1f} d)'
+    return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
 def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 16, late_steps: int = 14,
@@ -296,7 +345,8 @@ def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_step
         ocodec.encodec_decode(csd, cc, codes, fast_lstm=True)
         t_codec_1s = time.perf_counter() - t0
     wall = t_lm + t_codec_1s * duration
-    return dict(value=round(B * duration / wall, 4), unit='audio-s / wall-s', cores=cores, kind='reference' if use_ref else 'port',
+    return dict(value=round(B * duration / wall, 4), unit='audio-s / wall-s', cores=cores, threads=cores,
+                logical_cores=os.cpu_count(), threads_tried=cands, kind='reference' if use_ref else 'port',
                 sample=f"{early_steps} decode positions at context <= {early_steps} ({t_early * 1e3:.0f} ms/position) and "
                        f"{late_steps} positions at context {late_context} ({t_late * 1e3:.0f} ms/position), batch {B} "
                        f"(CFG rows {2 * B}); per-position cost linear in the context between the two, integrated over "
@@ -438,13 +488,22 @@ def main():
         if not args.no_roofline:
             r = measure_lin_kernel(model, 2 * B)
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
+            on_cfg2 = config_tag(args).endswith('configs[2]')
+            traffic, traffic_src = pmc_traffic_per_launch() if on_cfg2 else (None, 'the committed PMC passes are of the configs[2] chain')
             out["roofline"] = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4),
-                               # the committed PMC passes are of the configs[2] chain (MusicGen-medium, 16 rows)
-                               "traffic": pmc_traffic_per_launch() if config_tag(args).endswith('configs[2]') else None,
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_bw": round(ach / HBM_COPY_GBS, 4),
+                               "traffic": traffic, "traffic_source": traffic_src,
                                "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(r['avg_us'], 3),
                                "launches_per_position": r['launches_per_position']}
+            ra = measure_attn_kernel(model, 2 * B, T)
+            out["roofline_attn"] = {"kernel": "attn_decode_kernel (single-query self-attention over the bf16 KV cache)", "bound": "hbm",
+                                    "achieved": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "frac_of_copy_bw": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9 / HBM_COPY_GBS, 4),
+                                    "bytes_per_launch": int(ra['bytes_per_launch']), "avg_launch_us": round(ra['avg_us'], 3),
+                                    "context": ra['context'], "launches": ra['launches'],
+                                    "note": "one launch per layer at the mean context of the generate, every layer's own (cold) cache"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, B, args.duration, args.text_len, args.top_k)
         print(json.dumps(out), flush=True)
