@@ -59,7 +59,8 @@ class LMState(C.Structure):
                 ('x', vp), ('q', vp), ('stats', vp), ('xn', vp), ('xlo', vp), ('x_rbs', i32), ('xn2', vp), ('xlo2', vp), ('r', vp), ('att', vp), ('hidden', vp), ('logits', vp), ('step_logits', vp),
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32),
-                ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32), ('cvt_tcap', i32)]
+                ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32), ('cvt_tcap', i32),
+                ('row_off', vp)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -100,7 +101,7 @@ class AttnDesc(C.Structure):
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
                 ('Tcap', i32), ('len', i32), ('len_dev', vp), ('len_bias', i32), ('cache_rows', i32), ('q_stats', vp), ('q_stats_np', i32),
                 ('q_stats_cnt', i32), ('eps', f32), ('q_colsum', vp), ('q_bias', vp), ('len_rows', vp), ('past_context', i32),
-                ('q_shift', vp), ('active_rows', i32), ('pos_minor_rows', i32)]
+                ('q_shift', vp), ('active_rows', i32), ('pos_minor_rows', i32), ('start_rows', vp)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
@@ -371,7 +372,7 @@ def linear_pair(plain: LinearDesc, xcat: LinearDesc):
 
 def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_tiled=False, out_rbs=0, out_col0=0,
                 q_stats=None, q_np=0, q_cnt=0, q_colsum=None, q_bias=None, eps=1e-5, len_rows=None, past_context=0,
-                q_shift=None, active_rows=0):
+                q_shift=None, active_rows=0, start_rows=None):
     """q [Beff, H*hd] f32; out: [Beff, H*hd] f32 or a tiled activation buffer (out_tiled=True; out_rbs / out_col0
     place the head outputs inside a wider buffer).  q_colsum: LayerNorm hook on q (acmi_attn_desc)."""
     cache_rows, H, Tcap, hd = k_cache.shape
@@ -387,6 +388,7 @@ def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_
     d.len_rows = ptr(len_rows)
     d.past_context = int(past_context)
     d.q_shift, d.active_rows = ptr(q_shift), int(active_rows)
+    d.start_rows = ptr(start_rows)
     check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')
     return out
 

@@ -36,6 +36,7 @@ struct AttnArgs {
     const float* q_shift;  // shift of the raw row behind q (acmi_attn_desc.q_shift), or NULL
     int active_rows;       // > 0: cache rows >= active_rows are skipped (their output stays as the caller left it)
     int pm_n;              // > 0: position-minor query rows (row = cache row * pm_n + position), else row = position * rpp + cache row
+    const int* start_rows; // per cache row: first key position attended (acmi_attn_desc.start_rows), or NULL
 };
 
 // Leading arguments = what the first K / V requests need; with kernarg preload (audiocraft_amd/build.py) they arrive in
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* hq, const
     // the steady state: 27.4 us at t = 1500 either way, +0.4 ... 0.8 us at every length from the longer prologue and the
     // 214 VGPRs.  The slope of this kernel, 0.0159 us per position = 6.2 TB/s, IS the copy bandwidth of the chip: what is
     // left is the fixed 3.6 us, 1.55 of them the kernel boundary.  profiles/r03_attn_microbench.log)
-    const int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
+    int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
+    if (p.start_rows != nullptr) start = max(start, __builtin_amdgcn_readfirstlane(p.start_rows[b0]));   // left-padded stream
     lim = len;
     if (!spec) load_kv(start + wave * CH);
     if (QN) {  // Chan combination of the partials -> mean, rstd of row b; then the affine map of q
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* hq, const
             num += f * sm_o[w][threadIdx.x];
             den += f * sm_l[w];
         }
-        const float r = num / den;
+        const float r = den > 0.f ? num / den : 0.f;   // (no key at all: a left-padding position of its stream, acmi_lm_state.row_off)
         const int f = h * HD + threadIdx.x;
         if (!p.out_tiled) {
             reinterpret_cast<float*>(p.out)[(size_t)b * H * HD + f] = r;
@@ -241,7 +243,7 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     ACMI_REQUIRE(a.H <= 0xffff && a.Tcap <= 0xffff && a.rpp <= 0xffff && a.pm_n <= 0xffff && a.active_rows <= 0xffff,
                  "acmi_attn_decode: geometry beyond the packed launch words (H %d, Tcap %d, rows %d)", a.H, a.Tcap, a.rpp);
     // the first chunk may be requested before the length is known unless the window start or a per-row length decides it
-    const unsigned spec = (a.past_context <= 0 && a.len_rows == nullptr) ? 1u : 0u;
+    const unsigned spec = (a.past_context <= 0 && a.len_rows == nullptr && a.start_rows == nullptr) ? 1u : 0u;
     const unsigned g0 = (unsigned)a.H | ((unsigned)a.Tcap << 16), g1 = (unsigned)a.rpp | ((unsigned)a.pm_n << 16);
     const unsigned g2 = (unsigned)a.len, g3 = (unsigned)a.active_rows | (spec << 16) | ((unsigned)nwv << 24);
 #define ACMI_ATTN_CASE(HD)                                                                              \
@@ -298,6 +300,7 @@ extern "C" int acmi_attn_decode_ex(const acmi_attn_desc* dsc, void* stream) {
     ACMI_REQUIRE(c.pos_minor_rows >= 0 && (c.pos_minor_rows == 0 || c.Beff == a.rpp * c.pos_minor_rows),
                  "acmi_attn_decode: pos_minor_rows=%d does not match %d query rows over %d cache rows", c.pos_minor_rows, c.Beff, a.rpp);
     a.pm_n = c.pos_minor_rows;
+    a.start_rows = c.start_rows;
     return c.kvdtype == ACMI_BF16 ? launch_attn_t<bf16_t>(a, c.Beff, c.hd, (hipStream_t)stream)
                                   : launch_attn_t<float>(a, c.Beff, c.hd, (hipStream_t)stream);
 }

@@ -417,7 +417,7 @@ __device__ __forceinline__ void tl_chunk(const TlHot& h, LinArgs& p, const int a
 #ifndef ACMI_TL_ORDER
 #define ACMI_TL_ORDER 0
 #endif
-    constexpr int CW = (ACMI_TL_ORDER > 0 && LN != 2 && LN != 3) ? C - C / ACMI_TL_ORDER : C;   // weight fragments requested up front
+    constexpr int CW = (ACMI_TL_ORDER > 0 && LN != 2 && LN != 3) ? C - C / (ACMI_TL_ORDER > 0 ? ACMI_TL_ORDER : 1) : C;   // weight fragments requested up front
 #pragma unroll
     for (int i = 0; i < CW; ++i) {
         const int ko = (kc0 + i) * 64;
@@ -517,7 +517,7 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
                                             const EpiFn& epi_fn, f32x4 (&acc)[2 * MT], TlExtras& ex, TlTrace& tr) {
     const int lane = threadIdx.x & 63;
     u32x4 bv[C], av[MT][2 * C];
-    constexpr int CW = ACMI_TL_ORDER > 0 ? C - C / ACMI_TL_ORDER : C;
+    constexpr int CW = ACMI_TL_ORDER > 0 ? C - C / (ACMI_TL_ORDER > 0 ? ACMI_TL_ORDER : 1) : C;
 #pragma unroll
     for (int i = 0; i < CW; ++i) bv[i] = ld_frag_nt(wt + (ku0 + i) * 64 + lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -581,8 +581,28 @@ enum { EPI_GEN = 0, EPI_PRODX = 1, EPI_TILED = 2, EPI_F32 = 3, EPI_QKV = 4 };
 //   EPI_QKV    the QKV scatter of a decode step (one position per call, head size and model width multiples of 16, so
 //              that a 16-feature tile lies in ONE of q / k / v / r and in ONE head: all index divisions are per tile)
 
-// NW: the workgroup's wave count as a compile-time constant (8 / 4: the decode step's launches), or 0 = run time.  With it the
-// cross-wave sums are straight-line LDS reads, and a launch whose outputs fit one pass (MT = 1, 256 NT <= 64 NW) has no loop.
+// the nw partial sums of one tile element, added in wave order; nw is 1, 2, 4 or 8 (tiled_waves): one uniform branch, then
+// straight-line LDS reads (a run-time loop over nw costs a compare + branch per term and hides the reads from each other)
+__device__ __forceinline__ float tl_red_sum(const float* __restrict__ base, const int nw) {   // base[w * 256], w < nw
+    float v = 0.f;
+    if (nw == 8) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += base[w * 256];
+    } else if (nw == 4) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += base[w * 256];
+    } else if (nw == 2) {
+        v += base[0];
+        v += base[256];
+    } else {
+        for (int w = 0; w < nw; ++w) v += base[w * 256];
+    }
+    return v;
+}
+
+// NW: the workgroup's wave count as a compile-time constant (8 / 4 / 2: what the decode step's launches run with), or 0 = run
+// time.  With it the LDS index arithmetic folds, and a launch whose outputs fit one pass (MT = 1, 256 NT <= 64 NW) has no loop
+// and no "later pass" operand loads: same-box, the run-time form of the same source costs +0.37 us per launch (5.98 vs 5.61).
 template <typename WT, int MT, int LN, int NT, bool HT, int EPI, int NW>
 __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex, const float* __restrict__ red,
                                             const float* __restrict__ rowstat, const int nw_rt, const int ksp, const int kslice,
@@ -605,9 +625,7 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
         const int t = (e >> 8) % NT, u = (e >> 8) / NT, mm = (e >> 4) & 15, nn = e & 15;
         const bool first = ONE ? true : e == (int)threadIdx.x;
         const int idx = (((mm >> 2) * 16 + nn) << 2) + (mm & 3);
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < nw; ++w) v += red[((size_t)(t * MT + u) * nw + w) * 256 + idx];
+        float v = tl_red_sum(red + (size_t)(t * MT + u) * nw * 256 + idx, nw);
         const int gm = mg + 16 * u + mm, gn = n0 + 16 * t + nn;
         const bool valid = gm < p.M && gn < p.N && (!HT || nn < 8);
         if (split) {  // split-K: raw partial sums; bias / activation / residual are applied by the reducer
@@ -623,12 +641,8 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
                 // row sum (any column of the row's sums tile) and sum of squares (the diagonal of the Gram tile), summed over
                 // the waves' K slices in wave order like the products
                 const int idg = (((mm >> 2) * 16 + mm) << 2) + (mm & 3);
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < nw; ++w) {
-                    s1 += red[((size_t)(XT + 2 * u) * nw + w) * 256 + idx];
-                    s2 += red[((size_t)(XT + 2 * u + 1) * nw + w) * 256 + idg];
-                }
+                const float s1 = tl_red_sum(red + (size_t)(XT + 2 * u) * nw * 256 + idx, nw);
+                const float s2 = tl_red_sum(red + (size_t)(XT + 2 * u + 1) * nw * 256 + idg, nw);
                 const float rk = p.inv_K;   // 1 / K, rounded on the host
                 mean_s = s1 * rk;   // = mean - shift: the fragments are x - shift
                 rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * rk - mean_s * mean_s, 0.f) + p.eps);   // v_rsq_f32: 1 ulp
@@ -848,16 +862,17 @@ __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const in
     __syncthreads();
     ACMI_TR(tr.t, 6);
 
-    // the specialised forms exist for the wave count the decode step launches them with (the launcher sets p.epi accordingly:
-    // 8 waves, or 4 for the GEMMs with N = d); everything else takes the generic form
-#define ACMI_TL_EPI(E, W) tl_epilogue<WT, MT, LN, NT, HT, E, W>(p, ex, red, rowstat, nw, ksp, kslice, mg, mtv, n0, ntile, wgtile)
+#define ACMI_TL_EPI_W(E, W) tl_epilogue<WT, MT, LN, NT, HT, E, W>(p, ex, red, rowstat, nw, ksp, kslice, mg, mtv, n0, ntile, wgtile)
+#define ACMI_TL_EPI(E) do { if (nw == 8) ACMI_TL_EPI_W(E, 8); else if (nw == 4) ACMI_TL_EPI_W(E, 4); else if (nw == 2) ACMI_TL_EPI_W(E, 2); \
+                            else ACMI_TL_EPI_W(EPI_GEN, 0); } while (0)
     const int epi_kind = __builtin_amdgcn_readfirstlane(p.epi);
-    if (LN == 0 && NT == 1 && epi_kind == EPI_PRODX) { if (nw == 8) ACMI_TL_EPI(EPI_PRODX, 8); else ACMI_TL_EPI(EPI_PRODX, 4); }
-    else if (!HT && LN != 3 && epi_kind == EPI_TILED) ACMI_TL_EPI(EPI_TILED, 8);
-    else if (!HT && epi_kind == EPI_F32) { if (nw == 8) ACMI_TL_EPI(EPI_F32, 8); else ACMI_TL_EPI(EPI_F32, 4); }
-    else if (!HT && (LN == 1 || LN == 2 || LN == 4) && epi_kind == EPI_QKV) ACMI_TL_EPI(EPI_QKV, 8);
-    else ACMI_TL_EPI(EPI_GEN, 0);
+    if (LN == 0 && NT == 1 && epi_kind == EPI_PRODX) ACMI_TL_EPI(EPI_PRODX);
+    else if (!HT && LN != 3 && epi_kind == EPI_TILED) ACMI_TL_EPI(EPI_TILED);
+    else if (!HT && epi_kind == EPI_F32) ACMI_TL_EPI(EPI_F32);
+    else if (!HT && (LN == 1 || LN == 2 || LN == 4) && epi_kind == EPI_QKV) ACMI_TL_EPI(EPI_QKV);
+    else ACMI_TL_EPI_W(EPI_GEN, 0);
 #undef ACMI_TL_EPI
+#undef ACMI_TL_EPI_W
 #ifdef ACMI_TRACE
     ACMI_TR(tr.t, 7);
     ACMI_TR_WAIT_VM(0);
@@ -966,16 +981,15 @@ static int tiled_prepare(LinArgs& a) {
 }
 
 // which specialised epilogue the call's flags allow (tl_epilogue); HT / LayerNorm mode are checked in the kernel
-static int tiled_epi(const LinArgs& a, int nw) {
-    if (a.ksplit > 1 || (nw != 8 && nw != 4)) return EPI_GEN;
-    const bool w8 = nw == 8;   // QKV / tiled-output launches are specialised for 8 waves only
+static int tiled_epi(const LinArgs& a) {
+    if (a.ksplit > 1) return EPI_GEN;
     if (a.qkv)
-        return (w8 && a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && (a.hd & (a.hd - 1)) == 0 && a.N % 16 == 0 && a.N <= 4 * a.d &&
+        return (a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && (a.hd & (a.hd - 1)) == 0 && a.N % 16 == 0 && a.N <= 4 * a.d &&
                 a.stats_out == nullptr && a.xt_hi == nullptr) ? EPI_QKV : EPI_GEN;
     if (a.xt_hi != nullptr)
         return (a.out_mode == ACMI_OUT_F32 && a.residual != nullptr && a.xt_lo == nullptr && a.act == 0) ? EPI_PRODX : EPI_GEN;
     if (a.stats_out != nullptr) return EPI_GEN;
-    if (a.out_mode == ACMI_OUT_TILED) return (w8 && a.residual == nullptr) ? EPI_TILED : EPI_GEN;
+    if (a.out_mode == ACMI_OUT_TILED) return a.residual == nullptr ? EPI_TILED : EPI_GEN;
     if (a.out_mode == ACMI_OUT_F32) return a.act == 0 ? EPI_F32 : EPI_GEN;
     return EPI_GEN;
 }
@@ -993,7 +1007,7 @@ static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st
             attr_set = true;
         }
     }
-    a.epi = tiled_epi(a, nw);
+    a.epi = tiled_epi(a);
     a.inv_K = 1.0f / (float)a.K;
     a.hd_shift = 0;
     while (a.qkv && (1 << a.hd_shift) < a.hd) ++a.hd_shift;
@@ -1098,7 +1112,7 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
 #ifdef ACMI_TRACE
     p0.trace = p1.trace = acmi_trace_reserve(8 | 16 | (16 << 8), (int)(grid.x * grid.z), nw, p0.N + p1.N, p0.K, p0.M);
 #endif
-    p0.epi = tiled_epi(p0, nw); p1.epi = tiled_epi(p1, nw);
+    p0.epi = tiled_epi(p0); p1.epi = tiled_epi(p1);
     p0.inv_K = 1.0f / (float)p0.K; p1.inv_K = 1.0f / (float)p1.K;
 #define ACMI_PAIR_CASE(MTv)                                                                              \
     if (mt == MTv) {                                                                                     \

@@ -28,6 +28,7 @@ struct EmbedArgs {
     float* stats;  // [M][1][2]: (mean, M2) of every produced row (one partial of d elements)
     void* xt_hi; void* xt_lo; int xt_nkc, xt_lo_nkc;  // folded LayerNorm: the raw row in fragment order (hi / lo), or NULL
     float* shift_out;  // [M] or NULL: single-term fragments bf16(x - mean), the row mean stored here (acmi_lm_state.xshift)
+    const int* row_off; // per cache row: left padding of its stream (acmi_lm_state.row_off), or NULL
     int npos_pad, npos; // > 0: position-minor rows of the MFMA-tiled prefill (row = cache row * npos_pad + position; pad
                         // rows repeat the last position: finite, never stored to the caches); 0: row = position * Beff + cache row
 };
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     if (p.npos_pad > 0) { m0 = m / p.npos_pad; pidx = min(m - m0 * p.npos_pad, p.npos - 1); }
     else { pidx = m / p.Beff; m0 = m - pidx * p.Beff; }
     const int g = *p.pos + pidx;
+    const int gpos = p.row_off != nullptr ? max(g - p.row_off[m0], 0) : g;   // the row's own position (left-padded streams)
     const int b = m0 % p.B;
     float loc[8];  // d <= 2048
     float sum = 0.f;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int cch = min((int)threadIdx.x + i * 256, p.d - 1);
-        pv[i] = p.pos_table[(size_t)g * p.d + cch];
+        pv[i] = p.pos_table[(size_t)gpos * p.d + cch];
         pre[i] = prow[cch];
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
@@ -560,7 +562,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.Beff = s->Beff; e.K = m->n_q; e.S = s->S; e.card = m->card;
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
-    e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
+    e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats; e.row_off = s->row_off;
     e.npos_pad = npp; e.npos = npos;
 #define ACMI_EMBED_CASE(KQv)                                                                        \
     if (m->n_q <= KQv) {                                                                           \
@@ -649,6 +651,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     hipStream_t st = (hipStream_t)stream;
     ACMI_REQUIRE(m && s, "acmi_lm_step: null argument");
     if (mode == ACMI_STEP_PREFILL && s->pf_xn != nullptr && s->n_pos > 1) {
+        ACMI_REQUIRE(s->row_off == nullptr, "acmi_lm_step: the one-forward prefill does not take left-padded streams (row_off)");
         ACMI_REQUIRE(m->dim % m->num_heads == 0 && m->n_q <= 16 && s->use_cfg >= ACMI_CFG_NONE && s->use_cfg <= ACMI_CFG_DOUBLE &&
                      s->Beff == s->B * (s->use_cfg + 1), "acmi_lm_step: bad geometry");
         return lm_prefill_big(m, s, st);
@@ -663,6 +666,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     ACMI_REQUIRE(s->Beff == s->B * (s->use_cfg + 1), "acmi_lm_step: Beff=%d is not B=%d x %d row groups", s->Beff, s->B,
                  s->use_cfg + 1);
     ACMI_REQUIRE(mode == ACMI_STEP_PREFILL || s->n_pos <= 1, "acmi_lm_step: n_pos=%d only with ACMI_STEP_PREFILL", s->n_pos);
+    ACMI_REQUIRE(s->row_off == nullptr || m->rope_freq == nullptr, "acmi_lm_step: row_off (left-padded streams) with rotary positions");
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
     int rc;
 
@@ -696,7 +700,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.Beff = s->Beff; e.K = m->n_q; e.S = s->S; e.card = m->card;
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
-    e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats;
+    e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats; e.row_off = s->row_off;
     if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = c.use_lo ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
     if (shifted) { e.shift_out = shbuf[0]; c.xsh = shbuf[0]; }
 #define ACMI_EMBED_CASE(KQv)                                                                        \
@@ -737,6 +741,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         sa.q = s->q; sa.k_cache = L.k_cache; sa.v_cache = L.v_cache; sa.kvdtype = m->kvdtype;
         sa.out_mode = ACMI_OUT_TILED; sa.out_dtype = m->wdtype; sa.Beff = M; sa.H = H; sa.hd = hd; sa.Tcap = s->Tmax;
         sa.len_dev = s->pos; sa.len_bias = 1; sa.cache_rows = s->Beff; sa.past_context = m->past_context;
+        sa.start_rows = s->row_off;
         if (pair) { sa.out = c.xh; sa.out_rbs = c.rbs; sa.out_col0 = c.nkc_d * c.kt; }
         else sa.out = s->att;
         if ((rc = acmi_attn_decode_ex(&sa, stream))) return rc;

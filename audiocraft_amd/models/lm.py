@@ -503,8 +503,17 @@ class LMModel(nn.Module):
         return run
 
     def _make_state(self, run, B, use_cfg, Tmax, Lc, S, prepend, record_logits, use_sampling, temp, top_k, top_p,
-                    cfg_coef, seed, cfg_coef_beta: float = 0.0, cross_lens: tp.Optional[torch.Tensor] = None) -> _C.LMState:
+                    cfg_coef, seed, cfg_coef_beta: float = 0.0, cross_lens: tp.Optional[torch.Tensor] = None,
+                    row_off: tp.Optional[torch.Tensor] = None) -> _C.LMState:
         st = _C.LMState()
+        if row_off is not None:      # left padding of the rows' streams (two_step_cfg with unequal prepend lengths)
+            if self.positional_embedding in ('rope', 'sin_rope'):
+                raise NotImplementedError("two_step_cfg with prepended conditions of different lengths on a rotary model")
+            run['row_off'] = row_off.to(device=self.device, dtype=torch.int32).contiguous()
+            st.row_off = run['row_off'].data_ptr()
+        else:
+            run.pop('row_off', None)
+            st.row_off = None
         st.rope_first = st.rope_shift = 0
         st.cfg_coef_beta = float(cfg_coef_beta)
         if cross_lens is not None:   # per-row cross-attention length (two_step_cfg)
@@ -578,13 +587,25 @@ class LMModel(nn.Module):
             pad = lambda t: torch.nn.functional.pad(t.float(), (0, 0, 0, L - t.shape[1]))  # noqa: E731
             cross_src = torch.cat([pad(x_c), pad(x_n)], dim=0)
             lens = torch.tensor([Lc] * x_c.shape[0] + [Ln] * x_n.shape[0], dtype=torch.int32)
-        prepend = None
+        prepend, row_off = None, None
         if p_c is not None or p_n is not None:
-            if p_c is None or p_n is None or p_c.shape[1] != p_n.shape[1]:
-                raise NotImplementedError("two_step_cfg with prepended conditions of different lengths in the two passes: "
-                                          "the row groups would sit at different positions of the stream")
-            prepend = torch.cat([p_c.float(), p_n.float()], dim=0)
-        return prepend, cross_src, lens
+            # The two passes may prepend different numbers of condition rows (a melody model: 5 text positions against the
+            # 1 of an all-null batch), i.e. the same token sits at different transformer positions in the two streams.  The
+            # shorter stream is padded ON THE LEFT (zeros, never attended: acmi_lm_state.row_off), so that both reach their
+            # first token at the same stream position and one sampler launch serves both row groups.
+            d = (p_c if p_c is not None else p_n).shape[2]
+            rows_c = p_c.shape[0] if p_c is not None else x_c.shape[0] if x_c is not None else p_n.shape[0]
+            rows_n = p_n.shape[0] if p_n is not None else rows_c
+            dev_ = (p_c if p_c is not None else p_n).device
+            p_c = p_c.float() if p_c is not None else torch.zeros(rows_c, 0, d, device=dev_)
+            p_n = p_n.float() if p_n is not None else torch.zeros(rows_n, 0, d, device=dev_)
+            Pc, Pn = p_c.shape[1], p_n.shape[1]
+            P = max(Pc, Pn)
+            lpad = lambda t: torch.nn.functional.pad(t, (0, 0, P - t.shape[1], 0))  # noqa: E731
+            prepend = torch.cat([lpad(p_c), lpad(p_n)], dim=0)
+            if Pc != Pn:
+                row_off = torch.tensor([P - Pc] * p_c.shape[0] + [P - Pn] * p_n.shape[0], dtype=torch.int32)
+        return prepend, cross_src, lens, row_off
 
     # ------------------------------------------------------------------------------------- generate
     @torch.no_grad()
@@ -665,9 +686,9 @@ class LMModel(nn.Module):
         S = gen_sequence.shape[-1]
 
         # fuse conditions: what is prepended to the token stream, what is cross-attended to
-        cross_lens = None
+        cross_lens, row_off = None, None
         if two_step:
-            prepend, cross_src, cross_lens = self._fuse_two_step(*cfg_conditions)
+            prepend, cross_src, cross_lens, row_off = self._fuse_two_step(*cfg_conditions)
         else:
             prepend, cross_src = self.fuser.fuse(cfg_conditions)
         if self.has_cross_attention:
@@ -687,7 +708,7 @@ class LMModel(nn.Module):
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
         state = self._make_state(run, B, use_cfg, Tmax, Lc, S, prepend, return_logits, use_sampling, temp, top_k,
                                  top_p, coef, seed, cfg_coef_beta=0.0 if cfg_coef_beta is None else cfg_coef_beta,
-                                 cross_lens=cross_lens)
+                                 cross_lens=cross_lens, row_off=row_off)
         desc = self._packed['desc']
         desc.pos_table = run['pos_table'].data_ptr()
         run['gen_sequence'].copy_(gen_sequence)
@@ -822,7 +843,7 @@ class LMModel(nn.Module):
         of them when the stream is EMPTY and the geometry allows (`_big_prefill_ok`) -- lm_prefill_big sizes its time-minor V
         scratch for positions [0, n_positions) only, so a non-empty stream must take the other path -- else the same kernels
         as a decode position, several consecutive positions per call as extra rows (acmi_lm_state.n_pos)."""
-        if n_positions > 0 and start == 0 and self._big_prefill_ok(n_positions):
+        if n_positions > 0 and start == 0 and not state.row_off and self._big_prefill_ok(n_positions):
             return self._prefill_big(desc, state, self._run, n_positions)
         done = 0
         while done < n_positions:

@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 140 /* 0.1.4: acmi_conv1d takes pre-tiled weights + a work buffer (acmi_conv1d_tile_weights /
+#define ACMI_VERSION 150 /* 0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
+                            colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
+                            with prepended conditions of different lengths).  0.1.4: acmi_conv1d takes pre-tiled weights + a work buffer (acmi_conv1d_tile_weights /
                             _weight_floats / _work_floats); MultiBandDiffusion entry points.  0.1.3: single-term raw activations with a per-row shift (acmi_linear_desc.a_shift / xt_shift /
                             mean_out, acmi_lm_state.xshift), cross-attention restricted to the rows with a non-null
                             condition (active_rows), prefill as MFMA-tiled GEMMs + causal prefill attention */
@@ -278,6 +280,14 @@ typedef struct {
     void* pf_vt;            /* [Beff, H, hd, pf_tcap] in kvdtype, zero-initialised: V of this call's positions, time-minor */
     int pf_tcap;            /* positions pf_vt holds per (row, head): >= pos[0] + n_pos, a multiple of 32 */
     int cvt_tcap;           /* time extent of acmi_lm_layer.cvt_cache: a multiple of 32, >= Lc (0 = none) */
+    const int* row_off;     /* device int32[Beff] or NULL: LEFT PADDING of each cache row's stream.  Row b's own position is
+                               (stream position - row_off[b]): its sinusoidal embedding uses that position and its self-attention
+                               sees keys [row_off[b], position] only.  For row groups whose streams begin with different numbers of
+                               prepended condition rows (two_step_cfg on a prepend fuser, reference lm.py:378-390: the conditional
+                               and the unconditional pass keep separate streaming states): the shorter streams are padded on the
+                               left -- `prepend` holds zeros there -- so that every row reaches its first token at the same stream
+                               position and one sampler launch serves all of them.  Not with rotary positions, not with the
+                               one-forward prefill (pf_xn) */
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0
@@ -437,6 +447,8 @@ typedef struct {
                                caller zeroes those rows of `out` once and never runs them); 0 = all rows */
     int pos_minor_rows;     /* > 0: the Beff = cache_rows * pos_minor_rows query rows are position-minor (row = cache row *
                                pos_minor_rows + position: the layout of the MFMA-tiled prefill) instead of position-major */
+    const int* start_rows;  /* device int32[cache_rows] or NULL: keys before start_rows[cache row] are not attended
+                               (acmi_lm_state.row_off) */
 } acmi_attn_desc;
 int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 

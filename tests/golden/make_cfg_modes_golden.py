@@ -4,6 +4,9 @@
   lm_two_step.npz    two_step_cfg=True (lm.py:377-386, 498-505): conditional and unconditional forwards run
                      separately, each with its own padded condition length and its own streaming state; the
                      mix uses the MODEL's cfg_coef (lm.py:386), not the argument.
+  lm_two_step_prepend.npz  two_step_cfg=True on a PREPEND fuser (the melody models' fusing): the conditional pass prepends
+                     5 condition positions, the unconditional pass 1 (an all-null text batch), so the two streams sit at
+                     different transformer positions for the same token (lm.py:378-390: two streaming states).
   lm_double_cfg.npz  cfg_coef_beta (MusicGen-Style double CFG, lm.py:362-376, 490-496): rows
                      [text + wav; wav only; null], logits = u + coef * (w + beta * (c - w) - u).
 
@@ -60,6 +63,30 @@ def make_two_step():
             uncond_step_logits=torch.stack([r[:, :, -1] for r in rec[1::2]], dim=2))
 
 
+def make_two_step_prepend():
+    cfg = dict(dim=32, num_heads=4, num_layers=2, hidden_scale=4, n_q=4, card=32, cross_attention=False,
+               delays=[0, 1, 2, 3], cfg_coef=3.0, seed=6, cond_dim=8, Lc=5)
+    torch.manual_seed(1000 + cfg['seed'])
+    lm = mg.build_lm(cfg, {'description': SynthTextRagged(cfg['cond_dim'], cfg['dim'], cfg['Lc'])},
+                     {'cross': [], 'prepend': ['description'], 'sum': [], 'input_interpolate': []})
+    conds = [ConditioningAttributes(text={'description': f'q{i}'}) for i in range(3)]
+    rec = []
+    h = lm.register_forward_hook(lambda mod, inp, out: rec.append(out.detach().clone()))
+    tokens = lm.generate(None, conds, max_gen_len=11, use_sampling=False, two_step_cfg=True, cfg_coef=7.0)
+    h.remove()
+    null = mg.ClassifierFreeGuidanceDropout(p=1.0)(conds)
+    ct = lm.condition_provider(lm.condition_provider.tokenize(conds))
+    nt = lm.condition_provider(lm.condition_provider.tokenize(null))
+    assert ct['description'][0].shape[1] == 5 and nt['description'][0].shape[1] == 1
+    # a second case: a 4-token prompt (the first call of both streams then covers prepend + prompt)
+    gp = torch.Generator().manual_seed(9)
+    prompt = torch.randint(0, cfg['card'], (3, cfg['n_q'], 4), generator=gp)
+    tokens_p = lm.generate(prompt, conds, max_gen_len=12, use_sampling=False, two_step_cfg=True)
+    mg.save('lm_two_step_prepend', cfg, lm.state_dict(), prepend_src=ct['description'][0], null_prepend_src=nt['description'][0],
+            greedy_tokens=tokens, cond_step_logits=torch.stack([r[:, :, -1] for r in rec[0::2]], dim=2),
+            uncond_step_logits=torch.stack([r[:, :, -1] for r in rec[1::2]], dim=2), prompt=prompt, greedy_tokens_prompt=tokens_p)
+
+
 def make_double_cfg():
     cfg = dict(dim=32, num_heads=4, num_layers=2, hidden_scale=4, n_q=4, card=32, cross_attention=False,
                delays=[0, 1, 2, 3], cfg_coef=3.0, seed=4, cond_dim=8, Lc=3, P=6, cfg_coef_beta=5.0)
@@ -89,4 +116,5 @@ def make_double_cfg():
 
 if __name__ == '__main__':
     make_two_step()
+    make_two_step_prepend()
     make_double_cfg()

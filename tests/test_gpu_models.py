@@ -201,7 +201,9 @@ def build_lm(cfg, sd, weight_dtype=torch.float32):
     from audiocraft_amd.models import builders
     conds = {'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': cfg['cond_dim'], 'length': cfg['Lc']}}
     fuser = {'cross': ['description']} if cfg['cross_attention'] else {'prepend': ['self_wav', 'description']}
-    if not cfg['cross_attention']:
+    if not cfg['cross_attention'] and 'P' not in cfg:
+        fuser = {'prepend': ['description']}            # text prepended, no melody condition (lm_two_step_prepend)
+    elif not cfg['cross_attention']:
         conds['self_wav'] = {'kind': 'chroma', 'embedder': 'synthetic', 'n_frames': cfg['P']}
     lm = builders.get_lm_model(dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'],
                                     n_q=cfg['n_q'], card=cfg['card'], hidden_scale=cfg['hidden_scale'],
@@ -439,6 +441,31 @@ def test_lm_two_step_cfg_vs_reference_golden():
     nt2 = {'description': (torch.zeros(3, 8, cfg['dim']).cuda(), torch.ones(3, 8, dtype=torch.int64).cuda())}
     toks2 = lm.generate(None, [], num_samples=3, max_gen_len=10, use_sampling=False, condition_tensors=(ct, nt2))
     assert torch.equal(toks2.cpu(), a['greedy_tokens'])   # an all-zero source contributes exactly 0 at any length
+
+
+def test_lm_two_step_cfg_unequal_prepend_vs_reference_golden():
+    """two_step_cfg on a prepend fuser (reference lm.py:378-390: the two passes keep their own streaming states): the
+    conditional stream starts with 5 prepended rows, the unconditional one with 1.  On the device both are row groups of ONE
+    step, the shorter stream left-padded (acmi_lm_state.row_off): own positions for the sinusoidal embedding, own first key
+    for the self-attention.  Greedy tokens and step logits against the unmodified reference; also with a 4-token prompt."""
+    cfg, sd, a = load_golden('lm_two_step_prepend')
+    lm = build_lm(cfg, sd)
+    ones = lambda t: torch.ones(t.shape[:2], dtype=torch.int64).cuda()  # noqa: E731
+    ct = {'description': (a['prepend_src'].cuda(), ones(a['prepend_src']))}
+    nt = {'description': (a['null_prepend_src'].cuda(), ones(a['null_prepend_src']))}
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=11, use_sampling=False, condition_tensors=(ct, nt),
+                           cfg_coef=7.0, return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
+    assert rel(lg.cpu(), ref) < 1e-4
+    toks_p = lm.generate(a['prompt'].cuda(), [], max_gen_len=12, use_sampling=False, condition_tensors=(ct, nt))
+    assert torch.equal(toks_p.cpu(), a['greedy_tokens_prompt'])
+    # the roles swapped (the longer prefix in the unconditional pass) and equal lengths take the same path
+    toks_eq = lm.generate(None, [], num_samples=3, max_gen_len=11, use_sampling=False, condition_tensors=(ct, ct))
+    both = {'description': (torch.cat([a['prepend_src'], a['prepend_src']]).cuda(), ones(torch.cat([a['prepend_src'], a['prepend_src']])))}
+    toks_one = lm.generate(None, [], num_samples=3, max_gen_len=11, use_sampling=False, condition_tensors=both,
+                           cfg_coef=cfg['cfg_coef'])
+    assert torch.equal(toks_eq, toks_one)
 
 
 def test_lm_double_cfg_vs_reference_golden(prefill_mode):

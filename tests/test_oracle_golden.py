@@ -140,6 +140,23 @@ def test_lm_oracle_two_step_cfg_matches_reference():
     assert torch.allclose(logits, ref, atol=2e-5, rtol=1e-5)
 
 
+def test_lm_oracle_two_step_cfg_with_unequal_prepend_matches_reference():
+    """two_step_cfg on a PREPEND fuser (the melody models' fusing): the conditional stream carries 5 prepended condition
+    positions, the unconditional one 1, so the same token sits at different transformer positions in the two passes
+    (reference lm.py:378-390: two streaming states); also with a 4-token prompt behind the prepended rows."""
+    cfg, sd, a = load_golden('lm_two_step_prepend')
+    c = lm_cfg(cfg)
+    assert a['prepend_src'].shape[1] == 5 and a['null_prepend_src'].shape[1] == 1
+    toks, logits = olm.generate(sd, c, None, 3, None, a['prepend_src'], max_gen_len=11, use_sampling=False, cfg_coef=7.0,
+                                null_prepend_src=a['null_prepend_src'], return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
+    assert torch.allclose(logits, ref, atol=2e-5, rtol=1e-5)
+    toks_p = olm.generate(sd, c, a['prompt'], 3, None, a['prepend_src'], max_gen_len=12, use_sampling=False,
+                          null_prepend_src=a['null_prepend_src'])
+    assert torch.equal(toks_p, a['greedy_tokens_prompt'])
+
+
 def test_lm_oracle_double_cfg_matches_reference():
     """cfg_coef_beta (MusicGen-Style double CFG, reference lm.py:362-376, 490-496): rows [text + wav; wav only; null],
     logits = u + coef (w + beta (c - w) - u)."""
