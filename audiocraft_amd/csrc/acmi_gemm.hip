@@ -103,9 +103,11 @@ __device__ __forceinline__ void norm_store_row(float4 (&v)[ACMI_STAGE_JMAX], int
 // the consuming matrix (see acmi_lm_layer).  Doing this once per LayerNorm instead of once per GEMM
 // workgroup takes ~5 us of redundant VALU + LDS staging off the critical path of every GEMM workgroup.
 template <typename WT>
-__global__ __launch_bounds__(64) void ln_tile_kernel(float* __restrict__ x, WT* __restrict__ out, int M, int K, int nkc,
-                                                     float eps, const float* __restrict__ slabs, int nslabs) {
-    const int m = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void ln_tile_kernel(float* __restrict__ x, WT* __restrict__ out, int M, int K, int nkc,
+                                                      float eps, const float* __restrict__ slabs, int nslabs) {
+    // four rows per workgroup, one wave each (no LDS, no barrier): a one-wave workgroup per row left most of a CU's wave
+    // slots empty in the prefill's 9 600-row launches (3.0 TB/s)
+    const int m = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
     float4 v[ACMI_STAGE_JMAX];
     load_row(x + (size_t)m * K, K, lane, v);
@@ -153,10 +155,10 @@ int acmi_launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps
                         hipStream_t st) {
     ACMI_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && K <= 2048, "acmi_ln_tile: needs K %% 4 == 0 and K <= 2048 (K=%d)", K);
     if (wdtype == ACMI_BF16)
-        hipLaunchKernelGGL(ln_tile_kernel<bf16_t>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<bf16_t*>(out), M, K,
+        hipLaunchKernelGGL(ln_tile_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, st, x, reinterpret_cast<bf16_t*>(out), M, K,
                            (K + 31) / 32, eps, slabs, nslabs);
     else
-        hipLaunchKernelGGL(ln_tile_kernel<float>, dim3(M), dim3(64), 0, st, x, reinterpret_cast<float*>(out), M, K,
+        hipLaunchKernelGGL(ln_tile_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, x, reinterpret_cast<float*>(out), M, K,
                            (K + 15) / 16, eps, slabs, nslabs);
     return acmi_check_launch("ln_tile_kernel");
 }

@@ -32,16 +32,45 @@ __device__ __forceinline__ float big_gelu(float x) { return 0.5f * x * (1.0f + e
 // =====================================================================================================
 // MFMA-tiled GEMM on tiled operands
 // =====================================================================================================
-template <typename WT, int EPI>
+// DMA (round 4): the fragments of a stage go global -> LDS directly (`global_load_lds_dwordx4`: one op per 1 KB fragment, the
+// wave's lanes land at consecutive 16-byte slots -- exactly the fragment order), one stage ahead of the MFMAs, instead of
+// global -> VGPR -> ds_write_b128 two stages ahead.  Cycle budget of a K step per CU (two workgroups): 64 KB of ds_write_b128
+// at ~79 B/clk = ~830 cycles + 128 KB of ds_read_b128 at 256 B/clk = 512 cycles on ONE LDS pipe against 1024 cycles of MFMA
+// issue: the register staging made the LDS pipe, not the matrix pipe, the longer one.
+//   DMA 1: stages of two K fragments (32 KB), two LDS buffers, the next stage requested one K step ahead;
+//   DMA 2: stages of ONE K fragment (16 KB), a ring of four, requests three stages ahead (counted vmcnt: two stages stay in
+//          flight across every barrier) -- the same 64 KB of LDS, three times the latency tolerance.
+template <typename WT, int EPI, int DMA>
 __global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x 32 fragments x 1 KB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7, nb = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // workgroup b runs on XCD b % 8: one contiguous run of tiles per L2
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // Workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2.  Round 4: XCD x owns tiles_n / 8 ADJACENT COLUMN tiles
+    // and sweeps the row tiles: its weight panels (6 x 393 KB at N = 6144, K = 1536) stay in its L2 and every activation
+    // panel is read once per XCD.  A remainder of 1, 2 or 4 column tiles (N = 4608: 36 = 8 x 4 + 4, N = 1536: 12 = 8 + 4) is
+    // shared by 8 / remainder XCDs each, which take its row tiles in turn (big_grid below sizes the launch: workgroups past
+    // an XCD's list leave at once).  (Round 3 gave each XCD a contiguous run of ROW-major tiles: the 64 tiles it works on at
+    // a time then touch all N / 128 weight panels -- 18.9 MB, far beyond its L2 -- once per row tile: 1.4 GB from the memory
+    // side per FFN1 GEMM of a 600-position prefill, 6.7 TB/s for the 213-280 us it took.)
+    int bid = blockIdx.x, tm, tn;
+    const int P = tiles_n >> 3, R = tiles_n & 7;
+    if (R == 0) {
+        const int x = bid & 7, l = bid >> 3;
+        tm = l / P;
+        tn = x * P + (l - tm * P);
+    } else if (R == 1 || R == 2 || R == 4) {
+        const int share = 8 / R, G = share * P + 1;   // a group = `share` row tiles: their primary tiles + ONE tile of the shared column
+        const int x = bid & 7, l = bid >> 3, g = l / G, r = l - g * G;
+        if (r < share * P) { tm = g * share + r / P; tn = x * P + r % P; }
+        else { tm = g * share + x % share; tn = 8 * P + x / share; }
+        if (tm >= tiles_m) return;
+    } else {
+        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);   // one contiguous run of row-major tiles per L2
+        tm = bid / tiles_n;
+        tn = bid - tm * tiles_n;
+    }
     const int MT16 = p.M >> 4, NT16 = (p.N + 15) >> 4;
     const u32x4* __restrict__ A = reinterpret_cast<const u32x4*>(p.a);
     const u32x4* __restrict__ W = reinterpret_cast<const u32x4*>(p.w);
@@ -93,6 +122,78 @@ __global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
         __builtin_amdgcn_sched_barrier(0);   // the LDS writes of the next stage (and their vmcnt waits) stay behind the MFMAs
     };
 
+    if constexpr (DMA == 2) {
+        // The DMA ops are inline asm (hipcc would otherwise drain vmcnt to 0 in front of every barrier and every ds_read that
+        // may alias the DMA's destination -- no request would survive a K step); their completion is counted here by hand:
+        // each wave issues 4 per stage, `vmcnt(8)` = everything but the two youngest stages has landed.  The kernel's only
+        // other VMEM operations are the epilogue's, behind a vmcnt(0).
+        const int nst = p.NKC;
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+        auto dma = [&](int st) {   // this wave's 4 fragments of stage st (K fragment st) into ring slot st & 3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4* g = src + base[i] + (size_t)st * 64;
+                const unsigned dst = lds0 + (unsigned)(((st & 3) * 16 + wave * 4 + i) * 1024);   // wave-uniform: M0
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            }
+        };
+        auto bar = [&]() {         // workgroup barrier WITHOUT the fence of __syncthreads (that fence is a vmcnt(0))
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto comp1 = [&](int st) {
+            const u32x4* sb_ = lds + (st & 3) * 16 * 64 + lane;
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = sb_[(wm * 4 + i) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = sb_[(8 + wn * 4 + j) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) big_mma(a[i], b[j], acc[i][j], WT());
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        dma(0);
+        if (nst > 1) dma(1);
+        if (nst > 2) dma(2);
+        if (nst > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bar();
+        int st = 0;
+        for (; st + 3 < nst; ++st) {          // stage st is in LDS; st + 1, st + 2 in flight
+            dma(st + 3);                      // slot (st - 1) & 3: every wave finished reading it before the last barrier
+            comp1(st);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage st + 1 (this wave's part) has landed; two stages stay in flight
+            bar();
+        }
+        for (; st < nst; ++st) {              // the last (up to three) stages: nothing left to request
+            comp1(st);
+            if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+        }
+    } else if constexpr (DMA == 1) {
+        auto dma = [&](int ks) {   // this wave's 8 fragments of stage ks, straight into their slots of buffer ks & 1
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + base[i >> 1] + (size_t)(2 * ks + (i & 1)) * 64),
+                    (__attribute__((address_space(3))) void*)(lds + ((ks & 1) * 32 + wave * 8 + i) * 64), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ks = 0; ks < nks; ++ks) {
+            if (ks + 1 < nks) dma(ks + 1);   // the other buffer: every wave finished reading it before the last barrier
+            compute(ks);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's writes into LDS have landed ...
+            __syncthreads();                                    // ... and so have everybody's
+        }
+    } else {
     fetch(0, sa);
     stash(0, sa);
     if (nks >= 4) {
@@ -130,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
             if (more) stash(ks + 1, sa);
             __syncthreads();
         }
+    }
     }
 
     // ---- epilogue: lane (kg, n) of tile (i, j) holds rows kg * 4 + r, column n
@@ -224,22 +326,42 @@ __global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
     }
 }
 
+template <typename WT, int E, int DMA>
+static int launch_big_k(const BigArgs& a, int tiles, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E, DMA>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
+            acmi_set_error("acmi_linear_big: cannot set the dynamic LDS limit");
+            return ACMI_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lin_big_kernel<WT, E, DMA>), dim3(tiles), dim3(256), lds, st, a);
+    return ACMI_OK;
+}
+
+// workgroups of a launch under lin_big_kernel's tile -> XCD mapping
+static int big_grid(int M, int N) {
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, P = tiles_n >> 3, R = tiles_n & 7;
+    if (R == 1 || R == 2 || R == 4) {
+        const int share = 8 / R;
+        return 8 * ((tiles_m + share - 1) / share) * (share * P + 1);
+    }
+    return tiles_m * tiles_n;
+}
+
 template <typename WT>
 static int launch_big_t(const BigArgs& a, hipStream_t st) {
-    const int tiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const int tiles = big_grid(a.M, a.N);
     const size_t lds = 2 * 32 * 1024;
+    // A/B switch: ACMI_BIG_DMA = 0 (register staging of round 3), 1 (two-buffer DMA), 2 (four-slot DMA ring; default)
+    static const int dma = getenv("ACMI_BIG_DMA") != nullptr ? atoi(getenv("ACMI_BIG_DMA")) : 2;
 #define ACMI_BIG_CASE(E)                                                                                                  \
     case E: {                                                                                                             \
-        static bool attr_set = false;                                                                                     \
-        if (!attr_set) {                                                                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E>),                                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {               \
-                acmi_set_error("acmi_linear_big: cannot set the dynamic LDS limit");                                      \
-                return ACMI_ELAUNCH;                                                                                      \
-            }                                                                                                             \
-            attr_set = true;                                                                                              \
-        }                                                                                                                 \
-        hipLaunchKernelGGL((lin_big_kernel<WT, E>), dim3(tiles), dim3(256), lds, st, a);                                  \
+        const int rc = dma == 2 ? launch_big_k<WT, E, 2>(a, tiles, lds, st)                                               \
+                                : (dma == 1 ? launch_big_k<WT, E, 1>(a, tiles, lds, st) : launch_big_k<WT, E, 0>(a, tiles, lds, st)); \
+        if (rc) return rc;                                                                                                \
         break;                                                                                                            \
     }
     switch (a.epi) {
