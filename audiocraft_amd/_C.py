@@ -76,6 +76,7 @@ _rvq_norms = _sig('acmi_rvq_codebook_norms', [vp, vp, i32, i32, i32, vp])
 _rvq_encode = _sig('acmi_rvq_encode', [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp])
 _rvq_decode = _sig('acmi_rvq_decode', [vp, vp, vp, i32, i32, i32, i32, i32, vp])
 _conv1d = _sig('acmi_conv1d', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp])
+_conv1d_gn = _sig('acmi_conv1d_gn', [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, vp])
 _conv1d_tile = _sig('acmi_conv1d_tile_weights', [C.POINTER(ConvDesc), vp, vp, vp])
 _conv1d_wfloats = _sig('acmi_conv1d_weight_floats', [C.POINTER(ConvDesc)], C.c_size_t)
 _conv1d_work = _sig('acmi_conv1d_work_floats', [C.POINTER(ConvDesc)], C.c_size_t)
@@ -131,7 +132,7 @@ _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32
 
 EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
-           'acmi_conv1d', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
+           'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
 
@@ -208,6 +209,15 @@ def conv1d_tiled(desc: ConvDesc, x, wt, bias, residual, y):
     n = int(_conv1d_work(C.byref(desc)))
     work = torch.empty(n, device=x.device, dtype=torch.float32) if n else None
     check(_conv1d(C.byref(desc), ptr(x), ptr(wt), ptr(bias), ptr(residual), ptr(y), ptr(work), stream()), 'acmi_conv1d')
+
+
+def conv1d_tiled_gn(desc: ConvDesc, x, wt, bias, residual, y, gamma, beta, groups: int, eps: float, relu: bool):
+    """conv(relu?(GroupNorm(x))) without materialising the normalised tensor (acmi_conv1d_gn)."""
+    n = int(_conv1d_work(C.byref(desc)))
+    work = torch.empty(max(n, 1), device=x.device, dtype=torch.float32)
+    gn_work = torch.empty(max(int(_gn_work(desc.B, desc.Cin, desc.Tin, groups)), 1), device=x.device, dtype=torch.float32)
+    check(_conv1d_gn(C.byref(desc), ptr(x), ptr(wt), ptr(bias), ptr(residual), ptr(y), ptr(work), ptr(gn_work), ptr(gamma), ptr(beta),
+                     groups, eps, int(relu), stream()), 'acmi_conv1d_gn')
 
 
 def conv1d(desc: ConvDesc, x, w, bias, residual, y):

@@ -14,6 +14,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------- host-side error plumbing
 void acmi_set_error(const char* fmt, ...);
 int acmi_check_launch(const char* what);
+// GroupNorm statistics pass alone (acmi_diffusion.hip): (mean, M2) partials of chunks of *chunk elements per (batch item, group),
+// part [B groups][*nchunks][2] (acmi_group_norm_work_floats floats); consumed by acmi_conv1d_gn's pack pass
+int acmi_launch_gn_partial(const float* x, float* part, int B, int C, int T, int groups, int* nchunks, int* chunk, hipStream_t st);
 
 #define ACMI_REQUIRE(cond, ...)            \
     do {                                   \

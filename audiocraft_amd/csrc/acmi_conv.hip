@@ -41,6 +41,10 @@ struct ConvArgs {
     int ksplit;             // > 1: blockIdx.z = b * ksplit + part; part p multiplies the chunks [p cps, (p + 1) cps) into `part`
     int cps;                // chunks per part
     float* part;            // [ksplit][B][Cout rows][tq * 64] partial sums (GEMM layout)
+    // GroupNorm (+ ReLU) of the INPUT applied by the pack pass (acmi_conv1d_gn): gn_part = the (mean, M2) partials of
+    // acmi_diffusion.hip's gn_partial_kernel, [B groups][gn_nchunks][2], chunks of gn_chunk elements; NULL: none
+    const float* gn_part; const float* gn_gamma; const float* gn_beta;
+    int gn_groups, gn_nchunks, gn_chunk, gn_relu; float gn_eps;
 };
 
 // geometry shared by the weight tiler, the packer and the main kernel
@@ -106,16 +110,22 @@ static int conv_geometry(const acmi_conv_desc& d, ConvGeom& g) {
     return ACMI_OK;
 }
 
-__device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow, int pos) {
+struct GnCh { float mu, rstd, gamma, beta; };   // GroupNorm of the input channel a pack block works on
+
+__device__ __forceinline__ float conv_fetch(const ConvArgs& a, const float* xrow, int pos, const GnCh& gn) {
     const acmi_conv_desc& d = a.d;
     int src = pos;
     if (d.pad_mode == ACMI_PAD_REFLECT) {
         if (src < 0) src = -src;
         if (src >= d.reflect_len) src = 2 * (d.reflect_len - 1) - src;
     }
-    if (src < 0 || src >= d.Tin) return 0.f;
+    if (src < 0 || src >= d.Tin) return 0.f;        // (the padding of a GroupNorm'd input is zeros of the NORMALISED signal)
     float v = xrow[src];
     if (d.elu_in) v = v > 0.f ? v : d.elu_alpha * expm1f(v);
+    if (a.gn_part != nullptr) {                     // same expression as gn_apply_kernel (acmi_diffusion.hip)
+        v = (v - gn.mu) * gn.rstd * gn.gamma + gn.beta;
+        if (a.gn_relu) v = fmaxf(v, 0.f);
+    }
     return v;
 }
 
@@ -141,6 +151,41 @@ __global__ __launch_bounds__(256) void conv_tile_weights_kernel(const TileWArgs 
 __global__ __launch_bounds__(256) void conv_pack_kernel(const ConvArgs a, float* xp) {
     const acmi_conv_desc& d = a.d;
     const int ci = blockIdx.y, b = blockIdx.z, s = d.stride;
+    GnCh gn = {0.f, 1.f, 1.f, 0.f};
+    if (a.gn_part != nullptr) {
+        // mean / rstd of this block's (batch item, group) from the partials, combined in the order gn_apply_kernel uses (Chan;
+        // counts are gn_chunk except for the last chunk): every block of a group arrives at the same two numbers
+        __shared__ float s4[4];
+        __shared__ float stat[2];
+        const int cpg = d.Cin / a.gn_groups, g = min(ci, d.Cin - 1) / cpg;
+        const size_t n = (size_t)cpg * d.Tin;
+        const float* part = a.gn_part + ((size_t)b * a.gn_groups + g) * a.gn_nchunks * 2;
+        auto bsum = [&](float v) {
+            v = wave_sum(v);
+            if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+            __syncthreads();
+            const float r = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            __syncthreads();
+            return r;
+        };
+        float ws = 0.f;
+        for (int c = threadIdx.x; c < a.gn_nchunks; c += 256) {
+            const float cntc = (float)min((size_t)a.gn_chunk, n - (size_t)c * a.gn_chunk);
+            ws += part[(size_t)c * 2] * cntc;
+        }
+        const float mean = bsum(ws) / (float)n;
+        float m2 = 0.f;
+        for (int c = threadIdx.x; c < a.gn_nchunks; c += 256) {
+            const float cntc = (float)min((size_t)a.gn_chunk, n - (size_t)c * a.gn_chunk);
+            const float dlt = part[(size_t)c * 2] - mean;
+            m2 += part[(size_t)c * 2 + 1] + cntc * dlt * dlt;
+        }
+        m2 = bsum(m2);
+        if (threadIdx.x == 0) { stat[0] = mean; stat[1] = 1.0f / sqrtf(m2 / (float)n + a.gn_eps); }
+        __syncthreads();
+        gn.mu = stat[0]; gn.rstd = stat[1];
+        gn.gamma = a.gn_gamma[min(ci, d.Cin - 1)]; gn.beta = a.gn_beta[min(ci, d.Cin - 1)];
+    }
     const long long n = (long long)s * a.Qp;
     const long long u0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     float* dst = xp + ((size_t)b * a.cin_pad + ci) * (size_t)n;
@@ -150,8 +195,8 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const ConvArgs a, float*
         float4 v;
         const int pos = (int)u0 - d.pad_left;
         if (ci < d.Cin) {
-            v.x = conv_fetch(a, xrow, pos); v.y = conv_fetch(a, xrow, pos + 1);
-            v.z = conv_fetch(a, xrow, pos + 2); v.w = conv_fetch(a, xrow, pos + 3);
+            v.x = conv_fetch(a, xrow, pos, gn); v.y = conv_fetch(a, xrow, pos + 1, gn);
+            v.z = conv_fetch(a, xrow, pos + 2, gn); v.w = conv_fetch(a, xrow, pos + 3, gn);
         } else v = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(dst + u0) = v;
     } else {
@@ -160,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const ConvArgs a, float*
             const long long u = (long long)blockIdx.x * 1024 + i * 256 + threadIdx.x;   // coalesced reads, phase-scattered writes
             if (u < n) {
                 const long long qq = u / s;
-                dst[(u - qq * s) * a.Qp + qq] = ci < d.Cin ? conv_fetch(a, xrow, (int)u - d.pad_left) : 0.f;
+                dst[(u - qq * s) * a.Qp + qq] = ci < d.Cin ? conv_fetch(a, xrow, (int)u - d.pad_left, gn) : 0.f;
             }
         }
     }
@@ -365,7 +410,7 @@ __global__ __launch_bounds__(256) void conv_fewout_kernel(const ConvArgs a) {
             const int ci = idx / (NOUT + KS - 1), rel = idx - ci * (NOUT + KS - 1);
             const bool live = ci0 + ci < d.Cin;
             const float* xrow = a.x + ((size_t)b * d.Cin + min(ci0 + ci, d.Cin - 1)) * d.Tin;
-            xs[ci * SP + rel] = live ? conv_fetch(a, xrow, base_in + rel) : 0.f;
+            xs[ci * SP + rel] = live ? conv_fetch(a, xrow, base_in + rel, GnCh{0.f, 1.f, 1.f, 0.f}) : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -432,8 +477,10 @@ extern "C" int acmi_conv1d_tile_weights(const acmi_conv_desc* dp, const float* w
     return acmi_check_launch("conv_tile_weights_kernel");
 }
 
-extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float* wt, const float* bias, const float* residual,
-                           float* y, float* work, void* stream) {
+struct ConvGn { const float* part; const float* gamma; const float* beta; int groups, nchunks, chunk, relu; float eps; };
+
+static int conv1d_impl(const acmi_conv_desc* dp, const float* x, const float* wt, const float* bias, const float* residual,
+                       float* y, float* work, const ConvGn* gn, void* stream) {
     ACMI_REQUIRE(dp != nullptr, "acmi_conv1d: null descriptor");
     const acmi_conv_desc& d = *dp;
     ConvGeom g;
@@ -441,6 +488,12 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
     if (d.B == 0 || d.Tout <= 0) return ACMI_OK;
     ConvArgs a;
     a.d = d; a.x = x; a.w = wt; a.bias = bias; a.res = residual; a.y = y;
+    a.gn_part = nullptr; a.gn_gamma = a.gn_beta = nullptr; a.gn_groups = a.gn_nchunks = a.gn_chunk = a.gn_relu = 0; a.gn_eps = 0.f;
+    if (gn != nullptr) {
+        ACMI_REQUIRE(!g.fewout && !d.elu_in, "acmi_conv1d_gn: not for the few-output kernel / together with an input ELU");
+        a.gn_part = gn->part; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_groups = gn->groups; a.gn_nchunks = gn->nchunks;
+        a.gn_chunk = gn->chunk; a.gn_relu = gn->relu; a.gn_eps = gn->eps;
+    }
     a.Tq = g.Tq; a.CIC = g.cic; a.KCE = g.KCE; a.KCP = g.KCP; a.LP = g.LP; a.XSZ = g.XSZ;
     a.nchunks = g.nchunks; a.cin_pad = g.nchunks * g.cic; a.Qp = g.Qp; a.lp4_magic = 0;
     a.ksplit = 1; a.cps = g.nchunks; a.part = nullptr;
@@ -486,6 +539,25 @@ extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float
         return acmi_check_launch("conv_splitk_reduce_kernel");
     }
     return acmi_check_launch("conv_mfma_kernel");
+}
+
+extern "C" int acmi_conv1d(const acmi_conv_desc* dp, const float* x, const float* wt, const float* bias, const float* residual,
+                           float* y, float* work, void* stream) {
+    return conv1d_impl(dp, x, wt, bias, residual, y, work, nullptr, stream);
+}
+
+// conv(relu?(GroupNorm(x))): the normalisation's statistics pass (gn_partial_kernel), then the convolution whose pack pass applies
+// (x - mean) rstd gamma + beta (+ ReLU) on the way into the packed layout -- three launches and ONE extra read of x instead of
+// statistics + apply (read + write) + pack (read + write) + convolution (models/unet.py:32-53: norm -> ReLU -> conv of a ResBlock).
+extern "C" int acmi_conv1d_gn(const acmi_conv_desc* dp, const float* x, const float* wt, const float* bias, const float* residual,
+                              float* y, float* work, float* gn_work, const float* gamma, const float* beta, int groups, float eps,
+                              int relu, void* stream) {
+    ACMI_REQUIRE(dp != nullptr && gn_work != nullptr && gamma != nullptr && beta != nullptr, "acmi_conv1d_gn: null argument");
+    ACMI_REQUIRE(groups > 0 && dp->Cin % groups == 0, "acmi_conv1d_gn: Cin=%d not divisible into %d groups", dp->Cin, groups);
+    if (dp->B == 0 || dp->Tout <= 0) return ACMI_OK;
+    ConvGn gn = {gn_work, gamma, beta, groups, 0, 0, relu, eps};
+    if (int rc = acmi_launch_gn_partial(x, gn_work, dp->B, dp->Cin, dp->Tin, groups, &gn.nchunks, &gn.chunk, (hipStream_t)stream)) return rc;
+    return conv1d_impl(dp, x, wt, bias, residual, y, work, &gn, stream);
 }
 
 // =====================================================================================================

@@ -103,6 +103,17 @@ extern "C" size_t acmi_group_norm_work_floats(int B, int C, int T, int groups) {
     return (size_t)B * groups * ((n + GN_CHUNK - 1) / GN_CHUNK) * 2;
 }
 
+int acmi_launch_gn_partial(const float* x, float* part, int B, int C, int T, int groups, int* nchunks, int* chunk, hipStream_t st) {
+    ACMI_REQUIRE(B > 0 && C > 0 && T > 0 && groups > 0 && C % groups == 0, "acmi_group_norm: bad shape B=%d C=%d T=%d groups=%d", B, C, T, groups);
+    ACMI_REQUIRE(B * groups <= 65535, "acmi_group_norm: B x groups = %d exceeds the grid", B * groups);
+    GnArgs a = {x, nullptr, nullptr, nullptr, part, C, T, groups, 0, 0.f, 0};
+    const size_t n = (size_t)(C / groups) * T;
+    a.nchunks = (int)((n + GN_CHUNK - 1) / GN_CHUNK);
+    *nchunks = a.nchunks; *chunk = GN_CHUNK;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(a.nchunks, B * groups), dim3(256), 0, st, a);
+    return acmi_check_launch("gn_partial_kernel");
+}
+
 extern "C" int acmi_group_norm(const float* x, const float* gamma, const float* beta, float* y, float* work, int B, int C, int T,
                                int groups, float eps, int relu, void* stream) {
     ACMI_REQUIRE(B > 0 && C > 0 && T > 0 && groups > 0 && C % groups == 0, "acmi_group_norm: bad shape B=%d C=%d T=%d groups=%d", B, C, T, groups);

@@ -6,7 +6,9 @@ PARAMETER CONTAINERS only -- every operation of `forward` runs in libacmi:
 
  * Conv1d / ConvTranspose1d           acmi_conv1d (implicit-GEMM MFMA kernel; the transposed convolutions as their polyphase
                                       decomposition, like the SEANet decoder's)
- * GroupNorm + the ReLU behind it     acmi_group_norm (one launch pair, ReLU fused)
+ * GroupNorm + the ReLU behind it     folded into the following convolution's input pack (acmi_conv1d_gn: norm -> ReLU -> conv of a
+                                      ResBlock, the decoder layers' norm -> ReLU -> transposed conv); acmi_group_norm (one launch
+                                      pair, ReLU fused) where the normalised tensor itself is needed (the encoder layers' output)
  * residual adds                      fused into the second convolution of a ResBlock (its `residual` operand)
  * step embeddings, skip adds, the interpolated codec condition       acmi_channel_add / acmi_add_cropped / acmi_interp_add
  * BiLSTM bottleneck                  input projections as k = 1 convolutions, recurrences on acmi_lstm_layer (the reverse
@@ -40,8 +42,19 @@ class _Tiles(dict):
         return hit[1]
 
 
+def _launch_conv(d, x, wt, b, residual, y, gn: tp.Optional[tp.Tuple[nn.GroupNorm, int]]):
+    """gn = (GroupNorm module, groups): the convolution runs on relu(GroupNorm(x)) -- the normalisation is applied by the
+    convolution's own input pack (acmi_conv1d_gn) instead of being materialised by a launch of its own."""
+    if gn is None:
+        _C.conv1d_tiled(d, x, wt, b, residual, y)
+    else:
+        norm, groups = gn
+        _C.conv1d_tiled_gn(d, x, wt, b, residual, y, norm.weight, norm.bias, groups, norm.eps, True)
+
+
 def _conv1d(tiles: _Tiles, name: str, x: torch.Tensor, w: torch.Tensor, b: tp.Optional[torch.Tensor], stride: int = 1,
-            padding: int = 0, dilation: int = 1, residual: tp.Optional[torch.Tensor] = None, right_pad: int = 0) -> torch.Tensor:
+            padding: int = 0, dilation: int = 1, residual: tp.Optional[torch.Tensor] = None, right_pad: int = 0,
+            gn: tp.Optional[tp.Tuple[nn.GroupNorm, int]] = None) -> torch.Tensor:
     """nn.Conv1d(padding=padding, zero padding; `right_pad` more zeros on the right: F.pad before the conv) on x [B, Cin, T]."""
     B, Cin, T = x.shape
     Cout, _, k = w.shape
@@ -51,7 +64,7 @@ def _conv1d(tiles: _Tiles, name: str, x: torch.Tensor, w: torch.Tensor, b: tp.Op
     d.ksize, d.stride, d.dilation, d.pad_left = k, stride, dilation, padding
     d.pad_mode, d.reflect_len, d.elu_in, d.elu_alpha, d.shuffle, d.trim_left = _C.PAD_ZERO, T, 0, 0.0, 1, 0
     y = torch.empty(B, Cout, Tout, device=x.device, dtype=torch.float32)
-    _C.conv1d_tiled(d, x, tiles.get_tiled(name, d, w), b, residual, y)
+    _launch_conv(d, x, tiles.get_tiled(name, d, w), b, residual, y, gn)
     return y
 
 
@@ -63,7 +76,8 @@ def _polyphase(w: torch.Tensor, stride: int) -> tp.Tuple[torch.Tensor, int]:
     return wp.permute(1, 3, 0, 2).flip(-1).reshape(cout * stride, cin, ntaps).contiguous(), ntaps
 
 
-def _convtr1d(tiles: _Tiles, name: str, x: torch.Tensor, wq: torch.Tensor, ntaps: int, k: int, stride: int, padding: int) -> torch.Tensor:
+def _convtr1d(tiles: _Tiles, name: str, x: torch.Tensor, wq: torch.Tensor, ntaps: int, k: int, stride: int, padding: int,
+              gn: tp.Optional[tp.Tuple[nn.GroupNorm, int]] = None) -> torch.Tensor:
     """nn.ConvTranspose1d(k, stride, padding, bias=False): (T - 1) s + k - 2 padding output samples."""
     B, Cin, T = x.shape
     cout = wq.shape[0] // stride
@@ -74,7 +88,7 @@ def _convtr1d(tiles: _Tiles, name: str, x: torch.Tensor, wq: torch.Tensor, ntaps
     d.pad_mode, d.reflect_len, d.elu_in, d.elu_alpha = _C.PAD_ZERO, T, 0, 0.0
     d.shuffle, d.trim_left = stride, padding
     y = torch.empty(B, cout, Tout, device=x.device, dtype=torch.float32)
-    _C.conv1d_tiled(d, x, tiles.get_tiled(name, d, wq), None, None, y)
+    _launch_conv(d, x, tiles.get_tiled(name, d, wq), None, None, y, gn)
     return y
 
 
@@ -92,10 +106,12 @@ class ResBlock(nn.Module):
         self.conv2 = nn.Conv1d(channels, channels, kernel, 1, padding, dilation=dilation, device=device)
 
     def run(self, x: torch.Tensor) -> torch.Tensor:
-        h = _C.group_norm(x, self.norm1.weight, self.norm1.bias, self.norm_groups, self.norm1.eps, relu=True)
-        h = _conv1d(self._tiles, 'conv1', h, self.conv1.weight, self.conv1.bias, 1, self.padding, self.dilation)
-        h = _C.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm_groups, self.norm2.eps, relu=True, out=h)
-        return _conv1d(self._tiles, 'conv2', h, self.conv2.weight, self.conv2.bias, 1, self.padding, self.dilation, residual=x)
+        # norm -> ReLU -> conv twice: both normalisations ride in their convolution's input pack (round 4; before: a
+        # statistics + an apply launch and a read + write of the activation per normalisation)
+        h = _conv1d(self._tiles, 'conv1', x, self.conv1.weight, self.conv1.bias, 1, self.padding, self.dilation,
+                    gn=(self.norm1, self.norm_groups))
+        return _conv1d(self._tiles, 'conv2', h, self.conv2.weight, self.conv2.bias, 1, self.padding, self.dilation, residual=x,
+                       gn=(self.norm2, self.norm_groups))
 
 
 class EncoderLayer(nn.Module):
@@ -138,12 +154,12 @@ class DecoderLayer(nn.Module):
     def run(self, x: torch.Tensor) -> torch.Tensor:
         for rb in self.res_blocks:
             x = rb.run(x)
-        x = _C.group_norm(x, self.norm.weight, self.norm.bias, self.norm_groups, self.norm.eps, relu=True)
         stamp = (self.convtr.weight.data_ptr(), self.convtr.weight._version)
         if self._prep is None or self._prep[2] != stamp:
             wq, ntaps = _polyphase(self.convtr.weight.detach().float(), self.stride)
             self._prep = (wq, ntaps, stamp)
-        return _convtr1d(self._tiles, 'convtr', x, self._prep[0], self._prep[1], self.kernel, self.stride, (self.kernel - self.stride) // 2)
+        return _convtr1d(self._tiles, 'convtr', x, self._prep[0], self._prep[1], self.kernel, self.stride, (self.kernel - self.stride) // 2,
+                         gn=(self.norm, self.norm_groups))
 
 
 class BLSTM(nn.Module):

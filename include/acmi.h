@@ -104,6 +104,12 @@ typedef struct {
 size_t acmi_conv1d_weight_floats(const acmi_conv_desc* d);
 size_t acmi_conv1d_work_floats(const acmi_conv_desc* d);
 int acmi_conv1d_tile_weights(const acmi_conv_desc* d, const float* w, float* wt, void* stream);
+/* acmi_conv1d_gn: the same convolution on relu?(GroupNorm(x)) -- `norm -> ReLU -> conv` of the diffusion U-Net's ResBlock
+ * (audiocraft/models/unet.py:32-53) without materialising the normalised tensor: a statistics pass over x, then the
+ * convolution, whose input pack applies (x - mean) rstd gamma + beta (+ ReLU).  gn_work: acmi_group_norm_work_floats(B, Cin,
+ * Tin, groups) floats; gamma / beta [Cin]; not for descriptors with elu_in or the one / two output channel kernel. */
+int acmi_conv1d_gn(const acmi_conv_desc* d, const float* x, const float* wt, const float* bias, const float* residual, float* y,
+                   float* work, float* gn_work, const float* gamma, const float* beta, int groups, float eps, int relu, void* stream);
 int acmi_conv1d(const acmi_conv_desc* d, const float* x, const float* wt, const float* bias,
                 const float* residual, float* y, float* work, void* stream);
 

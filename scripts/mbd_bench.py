@@ -42,6 +42,27 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    # flops and activation bytes of one forward, counted at the convolution calls (GEMM rows x columns x K per descriptor)
+    acct = {'flops': 0.0, 'bytes': 0.0, 'convs': 0}
+    orig = (_C.conv1d_tiled, _C.conv1d_tiled_gn)
+
+    def count(d, xx, wt, y):
+        cols = (d.Tout + d.trim_left + d.shuffle - 1) // d.shuffle if d.shuffle > 1 else d.Tout
+        acct['flops'] += 2.0 * d.B * d.Cout * d.Cin * d.ksize * cols
+        acct['bytes'] += 4.0 * (xx.numel() + y.numel()) + 4.0 * d.Cout * d.Cin * d.ksize
+        acct['convs'] += 1
+
+    def c1(d, xx, wt, b, r, y):
+        count(d, xx, wt, y)
+        return orig[0](d, xx, wt, b, r, y)
+
+    def c2(d, xx, wt, b, r, y, *rest):
+        count(d, xx, wt, y)
+        return orig[1](d, xx, wt, b, r, y, *rest)
+
+    _C.conv1d_tiled, _C.conv1d_tiled_gn = c1, c2
+    m(x, 500, cond)
+    _C.conv1d_tiled, _C.conv1d_tiled_gn = orig
     t_fwd = timed(lambda: m(x, 500, cond), a.reps)
     proc = MultiBandProcessor(n_bands=4, sample_rate=32000, num_samples=1)
     proc.load_state_dict({'counts': torch.ones(1), 'sum_x': torch.zeros(4), 'sum_x2': torch.ones(4), 'sum_target_x2': torch.ones(4)})
@@ -57,7 +78,11 @@ def main():
         return _C.band_mix(x, lows, g)
 
     t_eq = timed(eq, 3)
+    F32_MFMA_TFLOPS, HBM_GBS = 157.3, 8000.0      # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate; HBM3E peak
     out = {'workload': f'MBD U-Net (hidden 48, depth 4, growth 4) B={a.batch} {a.seconds:g} s @ 32 kHz', 'unet_forward_ms': t_fwd * 1e3,
+           'unet_forward_gflop': acct['flops'] / 1e9, 'unet_forward_tflops_per_s': acct['flops'] / t_fwd / 1e12,
+           'f32_mfma_frac': acct['flops'] / t_fwd / 1e12 / F32_MFMA_TFLOPS, 'convolutions': acct['convs'],
+           'conv_activation_and_weight_gb': acct['bytes'] / 1e9, 'hbm_frac_if_streamed_once': acct['bytes'] / t_fwd / 1e9 / HBM_GBS,
            'reverse_process_20_steps_ms': t_proc * 1e3, 're_eq_32_bands_ms': t_eq * 1e3,
            'four_band_decode_rtf': a.batch * a.seconds / (4 * t_proc + t_eq)}
     print(json.dumps(out))
