@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['acmi_core.hip', 'acmi_gemm.hip', 'acmi_attn.hip', 'acmi_lm.hip', 'acmi_prefill.hip', 'acmi_rvq.hip', 'acmi_conv.hip', 'acmi_chroma.hip', 'acmi_audio.hip', 'acmi_diffusion.hip']
+SOURCES = ['acmi_core.hip', 'acmi_gemm.hip', 'acmi_gemm_f32.hip', 'acmi_attn.hip', 'acmi_lm.hip', 'acmi_prefill.hip', 'acmi_rvq.hip', 'acmi_conv.hip', 'acmi_chroma.hip', 'acmi_audio.hip', 'acmi_diffusion.hip']
 HEADERS = [os.path.join(ROOT, 'include', 'acmi.h'), os.path.join(CSRC, 'acmi_common.h'),
            os.path.join(CSRC, 'acmi_lm_internal.h')]
 OUT = os.path.join(CSRC, 'libacmi.so')
@@ -31,8 +31,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-faile
 # kernels of these files are written for it (acmi_gemm.hip: TlHot; acmi_attn.hip: attn_decode_kernel).  Firmware without the feature runs the compiler's
 # compatibility prologue, which loads the same registers.
 _PRELOAD = ['-mllvm', '-amdgpu-kernarg-preload-count=14']
-FILE_FLAGS = {'acmi_gemm.hip': _PRELOAD, 'acmi_attn.hip': _PRELOAD}
+FILE_FLAGS = {'acmi_gemm.hip': _PRELOAD, 'acmi_gemm_f32.hip': _PRELOAD, 'acmi_attn.hip': _PRELOAD}
 OBJDIR = os.path.join(CSRC, 'build')
+FILE_DEPS = {'acmi_gemm_f32.hip': ['acmi_gemm.hip']}   # sources a translation unit #includes
 
 
 def _stale(target: str, deps) -> bool:
@@ -59,7 +60,7 @@ def build(force: bool = False, verbose: bool = True, out: str = OUT, defines=())
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + tag + '.o')
         path = os.path.join(CSRC, src)
-        if force or _stale(obj, [path] + HEADERS):
+        if force or _stale(obj, [path] + [os.path.join(CSRC, d) for d in FILE_DEPS.get(src, [])] + HEADERS):
             cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + inc + ['-c', path, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)

@@ -8,6 +8,15 @@
 #include <math.h>
 #include <stdlib.h>
 
+// Two translation units, one source: the f32-weight instantiations of the launchers below (half of the kernels of this
+// file) are compiled by acmi_gemm_f32.hip, which defines ACMI_GEMM_F32_TU and includes this file; everything that is not
+// a template on the weight type -- the C entry points, the trace bookkeeping -- is compiled here only.
+#ifdef ACMI_GEMM_F32_TU
+#define ACMI_GEMM_MAIN 0
+#else
+#define ACMI_GEMM_MAIN 1
+#endif
+
 // =====================================================================================================
 // skinny GEMM   out[M,N] = act(LN?(a)[M,K] @ W[N,K]^T + bias) + residual
 //
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(float* __restrict__ x, WT*
     }
 }
 
+#if ACMI_GEMM_MAIN
 int acmi_launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps, const float* slabs, int nslabs,
                         hipStream_t st) {
     ACMI_REQUIRE(M > 0 && K > 0 && K % 4 == 0 && K <= 2048, "acmi_ln_tile: needs K %% 4 == 0 and K <= 2048 (K=%d)", K);
@@ -172,6 +182,7 @@ extern "C" int acmi_ln_tile_reduce(float* x, const float* slabs, int nslabs, voi
 extern "C" int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream) {
     return acmi_launch_ln_tile(const_cast<float*>(x), out, wdtype, M, K, eps, nullptr, 0, (hipStream_t)stream);
 }
+#endif  // ACMI_GEMM_MAIN
 
 // Folded LayerNorm, row statistics: a "group" is 4 rows (16 lanes each); every lane fetches up to NS (8, or 16 when the
 // producer ran with 8-feature workgroups) of the producer's equal-count (mean, M2) partials of its row (np <= 16 NS),
@@ -285,7 +296,7 @@ __global__ __launch_bounds__(1024) void lin_rowmajor_kernel(const LinArgs p) {
 }
 
 template <typename WT>
-static int launch_rowmajor(LinArgs& a, hipStream_t st) {
+int launch_rowmajor(LinArgs& a, hipStream_t st) {
     constexpr int KT = WTr<WT>::KT;
     a.NKC = (a.K + KT - 1) / KT;
     a.NKC_out = (a.N + KT - 1) / KT;
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(512) void lin_pair_kernel(const u32x4* hw0, const u
     else tl_body<WT, MT, LNB, 1, 8, false>(h, ACMI_TL_ARGS_OFF_PAIR + (int)sizeof(LinArgs), (int)blockIdx.x - tiles0, 0);
 }
 
-#ifdef ACMI_TRACE
+#if defined(ACMI_TRACE) && ACMI_GEMM_MAIN
 // Host side of the timeline: acmi_trace_config hands over a device buffer and restarts the launch index; every GEMM launch
 // of the decode step then reserves [workgroups][waves][ACMI_TRACE_NSTAMP] words of it (in launch order) and is described
 // by acmi_trace_info.  Captured into a hipGraph, a launch keeps its region: each replay overwrites the previous one's stamps.
@@ -1039,7 +1050,7 @@ static int launch_tiled_t(LinArgs& a, hipStream_t st) {
 }
 
 template <typename WT>
-static int launch_tiled(LinArgs& a, hipStream_t st) {
+int launch_tiled(LinArgs& a, hipStream_t st) {
     int rc = tiled_prepare<WT>(a);
     if (rc) return rc;
     const int mt = a.M > 32 ? 4 : (a.M > 16 ? 2 : 1);  // 1, 2 or 4 16-row blocks share each weight fragment
@@ -1090,7 +1101,7 @@ static int launch_tiled(LinArgs& a, hipStream_t st) {
 
 // p0 (plain tiled GEMM) and p1 (x | a concatenated along K, hi + lo for the x part) in one launch
 template <typename WT>
-static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
+int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
     int rc;
     if ((rc = tiled_prepare<WT>(p0)) || (rc = tiled_prepare<WT>(p1))) return rc;
     ACMI_REQUIRE(p0.M == p1.M && p0.ksplit == 1 && p1.ksplit == 1 && !p0.qkv && !p1.qkv && p0.colsum == nullptr &&
@@ -1125,6 +1136,15 @@ static int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
 #undef ACMI_PAIR_CASE
     return acmi_check_launch("lin_pair_kernel");
 }
+
+#if !ACMI_GEMM_MAIN
+template int launch_rowmajor<float>(LinArgs&, hipStream_t);
+template int launch_tiled<float>(LinArgs&, hipStream_t);
+template int launch_pair<float>(LinArgs&, LinArgs&, hipStream_t);
+#else
+extern template int launch_rowmajor<float>(LinArgs&, hipStream_t);
+extern template int launch_tiled<float>(LinArgs&, hipStream_t);
+extern template int launch_pair<float>(LinArgs&, LinArgs&, hipStream_t);
 
 int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st) {
     ACMI_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "acmi_linear: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -1209,3 +1229,4 @@ extern "C" int acmi_linear_pair(const acmi_linear_desc* plain, const acmi_linear
     ACMI_REQUIRE(p0.M > 0 && p0.N > 0 && p0.K > 0 && p1.N > 0 && p1.K > 0, "acmi_linear_pair: empty problem");
     return acmi_launch_pair(p0, p1, plain->wdtype, (hipStream_t)stream);
 }
+#endif  // ACMI_GEMM_MAIN

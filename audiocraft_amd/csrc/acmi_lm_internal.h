@@ -91,6 +91,7 @@ struct BigArgs {
     const float* bias;          // [N] f32 or NULL
     int M, N, K, NKC;           // M: rows, a multiple of 16 (row blocks past it are never read)
     int epi, act;               // ACMI_BIG_*; act 1 = exact GELU (tiled epilogue)
+    int vec;                    // set by acmi_launch_big: f32 output rows take 16-byte stores
     float* out; int ldo;        // F32 / RESID: row-major f32 [M, ldo] (RESID: out += result)
     void* out_t; int out_rbs;   // TILED: tiled activation in the weight's element type, K tiles per 16-row block
     // QKV (N = 3 d): q -> q_out [M, d] f32; K / V -> caches [rows, H, Tcap, hd] at position pos[0] + p of cache row

@@ -3,17 +3,18 @@
 // models/genmodel.py:233-262), instead of position by position through the decode kernels.
 //
 //   lin_big_kernel        MFMA-tiled GEMM  out[M, N] = a[M, K] W[N, K]^T  on the SAME tiled operands the decode step uses
-//                         (1 KB A / B fragments, include/acmi.h): 128 x 128 workgroup tiles, 4 waves of 64 x 64, K in steps
-//                         of two fragments, fragments staged through LDS in fragment order (every ds_read_b128 is lane
-//                         linear: conflict free), epilogues: f32 / residual add / tiled (+ GELU) / QKV scatter into the KV
+//                         (1 KB A / B fragments, include/acmi.h): 256 x 256 workgroup tiles of 8 waves (128 x 128 of 4
+//                         for small launches), fragments DMA'd into an LDS ring in fragment order (every ds_read_b128 is
+//                         lane linear: conflict free), epilogues: f32 / residual add / tiled (+ GELU) / QKV scatter into the KV
 //                         cache (+ V time-minor for the prefill attention).
 //   attn_prefill_kernel   causal attention of all prompt positions of a (cache row, head): flash-style over the K cache,
 //                         S^T = K Q^T so that a query's scores sit in one lane column, P feeds the second MFMA straight
 //                         from registers (its k slots are matched by the load pattern of the time-minor V), online softmax.
 //
 // Row layout of every prefill activation: POSITION-MINOR and padded, row = cache_row * npos_pad + position (npos_pad =
-// positions rounded up to 16), so that a 16-row MFMA block is 16 consecutive positions of ONE cache row: the QKV
-// epilogue then stores 4 consecutive positions of V^T with one 8-byte store and never straddles cache rows.
+// positions rounded up to 16), so that a 16-row MFMA block is 16 consecutive positions of ONE cache row: the 16 lanes that
+// hold one feature of such a block in the QKV epilogue store 16 consecutive entries of a V^T row and never straddle
+// cache rows.
 #include "acmi_lm_internal.h"
 
 #include <math.h>
@@ -28,39 +29,108 @@ __device__ __forceinline__ void big_mma(const u32x4& a, const u32x4& b, f32x4& a
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
 }
 __device__ __forceinline__ float big_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for a bf16 result: erfc(|x| / sqrt 2) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: one v_rcp_f32, one v_exp_f32
+// and six FMAs against erff's ~45 instructions -- the exact form cost the FFN1 epilogue more than its K loop's MFMAs).
+// |gelu - exact| <= 4.3e-7 everywhere, 1e-7 relative in norm; after rounding to bf16 9e-5 of N(0, 1) inputs land one ulp
+// off (never more above |y| = 1e-3): below what the order of the K sum already moves.  f32 results keep erff.
+__device__ __forceinline__ float big_gelu_bf16(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float q = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    q = __builtin_fmaf(q, t, 1.421413741f);
+    q = __builtin_fmaf(q, t, -0.284496736f);
+    q = __builtin_fmaf(q, t, 0.254829592f);
+    const float c = q * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erfc(z)
+    return 0.5f * x * (x >= 0.f ? 2.0f - c : c);                                      // 1 + erf(x / sqrt 2)
+}
 
 // =====================================================================================================
 // MFMA-tiled GEMM on tiled operands
 // =====================================================================================================
-// DMA (round 4): the fragments of a stage go global -> LDS directly (`global_load_lds_dwordx4`: one op per 1 KB fragment, the
-// wave's lanes land at consecutive 16-byte slots -- exactly the fragment order), one stage ahead of the MFMAs, instead of
-// global -> VGPR -> ds_write_b128 two stages ahead.  Cycle budget of a K step per CU (two workgroups): 64 KB of ds_write_b128
-// at ~79 B/clk = ~830 cycles + 128 KB of ds_read_b128 at 256 B/clk = 512 cycles on ONE LDS pipe against 1024 cycles of MFMA
-// issue: the register staging made the LDS pipe, not the matrix pipe, the longer one.
-//   DMA 1: stages of two K fragments (32 KB), two LDS buffers, the next stage requested one K step ahead;
-//   DMA 2: stages of ONE K fragment (16 KB), a ring of four, requests three stages ahead (counted vmcnt: two stages stay in
-//          flight across every barrier) -- the same 64 KB of LDS, three times the latency tolerance.
-template <typename WT, int EPI, int DMA>
-__global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 stages x 32 fragments x 1 KB
+// Tiles (BIG): 0 = 128 x 128, 4 waves (2 x 2) of 64 x 64, two workgroups per CU -- small launches, which a 256 x 256 grid
+// would not spread over the chip; 1 = 256 x 256, 8 waves (2 x 4) of 128 x 64, one workgroup per CU (128 KB of LDS), 128
+// accumulator VGPRs per lane: half the fragment bytes per flop through the CU's memory path, the LDS and the registers.
+//
+// Staging: the fragments of a stage (ONE K fragment of every 16-row / 16-feature block of the tile) go global -> LDS
+// directly (`global_load_lds_dwordx4`: one op per 1 KB fragment, the wave's lanes land at consecutive 16-byte slots --
+// exactly the fragment order, so every ds_read_b128 is lane linear: conflict free) into a ring of four stages.  Every wave
+// moves 4 fragments per stage as ONE block of inline asm: M0 (the LDS destination) written once, the fragments addressed
+// by an SGPR base + one VGPR offset + the instruction's immediate, which moves the LDS and the global address alike (the
+// bases are pre-decremented by it).  Inline asm because hipcc drains vmcnt to 0 in front of every barrier and every
+// ds_read that may alias a DMA destination -- no request would survive a K step; completion is counted by hand
+// (`vmcnt(8)` = all but this wave's two youngest stages have landed; the kernel's only other VMEM operations are the
+// epilogue's, behind a vmcnt(0)).
+//
+// K loop (the second half of round 4; timelines by scripts/big_gemm_bench.py --trace with a -DACMI_BIG_TRACE build,
+// profiles/r04_session14 .. 22_prefill_gemm.log; cycles per K step of the 256 x 256 tile, ideal = 1024: the SIMD's 64
+// MFMAs of 16 cycles):
+//   1735  every wave requests, then reads its 12 fragments from LDS, then multiplies: 96 KB of reads per CU at the top
+//         of the step starve the matrix pipes, the waves meet again at the barrier (no wait for memory at all: 24 cycles)
+//   1623  requests spread between the MFMAs
+//   1495  fragments read HALF A STEP AHEAD into registers (below)
+//   1400  + the requests as one block (a separate M0 write + 64-bit VGPR address per request cost ~25 cycles each)
+//   1374  the same loop without requests, 1192 without LDS reads either (timing only): what is left is the matrix pipe --
+//         of a SIMD's two waves the older one issues ALL its MFMAs first (17.8 cycles each), the younger one follows --
+//         and ~190 cycles in which LDS reads and MFMAs do not overlap.
+// A stage s is multiplied in two halves: half 0 takes the lower row blocks (`b`, `lo`: read during the previous half) while
+// the upper ones (`hi`) arrive; the barrier sits between the halves; half 1 takes the upper row blocks while `b`, `lo` of
+// stage s + 1 arrive, and requests stage s + 4 into the slot of stage s, which every wave has finished reading
+// (lgkmcnt(0) in front of the barrier).  The cycle counts are data independent; the clock is not: all-zero operands run
+// the same cycles 1.2-1.4x faster (r04_session17 / 21: 1.8-1.9 GHz under random operands) -- 2.5 PFLOP/s is 2.4 GHz.
+//
+// The MFMAs run TRANSPOSED (A operand = weight fragment, B operand = activation fragment; the two share one register
+// layout): lane (kg, nl) of accumulator (i, j) then holds 4 CONSECUTIVE FEATURES j * 16 + kg * 4 + r of activation row
+// i * 16 + nl, so every epilogue stores 16 bytes (f32) / 8 bytes (bf16) per lane -- a tiled bf16 output lands as contiguous
+// 512-byte halves of its fragments -- instead of four scattered scalars.
+template <int BIG> struct BigTile {
+    static constexpr int TS = BIG ? 8 : 7;     // log2 of the tile edge
+    static constexpr int T = 1 << TS;
+    static constexpr int FR = T / 16;          // fragments per operand per stage
+    static constexpr int NW = BIG ? 8 : 4;     // waves: 2 along m x (NW / 2) along n
+    static constexpr int WI = BIG ? 8 : 4;     // 16-row blocks of a wave's tile (its width is 64 features)
+    static constexpr int WNS = BIG ? 2 : 1;    // log2 of the waves along n
+    static constexpr int SLOT = 2 * FR;        // fragments (KB) per ring slot
+};
+
+#ifdef ACMI_BIG_TRACE
+// Lab build only (libacmi_bigtrace.so, scripts/big_gemm_bench.py --trace): per wave, the shader-clock cycles spent in each
+// part of the kernel: [0] prologue (start -> first barrier passed), [1] half 0, [2] half 1, [3] lgkmcnt / vmcnt wait,
+// [4] barrier wait (1-4 summed over the steady-state stages), [5] drain stages, [6] epilogue, [7] steady-state stages.
+__device__ unsigned long long g_big_trace[2048 * 8 * 8];
+extern "C" int acmi_big_trace_read(unsigned long long* out, int words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_trace), (size_t)words * 8) == hipSuccess ? ACMI_OK : ACMI_ELAUNCH;
+}
+#define ACMI_BT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define ACMI_BT_SET(var) var = __builtin_amdgcn_s_memtime()
+#define ACMI_BT_ADD(k, a, b) tr[k] += (b) - (a)
+#else
+#define ACMI_BT(var)
+#define ACMI_BT_SET(var)
+#define ACMI_BT_ADD(k, a, b)
+#endif
+
+template <typename WT, int EPI, int BIG>
+__global__ __launch_bounds__(BigTile<BIG>::NW * 64, BIG ? 1 : 2) void lin_big_kernel(const BigArgs p) {
+    using TC = BigTile<BIG>;
+    constexpr int TS = TC::TS, FR = TC::FR, WI = TC::WI, SLOT = TC::SLOT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 4 ring slots x SLOT fragments x 1 KB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7, nb = tiles_m * tiles_n;
-    // Workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2.  Round 4: XCD x owns tiles_n / 8 ADJACENT COLUMN tiles
-    // and sweeps the row tiles: its weight panels (6 x 393 KB at N = 6144, K = 1536) stay in its L2 and every activation
-    // panel is read once per XCD.  A remainder of 1, 2 or 4 column tiles (N = 4608: 36 = 8 x 4 + 4, N = 1536: 12 = 8 + 4) is
-    // shared by 8 / remainder XCDs each, which take its row tiles in turn (big_grid below sizes the launch: workgroups past
-    // an XCD's list leave at once).  (Round 3 gave each XCD a contiguous run of ROW-major tiles: the 64 tiles it works on at
-    // a time then touch all N / 128 weight panels -- 18.9 MB, far beyond its L2 -- once per row tile: 1.4 GB from the memory
-    // side per FFN1 GEMM of a 600-position prefill, 6.7 TB/s for the 213-280 us it took.)
+    const int wm = wave >> TC::WNS, wn = wave & ((1 << TC::WNS) - 1);
+    const int tiles_n = (p.N + TC::T - 1) >> TS, tiles_m = (p.M + TC::T - 1) >> TS, nb = tiles_m * tiles_n;
+    // Workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2.  XCD x owns tiles_n / 8 ADJACENT COLUMN tiles and
+    // sweeps the row tiles: its weight panels stay in its L2 and every activation panel is read once per XCD.  A remainder
+    // of 1, 2 or 4 column tiles is shared by 8 / remainder XCDs each, which take its row tiles in turn (big_grid below sizes
+    // the launch: workgroups past an XCD's list leave at once).  (Round 3 gave each XCD a contiguous run of ROW-major tiles:
+    // the tiles it works on at a time then touch all weight panels -- far beyond its L2 -- once per row tile: 1.4 GB from the
+    // memory side per FFN1 GEMM of a 600-position prefill.)
     int bid = blockIdx.x, tm, tn;
     const int P = tiles_n >> 3, R = tiles_n & 7;
     if (R == 0) {
         const int x = bid & 7, l = bid >> 3;
         tm = l / P;
         tn = x * P + (l - tm * P);
-    } else if (R == 1 || R == 2 || R == 4) {
+    } else if (P > 0 && (R == 1 || R == 2 || R == 4)) {
         const int share = 8 / R, G = share * P + 1;   // a group = `share` row tiles: their primary tiles + ONE tile of the shared column
         const int x = bid & 7, l = bid >> 3, g = l / G, r = l - g * G;
         if (r < share * P) { tm = g * share + r / P; tn = x * P + r % P; }
@@ -72,279 +142,246 @@ __global__ __launch_bounds__(256, 2) void lin_big_kernel(const BigArgs p) {
         tn = bid - tm * tiles_n;
     }
     const int MT16 = p.M >> 4, NT16 = (p.N + 15) >> 4;
-    const u32x4* __restrict__ A = reinterpret_cast<const u32x4*>(p.a);
-    const u32x4* __restrict__ W = reinterpret_cast<const u32x4*>(p.w);
-
-    // the 8 fragments of a stage this wave moves: waves 0, 1 the activation's (row block wave * 4 + i / 2, K fragment i & 1),
-    // waves 2, 3 the weight's; LDS fragment index = wave * 8 + i in both cases
-    size_t base[4];
+    // the 4 fragments of a stage this wave moves: the lower half of the waves the activation's (row block wq * 4 + h), the
+    // upper half the weight's; LDS fragment index within the slot = wave * 4 + h in both cases.  sb[h]: byte address of
+    // fragment (block, K fragment 0), pre-decremented by the immediate its request carries
+    constexpr int HW = TC::NW / 2;
+    const bool mine_a = wave < HW;
+    const int wq = wave & (HW - 1);
+    unsigned long long sb[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        if (wave < 2) base[h] = (size_t)min(tm * 8 + wave * 4 + h, MT16 - 1) * p.a_rbs * 64 + lane;
-        else base[h] = (size_t)min(tn * 8 + (wave - 2) * 4 + h, NT16 - 1) * p.NKC * 64 + lane;
+        const size_t blk = mine_a ? (size_t)min(tm * FR + wq * 4 + h, MT16 - 1) * p.a_rbs : (size_t)min(tn * FR + wq * 4 + h, NT16 - 1) * p.NKC;
+        sb[h] = reinterpret_cast<unsigned long long>(mine_a ? p.a : p.w) + blk * 1024 - (size_t)h * 1024;
     }
-    const u32x4* __restrict__ src = wave < 2 ? A : W;
-    u32x4* lds = reinterpret_cast<u32x4*>(smem);
-    const int nks = p.NKC >> 1;
-    // Two register sets: the fragments of stage ks + 2 are requested while stage ks is multiplied and stage ks + 1 (requested
-    // one step earlier) is written to the other LDS buffer -- a request has two steps (~2 x 500 MFMA cycles) to come back
-    // instead of one.  The steady-state loop is entered only with its prefetch in flight and its body is straight line, so
-    // that the compiler's vmcnt counts stay exact (cf. attn_decode_kernel); short K and the last stages are peeled.
-    u32x4 sa[8], sb[8];
-    auto fetch = [&](int ks, u32x4 (&st)[8]) {
+    const u32x4* lds = reinterpret_cast<const u32x4*>(smem);
+    f32x4 acc[WI][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) st[i] = src[base[i >> 1] + (size_t)(2 * ks + (i & 1)) * 64];
-        __builtin_amdgcn_sched_barrier(0);   // the requests stay HERE (the scheduler otherwise sinks them below the MFMAs, next to their use)
-    };
-    auto stash = [&](int stage, const u32x4 (&st)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds[((stage & 1) * 32 + wave * 8 + i) * 64 + lane] = st[i];
-    };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int ks) {
-        const u32x4* sb_ = lds + (ks & 1) * 32 * 64 + lane;
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            u32x4 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sb_[((wm * 4 + i) * 2 + kc) * 64];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sb_[(16 + (wn * 4 + j) * 2 + kc) * 64];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) big_mma(a[i], b[j], acc[i][j], WT());
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the LDS writes of the next stage (and their vmcnt waits) stay behind the MFMAs
-    };
 
-    if constexpr (DMA == 2) {
-        // The DMA ops are inline asm (hipcc would otherwise drain vmcnt to 0 in front of every barrier and every ds_read that
-        // may alias the DMA's destination -- no request would survive a K step); their completion is counted here by hand:
-        // each wave issues 4 per stage, `vmcnt(8)` = everything but the two youngest stages has landed.  The kernel's only
-        // other VMEM operations are the epilogue's, behind a vmcnt(0).
-        const int nst = p.NKC;
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
-        auto dma = [&](int st) {   // this wave's 4 fragments of stage st (K fragment st) into ring slot st & 3
+    const int nst = p.NKC;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+#ifdef ACMI_BIG_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_epi = 0;
+    ACMI_BT(t_start);
+#endif
+    auto dma = [&](int st) {   // this wave's 4 fragments of stage st (K fragment st) into ring slot st & 3
+        const unsigned dst = lds0 + (unsigned)(((st & 3) * SLOT + wave * 4) * 1024);   // wave-uniform: M0
+        const unsigned voff = (unsigned)lane * 16u + (unsigned)st * 1024u;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %5 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %6 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst), "s"(sb[0]), "s"(sb[1]), "s"(sb[2]), "s"(sb[3]) : "memory");
+    };
+    auto bar = [&]() {         // workgroup barrier WITHOUT the fence of __syncthreads (that fence is a vmcnt(0))
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    {
+        constexpr int HI = WI / 2;
+        u32x4 fb[2][4], flo[HI], fhi[HI];
+        auto slot = [&](int s_) { return lds + (s_ & 3) * SLOT * 64 + lane; };
+        auto rd_b = [&](int s_, u32x4 (&b)[4]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x4* g = src + base[i] + (size_t)st * 64;
-                const unsigned dst = lds0 + (unsigned)(((st & 3) * 16 + wave * 4 + i) * 1024);   // wave-uniform: M0
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+            for (int j = 0; j < 4; ++j) b[j] = slot(s_)[(FR + wn * 4 + j) * 64];
+        };
+        auto rd_lo = [&](int s_) {
+#pragma unroll
+            for (int i = 0; i < HI; ++i) flo[i] = slot(s_)[(wm * WI + i) * 64];
+        };
+        auto rd_hi = [&](int s_) {
+#pragma unroll
+            for (int i = 0; i < HI; ++i) fhi[i] = slot(s_)[(wm * WI + HI + i) * 64];
+        };
+        // MFMAs are pure register arithmetic to the compiler, which otherwise sinks them past the barriers and the requests
+        // (a half's 16 MFMAs were found behind the NEXT barrier): an empty volatile asm that "updates" a row block's four
+        // accumulators keeps them where they are written
+        auto pin = [&](f32x4 (&c)[4]) { asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])); };
+        auto wait_vm = [&](int young) {   // this wave's requests but the `young` most recent stages have landed
+            if (young >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (young == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        // stage s_: b = its weight fragments (in registers, like flo); bn receives the next stage's; pre: there is a next
+        // stage; req: stage s_ + 4 exists; young: own stages in flight behind s_ + 1 at the barrier
+        auto stage = [&](int s_, const u32x4 (&b)[4], u32x4 (&bn)[4], bool pre, bool req, int young) {
+            ACMI_BT(t0);
+#pragma unroll
+            for (int i = 0; i < HI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) big_mma(b[j], flo[i], acc[i][j], WT());   // transposed: see the header
+                pin(acc[i]);
+                if (i == 0) { rd_hi(s_); __builtin_amdgcn_sched_barrier(0); }   // behind the first MFMAs: nothing waits for them yet
             }
-        };
-        auto bar = [&]() {         // workgroup barrier WITHOUT the fence of __syncthreads (that fence is a vmcnt(0))
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        auto comp1 = [&](int st) {
-            const u32x4* sb_ = lds + (st & 3) * 16 * 64 + lane;
-            u32x4 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = sb_[(wm * 4 + i) * 64];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = sb_[(8 + wn * 4 + j) * 64];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) big_mma(a[i], b[j], acc[i][j], WT());
+            ACMI_BT(t1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // hi has arrived: this wave is done with the slot of stage s_
+            wait_vm(young);                                       // stage s_ + 1 (this wave's part) has landed
+            ACMI_BT(t2);
+            bar();
+            ACMI_BT(t3);
+            if (pre) { rd_b(s_ + 1, bn); rd_lo(s_ + 1); }
             __builtin_amdgcn_sched_barrier(0);
+            if (req) { dma(s_ + 4); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < HI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) big_mma(b[j], fhi[i], acc[HI + i][j], WT());
+                pin(acc[HI + i]);
+            }
+            ACMI_BT(t4);
+            ACMI_BT_ADD(1, t0, t1); ACMI_BT_ADD(3, t1, t2); ACMI_BT_ADD(4, t2, t3); ACMI_BT_ADD(2, t3, t4);
         };
         dma(0);
         if (nst > 1) dma(1);
         if (nst > 2) dma(2);
-        if (nst > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nst > 3) dma(3);
+        wait_vm(min(nst, 4) - 1);
         bar();
-        int st = 0;
-        for (; st + 3 < nst; ++st) {          // stage st is in LDS; st + 1, st + 2 in flight
-            dma(st + 3);                      // slot (st - 1) & 3: every wave finished reading it before the last barrier
-            comp1(st);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage st + 1 (this wave's part) has landed; two stages stay in flight
-            bar();
+        rd_b(0, fb[0]);
+        rd_lo(0);
+        ACMI_BT(t_loop);
+        ACMI_BT_ADD(0, t_start, t_loop);
+        int s_ = 0;
+        for (; s_ + 5 < nst; s_ += 2) {   // straight line: both stages of the iteration have a stage + 4 to request
+            stage(s_, fb[0], fb[1], true, true, 2);
+            stage(s_ + 1, fb[1], fb[0], true, true, 2);
         }
-        for (; st < nst; ++st) {              // the last (up to three) stages: nothing left to request
-            comp1(st);
-            if (st + 2 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bar();
+        ACMI_BT(t_drain);
+        ACMI_BT_ADD(7, t_loop, t_drain);
+        auto young_at = [&](int q) { return max(min(nst - 1, q + 3) - (q + 1), 0); };
+        for (; s_ < nst; s_ += 2) {
+            stage(s_, fb[0], fb[1], s_ + 1 < nst, s_ + 4 < nst, young_at(s_));
+            if (s_ + 1 < nst) stage(s_ + 1, fb[1], fb[0], s_ + 2 < nst, s_ + 5 < nst, young_at(s_ + 1));
         }
-    } else if constexpr (DMA == 1) {
-        auto dma = [&](int ks) {   // this wave's 8 fragments of stage ks, straight into their slots of buffer ks & 1
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + base[i >> 1] + (size_t)(2 * ks + (i & 1)) * 64),
-                    (__attribute__((address_space(3))) void*)(lds + ((ks & 1) * 32 + wave * 8 + i) * 64), 16, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        dma(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int ks = 0; ks < nks; ++ks) {
-            if (ks + 1 < nks) dma(ks + 1);   // the other buffer: every wave finished reading it before the last barrier
-            compute(ks);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's writes into LDS have landed ...
-            __syncthreads();                                    // ... and so have everybody's
-        }
-    } else {
-    fetch(0, sa);
-    stash(0, sa);
-    if (nks >= 4) {
-        fetch(1, sa);
-        __syncthreads();
-        int ks = 0;
-        do {                                  // sa = stage ks + 1 in flight
-            fetch(ks + 2, sb);
-            compute(ks);
-            stash(ks + 1, sa);                // the other buffer: every wave left it at the previous barrier
-            __syncthreads();
-            fetch(ks + 3, sa);
-            compute(ks + 1);
-            stash(ks + 2, sb);
-            __syncthreads();
-            ks += 2;
-        } while (ks + 3 < nks);
-        const bool three = nks - ks == 3;     // 2 or 3 stages left: ks in LDS, ks + 1 in sa
-        if (three) fetch(ks + 2, sb);
-        compute(ks);
-        stash(ks + 1, sa);
-        __syncthreads();
-        compute(ks + 1);
-        if (three) {
-            stash(ks + 2, sb);
-            __syncthreads();
-            compute(ks + 2);
-        }
-    } else {
-        __syncthreads();
-        for (int ks = 0; ks < nks; ++ks) {
-            const bool more = ks + 1 < nks;
-            if (more) fetch(ks + 1, sa);
-            compute(ks);
-            if (more) stash(ks + 1, sa);
-            __syncthreads();
-        }
-    }
+        ACMI_BT_SET(t_epi);
+        ACMI_BT_ADD(5, t_drain, t_epi);
     }
 
-    // ---- epilogue: lane (kg, n) of tile (i, j) holds rows kg * 4 + r, column n
+    // ---- epilogue: lane (kg, nl) of accumulator (i, j) holds row i * 16 + nl, features j * 16 + kg * 4 + (0..3)
     const int nl = lane & 15, kg = lane >> 4;
-    const int row0 = tm * 128 + wm * 64 + kg * 4, col0 = tn * 128 + wn * 64 + nl;
-    // every operand of the epilogue is requested before the first one is used (a load left inside the store loops is a
-    // memory round trip per element: 64 of them per lane)
+    const int row0 = (tm << TS) + wm * (WI * 16) + nl, col0 = (tn << TS) + wn * 64 + kg * 4;
+    // every operand of the epilogue is requested before the first one is used
     int pos0 = 0;
     if (EPI == ACMI_BIG_QKV) pos0 = *p.pos;
-    float biasv[4];
+    float biasv[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) biasv[j] = p.bias != nullptr ? p.bias[min(col0 + j * 16, p.N - 1)] : 0.f;
-    if (EPI == ACMI_BIG_RESID) {   // out += acc: the old values in two batches of 32 loads in flight (register budget: two
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int jh = 0; jh < 4; jh += 2) {   // workgroups per CU)
-            float old[4][2][4];
+        for (int r = 0; r < 4; ++r) biasv[j][r] = p.bias != nullptr ? p.bias[min(col0 + j * 16 + r, p.N - 1)] : 0.f;
+    // f32 rows: 16-byte aligned groups of 4 features (N, ldo multiples of 4); the large tile is launched only then
+    const bool vec = BIG ? true : p.vec != 0;
+    // RESID (out += result): the old values of feature block j + 1 are requested before block j is added and stored -- one
+    // block ahead, not all four at once: 4 x WI f32x4 next to the accumulators would not fit the register file
+    auto load_old = [&](int j, f32x4 (&old)[WI]) {
+        const int c = col0 + j * 16;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < WI; ++i) {
+            const float* src_ = p.out + (size_t)min(row0 + i * 16, p.M - 1) * p.ldo;
+            if (vec) {
+                old[i] = *reinterpret_cast<const f32x4*>(src_ + min(c, p.N - 4));
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        old[i][j][r] = p.out[(size_t)min(row0 + i * 16 + r, p.M - 1) * p.ldo + min(col0 + (jh + j) * 16, p.N - 1)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][jh + j][r] += old[i][j][r];
+                for (int r = 0; r < 4; ++r) old[i][r] = src_[min(c + r, p.N - 1)];
+            }
         }
-    }
+    };
+    f32x4 oldv[2][WI];
+    if (EPI == ACMI_BIG_RESID) load_old(0, oldv[0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = col0 + j * 16;
+        if (EPI == ACMI_BIG_RESID) {
+            if (j < 3) load_old(j + 1, oldv[(j + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < WI; ++i) acc[i][j] += oldv[j & 1][i];
+        }
         if (col >= p.N) continue;
-        const float bias = biasv[j];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rb = row0 + i * 16;           // first of this lane's 4 rows
-            if (rb >= p.M) continue;
-            float v[4];
+        for (int i = 0; i < WI; ++i) {
+            const int row = row0 + i * 16;
+            if (row >= p.M) continue;
+            f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bias;
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + biasv[j][r];
             if (EPI == ACMI_BIG_F32 || EPI == ACMI_BIG_RESID) {
+                float* dst = p.out + (size_t)row * p.ldo + col;
+                if (vec) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p.out[(size_t)(rb + r) * p.ldo + col] = v[r];
-            } else if (EPI == ACMI_BIG_TILED) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float y = p.act == 1 ? big_gelu(v[r]) : v[r];
-                    st_f32(reinterpret_cast<WT*>(p.out_t) + tiled_index<WT>(rb + r, col, p.out_rbs), y);
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < p.N) dst[r] = v[r];
                 }
-            } else {   // QKV: q to scratch, K / V appended to the cache, V also time-minor (4 positions = one store)
+            } else if (EPI == ACMI_BIG_TILED) {   // N % 4 == 0: the 4 features are one half / the whole of a lane's 16 bytes
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = sizeof(WT) == 2 ? big_gelu_bf16(v[r]) : big_gelu(v[r]);
+                }
+                WT* dst = reinterpret_cast<WT*>(p.out_t) + tiled_index<WT>(row, col, p.out_rbs);
+                if constexpr (sizeof(WT) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                else *reinterpret_cast<f32x4*>(dst) = v;
+            } else {   // QKV (d % 16 == 0, hd % 4 == 0): q to scratch, K / V appended to the cache, V also time-minor
                 const int part = col / p.d, f = col - part * p.d;
                 if (part == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p.q_out[(size_t)(rb + r) * p.d + f] = v[r];
+                    *reinterpret_cast<f32x4*>(p.q_out + (size_t)row * p.d + f) = v;
                 } else {
                     const int h = f / p.hd, dd = f - h * p.hd;
-                    const int brow = rb / p.npos_pad, pidx = rb - brow * p.npos_pad;   // 4 rows = positions pidx .. pidx + 3 of one cache row
+                    const int brow = row / p.npos_pad, pidx = row - brow * p.npos_pad;
+                    if (pidx >= p.npos) continue;   // pad rows of the position-minor layout
                     void* cache = part == 1 ? p.k_cache : p.v_cache;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (pidx + r >= p.npos) continue;
-                        const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + pos0 + pidx + r) * p.hd + dd;
-                        if (p.kv_bf16) reinterpret_cast<bf16_t*>(cache)[ci] = f32_to_bf16(v[r]);
-                        else reinterpret_cast<float*>(cache)[ci] = v[r];
-                    }
-                    if (part == 2 && p.vt != nullptr) {   // pad positions get the (finite) values of the pad rows: never attended to
+                    const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + pos0 + pidx) * p.hd + dd;
+                    if (p.kv_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(cache) + ci) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(cache) + ci) = v;
+                    if (part == 2 && p.vt != nullptr) {   // 16 lanes = 16 consecutive positions of one feature row
                         const size_t vi = (((size_t)brow * p.H + h) * p.hd + dd) * p.vt_tcap + pos0 + pidx;
-                        if (p.kv_bf16) {
-                            bf16_t* dst = reinterpret_cast<bf16_t*>(p.vt) + vi;
-                            if (((pos0 + pidx) & 3) == 0) {
-                                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                            } else {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) dst[r] = f32_to_bf16(v[r]);
-                            }
-                        } else {
-                            float* dst = reinterpret_cast<float*>(p.vt) + vi;
-                            if (((pos0 + pidx) & 3) == 0) {
-                                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) dst[r] = v[r];
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            if (p.kv_bf16) reinterpret_cast<bf16_t*>(p.vt)[vi + (size_t)r * p.vt_tcap] = f32_to_bf16(v[r]);
+                            else reinterpret_cast<float*>(p.vt)[vi + (size_t)r * p.vt_tcap] = v[r];
                         }
                     }
                 }
             }
         }
     }
+#ifdef ACMI_BIG_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ACMI_BT(t_end);
+    ACMI_BT_ADD(6, t_epi, t_end);
+    if (lane == 0 && blockIdx.x < 2048) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g_big_trace[((size_t)blockIdx.x * 8 + wave) * 8 + k] = tr[k];
+    }
+#endif
 }
 
-template <typename WT, int E, int DMA>
-static int launch_big_k(const BigArgs& a, int tiles, size_t lds, hipStream_t st) {
+template <typename WT, int E, int BIG>
+static int launch_big_k(const BigArgs& a, int tiles, hipStream_t st) {
+    constexpr size_t lds = 4 * BigTile<BIG>::SLOT * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E, DMA>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E, BIG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             acmi_set_error("acmi_linear_big: cannot set the dynamic LDS limit");
             return ACMI_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((lin_big_kernel<WT, E, DMA>), dim3(tiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((lin_big_kernel<WT, E, BIG>), dim3(tiles), dim3(BigTile<BIG>::NW * 64), lds, st, a);
     return ACMI_OK;
 }
 
-// workgroups of a launch under lin_big_kernel's tile -> XCD mapping
-static int big_grid(int M, int N) {
-    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, P = tiles_n >> 3, R = tiles_n & 7;
-    if (R == 1 || R == 2 || R == 4) {
+// workgroups of a launch under lin_big_kernel's tile -> XCD mapping (ts = log2 of the tile edge)
+static int big_grid(int M, int N, int ts) {
+    const int t = 1 << ts, tiles_m = (M + t - 1) >> ts, tiles_n = (N + t - 1) >> ts, P = tiles_n >> 3, R = tiles_n & 7;
+    if (P > 0 && (R == 1 || R == 2 || R == 4)) {
         const int share = 8 / R;
         return 8 * ((tiles_m + share - 1) / share) * (share * P + 1);
     }
@@ -353,16 +390,17 @@ static int big_grid(int M, int N) {
 
 template <typename WT>
 static int launch_big_t(const BigArgs& a, hipStream_t st) {
-    const int tiles = big_grid(a.M, a.N);
-    const size_t lds = 2 * 32 * 1024;
-    // A/B switch: ACMI_BIG_DMA = 0 (register staging of round 3), 1 (two-buffer DMA), 2 (four-slot DMA ring; default)
-    static const int dma = getenv("ACMI_BIG_DMA") != nullptr ? atoi(getenv("ACMI_BIG_DMA")) : 2;
-#define ACMI_BIG_CASE(E)                                                                                                  \
-    case E: {                                                                                                             \
-        const int rc = dma == 2 ? launch_big_k<WT, E, 2>(a, tiles, lds, st)                                               \
-                                : (dma == 1 ? launch_big_k<WT, E, 1>(a, tiles, lds, st) : launch_big_k<WT, E, 0>(a, tiles, lds, st)); \
-        if (rc) return rc;                                                                                                \
-        break;                                                                                                            \
+    // 256 x 256 tiles once they give most CUs a workgroup; ACMI_BIG_TILE = 0 / 1 forces the small / the large tile (A/B, tests)
+    static const int force = getenv("ACMI_BIG_TILE") != nullptr ? atoi(getenv("ACMI_BIG_TILE")) : -1;
+    const int t256 = ((a.M + 255) >> 8) * ((a.N + 255) >> 8);
+    const bool vec_ok = a.vec || a.epi == ACMI_BIG_TILED || a.epi == ACMI_BIG_QKV;   // the large tile has no scalar f32 epilogue
+    const int big = vec_ok && (force >= 0 ? (force != 0) : (t256 >= 128));
+    const int tiles = big_grid(a.M, a.N, big ? 8 : 7);
+#define ACMI_BIG_CASE(E)                                                                                            \
+    case E: {                                                                                                       \
+        const int rc = big ? launch_big_k<WT, E, 1>(a, tiles, st) : launch_big_k<WT, E, 0>(a, tiles, st);           \
+        if (rc) return rc;                                                                                          \
+        break;                                                                                                      \
     }
     switch (a.epi) {
         ACMI_BIG_CASE(ACMI_BIG_F32)
@@ -382,9 +420,13 @@ int acmi_launch_big(BigArgs& a, int wdtype, hipStream_t st) {
     ACMI_REQUIRE(a.M > 0 && a.M % 16 == 0 && a.N > 0 && a.K > 0, "acmi_linear_big: M=%d must be a positive multiple of 16 (N=%d K=%d)",
                  a.M, a.N, a.K);
     a.NKC = (a.K + kt - 1) / kt;
-    ACMI_REQUIRE(a.NKC % 2 == 0, "acmi_linear_big: K=%d must span an even number of %d-column tiles", a.K, kt);
     if (a.a_rbs <= 0) a.a_rbs = a.NKC;
     ACMI_REQUIRE(a.a_rbs >= a.NKC, "acmi_linear_big: a_rbs=%d < %d K tiles", a.a_rbs, a.NKC);
+    if (a.epi == ACMI_BIG_F32 || a.epi == ACMI_BIG_RESID)
+        a.vec = a.N % 4 == 0 && a.ldo % 4 == 0 && (reinterpret_cast<size_t>(a.out) & 15) == 0;
+    ACMI_REQUIRE(a.epi != ACMI_BIG_TILED || a.N % 4 == 0, "acmi_linear_big: a tiled output needs N %% 4 == 0 (N=%d)", a.N);
+    ACMI_REQUIRE(a.epi != ACMI_BIG_QKV || (a.d % 16 == 0 && a.hd % 4 == 0 && a.N == 3 * a.d && (reinterpret_cast<size_t>(a.q_out) & 15) == 0),
+                 "acmi_linear_big: the QKV epilogue needs d %% 16 == 0, hd %% 4 == 0 and N = 3 d (d=%d hd=%d N=%d)", a.d, a.hd, a.N);
     return wdtype == ACMI_BF16 ? launch_big_t<bf16_t>(a, st) : launch_big_t<float>(a, st);
 }
 

@@ -759,11 +759,14 @@ def test_attention_query_shift_and_active_rows(C):
     assert (out2[4:Beff] == 7.0).all() and (out2[Beff + 4:] == 7.0).all()
 
 
-@pytest.mark.parametrize('M,N,K', [(16, 96, 64), (128, 128, 128), (272, 1536, 512), (48, 4608, 1536), (608, 200, 256)])
+@pytest.mark.parametrize('M,N,K', [(16, 96, 64), (128, 128, 128), (272, 1536, 512), (48, 4608, 1536), (608, 200, 256), (32, 64, 32),
+                                   (2064, 4128, 96), (2048, 4608, 160), (4000, 2048, 64), (1040, 202, 64)])
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_linear_big_vs_torch(C, M, N, K, dt):
-    """acmi_linear_big (the prefill's MFMA-tiled GEMM, 128 x 128 tiles, on the decode step's tiled operands): plain f32
-    output with bias, accumulation onto a residual stream, tiled output with GELU; partial tiles in M and N."""
+    """acmi_linear_big (the prefill's MFMA-tiled GEMM on the decode step's tiled operands; 128 x 128 tiles, 256 x 256 once
+    the launch has >= 128 of them -- the three shapes of 2048+ rows, whose column tiles also cover the three tile -> XCD
+    mappings): plain f32 output with bias, accumulation onto a residual stream, tiled output with GELU; partial tiles in M
+    and N, one to six K fragments (the DMA ring's prologue / drain paths), N % 4 != 0 (scalar f32 epilogue)."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
