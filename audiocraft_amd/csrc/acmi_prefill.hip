@@ -457,7 +457,24 @@ extern "C" int acmi_linear_big(const void* a, int a_rbs, const void* w, int wdty
 // and the probabilities are already the B operand of the second MFMA  O^T[d, q] = sum_t V^T[d, t] P[q, t]  if that MFMA's
 // k slot (kg, j = tt * 4 + r) means key t0 + tt * 16 + kg * 4 + r -- which is how the A operand is fetched from the
 // time-minor V: lane (kg, m = d) reads keys t0 + tt * 16 + kg * 4 .. + 3 of row d (8 bytes per tt in bf16).
-template <typename KT, int HD>
+// What bounds it (round 4, rocprofv3 counters of the kernel alone at 16 rows x 24 heads x 600 positions,
+// profiles/r04_session25_prefill_attn.log): not the fragment loads -- halving them (two query blocks per wave) bought 9 % and
+// prefetching the next key block nothing -- but the vector ALU: 360 VALU instructions per key block and query block (8
+// libm expf, a hand-rolled bf16 rounding per probability, 64-bit address arithmetic per load, the 16 multiplies of the
+// running output by alpha) against 8 MFMAs, the VALU 60 % busy.  Hence: scores kept in log2 units (scale * log2 e folded
+// into one multiply, v_exp_f32 directly), v_cvt_pk_bf16_f32 for the probabilities, SGPR base + 32-bit lane offset
+// addressing (the V^T offsets are loop invariant), and the output is rescaled only in the blocks where some query's
+// running maximum moved: 175 -> 108 us (VALU instructions 54.7 M -> 26.5 M; what is left waits for the fragment loads
+// half of the time at two waves per SIMD, and requesting the next key block one iteration early did not change it:
+// r04_session26 / 27).
+// QB: 16-query blocks per wave (consecutive positions): a K / V^T fragment is fetched once and multiplied QB times.
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2_hw(float lo, float hi) {   // round to nearest even, like pack_bf16x2
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, hw_bf16x2));
+}
+
+template <typename KT, int HD, int QB>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillAttnArgs p) {
     constexpr int E = 16 / (int)sizeof(KT);       // elements per lane of a fragment: 8 (bf16) / 4 (f32)
     constexpr int KTILE = 4 * E;                  // k columns per fragment: 32 / 16
@@ -467,134 +484,158 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const PrefillAttnArgs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nl = lane & 15, kg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 16;   // first query position (index inside this call) of the wave
+    const int q0 = (blockIdx.x * 4 + wave) * 16 * QB;   // first query position (index inside this call) of the wave
     if (q0 >= p.npos) return;
     const int pos0 = *p.pos;
     const int d = p.H * HD;
-    const KT* __restrict__ kc = reinterpret_cast<const KT*>(p.k_cache) + ((size_t)b * p.H + h) * p.Tcap * HD;
-    const KT* __restrict__ vt = reinterpret_cast<const KT*>(p.vt) + ((size_t)b * p.H + h) * HD * p.vt_tcap;
+    const char* __restrict__ kc = reinterpret_cast<const char*>(reinterpret_cast<const KT*>(p.k_cache) + ((size_t)b * p.H + h) * p.Tcap * HD);
+    const char* __restrict__ vt = reinterpret_cast<const char*>(reinterpret_cast<const KT*>(p.vt) + ((size_t)b * p.H + h) * HD * p.vt_tcap);
 
-    // queries as B fragments: lane (kg, n) holds Q[q0 + n][kc * KTILE + kg * E .. + E), scaled, in the cache's element type
-    const int qi = min(q0 + nl, p.npos - 1);
-    const float* qrow = p.q + ((size_t)b * p.npos_pad + qi) * d + h * HD;
-    u32x4 qf[NKD];
+    // queries as B fragments: lane (kg, n) holds Q[q0 + g * 16 + n][kc * KTILE + kg * E .. + E), in the cache's element type
+    u32x4 qf[QB][NKD];
 #pragma unroll
-    for (int c = 0; c < NKD; ++c) {
-        float t[E];
+    for (int g = 0; g < QB; ++g) {
+        const int qi = min(q0 + g * 16 + nl, p.npos - 1);
+        const float* qrow = p.q + ((size_t)b * p.npos_pad + qi) * d + h * HD;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int f = c * KTILE + kg * E + e;
-            t[e] = f < HD ? qrow[min(f, HD - 1)] : 0.f;
-        }
-        if (sizeof(KT) == 2) {
-            qf[c] = u32x4{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2 % E], t[3 % E]), pack_bf16x2(t[4 % E], t[5 % E]),
-                          pack_bf16x2(t[6 % E], t[7 % E])};
-        } else {
-            qf[c] = u32x4{__float_as_uint(t[0]), __float_as_uint(t[1]), __float_as_uint(t[2 % E]), __float_as_uint(t[3 % E])};
+        for (int c = 0; c < NKD; ++c) {
+            float t[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int f = c * KTILE + kg * E + e;
+                t[e] = f < HD ? qrow[min(f, HD - 1)] : 0.f;
+            }
+            if (sizeof(KT) == 2) {
+                qf[g][c] = u32x4{pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2 % E], t[3 % E]), pack_bf16x2(t[4 % E], t[5 % E]),
+                                 pack_bf16x2(t[6 % E], t[7 % E])};
+            } else {
+                qf[g][c] = u32x4{__float_as_uint(t[0]), __float_as_uint(t[1]), __float_as_uint(t[2 % E]), __float_as_uint(t[3 % E])};
+            }
         }
     }
     // causal: keys <= the query's absolute position are visible; non-causal (cross-attention): keys [0, klen) of the row
     const int klen = p.causal ? 0 : (p.klen_rows != nullptr ? max(1, min(p.klen_rows[b], p.klen)) : p.klen);
-    const int tq = p.causal ? pos0 + q0 + nl : klen - 1;
-    const int tq_last = p.causal ? pos0 + min(q0 + 15, p.npos - 1) : klen - 1;
+    const int tq_last = p.causal ? pos0 + min(q0 + 16 * QB - 1, p.npos - 1) : klen - 1;
     int t_first = 0;
     if (p.causal && p.past_context > 0) t_first = max(0, pos0 + q0 - p.past_context) / KTILE * KTILE;
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[ND];
+    const float sl2 = p.scale * 1.4426950408889634f;   // scores in log2 units: softmax by v_exp_f32
+    float m_run[QB], l_run[QB];
+    f32x4 o[QB][ND];
 #pragma unroll
-    for (int i = 0; i < ND; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < QB; ++g) {
+        m_run[g] = -INFINITY; l_run[g] = 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) o[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // byte offsets of this lane inside a key block: K rows t0 + tt * 16 + nl (clamped to the cache: the scores of such keys
+    // are masked), 16 bytes at head feature kg * E; V^T rows d = i * 16 + nl, keys t0 + kg * 4 .. (+ 16): loop invariant
+    unsigned vlane[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) vlane[i] = (unsigned)((min(i * 16 + nl, HD - 1) * p.vt_tcap + kg * 4) * (int)sizeof(KT));
+    const unsigned klane = (unsigned)(kg * 16);
 
-    for (int t0 = t_first; t0 <= tq_last; t0 += KTILE) {
-        // K fragments (A operand of S^T) and V^T fragments (A operand of O^T) of this key block: all requested up front
-        u32x4 kf[TT][NKD];
+    // K fragments (A operand of S^T) and V^T fragments (A operand of O^T) of a key block: all requested up front
+    auto fetch = [&](int t0, u32x4 (&kf)[TT][NKD], u32x4 (&vf)[ND]) {
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
-            const int t = min(t0 + tt * 16 + nl, p.Tcap - 1);
+            const unsigned off = (unsigned)min(t0 + tt * 16 + nl, p.Tcap - 1) * (unsigned)(HD * sizeof(KT)) + klane;
 #pragma unroll
-            for (int c = 0; c < NKD; ++c) {
-                const int f = c * KTILE + kg * E;   // first head feature of this lane's 16 bytes
-                kf[tt][c] = f < HD ? *reinterpret_cast<const u32x4*>(kc + (size_t)t * HD + f) : u32x4{0u, 0u, 0u, 0u};
-            }
+            for (int c = 0; c < NKD; ++c)
+                kf[tt][c] = c * KTILE + kg * E < HD ? *reinterpret_cast<const u32x4*>(kc + off + c * 64) : u32x4{0u, 0u, 0u, 0u};
         }
-        u32x4 vf[ND];
+        const char* vb = vt + (size_t)t0 * sizeof(KT);   // wave-uniform
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int dd = min(i * 16 + nl, HD - 1);
-            const KT* vrow = vt + (size_t)dd * p.vt_tcap + t0 + kg * 4;   // keys t0 + tt * 16 + kg * 4 .. + 3
             if (sizeof(KT) == 2) {
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                const uint2 lo = *reinterpret_cast<const uint2*>(vb + vlane[i]);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vb + vlane[i] + 32);
                 vf[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
             } else {
-                vf[i] = *reinterpret_cast<const u32x4*>(vrow);
+                vf[i] = *reinterpret_cast<const u32x4*>(vb + vlane[i]);
             }
         }
-        // scores of this lane's query against keys t0 + tt * 16 + kg * 4 + r
-        f32x4 s[TT];
+    };
+    for (int t0 = t_first; t0 <= tq_last; t0 += KTILE) {
+        u32x4 kf[TT][NKD], vf[ND];
+        fetch(t0, kf, vf);
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-            s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < QB; ++g) {
+            const int tq = p.causal ? pos0 + q0 + g * 16 + nl : klen - 1;
+            // scores of this lane's query against keys t0 + tt * 16 + kg * 4 + r
+            f32x4 s[TT];
 #pragma unroll
-            for (int c = 0; c < NKD; ++c) big_mma(kf[tt][c], qf[c], s[tt], KT());
-        }
-        float cmax = -INFINITY;
+            for (int tt = 0; tt < TT; ++tt) {
+                s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = t0 + tt * 16 + kg * 4 + r;
-                const bool vis = t <= tq && (!p.causal || p.past_context <= 0 || t >= tq - p.past_context);
-                s[tt][r] = vis ? s[tt][r] * p.scale : -INFINITY;
-                cmax = fmaxf(cmax, s[tt][r]);
+                for (int c = 0; c < NKD; ++c) big_mma(kf[tt][c], qf[g][c], s[tt], KT());
             }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-        const float m_new = fmaxf(m_run, cmax);
-        // a query with no visible key so far (its window starts in a later block) keeps m = -inf: alpha = 1, p = 0
-        const float alpha = m_new == -INFINITY ? 1.f : expf(m_run - m_new);
-        float psum = 0.f, pr[TT * 4];
+            float cmax = -INFINITY;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
+            for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = s[tt][r] == -INFINITY ? 0.f : expf(s[tt][r] - m_new);
-                pr[tt * 4 + r] = e;
-                psum += e;
+                for (int r = 0; r < 4; ++r) {
+                    const int t = t0 + tt * 16 + kg * 4 + r;
+                    const bool vis = t <= tq && (!p.causal || p.past_context <= 0 || t >= tq - p.past_context);
+                    s[tt][r] = vis ? s[tt][r] * sl2 : -INFINITY;
+                    cmax = fmaxf(cmax, s[tt][r]);
+                }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            const float m_new = fmaxf(m_run[g], cmax);
+            // a query with no visible key so far (its window starts in a later block) has m = -inf: subtract 0 instead
+            // (every exponent is then 2^-inf = 0, and its running sums are still 0)
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_use);
+            float psum = 0.f, pr[TT * 4];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[tt][r] - m_use);
+                    pr[tt * 4 + r] = e;
+                    psum += e;
+                }
+            l_run[g] = l_run[g] * alpha + psum;
+            m_run[g] = m_new;
+            u32x4 pf;
+            if (sizeof(KT) == 2) {
+                pf = u32x4{pack_bf16x2_hw(pr[0], pr[1]), pack_bf16x2_hw(pr[2], pr[3]), pack_bf16x2_hw(pr[4 % (TT * 4)], pr[5 % (TT * 4)]),
+                           pack_bf16x2_hw(pr[6 % (TT * 4)], pr[7 % (TT * 4)])};
+            } else {
+                pf = u32x4{__float_as_uint(pr[0]), __float_as_uint(pr[1]), __float_as_uint(pr[2]), __float_as_uint(pr[3])};
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        u32x4 pf;
-        if (sizeof(KT) == 2) {
-            pf = u32x4{pack_bf16x2(pr[0], pr[1]), pack_bf16x2(pr[2], pr[3]), pack_bf16x2(pr[4 % (TT * 4)], pr[5 % (TT * 4)]),
-                       pack_bf16x2(pr[6 % (TT * 4)], pr[7 % (TT * 4)])};
-        } else {
-            pf = u32x4{__float_as_uint(pr[0]), __float_as_uint(pr[1]), __float_as_uint(pr[2]), __float_as_uint(pr[3])};
-        }
+            if (__ballot(alpha != 1.0f) != 0ull) {   // some query's maximum moved in this block (rare after the first ones)
 #pragma unroll
-        for (int i = 0; i < ND; ++i) {
+                for (int i = 0; i < ND; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[i][r] *= alpha;
-            big_mma(vf[i], pf, o[i], KT());
+                    for (int r = 0; r < 4; ++r) o[g][i][r] *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) big_mma(vf[i], pf, o[g][i], KT());
         }
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
     // O^T: lane (kg, n = q) holds head features i * 16 + kg * 4 + r -> 4 consecutive columns of the tiled output row
-    const int q = q0 + nl;
-    if (q >= p.npos) return;
-    const int row = b * p.npos_pad + q;
-    const float inv = 1.0f / l_run;
 #pragma unroll
-    for (int i = 0; i < ND; ++i) {
-        const int f = i * 16 + kg * 4;
-        if (f >= HD) continue;
-        const int col = h * HD + f;
-        if (p.out_bf16) {
-            bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + tiled_index<bf16_t>(row, col, p.out_rbs);
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[i][0] * inv, o[i][1] * inv), pack_bf16x2(o[i][2] * inv, o[i][3] * inv));
-        } else {
-            float* dst = reinterpret_cast<float*>(p.out) + tiled_index<float>(row, col, p.out_rbs);
-            *reinterpret_cast<float4*>(dst) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+    for (int g = 0; g < QB; ++g) {
+        float l = l_run[g];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int q = q0 + g * 16 + nl;
+        if (q >= p.npos) continue;
+        const int row = b * p.npos_pad + q;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int f = i * 16 + kg * 4;
+            if (f >= HD) continue;
+            const int col = h * HD + f;
+            if (p.out_bf16) {
+                bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + tiled_index<bf16_t>(row, col, p.out_rbs);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(o[g][i][0] * inv, o[g][i][1] * inv), pack_bf16x2(o[g][i][2] * inv, o[g][i][3] * inv));
+            } else {
+                float* dst = reinterpret_cast<float*>(p.out) + tiled_index<float>(row, col, p.out_rbs);
+                *reinterpret_cast<float4*>(dst) = make_float4(o[g][i][0] * inv, o[g][i][1] * inv, o[g][i][2] * inv, o[g][i][3] * inv);
+            }
         }
     }
 }
@@ -605,11 +646,16 @@ int acmi_launch_prefill_attn(PrefillAttnArgs& a, int kvdtype, int hd, int Beff, 
     ACMI_REQUIRE(a.causal || (a.klen > 0 && a.klen <= a.Tcap && a.klen <= a.vt_tcap), "acmi_attn_prefill: klen=%d outside the caches", a.klen);
     ACMI_REQUIRE(hd % 4 == 0, "acmi_attn_prefill: head dim %d", hd);
     a.scale = 1.0f / sqrtf((float)hd);
-    dim3 grid((a.npos + 63) / 64, a.H, Beff), block(256);
+    // ACMI_PFA_QB = 1: one query block per wave everywhere (same-box A/B)
+    static const int qb = getenv("ACMI_PFA_QB") != nullptr ? atoi(getenv("ACMI_PFA_QB")) : 2;
+    const int QBv = (qb == 2 && a.npos > 64 && hd <= 64) ? 2 : 1;   // hd 128: two query blocks do not fit the registers
+    dim3 grid((a.npos + 64 * QBv - 1) / (64 * QBv), a.H, Beff), block(256);
+#define ACMI_PFA_LAUNCH(KTv, HDv)                                                                                       \
+    if (QBv == 2) hipLaunchKernelGGL((attn_prefill_kernel<KTv, HDv, 2>), grid, block, 0, st, a);                        \
+    else hipLaunchKernelGGL((attn_prefill_kernel<KTv, HDv, 1>), grid, block, 0, st, a);
 #define ACMI_PFA_CASE(HDv)                                                                                              \
     case HDv:                                                                                                           \
-        if (kvdtype == ACMI_BF16) hipLaunchKernelGGL((attn_prefill_kernel<bf16_t, HDv>), grid, block, 0, st, a);        \
-        else hipLaunchKernelGGL((attn_prefill_kernel<float, HDv>), grid, block, 0, st, a);                              \
+        if (kvdtype == ACMI_BF16) { ACMI_PFA_LAUNCH(bf16_t, HDv) } else { ACMI_PFA_LAUNCH(float, HDv) }                 \
         break;
     switch (hd) {
         ACMI_PFA_CASE(8)
@@ -622,6 +668,7 @@ int acmi_launch_prefill_attn(PrefillAttnArgs& a, int kvdtype, int hd, int Beff, 
             return ACMI_EINVAL;
     }
 #undef ACMI_PFA_CASE
+#undef ACMI_PFA_LAUNCH
     return acmi_check_launch("attn_prefill_kernel");
 }
 
