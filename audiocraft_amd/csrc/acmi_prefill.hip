@@ -98,7 +98,11 @@ template <int BIG> struct BigTile {
 // [4] barrier wait (1-4 summed over the steady-state stages), [5] drain stages, [6] epilogue, [7] steady-state stages.
 __device__ unsigned long long g_big_trace[2048 * 8 * 8];
 extern "C" int acmi_big_trace_read(unsigned long long* out, int words) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_trace), (size_t)words * 8) == hipSuccess ? ACMI_OK : ACMI_ELAUNCH;
+    // read and clear (the next launch may have fewer workgroups)
+    void* sym = nullptr;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_big_trace), (size_t)words * 8) != hipSuccess) return ACMI_ELAUNCH;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_big_trace)) != hipSuccess) return ACMI_ELAUNCH;
+    return hipMemset(sym, 0, sizeof(g_big_trace)) == hipSuccess ? ACMI_OK : ACMI_ELAUNCH;
 }
 #define ACMI_BT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define ACMI_BT_SET(var) var = __builtin_amdgcn_s_memtime()
