@@ -82,6 +82,8 @@ _conv1d_wfloats = _sig('acmi_conv1d_weight_floats', [C.POINTER(ConvDesc)], C.c_s
 _conv1d_work = _sig('acmi_conv1d_work_floats', [C.POINTER(ConvDesc)], C.c_size_t)
 _lstm_layer = _sig('acmi_lstm_layer', [vp, vp, vp, vp, vp, i32, i32, i32, vp])
 _lstm_work = _sig('acmi_lstm_work_floats', [i32, i32], C.c_size_t)
+_lstm_layer_ex = _sig('acmi_lstm_layer_ex', [vp, vp, vp, vp, vp, C.c_size_t, i32, i32, i32, vp])
+_lstm_layer_work = _sig('acmi_lstm_layer_work_floats', [i32, i32, i32], C.c_size_t)
 _lm_step = _sig('acmi_lm_step', [C.POINTER(LMModelDesc), C.POINTER(LMState), i32, vp])
 _linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp])
 _attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
@@ -132,7 +134,7 @@ _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32
 
 EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
-           'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
+           'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_layer_ex', 'acmi_lstm_layer_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
 
 
@@ -226,7 +228,15 @@ def conv1d(desc: ConvDesc, x, w, bias, residual, y):
 
 
 def lstm_layer(gates_in, w_hh, skip, y, work, B, H, T):
-    check(_lstm_layer(ptr(gates_in), ptr(w_hh), ptr(skip), ptr(y), ptr(work), B, H, T, stream()), 'acmi_lstm_layer')
+    """One LSTM layer; `work` of lstm_layer_work_floats(B, H, T) floats lets H = 1024 run one recurrence per XCD."""
+    if work.numel() > 5 * B * H + 4:
+        check(_lstm_layer_ex(ptr(gates_in), ptr(w_hh), ptr(skip), ptr(y), ptr(work), work.numel(), B, H, T, stream()), 'acmi_lstm_layer_ex')
+    else:
+        check(_lstm_layer(ptr(gates_in), ptr(w_hh), ptr(skip), ptr(y), ptr(work), B, H, T, stream()), 'acmi_lstm_layer')
+
+
+def lstm_layer_work_floats(B, H, T) -> int:
+    return int(_lstm_layer_work(B, H, T))
 
 
 _lstm2 = _sig('acmi_lstm_stack2', [vp] * 8 + [i32] * 3 + [vp])
@@ -251,8 +261,9 @@ def lstm_check(err_word: torch.Tensor, what: str):
         sink.append((err_word, what))
         return
     if int(err_word.view(torch.int32)[0]) != 0:
-        raise AcmiError(f"{what}: the persistent LSTM kernel gave up waiting for a workgroup (set ACMI_LSTM_WAVE=0 for one launch "
-                        "per layer, ACMI_LSTM_PERSISTENT=0 for one per time step)")
+        raise AcmiError(f"{what}: the persistent LSTM kernel gave up waiting for a workgroup or found it on another XCD than expected (set "
+                        "ACMI_LSTM_XCD=0 for the all-CU form at H = 1024, ACMI_LSTM_WAVE=0 for one launch per layer, ACMI_LSTM_PERSISTENT=0 for one "
+                        "per time step)")
 
 
 def lstm_stack2_supported(B, H, T) -> bool:

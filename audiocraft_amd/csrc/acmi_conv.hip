@@ -804,6 +804,157 @@ __global__ __launch_bounds__(256, KI > 32 ? 2 : 1) void lstm_persistent_kernel(c
 }
 
 // -----------------------------------------------------------------------------------------------------
+// XCD-local form (H = 1024): ONE RECURRENCE PER XCD.  The batch rows are independent recurrences and an MI355X is 8 XCDs
+// of 32 CUs, each with its own L2: workgroup b (512 threads, one per CU) runs on XCD b % 8 and owns the 32 hidden units
+// [32 (b / 8), +32) -- 128 gate rows of W_hh, 512 KB: of every thread's 8 rows x 8 column chunks 45 chunks in registers
+// (180 floats), 19 in LDS (152 KB) -- for the batch rows r = b % 8, b % 8 + 8, ...  So the 32 workgroups of an XCD hold ALL of W_hh and a step's
+// all-gather moves the 4 KB of ONE hidden vector between 32 CUs through the XCD's own L2 (plain stores; `nt` polling
+// loads), instead of 32 KB for 8 rows between 256 CUs through the memory side
+// (lstm_persistent_kernel: 5.1-5.4 us per step; lab/xcd_local_lab.hip: 0.97 us per hand-off inside an XCD, 1.22-1.33
+// through the memory side).  Every (row, step) has its OWN 4 KB slot in the exchange array [B][T][H], pre-filled with the
+// LSTM_EMPTY pattern (the data is its own flag, as above): no re-arming, no rotation.
+// The XCD of a workgroup is not an API promise: every workgroup records its XCC_ID in its group's word (first writer
+// wins) and a workgroup that finds another id there raises the error word -- every spin is bounded and polls that word.
+// MEM = 1: write-through stores and agent-scope loads (correct for any placement; A/B).
+// -----------------------------------------------------------------------------------------------------
+#define LX_H 1024
+#define LX_UNITS 32
+#define LX_THREADS 512
+#define LX_SLABS 19        // 16-byte weight chunks per thread kept in LDS (of 64)
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int MEM>
+__global__ __launch_bounds__(LX_THREADS, 1) void lstm_xcd_kernel(const float* __restrict__ gates_in, const float* __restrict__ w_hh,
+                                                                 const float* __restrict__ skip, float* __restrict__ y, unsigned* hx,
+                                                                 unsigned* xcc_of_group, unsigned* err, int B, int T) {
+    constexpr int H = LX_H;
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    float4* wl = reinterpret_cast<float4*>(sh);                 // [LX_SLABS][512 threads]: rows 6, 7 (8 chunks each), row 5 chunks 5 .. 7
+    float* hs = sh + LX_SLABS * LX_THREADS * 4;                 // h_{t-1}: [H]
+    float* gs = hs + H;                                         // gate sums: [4 gates][32 units]
+    float* ga = gs + 4 * LX_UNITS;                              // gate activations: [4 gates][32 units]
+    int* s_abort = reinterpret_cast<int*>(ga + 4 * LX_UNITS);
+    const int tid = threadIdx.x;
+    const int grp = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (grp >= B) return;                                        // no batch row for this XCD
+    if (tid == 0) {
+        int bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (MEM != 1 && !bad) {
+            const unsigned me = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;   // XCC_ID
+            const unsigned seen = atomicCAS(xcc_of_group + grp, 0xffffffffu, me);
+            if (seen != 0xffffffffu && seen != me) { atomicAdd(err, 1u); bad = 1; }
+        }
+        *s_abort = bad;
+    }
+    const int rg = tid >> 5, ksl = tid & 31;                     // 16 groups of 8 local rows x 32 k slices
+    const int gate = rg >> 2, u0 = (rg & 3) * 8, j0 = idx * LX_UNITS;
+    // this thread's weights: rows gate H + j0 + u0 + r (r < 8), columns (i 32 + ksl) 4 .. + 3 (i < 8)
+    float4 wv[6][8];
+    {
+        const float* wbase = w_hh + ((size_t)gate * H + j0 + u0) * H + ksl * 4;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(wbase + (size_t)r * H + i * 128);
+                if (r < 5 || (r == 5 && i < 5)) wv[r][i] = w;
+                else if (r == 5) wl[(16 + i - 5) * LX_THREADS + tid] = w;
+                else wl[((r - 6) * 8 + i) * LX_THREADS + tid] = w;
+            }
+    }
+    __syncthreads();
+    if (*s_abort) return;
+    const bool owner = tid < LX_UNITS;                           // thread u: state of hidden unit j0 + u
+    const int j = j0 + tid;
+    // the four gate activations of a unit are computed side by side: lanes 0 .. 31 of wave g (one wave per SIMD) take gate g
+    const int ag = tid >> 6, au = tid & 63;
+    const bool act = ag < 4 && au < LX_UNITS;
+    const size_t hx_bytes = (size_t)B * T * H * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)hx_bytes, 0x00020000);
+    // MEM 0: plain stores (write-through L1 -> the XCD's L2) and `nt` polling loads, which are served by the L2 every time
+    // (measured, profiles/r04_session33_lstm.log: an `sc0` load keeps returning the CU's stale L1 line; `buffer_inv sc1` before a plain
+    // load works at 29 us per step); MEM 1: write-through stores, agent-scope loads (memory side)
+    constexpr int LD_AUX = MEM == 1 ? 16 : 2, ST_AUX = MEM == 1 ? 16 : 0;
+
+    for (int row = grp; row < B; row += 8) {
+        float c_reg = 0.f;
+        for (int t = 0; t < T; ++t) {
+            float gin = 0.f;                                     // requested before the wait for h_{t-1}
+            if (act) gin = gates_in[((size_t)row * 4 * H + (size_t)ag * H + j0 + au) * T + t];
+            if (t == 0) {
+                hs[2 * tid] = 0.f; hs[2 * tid + 1] = 0.f;
+            } else {
+                const unsigned off = (unsigned)((((size_t)row * T + (t - 1)) * H + 2 * tid) * 4);
+                u32x2_t v;
+                unsigned spins = 0;
+                for (;;) {
+                    v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, LD_AUX);
+                    if (v[0] != LSTM_EMPTY && v[1] != LSTM_EMPTY) break;
+                    if ((++spins & 0xffu) == 0u) {               // bounded wait, device-wide abort word
+                        if (spins > 400000u) { atomicAdd(err, 1u); *s_abort = 1; break; }
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *s_abort = 1; break; }
+                    }
+                }
+                *reinterpret_cast<float2*>(hs + 2 * tid) = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+            }
+            __syncthreads();
+            if (*s_abort) return;
+            // ---- 8 rows x 32 columns per thread: 192 weights from registers, 64 from LDS, h from LDS
+            float acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+            const float4* h4 = reinterpret_cast<const float4*>(hs) + ksl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 h = h4[i * 32];
+                const float4 w6 = wl[i * LX_THREADS + tid], w7 = wl[(8 + i) * LX_THREADS + tid];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const float4 w = (r == 5 && i >= 5) ? wl[(16 + i - 5) * LX_THREADS + tid] : wv[r][i];
+                    acc[r] = fmaf(w.x, h.x, acc[r]); acc[r] = fmaf(w.y, h.y, acc[r]);
+                    acc[r] = fmaf(w.z, h.z, acc[r]); acc[r] = fmaf(w.w, h.w, acc[r]);
+                }
+                acc[6] = fmaf(w6.x, h.x, acc[6]); acc[6] = fmaf(w6.y, h.y, acc[6]); acc[6] = fmaf(w6.z, h.z, acc[6]); acc[6] = fmaf(w6.w, h.w, acc[6]);
+                acc[7] = fmaf(w7.x, h.x, acc[7]); acc[7] = fmaf(w7.y, h.y, acc[7]); acc[7] = fmaf(w7.z, h.z, acc[7]); acc[7] = fmaf(w7.w, h.w, acc[7]);
+                __builtin_amdgcn_sched_barrier(0);   // one chunk's LDS operands in flight: the registers are full of weights
+            }
+            // sum over the 32 k slices: the 16 lanes of a row (DPP butterflies), then row_bcast:15 adds the lower row's total to
+            // every lane of the upper one: lanes 16 .. 31 / 48 .. 63 hold the totals of the wave's two row groups
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { acc[r] = row16_sum(acc[r]); acc[r] += dpp_f32<0x142>(acc[r]); }
+            if (ksl == 31) {
+                *reinterpret_cast<float4*>(gs + rg * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *reinterpret_cast<float4*>(gs + rg * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            }
+            __syncthreads();
+            if (act) {                                           // i, f, o: sigmoid; g: tanh (nn.LSTM's gate order i, f, g, o)
+                const float x = gs[ag * LX_UNITS + au] + gin;
+                ga[ag * LX_UNITS + au] = ag == 2 ? tanhf(x) : 1.f / (1.f + expf(-x));
+            }
+            __syncthreads();
+            if (tid < 64) {                                      // wave 0: lanes 0 .. 31 own a unit each (the DPP exchange needs the whole wave)
+                float hn = 0.f;
+                if (owner) {
+                    const float cn = ga[LX_UNITS + tid] * c_reg + ga[tid] * ga[2 * LX_UNITS + tid];
+                    hn = ga[3 * LX_UNITS + tid] * tanhf(cn);
+                    c_reg = cn;
+                }
+                // publish h_t: a quad's 4 units as one 16-byte store
+                const unsigned q0 = __float_as_uint(dpp_f32<0x00>(hn)), q1 = __float_as_uint(dpp_f32<0x55>(hn));
+                const unsigned q2 = __float_as_uint(dpp_f32<0xAA>(hn)), q3 = __float_as_uint(dpp_f32<0xFF>(hn));
+                if (owner && (tid & 3) == 0)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{q0, q1, q2, q3}, rs,
+                                                           (unsigned)((((size_t)row * T + t) * H + j) * 4), 0, ST_AUX);
+                if (owner) {
+                    const size_t yi = ((size_t)row * H + j) * T + t;
+                    y[yi] = skip ? hn + skip[yi] : hn;
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
 // Two-layer wavefront: ONE launch for a 2-layer nn.LSTM stack (EnCodec's `lstm=2`).  2 x ceil(H / 4) workgroups: the first half
 // runs layer 0 exactly like lstm_persistent_kernel and additionally leaves every h1_t in a [T][B, H] exchange array (the
 // data is its own flag again: all slots start EMPTY, nothing is ever re-armed, so layer 1 may lag by any number of steps);
@@ -1062,7 +1213,7 @@ extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H
 // Residency can still be lost to OTHER work on the device (another stream or process): the kernel's spins are bounded,
 // the first give-up raises a device-wide abort flag (the err word) that every workgroup polls, and the host raises.
 template <typename KernelT>
-static bool lstm_grid_resident(KernelT kernel, int grid, size_t lds_bytes) {
+static bool lstm_grid_resident(KernelT kernel, int grid, size_t lds_bytes, int threads = 256) {
     // answers are remembered per (kernel, grid, LDS, device): the queries are not free, and a call that arrives while its
     // stream is being captured into a hipGraph must not need them
     struct Seen { const void* k; int grid, dev; size_t lds; bool ok; };
@@ -1074,7 +1225,7 @@ static bool lstm_grid_resident(KernelT kernel, int grid, size_t lds_bytes) {
     for (int i = 0; i < n_seen; ++i)
         if (seen[i].k == kp && seen[i].grid == grid && seen[i].dev == dev && seen[i].lds == lds_bytes) return seen[i].ok;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return false;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu <= 0) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu <= 0) return false;
     if (per_cu > 1) per_cu -= 1;
     const bool ok = (long)grid <= (long)cus * per_cu;
     if (n_seen < 16) seen[n_seen++] = Seen{kp, grid, dev, lds_bytes, ok};
@@ -1089,11 +1240,72 @@ static int lstm_persistent_ok(int B, int H) {
 
 
 
+// work of the XCD-local form: the legacy layout (5 B H + 4 floats: its err word stays at 5 B H), 12 words (XCC id per group),
+// then the exchange array [B][T][H]
+static size_t lstm_xcd_work_floats(int B, int H, int T) { return (size_t)5 * B * H + 4 + 12 + (size_t)B * T * H; }
+extern "C" size_t acmi_lstm_layer_work_floats(int B, int H, int T) {
+    const size_t legacy = (size_t)5 * B * H + 4;
+    return (H == LX_H && T > 0 && (size_t)B * T * H * 4 <= ((size_t)1 << 30)) ? lstm_xcd_work_floats(B, H, T) : legacy;
+}
+
+// the XCD-local form when it applies: H = 1024, the caller's work area holds the exchange array, 8 XCDs x 32 CUs that can
+// each hold one 512-thread workgroup with 157 KB of LDS.  ACMI_LSTM_XCD = 0: off; 2: memory-side stores / loads (A/B)
+static int lstm_try_xcd(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, size_t work_floats,
+                        int B, int H, int T, hipStream_t st, bool* launched) {
+    *launched = false;
+    const char* env = getenv("ACMI_LSTM_XCD");   // read per call: tests switch it
+    const int mode = env != nullptr ? atoi(env) : 1;
+    // every XCD reads ALL of W_hh at the start (8 x 16.8 MB): a handful of steps is cheaper on the all-CU form
+    if (mode == 0 || H != LX_H || T < 16 || (size_t)B * T * H * 4 > ((size_t)1 << 30) || work_floats < lstm_xcd_work_floats(B, H, T)) return ACMI_OK;
+    constexpr size_t lds = (size_t)(LX_SLABS * LX_THREADS * 4 + LX_H + 8 * LX_UNITS) * sizeof(float) + 16;
+    const int grid = 8 * (LX_H / LX_UNITS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ACMI_OK;   // the other forms remain
+        attr_set = true;
+    }
+    if (!lstm_grid_resident(lstm_xcd_kernel<0>, grid, lds, LX_THREADS)) return ACMI_OK;
+    unsigned* err = reinterpret_cast<unsigned*>(work + (size_t)5 * B * H);
+    unsigned* xcc_of_group = err + 4;
+    unsigned* hx = err + 16;
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(xcc_of_group), (int)0xffffffffu, 12, st) != hipSuccess ||
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hx), (int)LSTM_EMPTY, (size_t)B * T * H, st) != hipSuccess) {
+        acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
+        return ACMI_ELAUNCH;
+    }
+#define ACMI_LX_LAUNCH(M) hipLaunchKernelGGL(lstm_xcd_kernel<M>, dim3(grid), dim3(LX_THREADS), lds, st, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T)
+    if (mode == 2) ACMI_LX_LAUNCH(1);
+    else ACMI_LX_LAUNCH(0);
+#undef ACMI_LX_LAUNCH
+    *launched = true;
+    return acmi_check_launch("lstm_xcd_kernel");
+}
+
+static int lstm_layer_impl(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, size_t work_floats,
+                           int B, int H, int T, void* stream);
+
 extern "C" int acmi_lstm_layer(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, int B,
                                int H, int T, void* stream) {
+    return lstm_layer_impl(gates_in, w_hh, skip, y, work, (size_t)5 * B * H + 4, B, H, T, stream);
+}
+extern "C" int acmi_lstm_layer_ex(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work,
+                                  size_t work_floats, int B, int H, int T, void* stream) {
+    ACMI_REQUIRE(B > 0 && H > 0 && work_floats >= (size_t)5 * B * H + 4, "acmi_lstm_layer_ex: work area of %zu floats is too small", work_floats);
+    return lstm_layer_impl(gates_in, w_hh, skip, y, work, work_floats, B, H, T, stream);
+}
+
+static int lstm_layer_impl(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, size_t work_floats,
+                           int B, int H, int T, void* stream) {
     ACMI_REQUIRE(B > 0 && H > 0 && T >= 0, "acmi_lstm_layer: bad shape");
     ACMI_REQUIRE((size_t)(LSTM_BB * H + 16 * LSTM_BB) * 4 <= 64 * 1024, "acmi_lstm_layer: H=%d too large", H);
     hipStream_t st = (hipStream_t)stream;
+    {
+        bool launched = false;
+        if (int rc = lstm_try_xcd(gates_in, w_hh, skip, y, work, work_floats, B, H, T, st, &launched)) return rc;
+        if (launched) return ACMI_OK;
+    }
     float* h0 = work;
     float* h1 = work + (size_t)B * H;
     float* c = work + (size_t)2 * B * H;

@@ -212,7 +212,9 @@ class StreamableLSTM(nn.Module):
                 bias = (getattr(p, f'bias_ih_l{layer}').detach().float()
                         + getattr(p, f'bias_hh_l{layer}').detach().float()).contiguous()
                 self._prep.append([w_ih, w_hh, bias, None])
-        work = torch.zeros(_C.lstm_work_floats(B, H), device=x.device, dtype=torch.float32)
+        nwork = _C.lstm_layer_work_floats(B, H, T)    # legacy area (+ the per-step exchange array of the XCD-local form)
+        work = torch.empty(nwork, device=x.device, dtype=torch.float32)
+        work[:5 * B * H + 4].zero_()
         d = _C.ConvDesc()
         d.B, d.Cin, d.Tin, d.Cout, d.Tout = B, H, T, 4 * H, T
         d.ksize, d.stride, d.dilation, d.pad_left = 1, 1, 1, 0
@@ -240,7 +242,7 @@ class StreamableLSTM(nn.Module):
             y = out
         # the persistent recurrence kernel counts bounded-spin give-ups of its all-gather in the last words of `work`
         # (never seen on an otherwise idle device; a non-zero count means the result is not to be trusted)
-        _C.lstm_check(work[5 * B * H:], 'acmi_lstm_layer')
+        _C.lstm_check(work[5 * B * H:5 * B * H + 4], 'acmi_lstm_layer')
         return y
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 150 /* 0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
+#define ACMI_VERSION 160 /* 0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
                             colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
                             with prepended conditions of different lengths).  0.1.4: acmi_conv1d takes pre-tiled weights + a work buffer (acmi_conv1d_tile_weights /
                             _weight_floats / _work_floats); MultiBandDiffusion entry points.  0.1.3: single-term raw activations with a per-row shift (acmi_linear_desc.a_shift / xt_shift /
@@ -129,6 +129,17 @@ int acmi_conv1d(const acmi_conv_desc* d, const float* x, const float* wt, const 
 int acmi_lstm_layer(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work,
                     int B, int H, int T, void* stream);
 size_t acmi_lstm_work_floats(int B, int H);
+/* The same layer with a work area whose size the caller states (0.1.6).  With acmi_lstm_layer_work_floats(B, H, T) floats --
+ * the layout above (err word at 5 * B * H) followed by a [B][T][H] exchange array -- a layer of H = 1024 runs ONE
+ * RECURRENCE PER XCD on a whole MI355X (8 XCDs x 32 CUs): workgroup b on XCD b % 8 holds the W_hh rows of 32 hidden units
+ * (registers + LDS) for the batch rows b % 8, b % 8 + 8, ...; a step's all-gather is the 4 KB of one hidden vector between the
+ * 32 CUs of one XCD through that XCD's L2 instead of B x 4 KB between all CUs through the memory side.  The placement
+ * (workgroup b on XCD b % 8) is verified by the kernel (XCC_ID): a mismatch raises the err word like a lost residency.
+ * With a smaller work area, another H or a device that cannot hold the grid the call is acmi_lstm_layer.
+ * ACMI_LSTM_XCD=0 switches the form off (2: the same kernel on memory-side stores / loads, placement independent). */
+int acmi_lstm_layer_ex(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work,
+                       size_t work_floats, int B, int H, int T, void* stream);
+size_t acmi_lstm_layer_work_floats(int B, int H, int T);
 
 /* ------------------------------------------------------------------------------------------
  * MusicGen LM decode step
