@@ -20,6 +20,7 @@
 //                              interleave are folded into the store index math.
 // Reference: audiocraft/modules/conv.py:47-88,185-243; audiocraft/modules/seanet.py:16-60; audiocraft/models/unet.py:32-104.
 #include "acmi_common.h"
+#include <type_traits>
 
 #include <math.h>
 #include <stdlib.h>
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256, KI > 32 ? 2 : 1) void lstm_persistent_kernel(c
 }
 
 // -----------------------------------------------------------------------------------------------------
-// XCD-local form (H = 1024): ONE RECURRENCE PER XCD.  The batch rows are independent recurrences and an MI355X is 8 XCDs
+// XCD-local form (H = 512, 768, 1024; the numbers below are H = 1024's): ONE RECURRENCE PER XCD.  The batch rows are independent recurrences and an MI355X is 8 XCDs
 // of 32 CUs, each with its own L2: workgroup b (512 threads, one per CU) runs on XCD b % 8 and owns the 32 hidden units
 // [32 (b / 8), +32) -- 128 gate rows of W_hh, 512 KB: of every thread's 8 rows x 8 column chunks 45 chunks in registers
 // (180 floats), 19 in LDS (152 KB) -- for the batch rows r = b % 8, b % 8 + 8, ...  So the 32 workgroups of an XCD hold ALL of W_hh and a step's
@@ -817,23 +818,40 @@ __global__ __launch_bounds__(256, KI > 32 ? 2 : 1) void lstm_persistent_kernel(c
 // wins) and a workgroup that finds another id there raises the error word -- every spin is bounded and polls that word.
 // MEM = 1: write-through stores and agent-scope loads (correct for any placement; A/B).
 // -----------------------------------------------------------------------------------------------------
-#define LX_H 1024
-#define LX_UNITS 32
-#define LX_THREADS 512
-#define LX_SLABS 19        // 16-byte weight chunks per thread kept in LDS (of 64)
+// geometry of the form for hidden size HH (512, 768, 1024): 32 workgroups per XCD, HH / 32 hidden units (HH / 8 gate rows) each;
+// a thread = 8 gate rows x one of 32 column slices: NI 16-byte column chunks per row, 8 NI chunks in all, the first REGCH of
+// them (row-major) in registers, the rest in LDS
+template <int HH> struct LxCfg {
+    static constexpr int UNITS = HH / 32;
+    static constexpr int THREADS = HH / 2;                    // (4 UNITS / 8) row groups x 32 column slices
+    static constexpr int NI = HH / 128;
+    static constexpr int REGCH = HH == 1024 ? 45 : HH == 768 ? 40 : 8 * NI;
+    static constexpr int SLABS = 8 * NI - REGCH;
+    static constexpr size_t LDS = (size_t)(SLABS * THREADS * 4 + HH + 8 * UNITS) * sizeof(float) + 16;
+};
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// compile-time loop: the body sees its index as a constant expression (`if constexpr` on it: no dead out-of-range access ever
+// reaches the optimiser, which otherwise leaves the weight array in scratch memory)
+template <int B_, int E_, typename F>
+__device__ __forceinline__ void lx_static_for(F&& f) {
+    if constexpr (B_ < E_) {
+        f(std::integral_constant<int, B_>{});
+        lx_static_for<B_ + 1, E_>(f);
+    }
+}
 
-template <int MEM>
-__global__ __launch_bounds__(LX_THREADS, 1) void lstm_xcd_kernel(const float* __restrict__ gates_in, const float* __restrict__ w_hh,
-                                                                 const float* __restrict__ skip, float* __restrict__ y, unsigned* hx,
-                                                                 unsigned* xcc_of_group, unsigned* err, int B, int T) {
-    constexpr int H = LX_H;
+template <int HH, int MEM>
+__global__ __launch_bounds__(LxCfg<HH>::THREADS, 1) void lstm_xcd_kernel(const float* __restrict__ gates_in, const float* __restrict__ w_hh,
+                                                                         const float* __restrict__ skip, float* __restrict__ y, unsigned* hx,
+                                                                         unsigned* xcc_of_group, unsigned* err, int B, int T) {
+    using CF = LxCfg<HH>;
+    constexpr int H = HH, UNITS = CF::UNITS, THREADS = CF::THREADS, NI = CF::NI, REGCH = CF::REGCH;
     extern __shared__ __attribute__((aligned(16))) float sh[];
-    float4* wl = reinterpret_cast<float4*>(sh);                 // [LX_SLABS][512 threads]: rows 6, 7 (8 chunks each), row 5 chunks 5 .. 7
-    float* hs = sh + LX_SLABS * LX_THREADS * 4;                 // h_{t-1}: [H]
-    float* gs = hs + H;                                         // gate sums: [4 gates][32 units]
-    float* ga = gs + 4 * LX_UNITS;                              // gate activations: [4 gates][32 units]
-    int* s_abort = reinterpret_cast<int*>(ga + 4 * LX_UNITS);
+    float4* wl = reinterpret_cast<float4*>(sh);                 // [SLABS][THREADS]: the weight chunks that do not fit the registers
+    float* hs = sh + CF::SLABS * THREADS * 4;                   // h_{t-1}: [H]
+    float* gs = hs + H;                                         // gate sums: [4 gates][UNITS]
+    float* ga = gs + 4 * UNITS;                                 // gate activations: [4 gates][UNITS]
+    int* s_abort = reinterpret_cast<int*>(ga + 4 * UNITS);
     const int tid = threadIdx.x;
     const int grp = blockIdx.x & 7, idx = blockIdx.x >> 3;
     if (grp >= B) return;                                        // no batch row for this XCD
@@ -842,33 +860,32 @@ __global__ __launch_bounds__(LX_THREADS, 1) void lstm_xcd_kernel(const float* __
         if (MEM != 1 && !bad) {
             const unsigned me = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu;   // XCC_ID
             const unsigned seen = atomicCAS(xcc_of_group + grp, 0xffffffffu, me);
-            if (seen != 0xffffffffu && seen != me) { atomicAdd(err, 1u); bad = 1; }
+            if (seen != 0xffffffffu && seen != me) { atomicAdd(err, 0x10000u); bad = 1; }   // (high half: placement, low half: give-ups)
         }
         *s_abort = bad;
     }
-    const int rg = tid >> 5, ksl = tid & 31;                     // 16 groups of 8 local rows x 32 k slices
-    const int gate = rg >> 2, u0 = (rg & 3) * 8, j0 = idx * LX_UNITS;
-    // this thread's weights: rows gate H + j0 + u0 + r (r < 8), columns (i 32 + ksl) 4 .. + 3 (i < 8)
-    float4 wv[6][8];
+    const int rg = tid >> 5, ksl = tid & 31;                     // UNITS / 2 groups of 8 local rows x 32 column slices
+    const int gate = rg / (UNITS / 8), u0 = (rg % (UNITS / 8)) * 8, j0 = idx * UNITS;
+    // this thread's weights: rows gate H + j0 + u0 + r (r < 8), columns (i 32 + ksl) 4 .. + 3 (i < NI); chunk q = r NI + i
+    float4 wv[REGCH];
     {
         const float* wbase = w_hh + ((size_t)gate * H + j0 + u0) * H + ksl * 4;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+        lx_static_for<0, 8>([&](auto rc) {
+            lx_static_for<0, NI>([&](auto ic) {
+                constexpr int r = decltype(rc)::value, i = decltype(ic)::value, q = r * NI + i;
                 const float4 w = *reinterpret_cast<const float4*>(wbase + (size_t)r * H + i * 128);
-                if (r < 5 || (r == 5 && i < 5)) wv[r][i] = w;
-                else if (r == 5) wl[(16 + i - 5) * LX_THREADS + tid] = w;
-                else wl[((r - 6) * 8 + i) * LX_THREADS + tid] = w;
-            }
+                if constexpr (q < REGCH) wv[q] = w;
+                else wl[(q - REGCH) * THREADS + tid] = w;
+            });
+        });
     }
     __syncthreads();
     if (*s_abort) return;
-    const bool owner = tid < LX_UNITS;                           // thread u: state of hidden unit j0 + u
+    const bool owner = tid < UNITS;                              // thread u: state of hidden unit j0 + u
     const int j = j0 + tid;
-    // the four gate activations of a unit are computed side by side: lanes 0 .. 31 of wave g (one wave per SIMD) take gate g
+    // the four gate activations of a unit are computed side by side: lanes 0 .. UNITS - 1 of wave g (one wave per SIMD) take gate g
     const int ag = tid >> 6, au = tid & 63;
-    const bool act = ag < 4 && au < LX_UNITS;
+    const bool act = ag < 4 && au < UNITS;
     const size_t hx_bytes = (size_t)B * T * H * 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)hx_bytes, 0x00020000);
     // MEM 0: plain stores (write-through L1 -> the XCD's L2) and `nt` polling loads, which are served by the L2 every time
@@ -899,26 +916,25 @@ __global__ __launch_bounds__(LX_THREADS, 1) void lstm_xcd_kernel(const float* __
             }
             __syncthreads();
             if (*s_abort) return;
-            // ---- 8 rows x 32 columns per thread: 192 weights from registers, 64 from LDS, h from LDS
+            // ---- 8 rows x NI chunks per thread: weights from registers / LDS, h from LDS
             float acc[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = 0.f;
             const float4* h4 = reinterpret_cast<const float4*>(hs) + ksl;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            lx_static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
                 const float4 h = h4[i * 32];
-                const float4 w6 = wl[i * LX_THREADS + tid], w7 = wl[(8 + i) * LX_THREADS + tid];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const float4 w = (r == 5 && i >= 5) ? wl[(16 + i - 5) * LX_THREADS + tid] : wv[r][i];
+                lx_static_for<0, 8>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value, q = r * NI + i;
+                    float4 w;
+                    if constexpr (q < REGCH) w = wv[q];
+                    else w = wl[(q - REGCH) * THREADS + tid];
                     acc[r] = fmaf(w.x, h.x, acc[r]); acc[r] = fmaf(w.y, h.y, acc[r]);
                     acc[r] = fmaf(w.z, h.z, acc[r]); acc[r] = fmaf(w.w, h.w, acc[r]);
-                }
-                acc[6] = fmaf(w6.x, h.x, acc[6]); acc[6] = fmaf(w6.y, h.y, acc[6]); acc[6] = fmaf(w6.z, h.z, acc[6]); acc[6] = fmaf(w6.w, h.w, acc[6]);
-                acc[7] = fmaf(w7.x, h.x, acc[7]); acc[7] = fmaf(w7.y, h.y, acc[7]); acc[7] = fmaf(w7.z, h.z, acc[7]); acc[7] = fmaf(w7.w, h.w, acc[7]);
-                __builtin_amdgcn_sched_barrier(0);   // one chunk's LDS operands in flight: the registers are full of weights
-            }
-            // sum over the 32 k slices: the 16 lanes of a row (DPP butterflies), then row_bcast:15 adds the lower row's total to
+                });
+                if (CF::SLABS > 0) __builtin_amdgcn_sched_barrier(0);   // one chunk's LDS operands in flight: the registers are full of weights
+            });
+            // sum over the 32 column slices: the 16 lanes of a row (DPP butterflies), then row_bcast:15 adds the lower row's total to
             // every lane of the upper one: lanes 16 .. 31 / 48 .. 63 hold the totals of the wave's two row groups
 #pragma unroll
             for (int r = 0; r < 8; ++r) { acc[r] = row16_sum(acc[r]); acc[r] += dpp_f32<0x142>(acc[r]); }
@@ -928,15 +944,15 @@ __global__ __launch_bounds__(LX_THREADS, 1) void lstm_xcd_kernel(const float* __
             }
             __syncthreads();
             if (act) {                                           // i, f, o: sigmoid; g: tanh (nn.LSTM's gate order i, f, g, o)
-                const float x = gs[ag * LX_UNITS + au] + gin;
-                ga[ag * LX_UNITS + au] = ag == 2 ? tanhf(x) : 1.f / (1.f + expf(-x));
+                const float x = gs[ag * UNITS + au] + gin;
+                ga[ag * UNITS + au] = ag == 2 ? tanhf(x) : 1.f / (1.f + expf(-x));
             }
             __syncthreads();
-            if (tid < 64) {                                      // wave 0: lanes 0 .. 31 own a unit each (the DPP exchange needs the whole wave)
+            if (tid < 64) {                                      // wave 0: lanes 0 .. UNITS - 1 own a unit each (the DPP exchange needs the whole wave)
                 float hn = 0.f;
                 if (owner) {
-                    const float cn = ga[LX_UNITS + tid] * c_reg + ga[tid] * ga[2 * LX_UNITS + tid];
-                    hn = ga[3 * LX_UNITS + tid] * tanhf(cn);
+                    const float cn = ga[UNITS + tid] * c_reg + ga[tid] * ga[2 * UNITS + tid];
+                    hn = ga[3 * UNITS + tid] * tanhf(cn);
                     c_reg = cn;
                 }
                 // publish h_t: a quad's 4 units as one 16-byte store
@@ -1243,44 +1259,72 @@ static int lstm_persistent_ok(int B, int H) {
 // work of the XCD-local form: the legacy layout (5 B H + 4 floats: its err word stays at 5 B H), 12 words (XCC id per group),
 // then the exchange array [B][T][H]
 static size_t lstm_xcd_work_floats(int B, int H, int T) { return (size_t)5 * B * H + 4 + 12 + (size_t)B * T * H; }
+// every XCD reads ALL of W_hh at the start (8 x 16.8 MB at H = 1024): a handful of steps is cheaper on the all-CU form
+static bool lstm_xcd_shape(int B, int H, int T) {
+    return (H == 512 || H == 768 || H == 1024) && B > 0 && T >= 16 && (size_t)B * T * H * 4 <= ((size_t)1 << 30);
+}
 extern "C" size_t acmi_lstm_layer_work_floats(int B, int H, int T) {
     const size_t legacy = (size_t)5 * B * H + 4;
-    return (H == LX_H && T > 0 && (size_t)B * T * H * 4 <= ((size_t)1 << 30)) ? lstm_xcd_work_floats(B, H, T) : legacy;
+    return (lstm_xcd_shape(B, H, T)) ? lstm_xcd_work_floats(B, H, T) : legacy;
 }
 
-// the XCD-local form when it applies: H = 1024, the caller's work area holds the exchange array, 8 XCDs x 32 CUs that can
-// each hold one 512-thread workgroup with 157 KB of LDS.  ACMI_LSTM_XCD = 0: off; 2: memory-side stores / loads (A/B)
+// arms a launch of lstm_xcd_kernel: the XCC words of the 8 groups and every slot of the exchange array.  A KERNEL, not
+// hipMemsetD32Async: inside a replayed hipGraph the memset nodes of this size were seen to take effect late (replay >= 1 of a
+// captured 8 x 1024 x 200 layer: all 256 workgroups found the previous replay's XCC words, profiles/r04_session36_lstm_graph.log)
+__global__ __launch_bounds__(256) void lstm_xcd_arm_kernel(u32x4_t* hx4, size_t n4, unsigned* xcc_of_group) {
+    if (blockIdx.x == 0 && threadIdx.x < 12) xcc_of_group[threadIdx.x] = 0xffffffffu;
+    const u32x4_t e = {LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) hx4[i] = e;
+}
+
+template <int HH>
+static int lstm_launch_xcd(int mode, const float* gates_in, const float* w_hh, const float* skip, float* y, unsigned* hx,
+                           unsigned* xcc_of_group, unsigned* err, int B, int T, hipStream_t st, bool* launched) {
+    constexpr size_t lds = LxCfg<HH>::LDS;
+    const int grid = 8 * 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<HH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ACMI_OK;   // the other forms remain
+        attr_set = true;
+    }
+    if (!lstm_grid_resident(lstm_xcd_kernel<HH, 0>, grid, lds, LxCfg<HH>::THREADS)) return ACMI_OK;
+    {
+        const size_t n4 = (size_t)B * T * HH / 4;   // (hx is 16-byte aligned: 5 B H + 16 words into a 256-byte aligned area, H % 4 == 0)
+        hipLaunchKernelGGL(lstm_xcd_arm_kernel, dim3((unsigned)min((size_t)2048, (n4 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<u32x4_t*>(hx), n4, xcc_of_group);
+    }
+    if (mode == 2) hipLaunchKernelGGL((lstm_xcd_kernel<HH, 1>), dim3(grid), dim3(LxCfg<HH>::THREADS), lds, st, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T);
+    else hipLaunchKernelGGL((lstm_xcd_kernel<HH, 0>), dim3(grid), dim3(LxCfg<HH>::THREADS), lds, st, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T);
+    *launched = true;
+    return acmi_check_launch("lstm_xcd_kernel");
+}
+
+// the XCD-local form when it applies: H = 512 / 768 / 1024, the caller's work area holds the exchange array, 8 XCDs x 32 CUs
+// that can each hold one workgroup of the form.  ACMI_LSTM_XCD = 0: off; 2: memory-side stores / loads (A/B)
 static int lstm_try_xcd(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, size_t work_floats,
                         int B, int H, int T, hipStream_t st, bool* launched) {
     *launched = false;
     const char* env = getenv("ACMI_LSTM_XCD");   // read per call: tests switch it
     const int mode = env != nullptr ? atoi(env) : 1;
-    // every XCD reads ALL of W_hh at the start (8 x 16.8 MB): a handful of steps is cheaper on the all-CU form
-    if (mode == 0 || H != LX_H || T < 16 || (size_t)B * T * H * 4 > ((size_t)1 << 30) || work_floats < lstm_xcd_work_floats(B, H, T)) return ACMI_OK;
-    constexpr size_t lds = (size_t)(LX_SLABS * LX_THREADS * 4 + LX_H + 8 * LX_UNITS) * sizeof(float) + 16;
-    const int grid = 8 * (LX_H / LX_UNITS);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ACMI_OK;   // the other forms remain
-        attr_set = true;
-    }
-    if (!lstm_grid_resident(lstm_xcd_kernel<0>, grid, lds, LX_THREADS)) return ACMI_OK;
+    if (mode == 0 || !lstm_xcd_shape(B, H, T) || work_floats < lstm_xcd_work_floats(B, H, T)) return ACMI_OK;
     unsigned* err = reinterpret_cast<unsigned*>(work + (size_t)5 * B * H);
     unsigned* xcc_of_group = err + 4;
     unsigned* hx = err + 16;
-    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(xcc_of_group), (int)0xffffffffu, 12, st) != hipSuccess ||
-        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hx), (int)LSTM_EMPTY, (size_t)B * T * H, st) != hipSuccess) {
-        acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
-        return ACMI_ELAUNCH;
-    }
-#define ACMI_LX_LAUNCH(M) hipLaunchKernelGGL(lstm_xcd_kernel<M>, dim3(grid), dim3(LX_THREADS), lds, st, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T)
-    if (mode == 2) ACMI_LX_LAUNCH(1);
-    else ACMI_LX_LAUNCH(0);
-#undef ACMI_LX_LAUNCH
-    *launched = true;
-    return acmi_check_launch("lstm_xcd_kernel");
+    if ((reinterpret_cast<size_t>(hx) & 15) != 0) return ACMI_OK;   // 16-byte stores into the exchange array
+    if (H == 1024) return lstm_launch_xcd<1024>(mode, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T, st, launched);
+    if (H == 768) return lstm_launch_xcd<768>(mode, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T, st, launched);
+    return lstm_launch_xcd<512>(mode, gates_in, w_hh, skip, y, hx, xcc_of_group, err, B, T, st, launched);
+}
+
+// would a layer of this shape (given a large enough work area) run the XCD-local form on the current device?
+static bool lstm_xcd_would_run(int B, int H, int T) {
+    const char* env = getenv("ACMI_LSTM_XCD");
+    if ((env != nullptr && atoi(env) == 0) || !lstm_xcd_shape(B, H, T)) return false;
+    if (H == 1024) return lstm_grid_resident(lstm_xcd_kernel<1024, 0>, 256, LxCfg<1024>::LDS, LxCfg<1024>::THREADS);
+    if (H == 768) return lstm_grid_resident(lstm_xcd_kernel<768, 0>, 256, LxCfg<768>::LDS, LxCfg<768>::THREADS);
+    return lstm_grid_resident(lstm_xcd_kernel<512, 0>, 256, LxCfg<512>::LDS, LxCfg<512>::THREADS);
 }
 
 static int lstm_layer_impl(const float* gates_in, const float* w_hh, const float* skip, float* y, float* work, size_t work_floats,
@@ -1388,6 +1432,9 @@ extern "C" int acmi_lstm_stack2_supported(int B, int H, int T) {
     // H = 1024, B = 8: 15.5 us per wavefront step against 2 x 6.4 + the input projection (23.2 vs 20.3 ms per 1500 steps): two
     // 32 KB gathers per layer-1 step, each in two rounds (register budget of two workgroups per CU), do not pay
     if (want == 1 && H > 512) return 0;
+    // two launches of the XCD-local form (2 T steps of 1.4 us at H = 512) beat the wavefront's T + 1 steps: EnCodec-24k geometry,
+    // 1 x 10 s: decode 4.58 -> 3.29 ms, encode 4.95 -> 3.63 ms (profiles/r04_session37_lstm.log)
+    if (want == 1 && lstm_xcd_would_run(B, H, T)) return 0;
     return lstm_wave2_can(B, H, T, lstm_wave2_lds(H)) ? 1 : 0;
 }
 

@@ -535,7 +535,8 @@ int acmi_resample_frac(const float* x, float* y, const float* kernel, int rows, 
  * b_ih1 + b_hh1; skip [B, H, T] or NULL is added to the output y [B, H, T] of layer 1.
  * acmi_lstm_stack2_supported: 1 when the launch can run on the current device (H % 4 == 0, H <= 1024, the residency rule of
  * acmi_lstm_layer per layer: if only one layer's workgroups fit at a time the launch degrades to layer 0, then layer 1) AND is
- * the faster form (H <= 512 by default; ACMI_LSTM_WAVE=2 lifts that, =0 answers 0); otherwise use two acmi_lstm_layer calls.  work: acmi_lstm_stack2_work_floats(B, H, T) floats; its LAST four
+ * the faster form (H <= 512 and a shape the XCD-local form of acmi_lstm_layer_ex does not take, by default; ACMI_LSTM_WAVE=2 lifts
+ * that, =0 answers 0); otherwise use two acmi_lstm_layer(_ex) calls.  work: acmi_lstm_stack2_work_floats(B, H, T) floats; its LAST four
  * words hold the give-up count: the caller zeroes them before the call and reads word 0 of them after it. */
 size_t acmi_lstm_stack2_work_floats(int B, int H, int T);
 int acmi_lstm_stack2_supported(int B, int H, int T);

@@ -146,15 +146,17 @@ def test_convtr1d_vs_oracle(C, Cin, Cout, k, stride, causal, trr, T):
 @pytest.mark.parametrize('wave', ['force', 'off'])
 @pytest.mark.parametrize('B,H,T,layers', [(2, 32, 17, 2), (8, 1024, 20, 2), (3, 64, 5, 1), (11, 128, 9, 2), (1, 512, 301, 2),
                                           (8, 1024, 150, 2), (2, 100, 33, 2), (17, 512, 6, 2), (1, 4, 3, 2), (16, 512, 40, 2), (33, 64, 7, 2),
-                                          (9, 1024, 12, 1)])
+                                          (9, 1024, 12, 1), (3, 768, 33, 1), (10, 1024, 24, 1)])
 def test_lstm_vs_oracle(C, B, H, T, layers, wave, monkeypatch):
     """StreamableLSTM (with its skip) against the oracle: the two-layer wavefront launch (acmi_lstm_stack2) and, with it switched
-    off on the host side, one acmi_lstm_layer launch per layer."""
+    off on the host side, one acmi_lstm_layer launch per layer (H = 512 / 768 / 1024 with T >= 16: one recurrence per XCD,
+    lstm_xcd_kernel, more than 8 rows = several rows per XCD; otherwise the all-CU persistent form)."""
     from audiocraft_amd.modules.seanet import StreamableLSTM
     if wave == 'off':
         monkeypatch.setattr(C, 'lstm_stack2_supported', lambda *a: False)
     else:   # also where the library would advise against it (H = 1024: measured slower than two launches)
-        assert C.lstm_stack2_supported(min(B, 8), min(H, 512), T)   # an idle whole MI355X holds every workgroup of these shapes
+        # an idle whole MI355X holds every workgroup of these shapes (T < 16: a shape the XCD-local per-layer form leaves to it)
+        assert C.lstm_stack2_supported(min(B, 8), min(H, 512), min(T, 15))
         monkeypatch.setattr(C, 'lstm_stack2_supported', lambda *a: True)
     g = torch.Generator().manual_seed(H + T)
     m = StreamableLSTM(H, layers, device='cuda')
@@ -168,6 +170,29 @@ def test_lstm_vs_oracle(C, B, H, T, layers, wave, monkeypatch):
     got = m.run(x.cuda()).cpu()
     err = (got - ref).abs().max().item()
     assert err < 2e-5, f"max abs err {err}"
+
+
+@pytest.mark.parametrize('B,H,T', [(8, 1024, 40), (3, 512, 64), (12, 1024, 17)])
+def test_lstm_layer_forms_agree(C, B, H, T, monkeypatch):
+    """acmi_lstm_layer_ex: the XCD-local form (default), the same kernel on memory-side stores / loads (ACMI_LSTM_XCD=2) and
+    the all-CU form (ACMI_LSTM_XCD=0) compute the same recurrence (summation orders differ: 1e-5), and none gives up."""
+    g = torch.Generator().manual_seed(B + H + T)
+    gates = torch.randn(B, 4 * H, T, generator=g).cuda()
+    w_hh = torch.empty(4 * H, H).uniform_(-1 / math.sqrt(H), 1 / math.sqrt(H), generator=g).cuda()
+    skip = torch.randn(B, H, T, generator=g).cuda()
+    outs = []
+    for mode in ('1', '2', '0'):
+        monkeypatch.setenv('ACMI_LSTM_XCD', mode)
+        work = torch.empty(C.lstm_layer_work_floats(B, H, T), device='cuda')
+        work[:5 * B * H + 4].zero_()
+        y = torch.full((B, H, T), float('nan'), device='cuda')
+        C.lstm_layer(gates, w_hh, skip, y, work, B, H, T)
+        torch.cuda.synchronize()
+        assert int(work[5 * B * H:5 * B * H + 1].view(torch.int32)[0]) == 0
+        outs.append(y.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert (outs[0] - outs[2]).abs().max().item() < 1e-5
+    assert torch.equal(outs[0], outs[1])     # same kernel, same arithmetic: only the memory path differs
 
 
 # ------------------------------------------------------------------------------------------ LM operators
