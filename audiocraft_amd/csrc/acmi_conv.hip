@@ -1221,6 +1221,20 @@ __global__ __launch_bounds__(256, KI > 32 ? 2 : 1) void lstm_wave2_kernel(const 
 // hidden-state buffers (3 * B * H floats) and an error word: 5 * B * H + 4 floats cover both
 extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H + 4; }
 
+// The recurrence kernels' work areas are armed by a KERNEL, not by hipMemset*Async: inside a replayed hipGraph a large memset
+// node was seen to take effect late (replay >= 1 of a captured 8 x 1024 x 200 layer found the previous replay's words,
+// profiles/r04_session36_lstm_graph.log); a kernel node is ordered like every other launch of the pass.
+__global__ __launch_bounds__(256) void lstm_fill_kernel(unsigned* a, size_t na, unsigned va, unsigned* b, size_t nb, unsigned vb) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < na; i += step) a[i] = va;
+    for (size_t i = i0; i < nb; i += step) b[i] = vb;
+}
+static int lstm_fill(unsigned* a, size_t na, unsigned va, unsigned* b, size_t nb, unsigned vb, hipStream_t st) {
+    const size_t n = na > nb ? na : nb;
+    hipLaunchKernelGGL(lstm_fill_kernel, dim3((unsigned)min((size_t)2048, (n + 255) / 256)), dim3(256), 0, st, a, na, va, b, nb, vb);
+    return acmi_check_launch("lstm_fill_kernel");
+}
+
 // Every workgroup of the persistent form must be RESIDENT for its all-gather to complete.  The grid ((H + 3) / 4
 // workgroups) is checked against what the device this call runs on can hold: CUs (hipDeviceProp_t.multiProcessorCount:
 // 256 on a whole MI355X, fewer on a partitioned one) x the occupancy the runtime reports for this kernel with its LDS,
@@ -1268,9 +1282,9 @@ extern "C" size_t acmi_lstm_layer_work_floats(int B, int H, int T) {
     return (lstm_xcd_shape(B, H, T)) ? lstm_xcd_work_floats(B, H, T) : legacy;
 }
 
-// arms a launch of lstm_xcd_kernel: the XCC words of the 8 groups and every slot of the exchange array.  A KERNEL, not
-// hipMemsetD32Async: inside a replayed hipGraph the memset nodes of this size were seen to take effect late (replay >= 1 of a
-// captured 8 x 1024 x 200 layer: all 256 workgroups found the previous replay's XCC words, profiles/r04_session36_lstm_graph.log)
+// arms a launch of lstm_xcd_kernel: the XCC words of the 8 groups and every slot of the exchange array (a kernel, like
+// lstm_fill: replay >= 1 of a captured 8 x 1024 x 200 layer armed by memset nodes had all 256 workgroups find the previous replay's
+// XCC words)
 __global__ __launch_bounds__(256) void lstm_xcd_arm_kernel(u32x4_t* hx4, size_t n4, unsigned* xcc_of_group) {
     if (blockIdx.x == 0 && threadIdx.x < 12) xcc_of_group[threadIdx.x] = 0xffffffffu;
     const u32x4_t e = {LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY, LSTM_EMPTY};
@@ -1355,10 +1369,7 @@ static int lstm_layer_impl(const float* gates_in, const float* w_hh, const float
     float* c = work + (size_t)2 * B * H;
     // (the err word at work[5 B H] is NOT cleared here: it accumulates over the layers of a stack and the caller, who
     // zeroed it, reads it once at the end -- a give-up in layer 0 must not be erased by layer 1's call)
-    if (hipMemsetAsync(work, 0, sizeof(float) * 3 * B * H, st) != hipSuccess) {
-        acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");
-        return ACMI_ELAUNCH;
-    }
+    if (int rc = lstm_fill(reinterpret_cast<unsigned*>(work), (size_t)3 * B * H, 0u, nullptr, 0, 0u, st)) return rc;
     const size_t lds = (size_t)(LSTM_BB * H + 16 * LSTM_BB) * sizeof(float);
     dim3 grid((H + 3) / 4), block(256);
     if (T > 0 && lstm_persistent_ok(B, H)) {
@@ -1377,11 +1388,9 @@ static int lstm_layer_impl(const float* gates_in, const float* w_hh, const float
 #define ACMI_LSTM_CASE(KIv)                                                                                                  \
         if (ki <= KIv) {                                                                                                     \
             if (lstm_grid_resident(lstm_persistent_kernel<KIv>, (int)grid.x, lds_p)) {                              \
-                if (hipMemsetAsync(work, 0, sizeof(float) * (size_t)5 * B * H, st) != hipSuccess ||                          \
-                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, (size_t)3 * B * H, st) != hipSuccess) { \
-                    acmi_set_error("acmi_lstm_layer: hipMemsetAsync failed");                                                \
-                    return ACMI_ELAUNCH;                                                                                     \
-                }                                                                                                            \
+                /* cell state zero, the three hidden-state buffers EMPTY, the tail of the 5 B H area zero */                 \
+                if (int rc = lstm_fill(reinterpret_cast<unsigned*>(work), (size_t)5 * B * H, 0u, nullptr, 0, 0u, st)) return rc; \
+                if (int rc = lstm_fill(hbuf, (size_t)3 * B * H, LSTM_EMPTY, nullptr, 0, 0u, st)) return rc;                  \
                 hipLaunchKernelGGL(lstm_persistent_kernel<KIv>, pgrid, block, lds_p, st, gates_in, w_hh, work, skip, y, hbuf, \
                                    err, B, H, T, nsplit);                                                                    \
                 return acmi_check_launch("lstm_persistent_kernel");                                                          \
@@ -1449,11 +1458,7 @@ extern "C" int acmi_lstm_stack2(const float* gates_in0, const float* w_hh0, cons
     unsigned* hbuf = reinterpret_cast<unsigned*>(work + 2 * BH);
     unsigned* x01 = hbuf + 6 * BH;
     unsigned* err = x01 + (size_t)T * BH;
-    if (hipMemsetAsync(work, 0, sizeof(float) * 2 * BH, st) != hipSuccess ||
-        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hbuf), (int)LSTM_EMPTY, 6 * BH + (size_t)T * BH, st) != hipSuccess) {
-        acmi_set_error("acmi_lstm_stack2: hipMemsetAsync failed");
-        return ACMI_ELAUNCH;
-    }
+    if (int rc = lstm_fill(reinterpret_cast<unsigned*>(work), 2 * BH, 0u, hbuf, 6 * BH + (size_t)T * BH, LSTM_EMPTY, st)) return rc;
     dim3 grid(2 * ((H + 3) / 4)), block(256);
     const int ki = (H + 15) / 16;
 #define ACMI_LSTM2_CASE(KIv)                                                                                              \
