@@ -253,6 +253,53 @@ def pmc_traffic_per_launch():
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
+def pmc_traffic_live(timeout_s: int = 150):
+    """-> (HBM bytes per GEMM launch, source) MEASURED in this run: two `rocprofv3 --pmc` child processes (FETCH_SIZE and
+    WRITE_SIZE in separate passes, counters only -- no trace domains -- as MI355X_MICROARCH.md prescribes) over
+    scripts/dbg_chain.py, the same launch chain `measure_lin_kernel` times; same arithmetic as pmc_traffic_per_launch.
+    (None, reason) when rocprofv3 is absent, this process is itself being profiled, ACMI_BENCH_PMC=0, or a pass fails / times
+    out: the caller then falls back to the committed passes and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get('ACMI_BENCH_PMC', '1') == '0':
+        return None, 'ACMI_BENCH_PMC=0'
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    if any(k.startswith(('ROCPROF', 'ROCP_', 'ROCPROFILER')) for k in os.environ):
+        return None, 'this process runs under a profiler'
+    vals = {}
+    t0 = time.time()
+    for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix=f'acmi_pmc_{name}_', dir='/tmp')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            cmd = [exe, '--pmc', name, '--output-format', 'csv', '-d', tmp, '--', sys.executable,
+                   os.path.join(ROOT, 'scripts', 'dbg_chain.py')]
+            subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True)
+            if not files:
+                return None, f'the {name} pass wrote no counter_collection.csv'
+            total = n = 0.0
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row['Counter_Name'] == name and ('lin_tiled_kernel' in row['Kernel_Name'] or 'lin_pair_kernel' in row['Kernel_Name']):
+                        total += float(row['Counter_Value'])
+                        n += 1
+            if n == 0:
+                return None, f'no GEMM dispatches in the {name} pass'
+            vals[name] = total / n
+        except Exception as e:   # noqa: BLE001  (a failed profiler pass must never cost the bench line)
+            return None, f'the {name} pass failed: {type(e).__name__}'
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    src = f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/dbg_chain.py, {time.time() - t0:.0f} s'
+    return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
+
+
 def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 16, late_steps: int = 14,
                  late_context: int = 1400):
     """The reference's CPU path on the host cores, on a bounded sample of the same workload, as SURVEY.md section 8(d)
@@ -489,7 +536,14 @@ def main():
             r = measure_lin_kernel(model, 2 * B)
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
             on_cfg2 = config_tag(args).endswith('configs[2]')
-            traffic, traffic_src = pmc_traffic_per_launch() if on_cfg2 else (None, 'the committed PMC passes are of the configs[2] chain')
+            if not on_cfg2:
+                traffic, traffic_src = None, 'the PMC passes are of the configs[2] chain'
+            else:
+                traffic, traffic_src = pmc_traffic_live() if world == 1 else (None, 'multi-GPU run')
+                if traffic is None:   # fall back to the committed passes, and say why
+                    why = traffic_src
+                    traffic, traffic_src = pmc_traffic_per_launch()
+                    traffic_src = f'{traffic_src}; not measured live: {why}'
             out["roofline"] = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_bw": round(ach / HBM_COPY_GBS, 4),

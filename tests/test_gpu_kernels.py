@@ -195,6 +195,42 @@ def test_lstm_layer_forms_agree(C, B, H, T, monkeypatch):
     assert torch.equal(outs[0], outs[1])     # same kernel, same arithmetic: only the memory path differs
 
 
+@pytest.mark.parametrize('B,H,T', [(8, 1024, 200), (1, 512, 300)])
+def test_lstm_stack_graph_replay_with_changing_inputs(C, B, H, T, monkeypatch):
+    """A captured StreamableLSTM pass replayed with NEW inputs equals the eager pass every time, and no replay raises the give-up
+    word: the recurrence kernels' work areas (slots of the exchange array that are their own flags, XCC words) must be re-armed
+    by every replay -- armed by memset nodes, replay >= 1 of the 8 x 1024 x 200 case consumed the previous replay's state."""
+    from audiocraft_amd.modules.seanet import StreamableLSTM
+    monkeypatch.setattr(C, 'lstm_stack2_supported', lambda *a: False)   # per-layer launches (the XCD-local form at these shapes)
+    torch.manual_seed(B + H)
+    m = StreamableLSTM(H, 2, device='cuda')
+    x = torch.randn(B, H, T, device='cuda')
+    m.run(x)                                   # eager first: host-side caches
+    torch.cuda.synchronize()
+    checks = []
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    static_in = x.clone()
+    with torch.cuda.stream(side):
+        C.defer_lstm_checks(checks)
+        graph.capture_begin()
+        try:
+            out = m.run(static_in)
+        finally:
+            graph.capture_end()
+            C.defer_lstm_checks(None)
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(3):
+        x2 = torch.randn(B, H, T, device='cuda')
+        static_in.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(int(w.view(torch.int32)[0]) == 0 for w, _ in checks)
+        want = m.run(x2)
+        assert torch.equal(out, want), f"replay {rep}: max diff {(out - want).abs().max().item()}"
+
+
 # ------------------------------------------------------------------------------------------ LM operators
 
 @pytest.mark.parametrize('M,N,K', [(16, 4608, 1536), (2, 3072, 1024), (16, 1536, 6144), (32, 1536, 1536),
