@@ -36,6 +36,10 @@ class LMConfig:
     positional_embedding: str = 'sin'      # 'sin' | 'rope' | 'sin_rope' (transformer.py:632-637, 701-704)
     xpos: bool = False
     past_context: tp.Optional[int] = None
+    # attention options of config/model/lm/default.yaml:43-46 (off in every release)
+    kv_repeat: int = 1                      # H / kv_repeat key / value heads (transformer.py:196-200, 373-386, 398-400)
+    qk_layer_norm: bool = False             # LayerNorm on the projected queries / keys (transformer.py:216-222, 388-392)
+    qk_layer_norm_cross: bool = False       # same in the cross-attention (transformer.py:358-360, 526-529)
 
 
 def create_sin_embedding(positions: torch.Tensor, dim: int, max_period: float = 10000.) -> torch.Tensor:
@@ -121,8 +125,20 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
         # --- self attention (pre-norm)
         h = _ln(x, sd, p + '.norm1', cfg.eps)
         proj = F.linear(h, sd[p + '.self_attn.in_proj_weight'], sd.get(p + '.self_attn.in_proj_bias'))
-        packed = proj.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)  # "b t (p h d) -> p b h t d"
-        q, k, v = packed[0], packed[1], packed[2]
+        if cfg.kv_repeat == 1:
+            packed = proj.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)  # "b t (p h d) -> p b h t d"
+            q, k, v = packed[0], packed[1], packed[2]
+        else:
+            # transformer.py:373-386: the projection emits C query features, then kv_heads * hd key and as many value features
+            kvh = H // cfg.kv_repeat
+            q = proj[..., :C].view(B, T, H, hd).transpose(1, 2)
+            k = proj[..., C:C + kvh * hd].view(B, T, kvh, hd).transpose(1, 2)
+            v = proj[..., C + kvh * hd:].view(B, T, kvh, hd).transpose(1, 2)
+        if cfg.qk_layer_norm:
+            # transformer.py:388-392: over the full model dimension ("b t (h d)"), before the rotary positions and the cache
+            assert cfg.kv_repeat == 1
+            q = _ln(q.transpose(1, 2).reshape(B, T, C), sd, p + '.self_attn.q_layer_norm', cfg.eps).view(B, T, H, hd).transpose(1, 2)
+            k = _ln(k.transpose(1, 2).reshape(B, T, C), sd, p + '.self_attn.k_layer_norm', cfg.eps).view(B, T, H, hd).transpose(1, 2)
         # _get_mask (transformer.py:233-247): no mask for one step; lower-triangular for T>1, which
         # the reference only supports when there is no past (raises otherwise).
         causal = T > 1
@@ -145,6 +161,8 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
             keep = 0 if cfg.past_context is None else max(0, k.shape[2] - cfg.past_context)   # :286-293
             state.past_k[li], state.past_v[li] = k[:, :, keep:], v[:, :, keep:]
             state.ctx_offset[li] = 0 if state.ctx_offset[li] is None else state.ctx_offset[li] + keep
+        if cfg.kv_repeat > 1:   # expand_repeated_kv (transformer.py:90-107, 398-400): AFTER the cache, which keeps kv_heads heads
+            k, v = k.repeat_interleave(cfg.kv_repeat, dim=1), v.repeat_interleave(cfg.kv_repeat, dim=1)
         a = _attention(q, k, v, causal, cfg.past_context)
         a = a.permute(0, 2, 1, 3).reshape(B, T, C)
         x = x + ls(p + '.layer_scale_1') * F.linear(a, sd[p + '.self_attn.out_proj.weight'], sd.get(p + '.self_attn.out_proj.bias'))
@@ -157,8 +175,12 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
             bq = bk = bv = None
             if p + '.cross_attention.in_proj_bias' in sd:
                 bq, bk, bv = sd[p + '.cross_attention.in_proj_bias'].chunk(3)
-            qc = F.linear(h, w[:C], bq).view(B, T, H, hd).transpose(1, 2)
-            kc = F.linear(cross_src, w[C:2 * C], bk).view(B, -1, H, hd).transpose(1, 2)
+            qc, kc = F.linear(h, w[:C], bq), F.linear(cross_src, w[C:2 * C], bk)
+            if cfg.qk_layer_norm_cross:   # transformer.py:358-360
+                qc = _ln(qc, sd, p + '.cross_attention.q_layer_norm', cfg.eps)
+                kc = _ln(kc, sd, p + '.cross_attention.k_layer_norm', cfg.eps)
+            qc = qc.view(B, T, H, hd).transpose(1, 2)
+            kc = kc.view(B, -1, H, hd).transpose(1, 2)
             vc = F.linear(cross_src, w[2 * C:], bv).view(B, -1, H, hd).transpose(1, 2)
             a = _attention(qc, kc, vc, False).transpose(1, 2).reshape(B, T, C)
             x = x + ls(p + '.layer_scale_cross') * F.linear(a, sd[p + '.cross_attention.out_proj.weight'],
@@ -172,15 +194,35 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
     return x
 
 
+def cross_pos_emb(cross_src: torch.Tensor, scale: float) -> torch.Tensor:
+    """ConditionFuser's cross_attention_pos_emb (conditioners.py:1750-1757): a sinusoidal embedding of the source positions,
+    times cross_attention_pos_emb_scale, added to the concatenated cross-attention source."""
+    positions = torch.arange(cross_src.shape[1]).view(1, -1, 1)
+    return cross_src + scale * create_sin_embedding(positions, cross_src.shape[-1])
+
+
 def lm_forward(sd: dict, cfg: LMConfig, sequence: torch.Tensor, cross_src: tp.Optional[torch.Tensor],
                prepend_src: tp.Optional[torch.Tensor] = None,
-               state: tp.Optional[LMState] = None) -> torch.Tensor:
+               state: tp.Optional[LMState] = None,
+               input_ops: tp.Sequence[tp.Tuple[str, torch.Tensor]] = ()) -> torch.Tensor:
     """LMModel.forward (audiocraft/models/lm.py:221-268) with precomputed condition tensors.
     sequence [B, K, S] int64 -> logits [B, K, S, card].  `prepend_src` [B, P, C] is concatenated
     before the tokens on the first (or non-streaming) call only (ConditionFuser.forward,
-    conditioners.py:1739-1741) and the logits are cropped back to the last S steps (lm.py:265-266)."""
+    conditioners.py:1739-1741) and the logits are cropped back to the last S steps (lm.py:265-266).
+    `input_ops`: the fuser's 'sum' / 'input_interpolate' conditions in dict order, applied to the embedded input of EVERY
+    call before `prepend_src` joins it (conditioners.py:1733-1737): ('sum', cond [B, 1 | T, C]) is added (broadcast like
+    the reference's in-place `input += cond`), ('input_interpolate', cond [B, Tc, C]) is nearest-resampled to the call's
+    length first -- a one-step streaming call therefore always receives its frame 0."""
     B, K, S = sequence.shape
     x = sum(F.embedding(sequence[:, k], sd[f'emb.{k}.weight']) for k in range(K))
+    for op, cond in input_ops:
+        if op == 'sum':
+            assert cond.shape[1] in (1, x.shape[1]), "the reference's in-place add cannot broadcast this"
+            x = x + cond
+        elif op == 'input_interpolate':
+            x = x + F.interpolate(cond.transpose(1, 2), size=x.shape[1]).transpose(1, 2)
+        else:
+            raise ValueError(op)
     first = state.first_step if state is not None else True
     if prepend_src is not None and first:
         x = torch.cat([prepend_src, x], dim=1)
@@ -256,7 +298,9 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
              top_p: float = 0.0, cfg_coef: tp.Optional[float] = None, remove_prompts: bool = False,
              generator=None, callback=None, return_logits: bool = False, max_steps: tp.Optional[int] = None,
              cfg_coef_beta: tp.Optional[float] = None, null_cross_src: tp.Optional[torch.Tensor] = None,
-             null_prepend_src: tp.Optional[torch.Tensor] = None):
+             null_prepend_src: tp.Optional[torch.Tensor] = None,
+             input_ops: tp.Sequence[tp.Tuple[str, torch.Tensor]] = (),
+             null_input_ops: tp.Sequence[tp.Tuple[str, torch.Tensor]] = ()):
     """LMModel.generate (audiocraft/models/lm.py:420-587).
 
     Default one-forward CFG mode: `cross_src` / `prepend_src` hold the already-batched `[cond; uncond]` condition
@@ -265,9 +309,10 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
     `null_cross_src` / `null_prepend_src` (two_step_cfg, lm.py:377-386): the conditional tensors hold B rows and
     the unconditional pass runs separately on these, with its own condition length and streaming state; the mix
     then uses the model's `cfg.cfg_coef` -- the reference ignores the `cfg_coef` argument on that branch.
+    `input_ops` / `null_input_ops`: see lm_forward (rows batched like the other condition tensors).
     """
     coef = cfg.cfg_coef if cfg_coef is None else cfg_coef
-    use_cfg = cross_src is not None or prepend_src is not None
+    use_cfg = cross_src is not None or prepend_src is not None or len(input_ops) > 0
     two_step = null_cross_src is not None or null_prepend_src is not None
     assert not (two_step and cfg_coef_beta is not None)
     null_state = LMState(cfg.num_layers) if two_step else None
@@ -290,15 +335,15 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
             break
         curr = gen_sequence[..., prev:offset]
         if two_step:
-            cond = lm_forward(sd, cfg, curr, cross_src, prepend_src, state)
-            uncond = lm_forward(sd, cfg, curr, null_cross_src, null_prepend_src, null_state)
+            cond = lm_forward(sd, cfg, curr, cross_src, prepend_src, state, input_ops)
+            uncond = lm_forward(sd, cfg, curr, null_cross_src, null_prepend_src, null_state, null_input_ops)
             logits = uncond + (cond - uncond) * cfg.cfg_coef
         elif cfg_coef_beta is not None:
-            logits = lm_forward(sd, cfg, torch.cat([curr, curr, curr], dim=0), cross_src, prepend_src, state)
+            logits = lm_forward(sd, cfg, torch.cat([curr, curr, curr], dim=0), cross_src, prepend_src, state, input_ops)
             logits = double_cfg_mix(logits, coef, cfg_coef_beta)
         else:
             seq = torch.cat([curr, curr], dim=0) if use_cfg else curr
-            logits = lm_forward(sd, cfg, seq, cross_src, prepend_src, state)
+            logits = lm_forward(sd, cfg, seq, cross_src, prepend_src, state, input_ops)
             if use_cfg:
                 logits = cfg_mix(logits, coef)
         logits = logits[:, :, -1]  # [B, K, card]

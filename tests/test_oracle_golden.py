@@ -19,7 +19,8 @@ def codec_cfg(cfg):
     return ocodec.CodecConfig(**{k: cfg[k] for k in CODEC_KEYS})
 
 
-LM_OPT_KEYS = ['positional_embedding', 'xpos', 'past_context', 'positional_scale']
+LM_OPT_KEYS = ['positional_embedding', 'xpos', 'past_context', 'positional_scale', 'kv_repeat', 'qk_layer_norm',
+               'qk_layer_norm_cross']
 
 
 def lm_cfg(cfg):
@@ -99,6 +100,38 @@ def test_lm_rope_oracle_matches_reference(name):
     assert torch.equal(toks, a['greedy_tokens'])
     assert torch.allclose(lg, olm.cfg_mix(a['greedy_step_logits'], c.cfg_coef), atol=1e-4, rtol=1e-4)
     toks = olm.generate(sd, c, a['prompt'], 3, a['cross_src'], max_gen_len=14, use_sampling=False)
+    assert torch.equal(toks, a['cont_tokens'])
+
+
+def options_inputs(name, cfg, a):
+    """(cross_src, input_ops) of an options golden (tests/golden/make_options_golden.py), as the reference's fuser builds them."""
+    cross, ops = a['cond_description'], []
+    if name == 'lm_fuser_sum':
+        cross = olm.cross_pos_emb(cross, cfg['cross_attention_pos_emb_scale'])
+        ops = [('sum', a['cond_genre']), ('input_interpolate', a['cond_curve'])]   # the provider's dict order
+    return cross, ops
+
+
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum'])
+def test_lm_options_oracle_matches_reference(name):
+    """kv_repeat, qk_layer_norm (+ cross), the fuser's 'sum' / 'input_interpolate' methods and cross_attention_pos_emb
+    (transformer.py:196-222, 358-400; conditioners.py:1733-1757) against goldens of the unmodified reference."""
+    cfg, sd, a = load_golden(name)
+    c = lm_cfg(cfg)
+    cross, ops = options_inputs(name, cfg, a)
+    assert (c.kv_repeat, c.qk_layer_norm, bool(ops)) != (1, False, False)
+    logits = olm.lm_forward(sd, c, a['tf_sequence'], cross, input_ops=ops)
+    assert torch.allclose(logits, a['tf_logits'], atol=2e-5, rtol=1e-4)
+    if c.kv_repeat > 1:     # the in-projection really is narrower, and the cache keeps the un-repeated heads
+        assert sd['transformer.layers.0.self_attn.in_proj_weight'].shape[0] == c.dim + 2 * c.dim // c.kv_repeat
+        st = olm.LMState(c.num_layers)
+        olm.lm_forward(sd, c, a['tf_sequence'][..., :1], cross, None, st)
+        assert st.past_k[0].shape[1] == c.num_heads // c.kv_repeat
+    toks, lg = olm.generate(sd, c, None, 3, cross, max_gen_len=12, use_sampling=False, return_logits=True, input_ops=ops)
+    assert torch.equal(toks, a['greedy_tokens'])
+    assert torch.allclose(lg, olm.cfg_mix(a['greedy_step_logits'], c.cfg_coef), atol=1e-4, rtol=1e-4)
+    # continuation: the first call spans the 4-step prompt (the interpolated condition is resampled to that length)
+    toks = olm.generate(sd, c, a['prompt'], 3, cross, max_gen_len=11, use_sampling=False, input_ops=ops)
     assert torch.equal(toks, a['cont_tokens'])
 
 
