@@ -6,6 +6,7 @@ Build it with `python -c "import __graft_entry__ as g; g.build()"` or `python -m
 import ctypes as C
 import os
 import threading
+import typing as tp
 
 import torch
 
@@ -42,7 +43,8 @@ class LMLayer(C.Structure):
                 ('b_qkv', vp), ('b_cq', vp), ('b_ff1', vp), ('cs_qkv', vp), ('cs_cq', vp), ('cs_ff1', vp),
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp),
                 ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp),
-                ('b_out', vp), ('b_cout', vp), ('b_ff2', vp), ('b_mq', vp), ('cvt_cache', vp)]
+                ('b_out', vp), ('b_cout', vp), ('b_ff2', vp), ('b_mq', vp), ('cvt_cache', vp),
+                ('q_ln_g', vp), ('q_ln_b', vp), ('k_ln_g', vp), ('k_ln_b', vp), ('cq_ln_g', vp), ('cq_ln_b', vp)]
 
 
 class LMModelDesc(C.Structure):
@@ -60,7 +62,7 @@ class LMState(C.Structure):
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32),
                 ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32), ('cvt_tcap', i32),
-                ('row_off', vp)]
+                ('row_off', vp), ('input_add', vp), ('n_add', i32)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -89,6 +91,7 @@ _linear = _sig('acmi_linear', [vp, i32, vp, vp, f32, vp, i32, vp, vp, vp, i32, i
 _attn = _sig('acmi_attn_decode', [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp])
 _pos_table = _sig('acmi_pos_table', [vp, vp, i32, i32, vp])
 _ln_tile = _sig('acmi_ln_tile', [vp, vp, i32, i32, i32, f32, vp])
+_layer_norm_rows = _sig('acmi_layer_norm_rows', [vp, vp, vp, vp, i32, i32, f32, vp])
 
 
 class LinearDesc(C.Structure):
@@ -135,7 +138,13 @@ _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32
 EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_layer_ex', 'acmi_lstm_layer_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
-           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex']
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex', 'acmi_layer_norm_rows']
+
+
+# ctypes mirror -> C type of include/acmi.h (tests/test_host_cpu.py compiles the header with gcc and compares every
+# field's offset: a mirror that drifts from the header would corrupt every call silently)
+STRUCT_MIRRORS = {'acmi_conv_desc': ConvDesc, 'acmi_lm_layer': LMLayer, 'acmi_lm_model': LMModelDesc, 'acmi_lm_state': LMState,
+                  'acmi_linear_desc': LinearDesc, 'acmi_attn_desc': AttnDesc}
 
 
 def version() -> int:
@@ -426,6 +435,19 @@ def ln_tile_reduce(x: torch.Tensor, slabs: torch.Tensor, out: torch.Tensor, eps:
     M, K = x.shape
     check(_ln_tile_reduce(ptr(x), ptr(slabs), slabs.shape[0], ptr(out), dtype_code(out.dtype), M, K, eps, stream()),
           'acmi_ln_tile_reduce')
+    return out
+
+
+def layer_norm_rows(x: torch.Tensor, gamma: tp.Optional[torch.Tensor], beta: tp.Optional[torch.Tensor], eps: float = 1e-5,
+                    out: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.LayerNorm over the last dimension of x [M, d] f32 (acmi_layer_norm_rows); `out` may be x itself."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()
+    M, d = x.shape
+    out = torch.empty_like(x) if out is None else out
+    for t in (gamma, beta):
+        assert t is None or (t.dtype == torch.float32 and t.numel() == d and t.is_contiguous())
+    check(_layer_norm_rows(ptr(x), None if gamma is None else ptr(gamma), None if beta is None else ptr(beta), ptr(out),
+                           M, d, eps, stream()), 'acmi_layer_norm_rows')
     return out
 
 

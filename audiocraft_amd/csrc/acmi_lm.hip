@@ -31,12 +31,15 @@ struct EmbedArgs {
     const int* row_off; // per cache row: left padding of its stream (acmi_lm_state.row_off), or NULL
     int npos_pad, npos; // > 0: position-minor rows of the MFMA-tiled prefill (row = cache row * npos_pad + position; pad
                         // rows repeat the last position: finite, never stored to the caches); 0: row = position * Beff + cache row
+    const float* input_add; int n_add;   // ADD variant only: acmi_lm_state.input_add / n_add (fuser 'sum' / 'input_interpolate')
 };
 
 // BF16: element type of the tables; KQ >= n_q: codebook tables read per row (compile time, so that every load of a phase
 // is an unconditional, branch-free request: with `if (k < K)` / `bf16 ? .. : ..` around them hipcc put each load in its own
 // basic block followed by its own s_waitcnt vmcnt(0) -- 24 serialised memory round trips, 17 us of an 18.7 us kernel)
-template <bool BF16, int KQ>
+// ADD: the fuser's 'sum' / 'input_interpolate' conditions (acmi_lm_state.input_add) -- a variant of its own so that the
+// kernel every released model runs is unchanged.
+template <bool BF16, int KQ, bool ADD = false>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     __shared__ float sred[4];
     const int m = blockIdx.x;              // row = position-of-the-call * Beff + CFG row
@@ -67,11 +70,15 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
     float pv[CPT], pre[CPT];
     const bool is_prepend = g < p.P;       // block uniform
     const float* prow = p.prepend != nullptr ? p.prepend + ((size_t)m0 * p.P + min(g, max(p.P - 1, 0))) * p.d : p.pos_table;
+    float av[CPT];
+    const float* arow = p.pos_table;
+    if constexpr (ADD) arow = p.input_add + ((size_t)m0 * p.n_add + min(sidx, p.n_add - 1)) * p.d;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int cch = min((int)threadIdx.x + i * 256, p.d - 1);
         pv[i] = p.pos_table[(size_t)gpos * p.d + cch];
         pre[i] = prow[cch];
+        if constexpr (ADD) av[i] = arow[cch];
 #pragma unroll
         for (int k = 0; k < KQ; ++k)
             ev[i][k] = reinterpret_cast<const ET*>(p.emb[min(k, p.K - 1)])[(size_t)toks[k] * p.d + cch];
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
 #pragma unroll
         for (int k = 0; k < KQ; ++k)       // same order as the reference's sum over codebooks (lm.py:241)
             if (k < p.K) v += ld_f32<ET>(&ev[i][k]);
+        if constexpr (ADD) v += av[i];     // `input += cond` of the fuser, before the positional embedding (conditioners.py:1733-1737)
         if (is_prepend) v = pre[i];
         v += p.pos_scale * pv[i];
         p.x[(size_t)m * p.d + cch] = v;
@@ -483,6 +491,87 @@ __global__ __launch_bounds__(1024) void rope_qk_kernel(const RopeArgs p) {
     }
 }
 
+// qk_layer_norm (include/acmi.h, acmi_lm_layer.q_ln_g ..; transformer.py:216-222, 358-360, 388-392) as a launch of its own after
+// the QKV GEMM and before the rotary positions -- like those, an option no released model switches on, kept out of the GEMM
+// epilogues.  One workgroup per (row, operand): blockIdx.y = 0 normalises the q row in place (row-major f32), blockIdx.y = 1
+// the k row the GEMM has just appended to the cache, whose d features lie in H pieces of hd (one per head).  Two-pass
+// statistics over the full model dimension, biased variance, like nn.LayerNorm.
+struct QkLnArgs {
+    float* q; void* kc; int kv_bf16; int H, hd, Tcap, d, rpp; const int* pos;
+    const float* qg; const float* qb; const float* kg; const float* kb; float eps;
+    int npos_pad, npos;   // > 0: position-minor rows (see EmbedArgs); pad rows are skipped
+};
+
+__global__ __launch_bounds__(256) void qk_ln_kernel(const QkLnArgs p) {
+    __shared__ float sred[4];
+    const int gm = blockIdx.x;
+    const bool is_k = blockIdx.y == 1;
+    int pidx, brow;
+    if (p.npos_pad > 0) { brow = gm / p.npos_pad; pidx = gm - brow * p.npos_pad; if (pidx >= p.npos) return; }
+    else { pidx = gm / p.rpp; brow = gm - pidx * p.rpp; }
+    const int tpos = is_k ? *p.pos + pidx : 0;
+    const float* g = is_k ? p.kg : p.qg;
+    const float* b = is_k ? p.kb : p.qb;
+    float loc[8];   // d <= 2048
+    size_t at[8];
+    float sum = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (int)threadIdx.x + i * 256;
+        if (c >= p.d) break;
+        if (is_k) {
+            const int h = c / p.hd, j = c - h * p.hd;
+            at[i] = (((size_t)brow * p.H + h) * p.Tcap + tpos) * p.hd + j;
+            loc[i] = p.kv_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(p.kc)[at[i]]) : reinterpret_cast<const float*>(p.kc)[at[i]];
+        } else {
+            at[i] = (size_t)gm * p.d + c;
+            loc[i] = p.q[at[i]];
+        }
+        sum += loc[i];
+        cnt = i + 1;
+    }
+    const float mean = block_sum(sum, sred) / (float)p.d;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= cnt) break;
+        m2 += (loc[i] - mean) * (loc[i] - mean);
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(m2, sred) / (float)p.d + p.eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= cnt) break;
+        const int c = (int)threadIdx.x + i * 256;
+        float v = (loc[i] - mean) * rstd;
+        if (g != nullptr) v *= g[c];
+        if (b != nullptr) v += b[c];
+        if (!is_k) p.q[at[i]] = v;
+        else if (p.kv_bf16) reinterpret_cast<bf16_t*>(p.kc)[at[i]] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(p.kc)[at[i]] = v;
+    }
+}
+
+// q (and, with kc, the freshly appended k rows) of M rows of this call
+static int launch_qk_ln(const QkLnArgs& a, int M, bool with_k, hipStream_t st) {
+    ACMI_REQUIRE(a.d > 0 && a.d <= 2048 && M > 0, "qk_layer_norm: d=%d (<= 2048) M=%d", a.d, M);
+    hipLaunchKernelGGL(qk_ln_kernel, dim3(M, with_k ? 2 : 1), dim3(256), 0, st, a);
+    return acmi_check_launch("qk_ln_kernel");
+}
+
+extern "C" int acmi_layer_norm_rows(const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps,
+                                    void* stream) {
+    ACMI_REQUIRE(x && y && M > 0 && d > 0 && d <= 2048, "acmi_layer_norm_rows: bad arguments (M=%d d=%d, d <= 2048)", M, d);
+    hipStream_t st = (hipStream_t)stream;
+    if (y != x) {
+        hipError_t e = hipMemcpyAsync(y, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+        ACMI_REQUIRE(e == hipSuccess, "acmi_layer_norm_rows: copy failed: %s", hipGetErrorString(e));
+    }
+    QkLnArgs a = {};
+    a.q = y; a.d = d; a.rpp = 1; a.qg = gamma; a.qb = beta; a.eps = eps;
+    return launch_qk_ln(a, M, false, st);
+}
+
 // The residual stream x lives in four forms (include/acmi.h, acmi_lm_state): f32 row-major `x`, raw fragments
 // xh / xl (hi / lo) and the statistics partials.  StepCtx tracks which fragment buffers currently hold x.
 struct StepCtx {
@@ -557,6 +646,8 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
                  s->pf_tcap, npos);
     ACMI_REQUIRE(m->layers[0].w_qkv != nullptr && m->layers[0].b_qkv != nullptr && m->layers[0].b_ff1 != nullptr,
                  "acmi_lm_step: the tiled prefill needs the folded-LayerNorm matrices");
+    ACMI_REQUIRE(m->layers[0].q_ln_g == nullptr && m->layers[0].k_ln_g == nullptr && m->layers[0].cq_ln_g == nullptr,
+                 "acmi_lm_step: qk_layer_norm models prefill through the decode kernels (no pf_xn)");
     int rc;
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
@@ -564,9 +655,13 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats; e.row_off = s->row_off;
     e.npos_pad = npp; e.npos = npos;
+    e.input_add = s->input_add; e.n_add = s->n_add;
 #define ACMI_EMBED_CASE(KQv)                                                                        \
     if (m->n_q <= KQv) {                                                                           \
-        if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
+        if (e.input_add != nullptr) {                                                              \
+            if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv, true>), dim3(M), dim3(256), 0, st, e);   \
+            else hipLaunchKernelGGL((embed_kernel<false, KQv, true>), dim3(M), dim3(256), 0, st, e);      \
+        } else if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
         else hipLaunchKernelGGL((embed_kernel<false, KQv>), dim3(M), dim3(256), 0, st, e);         \
     } else
     ACMI_EMBED_CASE(4) ACMI_EMBED_CASE(8) ACMI_EMBED_CASE(16) {}
@@ -690,6 +785,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     // LayerNorm, the [W_cq' | W_cq' W_out] matrices, xh buffers wide enough for [x | att] and a second pair.
     static const bool pair_enabled = !(getenv("ACMI_CROSS_FUSED") != nullptr && getenv("ACMI_CROSS_FUSED")[0] == '0');
     const bool pair = pair_enabled && m->cross_attention && c.lnm == LN_FOLD && m->layers[0].w_qkvx != nullptr &&
+                      m->layers[0].cq_ln_g == nullptr &&   // qk_layer_norm_cross: the query is not linear in x1 any more
                       m->layers[0].w_mq != nullptr && s->xn2 != nullptr && (!c.use_lo || s->xlo2 != nullptr) && s->r != nullptr &&
                       c.rbs >= 2 * c.nkc_d;
     void* const xh2[2] = {s->xn, s->xn2};
@@ -702,10 +798,14 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     e.prepend = s->prepend; e.P = s->prepend ? s->n_prepend : 0; e.pos_table = m->pos_table;
     e.pos_scale = m->positional_scale; e.pos = s->pos; e.x = s->x; e.d = d; e.stats = s->stats; e.row_off = s->row_off;
     if (c.lnm == LN_FOLD) { e.xt_hi = c.xh; e.xt_lo = c.use_lo ? c.xl : nullptr; e.xt_nkc = c.rbs; e.xt_lo_nkc = c.nkc_d; }
+    e.input_add = s->input_add; e.n_add = s->n_add;
     if (shifted) { e.shift_out = shbuf[0]; c.xsh = shbuf[0]; }
 #define ACMI_EMBED_CASE(KQv)                                                                        \
     if (m->n_q <= KQv) {                                                                           \
-        if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
+        if (e.input_add != nullptr) {                                                              \
+            if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv, true>), dim3(M), dim3(256), 0, st, e);   \
+            else hipLaunchKernelGGL((embed_kernel<false, KQv, true>), dim3(M), dim3(256), 0, st, e);      \
+        } else if (wbf) hipLaunchKernelGGL((embed_kernel<true, KQv>), dim3(M), dim3(256), 0, st, e);      \
         else hipLaunchKernelGGL((embed_kernel<false, KQv>), dim3(M), dim3(256), 0, st, e);         \
     } else
     ACMI_EMBED_CASE(4) ACMI_EMBED_CASE(8) ACMI_EMBED_CASE(16) {}
@@ -726,6 +826,13 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 a.r_out = s->r;
                 if ((rc = gemm_ln_x(c, a, L.w_qkvx, L.b_qkvx, L.cs_qkvx, 4 * d))) return rc;
             } else if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
+            if (L.q_ln_g != nullptr || L.k_ln_g != nullptr) {   // qk_layer_norm on the new q / k rows (before the rotary positions)
+                ACMI_REQUIRE(L.q_ln_g != nullptr && L.k_ln_g != nullptr, "acmi_lm_step: q_ln_g and k_ln_g come together");
+                QkLnArgs qa = {};
+                qa.q = s->q; qa.kc = L.k_cache; qa.kv_bf16 = kvbf; qa.H = H; qa.hd = hd; qa.Tcap = s->Tmax; qa.d = d; qa.rpp = s->Beff;
+                qa.pos = s->pos; qa.qg = L.q_ln_g; qa.qb = L.q_ln_b; qa.kg = L.k_ln_g; qa.kb = L.k_ln_b; qa.eps = m->eps;
+                if ((rc = launch_qk_ln(qa, M, true, st))) return rc;
+            }
             if (m->rope_freq != nullptr) {   // rotary positions on the new q / k rows (rotary models only)
                 RopeArgs ra = {};
                 ra.q = s->q; ra.kc = L.k_cache; ra.kv_bf16 = kvbf; ra.H = H; ra.hd = hd; ra.Tcap = s->Tmax; ra.d = d; ra.rpp = s->Beff;
@@ -774,6 +881,11 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 LinArgs a = {};
                 a.out = s->q; a.out_mode = ACMI_OUT_F32;
                 if ((rc = gemm_ln_x(c, a, L.w_cq, L.b_cq, L.cs_cq, d))) return rc;
+                if (L.cq_ln_g != nullptr) {   // qk_layer_norm_cross on the queries (the keys were normalised when the cache was filled)
+                    QkLnArgs qa = {};
+                    qa.q = s->q; qa.d = d; qa.rpp = s->Beff; qa.qg = L.cq_ln_g; qa.qb = L.cq_ln_b; qa.eps = m->eps;
+                    if ((rc = launch_qk_ln(qa, M, false, st))) return rc;
+                }
                 ca.q = s->q;
             }
             if ((rc = acmi_attn_decode_ex(&ca, stream))) return rc;

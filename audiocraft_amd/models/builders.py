@@ -97,7 +97,8 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
     provider = ConditioningProvider(conds, device=device)
     fuse = {'cross': [], 'prepend': [], 'sum': [], 'input_interpolate': []}
     fuse.update(cfg.get('fuser', {}))
-    fuser = ConditionFuser(fuse)
+    fuser = ConditionFuser(fuse, cross_attention_pos_emb=cfg.get('cross_attention_pos_emb', False),
+                           cross_attention_pos_emb_scale=cfg.get('cross_attention_pos_emb_scale', 1.0))
     n_q = cfg.get('n_q', 4)
     lm = LMModel(get_codebooks_pattern_provider(n_q, cfg.get('codebooks_pattern')), provider, fuser, n_q=n_q,
                  card=cfg.get('card', 2048), dim=dim, num_heads=cfg['num_heads'],
@@ -108,6 +109,8 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
                  positional_embedding=cfg.get('positional_embedding', 'sin'), max_period=cfg.get('max_period', 10000.),
                  positional_scale=cfg.get('positional_scale', 1.0), xpos=cfg.get('xpos', False),
                  past_context=cfg.get('past_context'), layer_scale=cfg.get('layer_scale'),
+                 kv_repeat=cfg.get('kv_repeat', 1), qk_layer_norm=cfg.get('qk_layer_norm', False),
+                 qk_layer_norm_cross=cfg.get('qk_layer_norm_cross', False),
                  weight_dtype=weight_dtype, kv_dtype=kv_dtype, device=device)
     return lm.to(device)
 

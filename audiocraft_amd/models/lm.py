@@ -39,13 +39,36 @@ def _trunc_normal_(t: torch.Tensor, std: float):
     return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-3 * std, b=3 * std)
 
 
+def expand_kv_in_proj(w: torch.Tensor, b: tp.Optional[torch.Tensor], d: int, num_heads: int, kv_repeat: int):
+    """in_proj_weight / bias of a kv_repeat self-attention ([d + 2 kv_dim, d] / [d + 2 kv_dim], transformer.py:196-200) as the
+    [3d, d] / [3d] of an ordinary one: every stored key / value head is laid out once per query head that shares it (query
+    head h reads kv head h // kv_repeat: expand_repeated_kv, transformer.py:90-107, 398-400), so the QKV launch appends
+    ordinary per-head K / V rows to the caches and no kernel knows about the option."""
+    if kv_repeat == 1:
+        return w, b
+    hd, kvd = d // num_heads, d // kv_repeat
+
+    def ex(t):
+        return t.reshape(kvd // hd, hd, *t.shape[1:]).repeat_interleave(kv_repeat, dim=0).reshape(d, *t.shape[1:])
+    w = torch.cat([w[:d], ex(w[d:d + kvd]), ex(w[d + kvd:])], dim=0)
+    if b is not None:
+        b = torch.cat([b[:d], ex(b[d:d + kvd]), ex(b[d + kvd:])], dim=0)
+    return w, b
+
+
 class _Attn(nn.Module):
-    """Parameter container named like StreamingMultiheadAttention (custom / memory-efficient layout)."""
-    def __init__(self, dim: int, bias: bool, device=None):
+    """Parameter container named like StreamingMultiheadAttention (custom / memory-efficient layout).
+    kv_dim < dim: kv_repeat (transformer.py:196-200: the in-projection emits dim query features and kv_dim key / value
+    features each); qk_layer_norm: `q_layer_norm` / `k_layer_norm` over the model dimension (transformer.py:216-222)."""
+    def __init__(self, dim: int, bias: bool, device=None, kv_dim: tp.Optional[int] = None, qk_layer_norm: bool = False):
         super().__init__()
-        self.in_proj_weight = nn.Parameter(torch.empty(3 * dim, dim, device=device))
-        self.in_proj_bias = nn.Parameter(torch.zeros(3 * dim, device=device)) if bias else None
+        kv_dim = dim if kv_dim is None else kv_dim
+        self.in_proj_weight = nn.Parameter(torch.empty(dim + 2 * kv_dim, dim, device=device))
+        self.in_proj_bias = nn.Parameter(torch.zeros(dim + 2 * kv_dim, device=device)) if bias else None
         self.out_proj = nn.Linear(dim, dim, bias=bias, device=device)
+        if qk_layer_norm:
+            self.q_layer_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
+            self.k_layer_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
 
 
 class _Rope(nn.Module):
@@ -73,16 +96,17 @@ class _LayerScale(nn.Module):
 class _Layer(nn.Module):
     """Parameter container named like StreamingTransformerLayer (transformer.py:454-574)."""
     def __init__(self, dim: int, ffn: int, cross_attention: bool, bias_ff: bool, bias_attn: bool, device=None,
-                 layer_scale: tp.Optional[float] = None):
+                 layer_scale: tp.Optional[float] = None, kv_dim: tp.Optional[int] = None, qk_layer_norm: bool = False,
+                 qk_layer_norm_cross: bool = False):
         super().__init__()
-        self.self_attn = _Attn(dim, bias_attn, device)
+        self.self_attn = _Attn(dim, bias_attn, device, kv_dim, qk_layer_norm)
         self.linear1 = nn.Linear(dim, ffn, bias=bias_ff, device=device)
         self.linear2 = nn.Linear(ffn, dim, bias=bias_ff, device=device)
         self.norm1 = nn.LayerNorm(dim, eps=1e-5, device=device)
         self.norm2 = nn.LayerNorm(dim, eps=1e-5, device=device)
         self.cross_attention: tp.Optional[_Attn] = None
         if cross_attention:
-            self.cross_attention = _Attn(dim, bias_attn, device)
+            self.cross_attention = _Attn(dim, bias_attn, device, None, qk_layer_norm_cross)
             self.norm_cross = nn.LayerNorm(dim, eps=1e-5, device=device)
         if layer_scale is not None:   # LayerScale (transformer.py:92-110, 526-538): folded into the branch's last matrix at pack time
             self.layer_scale_1 = _LayerScale(dim, layer_scale, device)
@@ -93,10 +117,12 @@ class _Layer(nn.Module):
 
 class _Transformer(nn.Module):
     def __init__(self, dim, ffn, num_layers, cross_attention, bias_ff, bias_attn, device=None, layer_scale=None,
-                 rope: tp.Optional[_Rope] = None):
+                 rope: tp.Optional[_Rope] = None, kv_dim: tp.Optional[int] = None, qk_layer_norm: bool = False,
+                 qk_layer_norm_cross: bool = False):
         super().__init__()
         self.rope = rope
-        self.layers = nn.ModuleList([_Layer(dim, ffn, cross_attention, bias_ff, bias_attn, device, layer_scale)
+        self.layers = nn.ModuleList([_Layer(dim, ffn, cross_attention, bias_ff, bias_attn, device, layer_scale, kv_dim,
+                                            qk_layer_norm, qk_layer_norm_cross)
                                      for _ in range(num_layers)])
         if rope is not None:
             for layer in self.layers:
@@ -110,8 +136,10 @@ class LMModel(nn.Module):
         weight_dtype: torch.bfloat16 (bench / serving) or torch.float32 (parity mode) for the packed matrices.
         kv_dtype: dtype of the KV caches (defaults to weight_dtype).
     Beyond the MusicGen configuration the decode step also implements the transformer options no release uses
-    (config/model/lm/default.yaml:25-33): positional_embedding 'rope' / 'sin_rope' (+ xpos), past_context and
-    layer_scale.  Unsupported reference options raise: norm_first=False, kv_repeat > 1, qk_layer_norm.
+    (config/model/lm/default.yaml:25-46): positional_embedding 'rope' / 'sin_rope' (+ xpos), past_context, layer_scale,
+    kv_repeat (the shared key / value heads are laid out per query head when the weights are packed: no kernel knows),
+    qk_layer_norm / qk_layer_norm_cross (a launch of their own after the projections).  Unsupported reference options
+    raise: norm_first=False, norms other than 'layer_norm', non-causal / non-GELU transformers.
     """
 
     def __init__(self, pattern_provider: CodebooksPatternProvider, condition_provider: ConditioningProvider,
@@ -133,9 +161,14 @@ class LMModel(nn.Module):
             raise ValueError(f"positional_embedding {positional_embedding!r} (transformer.py:632)")
         if activation != 'gelu' or not causal:
             raise NotImplementedError("only causal, GELU transformers")
-        if kwargs.get('kv_repeat', 1) != 1 or kwargs.get('qk_layer_norm', False):
-            raise NotImplementedError("kv_repeat / qk_layer_norm are not used by MusicGen")
         assert dim % num_heads == 0 and dim % 8 == 0
+        self.kv_repeat = int(kwargs.get('kv_repeat', 1))
+        self.qk_layer_norm = bool(kwargs.get('qk_layer_norm', False))
+        self.qk_layer_norm_cross = bool(kwargs.get('qk_layer_norm_cross', False))
+        assert self.kv_repeat >= 1 and num_heads % self.kv_repeat == 0, "kv_repeat must divide num_heads (transformer.py:197)"
+        assert not self.qk_layer_norm or self.kv_repeat == 1, "qk_layer_norm needs kv_repeat == 1 (transformer.py:219)"
+        if dim > 2048 and (self.qk_layer_norm or self.qk_layer_norm_cross):
+            raise NotImplementedError("qk_layer_norm for dim > 2048 (acmi_layer_norm_rows)")
         self.positional_embedding = positional_embedding
         self.xpos = bool(kwargs.get('xpos', False))
         self.past_context: tp.Optional[int] = kwargs.get('past_context')
@@ -162,8 +195,9 @@ class LMModel(nn.Module):
         rope = None
         if positional_embedding in ('rope', 'sin_rope'):
             rope = _Rope(dim // num_heads, max_period, self.xpos, device)
+        kv_dim = (dim // num_heads) * (num_heads // self.kv_repeat)
         self.transformer = _Transformer(dim, self.ffn_dim, num_layers, cross_attention, bias_ff, bias_attn, device, layer_scale,
-                                        rope)
+                                        rope, kv_dim, self.qk_layer_norm, self.qk_layer_norm_cross and cross_attention)
         self.out_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
         self.linears = nn.ModuleList([nn.Linear(dim, card, bias=bias_proj, device=device) for _ in range(n_q)])
         self._init_weights(weight_init, depthwise_init, zero_bias_init)
@@ -280,6 +314,11 @@ class LMModel(nn.Module):
             return W(wf), Fp(bias), Fp(wf.to(wd).double().sum(dim=1).float())
 
         d = self.dim
+
+        def self_in_proj(attn):
+            return expand_kv_in_proj(attn.in_proj_weight.detach(), None if attn.in_proj_bias is None else attn.in_proj_bias.detach(),
+                                     d, self.num_heads, self.kv_repeat)
+
         layers = (_C.LMLayer * self.num_layers)()
         pk: dict = {'keep': keep, 'layers': layers, 'per_layer': []}
         for li, layer in enumerate(self.transformer.layers):
@@ -304,7 +343,11 @@ class LMModel(nn.Module):
             if d % 8 == 0 and d // 8 <= 256 and self.ffn_dim % kt2 == 0:
                 # 8-feature workgroups for FFN2 in calls of <= 32 rows (acmi_lm_layer.w_ff2h): a second copy of the weight
                 ent['w_ff2h'] = W(w_ff2_32, half=True)
-            ent['w_qkv'], ent['b_qkv'], ent['cs_qkv'] = folded(layer.self_attn.in_proj_weight, layer.norm1, layer.self_attn.in_proj_bias)
+            sa_w, sa_b = self_in_proj(layer.self_attn)
+            ent['w_qkv'], ent['b_qkv'], ent['cs_qkv'] = folded(sa_w, layer.norm1, sa_b)
+            if self.qk_layer_norm:
+                for key, mod in (('q_ln', layer.self_attn.q_layer_norm), ('k_ln', layer.self_attn.k_layer_norm)):
+                    ent[key + '_g'], ent[key + '_b'] = Fp(mod.weight), Fp(mod.bias)
             ent['w_ff1'], ent['b_ff1'], ent['cs_ff1'] = folded(layer.linear1.weight, layer.norm2, layer.linear1.bias)
             if layer.cross_attention is not None:
                 ca = layer.cross_attention
@@ -313,19 +356,25 @@ class LMModel(nn.Module):
                 if ipb is not None:   # k / v biases: added when the cross-attention caches are filled (_project_cross_kv)
                     ent['b_ck'], ent['b_cv'] = Fp(ipb[d:2 * d]), Fp(ipb[2 * d:])
                     pk['cross_kv_bias'] = pk.get('cross_kv_bias', False) or bool((ipb[d:] != 0).any())
-                # x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T: the x0 part is a fourth block of
-                # output features of the QKV launch (raw, no LayerNorm epilogue), the att part rides in the out-projection
-                # launch (include/acmi.h, acmi_lm_layer.w_qkvx / w_mq)
-                g_c = layer.norm_cross.weight.detach().to(device=dev, dtype=torch.float32)
-                wq = ipw[:d].detach().to(device=dev, dtype=torch.float32) * g_c[None, :]
-                g_1 = layer.norm1.weight.detach().to(device=dev, dtype=torch.float32)
-                wqkv = layer.self_attn.in_proj_weight.detach().to(device=dev, dtype=torch.float32) * g_1[None, :]
-                ent['w_qkvx'] = W(torch.cat([wqkv, wq], dim=0))
-                ent['b_qkvx'] = Fp(torch.cat([ent['b_qkv'], torch.zeros(d, device=dev)]))
-                ent['cs_qkvx'] = Fp(torch.cat([ent['cs_qkv'], torch.zeros(d, device=dev)]))
-                ent['w_mq'] = W(wq @ w_out32)
-                if 'b_out' in ent:   # r = x1 W_cq'^T with x1 = x0 + att W_out^T + b_out
-                    ent['b_mq'] = Fp(wq @ ent['b_out'])
+                if self.qk_layer_norm_cross:
+                    # the query goes through q_layer_norm: it is no longer linear in x1, so it keeps a projection launch of
+                    # its own (no w_qkvx / w_mq); the keys are normalised when the cross-attention caches are filled
+                    ent['cq_ln_g'], ent['cq_ln_b'] = Fp(ca.q_layer_norm.weight), Fp(ca.q_layer_norm.bias)
+                    ent['ck_ln_g'], ent['ck_ln_b'] = Fp(ca.k_layer_norm.weight), Fp(ca.k_layer_norm.bias)
+                else:
+                    # x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T: the x0 part is a fourth block of
+                    # output features of the QKV launch (raw, no LayerNorm epilogue), the att part rides in the out-projection
+                    # launch (include/acmi.h, acmi_lm_layer.w_qkvx / w_mq)
+                    g_c = layer.norm_cross.weight.detach().to(device=dev, dtype=torch.float32)
+                    wq = ipw[:d].detach().to(device=dev, dtype=torch.float32) * g_c[None, :]
+                    g_1 = layer.norm1.weight.detach().to(device=dev, dtype=torch.float32)
+                    wqkv = sa_w.to(device=dev, dtype=torch.float32) * g_1[None, :]
+                    ent['w_qkvx'] = W(torch.cat([wqkv, wq], dim=0))
+                    ent['b_qkvx'] = Fp(torch.cat([ent['b_qkv'], torch.zeros(d, device=dev)]))
+                    ent['cs_qkvx'] = Fp(torch.cat([ent['cs_qkv'], torch.zeros(d, device=dev)]))
+                    ent['w_mq'] = W(wq @ w_out32)
+                    if 'b_out' in ent:   # r = x1 W_cq'^T with x1 = x0 + att W_out^T + b_out
+                        ent['b_mq'] = Fp(wq @ ent['b_out'])
                 sb = scaled_bias(ca.out_proj.bias, 'layer_scale_cross')
                 if sb is not None:
                     ent['b_cout'] = sb
@@ -333,7 +382,8 @@ class LMModel(nn.Module):
                             'w_cout': W(scaled(ca.out_proj.weight, 'layer_scale_cross'))})
             L = layers[li]
             for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
-                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h', 'b_out', 'b_cout', 'b_ff2', 'b_mq'):
+                      'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h', 'b_out', 'b_cout', 'b_ff2', 'b_mq',
+                      'q_ln_g', 'q_ln_b', 'k_ln_g', 'k_ln_b', 'cq_ln_g', 'cq_ln_b'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]
@@ -420,7 +470,12 @@ class LMModel(nn.Module):
             ls = getattr(layer, ls_name, None)
             return m if ls is None else m / ls.scale.detach().float()[:, None]
         if key == 'self_attn.in_proj_weight':
-            return (plain(ent['w_qkv']) / norm_w(layer.norm1)[None, :]).to(dtype)
+            m = plain(ent['w_qkv']) / norm_w(layer.norm1)[None, :]
+            if self.kv_repeat > 1:   # the packs hold every shared key / value head once per query head: keep the first copy
+                hd, rep = d // self.num_heads, self.kv_repeat
+                first = lambda t: t.reshape(self.num_heads // rep, rep, hd, d)[:, 0].reshape(-1, d)  # noqa: E731
+                m = torch.cat([m[:d], first(m[d:2 * d]), first(m[2 * d:])], dim=0)
+            return m.to(dtype)
         if key == 'self_attn.out_proj.weight':
             return unscale(plain(ent['w_out']), 'layer_scale_1').to(dtype)
         if key == 'linear1.weight':
@@ -504,8 +559,15 @@ class LMModel(nn.Module):
 
     def _make_state(self, run, B, use_cfg, Tmax, Lc, S, prepend, record_logits, use_sampling, temp, top_k, top_p,
                     cfg_coef, seed, cfg_coef_beta: float = 0.0, cross_lens: tp.Optional[torch.Tensor] = None,
-                    row_off: tp.Optional[torch.Tensor] = None) -> _C.LMState:
+                    row_off: tp.Optional[torch.Tensor] = None, input_add: tp.Optional[torch.Tensor] = None) -> _C.LMState:
         st = _C.LMState()
+        if input_add is not None:    # fuser 'sum' / 'input_interpolate' (acmi_lm_state.input_add): [Beff, n_add, d] f32
+            assert input_add.dim() == 3 and input_add.shape[0] == run['Beff'] and input_add.shape[2] == self.dim, input_add.shape
+            run['input_add'] = input_add.to(device=self.device, dtype=torch.float32).contiguous()
+            st.input_add, st.n_add = run['input_add'].data_ptr(), run['input_add'].shape[1]
+        else:
+            run.pop('input_add', None)
+            st.input_add, st.n_add = None, 0
         if row_off is not None:      # left padding of the rows' streams (two_step_cfg with unequal prepend lengths)
             if self.positional_embedding in ('rope', 'sin_rope'):
                 raise NotImplementedError("two_step_cfg with prepended conditions of different lengths on a rotary model")
@@ -551,6 +613,8 @@ class LMModel(nn.Module):
         for li in range(self.num_layers):
             ent = pk['per_layer'][li]
             _C.linear(flat, ent['w_ck'], tmp, bias=ent.get('b_ck'))
+            if 'ck_ln_g' in ent:     # qk_layer_norm_cross: k_layer_norm on the projected keys (transformer.py:358-360)
+                _C.layer_norm_rows(tmp, ent['ck_ln_g'], ent['ck_ln_b'], 1e-5, out=tmp)
             _C.kv_store(tmp.view(Beff, Lc, d), run['ck'][li], 0)
             _C.linear(flat, ent['w_cv'], tmp, bias=ent.get('b_cv'))
             _C.kv_store(tmp.view(Beff, Lc, d), run['cv'][li], 0)
@@ -606,6 +670,16 @@ class LMModel(nn.Module):
             if Pc != Pn:
                 row_off = torch.tensor([P - Pc] * p_c.shape[0] + [P - Pn] * p_n.shape[0], dtype=torch.int32)
         return prepend, cross_src, lens, row_off
+
+    def _input_add_table(self, ops_groups, lengths: tp.Sequence[int]) -> tp.Optional[torch.Tensor]:
+        """acmi_lm_state.input_add for consecutive reference calls of `lengths` token steps: [rows, sum(lengths), d], rows =
+        the row groups' conditions stacked like the other condition tensors (`ops_groups`: one `ConditionFuser.input_ops`
+        list per separately encoded group -- one for the batched CFG modes, two for two_step_cfg).  None without ops."""
+        if not any(ops_groups):
+            return None
+        assert all(ops_groups), "every row group needs the same 'sum' / 'input_interpolate' conditions"
+        per_call = [torch.cat([ConditionFuser.input_add_rows(ops, T) for ops in ops_groups], dim=0) for T in lengths]
+        return torch.cat(per_call, dim=1)
 
     # ------------------------------------------------------------------------------------- generate
     @torch.no_grad()
@@ -689,8 +763,13 @@ class LMModel(nn.Module):
         cross_lens, row_off = None, None
         if two_step:
             prepend, cross_src, cross_lens, row_off = self._fuse_two_step(*cfg_conditions)
+            ops_groups = [self.fuser.input_ops(c) for c in cfg_conditions]
         else:
             prepend, cross_src = self.fuser.fuse(cfg_conditions)
+            ops_groups = [self.fuser.input_ops(cfg_conditions)]
+        # 'sum' / 'input_interpolate' conditions: the reference's first call covers the steps before the first generated one,
+        # every later call is one step (lm.py:536-543)
+        input_add = self._input_add_table(ops_groups, [start_offset_sequence, 1])
         if self.has_cross_attention:
             assert cross_src is not None, "this model cross-attends to a condition but none was given"
         else:
@@ -708,7 +787,7 @@ class LMModel(nn.Module):
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
         state = self._make_state(run, B, use_cfg, Tmax, Lc, S, prepend, return_logits, use_sampling, temp, top_k,
                                  top_p, coef, seed, cfg_coef_beta=0.0 if cfg_coef_beta is None else cfg_coef_beta,
-                                 cross_lens=cross_lens, row_off=row_off)
+                                 cross_lens=cross_lens, row_off=row_off, input_add=input_add)
         desc = self._packed['desc']
         desc.pos_table = run['pos_table'].data_ptr()
         run['gen_sequence'].copy_(gen_sequence)
@@ -796,7 +875,7 @@ class LMModel(nn.Module):
         fits its tiles; ACMI_PREFILL=chunk forces the decode kernels on PREFILL_CHUNK positions per call (A/B, tests)."""
         import os
         mode = os.environ.get('ACMI_PREFILL', '')
-        if mode == 'chunk':
+        if mode == 'chunk' or self.qk_layer_norm or self.qk_layer_norm_cross:   # qk_layer_norm: decode kernels only
             return False
         kt = _C._tile_params(self.weight_dtype)[1]
         hd = self.dim // self.num_heads
@@ -882,7 +961,12 @@ class LMModel(nn.Module):
         run = self._prepare_run(B, _C.CFG_NONE, P + cap + 1, Lc, cap + 1)
         if prepend is not None:
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
-        state = self._make_state(run, B, _C.CFG_NONE, P + cap + 1, Lc, cap + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
+        ops = self.fuser.input_ops(condition_tensors)
+        # 'sum' / 'input_interpolate': one entry per stream step, filled call by call (each call's length is what the
+        # reference's fuser resamples to: _streaming_forward)
+        input_add = torch.zeros(B, cap + 1, self.dim, device=dev) if ops else None
+        state = self._make_state(run, B, _C.CFG_NONE, P + cap + 1, Lc, cap + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0,
+                                 input_add=input_add)
         desc = self._packed['desc']
         desc.pos_table = run['pos_table'].data_ptr()
         run['gen_sequence'].fill_(-1)
@@ -891,7 +975,7 @@ class LMModel(nn.Module):
         if cross_src is not None:
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
         self._prefill(desc, state, P)   # the fuser prepends on the first call only (conditioners.py:1722-1741)
-        self._stream = {'run': run, 'state': state, 'desc': desc, 'prepend': prepend, 'P': P, 'steps': 0, 'B': B}
+        self._stream = {'run': run, 'state': state, 'desc': desc, 'prepend': prepend, 'P': P, 'steps': 0, 'B': B, 'ops': ops}
         return self._stream
 
     def _streaming_forward(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
@@ -905,6 +989,8 @@ class LMModel(nn.Module):
         assert st['steps'] + S <= self.streaming_capacity, "stream longer than LMModel.streaming_capacity"
         run, off = st['run'], st['steps']
         run['gen_sequence'][:, :, off:off + S] = sequence.to(self.device)
+        if st.get('ops'):
+            run['input_add'][:, off:off + S] = ConditionFuser.input_add_rows(st['ops'], S).to(self.device)
         outs = []
         for _ in range(S):
             _C.lm_step(st['desc'], st['state'], _C.STEP_DECODE)
@@ -931,8 +1017,9 @@ class LMModel(nn.Module):
         dropped = 0 if not pc else max(0, t - pc) - max(0, st.get('first_len', t) - pc)
         for li in range(self.num_layers):
             pre = f'transformer.layers.{li}.self_attn.'
-            state[pre + 'past_keys'] = run['k'][li][:, :, :t]
-            state[pre + 'past_values'] = run['v'][li][:, :, :t]
+            # kv_repeat: the caches hold every shared head once per query head; the state lists the H / kv_repeat stored heads
+            state[pre + 'past_keys'] = run['k'][li][:, ::self.kv_repeat, :t]
+            state[pre + 'past_values'] = run['v'][li][:, ::self.kv_repeat, :t]
             state[pre + 'offset'] = torch.tensor(dropped, dtype=torch.long, device=dev)
         return state
 
@@ -956,7 +1043,9 @@ class LMModel(nn.Module):
                 # full length (this class's own states) or trimmed to the last past_context keys (a reference-format state)
                 n = src.shape[2]
                 assert n == t or (pc and n == min(t, pc)), (src.shape, t, pc)
-                if src.data_ptr() != cache.data_ptr():
+                if self.kv_repeat > 1:
+                    cache[:, :, t - n:t].copy_(src.repeat_interleave(self.kv_repeat, dim=1) if src.shape[1] != cache.shape[1] else src)
+                elif src.data_ptr() != cache.data_ptr():
                     cache[:, :, t - n:t].copy_(src)
                 known.add(pre + name)
             known.add(pre + 'offset')
@@ -989,7 +1078,10 @@ class LMModel(nn.Module):
         run = self._prepare_run(B, _C.CFG_NONE, P + S + 1, Lc, S + 1)
         if prepend is not None:
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
-        state = self._make_state(run, B, _C.CFG_NONE, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0)
+        # the reference's forward is ONE call of S steps: that is the length its fuser interpolates a condition to
+        input_add = self._input_add_table([self.fuser.input_ops(condition_tensors)], [S])
+        state = self._make_state(run, B, _C.CFG_NONE, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0,
+                                 input_add=input_add)
         desc = self._packed['desc']
         desc.pos_table = run['pos_table'].data_ptr()
         seq = torch.full((B, K, S + 1), -1, dtype=torch.long, device=dev)

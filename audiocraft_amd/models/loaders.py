@@ -74,7 +74,8 @@ def parse_cfg(text_or_dict) -> dict:
 
 
 TRANSFORMER_OPTIONS = ('positional_embedding', 'xpos', 'past_context', 'layer_scale', 'positional_scale', 'max_period',
-                       'bias_ff', 'bias_attn', 'bias_proj')   # biases: true in config/model/lm/default.yaml, false in the releases
+                       'bias_ff', 'bias_attn', 'bias_proj',   # biases: true in config/model/lm/default.yaml, false in the releases
+                       'kv_repeat', 'qk_layer_norm', 'qk_layer_norm_cross')   # config/model/lm/default.yaml:43-46
 
 
 def lm_cfg_from_xp(cfg: dict) -> dict:
@@ -110,6 +111,9 @@ def lm_cfg_from_xp(cfg: dict) -> dict:
     out['conditioners'] = conds
     fuser = dict(cfg.get('fuser') or {})
     out['fuser'] = {k: list(v) for k, v in fuser.items() if k in ('cross', 'prepend', 'sum', 'input_interpolate')}
+    for k in ('cross_attention_pos_emb', 'cross_attention_pos_emb_scale'):   # reference builders.py get_condition_fuser
+        if fuser.get(k) is not None:
+            out[k] = fuser[k]
     return out
 
 

@@ -396,7 +396,9 @@ class ConditioningProvider(nn.Module):
 
 class ConditionFuser(nn.Module):
     """How each condition enters the LM (reference conditioners.py:1672-1763).  MusicGen uses 'cross'
-    (text models) or 'prepend' (melody models); 'sum' / 'input_interpolate' are not on this path."""
+    (text models) or 'prepend' (melody models).  'sum' / 'input_interpolate' conditions are added to the embedded input by
+    the embedding kernel (`input_ops` -> acmi_lm_state.input_add); `cross_attention_pos_emb` adds a sinusoidal embedding to
+    the cross-attention source."""
     FUSING_METHODS = ["sum", "prepend", "cross", "ignore", "input_interpolate"]
 
     def __init__(self, fuse2cond: tp.Dict[str, tp.List[str]], cross_attention_pos_emb: bool = False,
@@ -404,16 +406,18 @@ class ConditionFuser(nn.Module):
         super().__init__()
         assert all(k in self.FUSING_METHODS for k in fuse2cond.keys()), \
             f"Got invalid fuse method, allowed methods: {self.FUSING_METHODS}"
-        if cross_attention_pos_emb:
-            raise NotImplementedError("cross_attention_pos_emb is not used by MusicGen")
-        for k in ('sum', 'input_interpolate'):
-            if fuse2cond.get(k):
-                raise NotImplementedError(f"fuse method '{k}' is not used by MusicGen")
+        self.cross_attention_pos_emb = cross_attention_pos_emb
+        self.cross_attention_pos_emb_scale = cross_attention_pos_emb_scale
         self.fuse2cond = fuse2cond
         self.cond2fuse: tp.Dict[str, str] = {}
         for fuse_method, conditions in fuse2cond.items():
             for condition in conditions:
                 self.cond2fuse[condition] = fuse_method
+
+    def _check_known(self, conditions):
+        assert set(conditions.keys()).issubset(set(self.cond2fuse.keys())), \
+            f"given conditions contain unknown attributes for fuser, expected {self.cond2fuse.keys()}, " \
+            f"got {conditions.keys()}"
 
     def fuse(self, conditions: tp.Dict[str, ConditionType]) -> tp.Tuple[tp.Optional[torch.Tensor],
                                                                           tp.Optional[torch.Tensor]]:
@@ -422,10 +426,8 @@ class ConditionFuser(nn.Module):
         Same ordering as the reference loop (conditioners.py:1730-1748): 'cross' conditions are
         concatenated in dict order; every 'prepend' condition is put IN FRONT of what has been
         built so far, so with the provider's dict order {description, self_wav} the prefix is
-        [self_wav ; description]."""
-        assert set(conditions.keys()).issubset(set(self.cond2fuse.keys())), \
-            f"given conditions contain unknown attributes for fuser, expected {self.cond2fuse.keys()}, " \
-            f"got {conditions.keys()}"
+        [self_wav ; description].  'sum' / 'input_interpolate' conditions are returned by `input_ops`."""
+        self._check_known(conditions)
         prepend = None
         cross = None
         for cond_type, (cond, _mask) in conditions.items():
@@ -434,8 +436,49 @@ class ConditionFuser(nn.Module):
                 prepend = cond if prepend is None else torch.cat([cond, prepend], dim=1)
             elif op == 'cross':
                 cross = cond if cross is None else torch.cat([cross, cond], dim=1)
+            elif op in ('sum', 'input_interpolate'):
+                if prepend is not None:
+                    # the reference would add this condition to the already prepended rows as well (its loop works on the
+                    # concatenated input); the provider's dict order (text, then wav, then joint conditions) decides
+                    raise NotImplementedError(f"'{op}' condition {cond_type!r} after a 'prepend' condition in the provider's order")
             elif op == 'ignore':
                 continue
             else:
                 raise ValueError(f"unknown op ({op})")
+        if self.cross_attention_pos_emb and cross is not None:
+            # conditioners.py:1750-1757: create_sin_embedding (transformer.py:70-89) of the source positions, default period
+            L, d = cross.shape[1], cross.shape[2]
+            half = d // 2
+            pos = torch.arange(L, device=cross.device, dtype=torch.float32).view(1, -1, 1)
+            adim = torch.arange(half, device=cross.device, dtype=torch.float32).view(1, 1, -1)
+            phase = pos / (torch.full([], 10000., device=cross.device) ** (adim / (half - 1)))
+            cross = cross + self.cross_attention_pos_emb_scale * torch.cat([torch.cos(phase), torch.sin(phase)], dim=-1).to(cross)
         return prepend, cross
+
+    def input_ops(self, conditions: tp.Dict[str, ConditionType]) -> tp.List[tp.Tuple[str, torch.Tensor]]:
+        """The 'sum' / 'input_interpolate' conditions in dict order: [(op, cond [B, Tc, d])] (conditioners.py:1733-1737)."""
+        self._check_known(conditions)
+        return [(self.cond2fuse[k], cond) for k, (cond, _mask) in conditions.items()
+                if self.cond2fuse[k] in ('sum', 'input_interpolate')]
+
+    @staticmethod
+    def input_add_rows(ops: tp.Sequence[tp.Tuple[str, torch.Tensor]], T: int) -> tp.Optional[torch.Tensor]:
+        """What the reference's fuser adds to the embedded input of ONE call of T steps: [B, T, d] f32 (None without ops).
+        'sum': the condition itself, one frame broadcast over the call or one frame per step (its in-place `input += cond`
+        allows nothing else); 'input_interpolate': F.interpolate(cond, size=T), i.e. frame min(floor(t * f32(Tc / T)), Tc - 1)
+        for step t -- a gather, evaluated in f32 like ATen's nearest kernel."""
+        total = None
+        for op, cond in ops:
+            cond = cond.float()
+            Tc = cond.shape[1]
+            if op == 'sum':
+                if Tc not in (1, T):
+                    raise RuntimeError(f"'sum' condition of {Tc} frames cannot be added to a call of {T} steps "
+                                       "(the reference's in-place add fails the same way)")
+                add = cond.expand(-1, T, -1)
+            else:
+                scale = torch.tensor(Tc, dtype=torch.float32) / T
+                idx = torch.floor(torch.arange(T, dtype=torch.float32) * scale).long().clamp_max(Tc - 1)
+                add = cond[:, idx.to(cond.device)]
+            total = add if total is None else total + add
+        return total

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 160 /* 0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
+#define ACMI_VERSION 170 /* 0.1.7: qk_layer_norm (acmi_lm_layer.q_ln_g .. cq_ln_b, acmi_layer_norm_rows), fuser 'sum' / 'input_interpolate'
+                            (acmi_lm_state.input_add).  0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
                             colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
                             with prepended conditions of different lengths).  0.1.4: acmi_conv1d takes pre-tiled weights + a work buffer (acmi_conv1d_tile_weights /
                             _weight_floats / _work_floats); MultiBandDiffusion entry points.  0.1.3: single-term raw activations with a per-row shift (acmi_linear_desc.a_shift / xt_shift /
@@ -206,6 +207,16 @@ typedef struct {
     const float* b_out; const float* b_cout; const float* b_ff2; const float* b_mq;
     const void* cvt_cache;  /* cross-attention values TIME-MINOR [Beff, H, hd, cvt_tcap] in kvdtype (acmi_lm_state.cvt_tcap; zero
                                beyond Lc), for the MFMA-tiled prefill's cross-attention; NULL = it runs the decode kernel per row */
+    /* qk_layer_norm (transformer.py:216-222, 388-392; config/model/lm/default.yaml:43, off in every release): LayerNorm over
+     * the full model dimension of the projected queries and of the projected keys, f32 [d] weight / bias each, applied by a
+     * launch of its own right after the QKV GEMM (before the rotary positions): q in place in state->q, k in place in the
+     * cache row the GEMM has just appended (a bf16 cache therefore rounds k twice; exact with an f32 cache).  All four NULL =
+     * off.  Not with the one-forward prefill (pf_xn). */
+    const float* q_ln_g; const float* q_ln_b; const float* k_ln_g; const float* k_ln_b;
+    /* qk_layer_norm_cross (transformer.py:358-360, 526-529): the same on the cross-attention's queries, f32 [d] each or NULL.
+     * The step then runs the cross query as a projection of its own (the split of w_qkvx / w_mq needs a query that is linear
+     * in x1).  The cross-attention KEYS are normalised by the caller when it fills ck_cache (acmi_layer_norm_rows). */
+    const float* cq_ln_g; const float* cq_ln_b;
 } acmi_lm_layer;
 
 typedef struct {
@@ -305,6 +316,13 @@ typedef struct {
                                left -- `prepend` holds zeros there -- so that every row reaches its first token at the same stream
                                position and one sampler launch serves all of them.  Not with rotary positions, not with the
                                one-forward prefill (pf_xn) */
+    const float* input_add; /* device f32 [Beff, n_add, d] or NULL: what the fuser's 'sum' / 'input_interpolate' conditions add to
+                               the embedded input (conditioners.py:1733-1737: `input += cond` before the positional embedding).
+                               Token step t of cache row b (t = stream position - n_prepend; prepended rows take nothing) adds
+                               input_add[b, min(t, n_add - 1)]: the host lays out one entry per step of the reference's first
+                               call (an interpolated condition is resampled to that call's length) and one last entry for
+                               every later single-step call */
+    int n_add;              /* entries per row of input_add (>= 1 when input_add is not NULL) */
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0
@@ -320,6 +338,12 @@ typedef struct {
  * the device, so a captured hipGraph of this call can be replayed for every step; pos[0] is
  * incremented at the end. */
 int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int mode, void* stream);
+
+/* nn.LayerNorm over the last dimension of a row-major f32 matrix x [M, d] (two-pass statistics, biased variance,
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta; gamma / beta f32 [d] or NULL = 1 / 0); y may alias x.  d <= 2048.
+ * The kernel behind acmi_lm_layer.q_ln_g ..; exported for the cross-attention keys of qk_layer_norm_cross models, which
+ * the caller normalises once per generate before acmi_kv_store (transformer.py:358-360). */
+int acmi_layer_norm_rows(const float* x, const float* gamma, const float* beta, float* y, int M, int d, float eps, void* stream);
 
 /* create_sin_embedding (transformer.py:70-89) for positions 0..T-1: table[t, :d/2] = cos(t / f_i),
  * table[t, d/2:] = sin(t / f_i), f_i = freq[i] = max_period ** (i / (d/2 - 1)) supplied by the host

@@ -1,0 +1,190 @@
+"""-m gpu: the transformer / fuser options of the reference that no MusicGen release switches on -- kv_repeat,
+qk_layer_norm (+ cross), the fuser's 'sum' / 'input_interpolate' methods and cross_attention_pos_emb
+(config/model/lm/default.yaml:43-46; transformer.py:196-222, 358-400; conditioners.py:1733-1757) -- on the HIP path, against
+goldens of the unmodified reference (tests/golden/make_options_golden.py) and the CPU oracle at a larger size.
+
+(File name: sorts after the suites of the released configurations, which the driver's `-x` run therefore finishes first.)"""
+import dataclasses
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from oracle import lm as olm  # noqa: E402
+from test_host_cpu import options_lm_cfg  # noqa: E402
+from test_oracle_golden import lm_cfg, options_inputs  # noqa: E402
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def build(cfg, sd, wdt=torch.float32):
+    from audiocraft_amd.models import builders
+    lm = builders.get_lm_model(options_lm_cfg(cfg), 'cuda', wdt)
+    lm.load_state_dict({k: v for k, v in sd.items()
+                        if not (k.startswith('condition_provider.conditioners.') and '.description.' not in k)})
+    return lm
+
+
+def condition_tensors(name, a):
+    ones = lambda t: torch.ones(t.shape[:2], dtype=torch.int64).cuda()  # noqa: E731
+    ct = {'description': (a['cond_description'].cuda(), ones(a['cond_description']))}
+    if name == 'lm_fuser_sum':      # the provider's dict order: description, genre, curve
+        ct['genre'] = (a['cond_genre'].cuda(), ones(a['cond_genre']))
+        ct['curve'] = (a['cond_curve'].cuda(), ones(a['cond_curve']))
+    return ct
+
+
+@pytest.mark.parametrize('M,d', [(1, 32), (6, 256), (48, 1536), (5, 2048), (3, 1000)])
+def test_layer_norm_rows_vs_torch(M, d):
+    """acmi_layer_norm_rows (the kernel behind qk_layer_norm) against torch's fp32 layer_norm: affine, plain, in place."""
+    from audiocraft_amd import _C
+    g = torch.Generator().manual_seed(M * 7 + d)
+    x = (3.0 * torch.randn(M, d, generator=g) + 5.0).cuda()
+    gamma, beta = (1.0 + 0.2 * torch.randn(d, generator=g)).cuda(), (0.3 * torch.randn(d, generator=g)).cuda()
+    ref = torch.nn.functional.layer_norm(x.double(), (d,), gamma.double(), beta.double(), 1e-5)
+    got = _C.layer_norm_rows(x, gamma, beta, 1e-5)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+    ref0 = torch.nn.functional.layer_norm(x.double(), (d,), None, None, 1e-5)
+    assert (_C.layer_norm_rows(x, None, None, 1e-5).double() - ref0).abs().max().item() < 2e-5
+    y = x.clone()
+    _C.layer_norm_rows(y, gamma, beta, 1e-5, out=y)
+    assert torch.equal(y, got)
+    with pytest.raises(_C.AcmiError):
+        _C.layer_norm_rows(torch.zeros(2, 4096, device='cuda'), None, None)
+
+
+@pytest.fixture(params=['big', 'chunk'])
+def prefill_mode(request, monkeypatch):
+    monkeypatch.setenv('ACMI_PREFILL', request.param)
+    return request.param
+
+
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum'])
+def test_lm_options_vs_reference_golden(name, prefill_mode):
+    """Teacher-forced logits, greedy tokens + per-step CFG logits without and with a 4-step prompt (the first call then spans
+    several positions: the multi-position prefill, and the length an interpolated condition is resampled to), graph replay ==
+    eager launches, bf16 packs."""
+    cfg, sd, a = load_golden(name)
+    lm = build(cfg, sd)
+    ct = condition_tensors(name, a)
+    logits = lm.forward_steps(a['tf_sequence'].cuda(), ct).cpu()
+    r = rel(logits, a['tf_logits'])
+    assert r < 1e-4, f"teacher-forced logits rel-L2 {r}"
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
+    toks, lg = lm.generate(a['prompt'].cuda(), [], max_gen_len=11, use_sampling=False, condition_tensors=ct, check=True,
+                           return_logits=True)
+    assert torch.equal(toks.cpu(), a['cont_tokens'])
+    first = olm.cfg_mix(a['cont_first_logits'][:, :, -1:], cfg['cfg_coef'])      # the reference's first call, last step
+    assert rel(lg[:, :, :1].cpu(), first) < 1e-4
+    t1 = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct, use_graph=False)
+    assert torch.equal(t1.cpu(), a['greedy_tokens'])
+    lm16 = build(cfg, sd, torch.bfloat16)
+    assert rel(lm16.forward_steps(a['tf_sequence'].cuda(), ct).cpu(), a['tf_logits']) < 3e-2
+
+
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_fuser_sum'])
+def test_lm_options_streaming_calls_vs_oracle(name):
+    """The StreamingModule protocol on these options: a first call of 4 steps, then single steps, against the oracle run on the
+    same split (every call resamples an 'input_interpolate' condition to ITS length; a kv_repeat stream lists the stored
+    H / kv_repeat heads and can be rewound from that state)."""
+    cfg, sd, a = load_golden(name)
+    c = lm_cfg(cfg)
+    lm = build(cfg, sd)
+    ct = condition_tensors(name, a)
+    cross, ops = options_inputs(name, cfg, a)
+    seq = a['tf_sequence']
+    st = olm.LMState(c.num_layers)
+    ref = [olm.lm_forward(sd, c, seq[..., :4], cross, None, st, ops)]
+    ref += [olm.lm_forward(sd, c, seq[..., i:i + 1], cross, None, st, ops) for i in range(4, 7)]
+    with lm.streaming():
+        got = [lm(seq[..., :4].cuda(), [], ct).cpu()]
+        state5 = None
+        for i in range(4, 7):
+            got.append(lm(seq[..., i:i + 1].cuda(), [], ct).cpu())
+            if i == 4:
+                state5 = {k: v.clone() for k, v in lm.get_streaming_state().items()}
+        assert rel(torch.cat(got, dim=2), torch.cat(ref, dim=2)) < 1e-4
+        k0 = state5['transformer.layers.0.self_attn.past_keys']
+        assert k0.shape == (seq.shape[0], c.num_heads // c.kv_repeat, 5, c.dim // c.num_heads)
+        assert rel(k0.cpu(), st.past_k[0][:, :, :5]) < 1e-5
+        lm.set_streaming_state(state5)            # rewind to 5 steps and replay step 5
+        again = lm(seq[..., 5:6].cuda(), [], ct).cpu()
+        assert rel(again, ref[2]) < 1e-4
+
+
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize('B', [3, 12])       # CFG rows 6 / 24: one and two 16-row blocks per GEMM
+def test_lm_options_midsize_vs_oracle(wdt, tol, B):
+    """d = 256, 4 layers, card 2048: qk_layer_norm + qk_layer_norm_cross + attention biases, a 'sum' and an 'input_interpolate'
+    condition, and (second model) kv_repeat = 4 with rotary positions, against the oracle."""
+    from audiocraft_amd.models import builders
+    for extra in (dict(qk_layer_norm=True, qk_layer_norm_cross=True, bias_attn=True,
+                       fuser={'cross': ['description'], 'sum': ['genre'], 'input_interpolate': ['curve']}),
+                  dict(kv_repeat=4, positional_embedding='sin_rope', bias_attn=True, fuser={'cross': ['description']})):
+        torch.manual_seed(1)
+        cfg = dict(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0,
+                   conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 64, 'length': 6}}, **extra)
+        lm = builders.get_lm_model(cfg, 'cuda', wdt)
+        with torch.no_grad():
+            for k, p in lm.named_parameters():
+                if 'norm' in k:
+                    p.add_(0.1 * torch.randn_like(p))
+                if k.endswith('in_proj_bias') or k.endswith('out_proj.bias'):
+                    p.add_(0.05 * torch.randn_like(p))
+        sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+        if wdt == torch.bfloat16:   # the oracle sees the same bf16-rounded matrices; activations stay f32 there
+            sd = {k: (v.bfloat16().float() if v.dim() == 2 and 'output_proj' not in k else v) for k, v in sd.items()}
+        oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True,
+                          kv_repeat=extra.get('kv_repeat', 1), qk_layer_norm=extra.get('qk_layer_norm', False),
+                          qk_layer_norm_cross=extra.get('qk_layer_norm_cross', False),
+                          positional_embedding=extra.get('positional_embedding', 'sin'))
+        g = torch.Generator().manual_seed(5)
+        cross = torch.randn(2 * B, 6, 256, generator=g)
+        cross[B:] = 0
+        ones = lambda n: torch.ones(2 * B, n, dtype=torch.int64).cuda()  # noqa: E731
+        ct = {'description': (cross.cuda(), ones(6))}
+        ops = []
+        if 'sum' in extra['fuser']:
+            genre, curve = 0.5 * torch.randn(2 * B, 1, 256, generator=g), 0.5 * torch.randn(2 * B, 7, 256, generator=g)
+            genre[B:], curve[B:] = 0, 0
+            ct.update({'genre': (genre.cuda(), ones(1)), 'curve': (curve.cuda(), ones(7))})
+            ops = [('sum', genre), ('input_interpolate', curve)]
+        seq = torch.randint(0, 2049, (2 * B, 4, 12), generator=g)
+        ref = olm.lm_forward(sd, oc, seq, cross, input_ops=ops)
+        got = lm.forward_steps(seq.cuda(), ct).cpu()
+        r = rel(got, ref)
+        assert r < tol, f"{sorted(extra)}: teacher-forced logits rel-L2 {r} (tol {tol})"
+        if wdt == torch.float32 and B == 3:
+            prompt = torch.randint(0, 2048, (B, 4, 5), generator=g)
+            toks = lm.generate(prompt.cuda(), [], max_gen_len=14, use_sampling=False, condition_tensors=ct)
+            ref_t = olm.generate(sd, oc, prompt, B, cross, max_gen_len=14, use_sampling=False, input_ops=ops)
+            assert torch.equal(toks.cpu(), ref_t)
+
+
+def test_kv_repeat_state_dict_survives_release_of_the_masters():
+    """release_master_weights rebuilds in_proj_weight from the packs: with kv_repeat the packs hold every shared head once per
+    query head, the state dict must come back in the reference's narrow [d + 2 kv_dim, d] layout."""
+    cfg, sd, a = load_golden('lm_kv_repeat')
+    lm = build(cfg, sd)
+    ct = condition_tensors('lm_kv_repeat', a)
+    before = lm.forward_steps(a['tf_sequence'].cuda(), ct).cpu()
+    lm.release_master_weights()
+    back = lm.state_dict()
+    k = 'transformer.layers.1.self_attn.in_proj_weight'
+    assert back[k].shape == sd[k].shape and torch.allclose(back[k].cpu(), sd[k], atol=1e-6, rtol=1e-5)
+    assert torch.equal(lm.forward_steps(a['tf_sequence'].cuda(), ct).cpu(), before)
+    lm2 = build(cfg, {k: v.cpu() for k, v in back.items()})
+    assert rel(lm2.forward_steps(a['tf_sequence'].cuda(), ct).cpu(), a['tf_logits']) < 1e-4

@@ -29,6 +29,41 @@ def test_library_exports_every_declared_symbol():
     assert _C.version() >= 110
 
 
+def _header_struct_fields(cname):
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'acmi.h')).read(), flags=re.S)
+    m = re.search(r'typedef struct\s*\{([^{}]*)\}\s*' + cname + r'\s*;', hdr)
+    assert m, f"include/acmi.h has no struct {cname}"
+    names = []
+    for decl in m.group(1).split(';'):
+        for part in ' '.join(decl.split()).split(','):
+            if part.strip():
+                names.append(re.findall(r'([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\d+\])?\s*$', part.strip())[0])
+    return names
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
+    """Every descriptor crosses the C ABI as a ctypes mirror written by hand (_C.py); a field added to one side only would
+    shift everything behind it and corrupt calls silently.  The header is compiled as C (gcc) and every field's offset and
+    each struct's size are compared with the mirror's."""
+    import subprocess
+    from audiocraft_amd import _C
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "acmi.h"', 'int main(void) {']
+    for cname, cls in _C.STRUCT_MIRRORS.items():
+        fields = _header_struct_fields(cname)
+        assert fields == [f[0] for f in cls._fields_], f"{cname}: field names / order differ from _C.{cls.__name__}"
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        lines += [f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));' for f in fields]
+    lines += ['  return 0;', '}']
+    src, exe = tmp_path / 'layout.c', tmp_path / 'layout'
+    src.write_text('\n'.join(lines))
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in _C.STRUCT_MIRRORS.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), f"sizeof({cname}) = {got[cname]}, the mirror has {ctypes.sizeof(cls)}"
+        for f, _ in cls._fields_:
+            assert int(got[f'{cname}.{f}']) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
 def test_argument_validation_without_gpu():
     """Error paths never touch the device: negative return code + thread-local message."""
     from audiocraft_amd import _C
@@ -249,6 +284,97 @@ def test_state_dict_keys_match_reference_golden():
     assert set(m.state_dict().keys()) == set(sd.keys())
 
 
+OPTION_KEYS = ('kv_repeat', 'qk_layer_norm', 'qk_layer_norm_cross', 'bias_attn', 'bias_ff', 'cross_attention_pos_emb',
+               'cross_attention_pos_emb_scale')
+
+
+def options_lm_cfg(cfg):
+    """builders.get_lm_model cfg of an options golden (tests/golden/make_options_golden.py)."""
+    fuser = {'cross': ['description']}
+    if 'curve_frames' in cfg:
+        fuser.update({'sum': ['genre'], 'input_interpolate': ['curve']})
+    return dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'], n_q=cfg['n_q'], card=cfg['card'],
+                hidden_scale=cfg['hidden_scale'], cfg_coef=cfg['cfg_coef'],
+                conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': cfg['cond_dim'], 'length': cfg['Lc']}},
+                fuser=fuser, codebooks_pattern={'modeling': 'delay', 'delay': {'delays': cfg['delays']}},
+                **{k: cfg[k] for k in OPTION_KEYS if k in cfg})
+
+
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum'])
+def test_option_goldens_load_strictly(name):
+    """kv_repeat narrows in_proj_weight, qk_layer_norm adds q_layer_norm / k_layer_norm under self_attn (and under
+    cross_attention for qk_layer_norm_cross): same names and shapes as the reference's modules (transformer.py:196-222)."""
+    from conftest import load_golden
+    from audiocraft_amd.models import builders
+    cfg, sd, _ = load_golden(name)
+    lm = builders.get_lm_model(options_lm_cfg(cfg), 'cpu', torch.float32)
+    own = lm.state_dict()
+    extra = {k for k in sd if k.startswith('condition_provider.conditioners.') and '.description.' not in k}   # test-only conditioners
+    assert set(own.keys()) == set(sd.keys()) - extra, set(own.keys()) ^ (set(sd.keys()) - extra)
+    for k, v in own.items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    lm.load_state_dict({k: v for k, v in sd.items() if k not in extra})   # strict
+
+
+def test_kv_repeat_expansion_is_the_reference_attention():
+    """expand_kv_in_proj lays every shared key / value head out once per query head: an ordinary attention on the expanded
+    projection IS the kv_repeat attention (checked through the oracle, which is pinned to the reference's golden)."""
+    from conftest import load_golden
+    from audiocraft_amd.models.lm import expand_kv_in_proj
+    from oracle import lm as olm
+    from test_oracle_golden import lm_cfg
+    cfg, sd, a = load_golden('lm_kv_repeat')
+    c = lm_cfg(cfg)
+    assert c.kv_repeat == 2
+    ex = dict(sd)
+    for li in range(c.num_layers):
+        p = f'transformer.layers.{li}.self_attn.'
+        w, b = expand_kv_in_proj(sd[p + 'in_proj_weight'], sd[p + 'in_proj_bias'], c.dim, c.num_heads, c.kv_repeat)
+        assert w.shape == (3 * c.dim, c.dim) and b.shape == (3 * c.dim,)
+        ex[p + 'in_proj_weight'], ex[p + 'in_proj_bias'] = w, b
+    import dataclasses
+    plain = dataclasses.replace(c, kv_repeat=1)
+    got = olm.lm_forward(ex, plain, a['tf_sequence'], a['cond_description'])
+    assert torch.allclose(got, a['tf_logits'], atol=2e-5, rtol=1e-4)
+    w, b = expand_kv_in_proj(sd[p + 'in_proj_weight'], None, c.dim, c.num_heads, 1)
+    assert w is sd[p + 'in_proj_weight'] and b is None
+
+
+def test_fuser_sum_interpolate_and_cross_pos_emb_host_side():
+    """ConditionFuser: 'sum' / 'input_interpolate' conditions become the rows the embedding kernel adds (input_add_rows ==
+    what the reference's in-place add / F.interpolate give for a call of T steps); cross_attention_pos_emb == the oracle's
+    restatement (pinned to the reference by lm_fuser_sum.npz)."""
+    import torch.nn.functional as F
+    from audiocraft_amd.modules.conditioners import ConditionFuser
+    from oracle import lm as olm
+    g = torch.Generator().manual_seed(0)
+    one, many = torch.randn(3, 1, 8, generator=g), torch.randn(3, 5, 8, generator=g)
+    for T in (1, 2, 3, 4, 5, 7, 9, 10, 11, 13, 64, 1503):
+        rows = ConditionFuser.input_add_rows([('sum', one), ('input_interpolate', many)], T)
+        ref = one.expand(-1, T, -1) + F.interpolate(many.transpose(1, 2), size=T).transpose(1, 2)
+        assert torch.equal(rows, ref), T
+    for Tc, T in ((3, 9), (7, 3), (11, 1000), (1500, 1499), (6, 36), (29, 87)):   # ATen's f32 index arithmetic, not exact integers
+        cond = torch.randn(2, Tc, 4, generator=g)
+        assert torch.equal(ConditionFuser.input_add_rows([('input_interpolate', cond)], T),
+                           F.interpolate(cond.transpose(1, 2), size=T).transpose(1, 2)), (Tc, T)
+    assert torch.equal(ConditionFuser.input_add_rows([('sum', many)], 5), many)   # one frame per step
+    with pytest.raises(RuntimeError):
+        ConditionFuser.input_add_rows([('sum', many)], 4)
+    assert ConditionFuser.input_add_rows([], 4) is None
+    fuse = {'cross': ['description'], 'sum': ['genre'], 'input_interpolate': ['curve'], 'prepend': ['wav']}
+    fuser = ConditionFuser(fuse, cross_attention_pos_emb=True, cross_attention_pos_emb_scale=0.7)
+    src = torch.randn(3, 6, 8, generator=g)
+    m = torch.ones(3, 6)
+    conds = {'description': (src, m), 'genre': (one, m[:, :1]), 'curve': (many, m[:, :5])}
+    prepend, cross = fuser.fuse(conds)
+    assert prepend is None and torch.allclose(cross, olm.cross_pos_emb(src, 0.7), atol=1e-6)
+    assert [op for op, _ in fuser.input_ops(conds)] == ['sum', 'input_interpolate']
+    with pytest.raises(NotImplementedError):   # the reference would add to the prepended rows too: not built
+        fuser.fuse({'wav': (src, m), 'genre': (one, m[:, :1])})
+    with pytest.raises(AssertionError):
+        fuser.input_ops({'unknown': (src, m)})
+
+
 def test_loader_passes_transformer_options_and_bench_tags():
     from audiocraft_amd.models import loaders
     xp = {'transformer_lm': {'dim': 16, 'num_heads': 4, 'num_layers': 2, 'positional_embedding': 'sin_rope', 'xpos': False,
@@ -257,6 +383,11 @@ def test_loader_passes_transformer_options_and_bench_tags():
     cfg = loaders.lm_cfg_from_xp(loaders.parse_cfg(xp))
     assert cfg['positional_embedding'] == 'sin_rope' and cfg['past_context'] == 12 and cfg['positional_scale'] == 0.5
     assert 'layer_scale' not in cfg and cfg['xpos'] is False
+    xp['transformer_lm'].update(kv_repeat=2, qk_layer_norm_cross=True)
+    xp['fuser'] = {'cross': ['description'], 'sum': ['genre'], 'cross_attention_pos_emb': True, 'cross_attention_pos_emb_scale': 0.5}
+    cfg = loaders.lm_cfg_from_xp(loaders.parse_cfg(xp))
+    assert cfg['kv_repeat'] == 2 and cfg['qk_layer_norm_cross'] is True and 'qk_layer_norm' not in cfg
+    assert cfg['fuser'] == {'cross': ['description'], 'sum': ['genre']} and cfg['cross_attention_pos_emb_scale'] == 0.5
     import argparse
     import bench
     ns = argparse.Namespace(model='facebook/musicgen-medium', batch=8, duration=30.0, greedy=False)
