@@ -9,22 +9,13 @@ import math
 import os
 import typing as tp
 from abc import ABC, abstractmethod
-from dataclasses import dataclass
 
 import torch
 from torch import nn
 
 from .. import _C
 from ..modules.seanet import invalidate_prepared
-from ..quantization.vq import BaseQuantizer
-
-
-@dataclass
-class QuantizedResult:
-    x: torch.Tensor
-    codes: torch.Tensor
-    bandwidth: torch.Tensor          # kb/s
-    penalty: tp.Optional[torch.Tensor] = None
+from ..quantization.vq import BaseQuantizer, QuantizedResult  # noqa: F401  (QuantizedResult: also exported from here)
 
 
 def _abstract_property(name: str, doc: str):

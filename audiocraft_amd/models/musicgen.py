@@ -71,6 +71,15 @@ class MusicGen(BaseGenModel):
         return MusicGen(name, codec, lm, max_duration=30)
 
     # ------------------------------------------------------------------------------------- parameters
+    def set_style_conditioner_params(self, eval_q: int = 3, excerpt_length: float = 3.0, ds_factor: tp.Optional[int] = None,
+                                     encodec_n_q: tp.Optional[int] = None) -> None:
+        """reference musicgen.py:134-153 (MusicGen-Style): forwarded to the `self_wav` conditioner's `set_params`.  The style
+        conditioner is a model of its own outside this path; the call is accepted for any plugged-in
+        `self_wav` conditioner that offers `set_params` and fails like the reference's assert otherwise."""
+        cond = self.lm.condition_provider.conditioners['self_wav'] if 'self_wav' in self.lm.condition_provider.conditioners else None
+        assert cond is not None and hasattr(cond, 'set_params'), "Only use this function if you model is MusicGen-Style"
+        cond.set_params(eval_q=eval_q, excerpt_length=excerpt_length, ds_factor=ds_factor, encodec_n_q=encodec_n_q)
+
     def set_generation_params(self, use_sampling: bool = True, top_k: int = 250, top_p: float = 0.0,
                               temperature: float = 1.0, duration: float = 30.0, cfg_coef: float = 3.0,
                               cfg_coef_beta: tp.Optional[float] = None, two_step_cfg: bool = False,

@@ -1,1 +1,1 @@
-from .vq import ResidualVectorQuantizer, BaseQuantizer  # noqa: F401
+from .vq import ResidualVectorQuantizer, BaseQuantizer, QuantizedResult  # noqa: F401

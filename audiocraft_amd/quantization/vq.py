@@ -3,16 +3,27 @@
 API mirror of `audiocraft.quantization.vq.ResidualVectorQuantizer` / `base.BaseQuantizer`
 (reference audiocraft/quantization/vq.py:16-115, base.py:27-60) for encode / decode; buffer names
 mirror `core_vq.py` (`vq.layers.{q}._codebook.{inited,cluster_size,embed,embed_avg}`) so EnCodec
-checkpoints load unchanged.  k-means init, EMA updates, dead-code expiry and the straight-through
-`forward` are training-only and out of scope.
+checkpoints load unchanged.  k-means init, EMA updates, dead-code expiry and the straight-through gradient are
+training-only and out of scope; `forward` is the reference's in eval mode.
 """
 import math
 import typing as tp
+from dataclasses import dataclass, field
 
 import torch
 from torch import nn
 
 from .. import _C
+
+
+@dataclass
+class QuantizedResult:
+    """quantization/base.py:18-24"""
+    x: torch.Tensor
+    codes: torch.Tensor
+    bandwidth: torch.Tensor          # kb/s used, per batch item
+    penalty: tp.Optional[torch.Tensor] = None
+    metrics: dict = field(default_factory=dict)
 
 
 class _Codebook(nn.Module):
@@ -39,6 +50,9 @@ class _RVQ(nn.Module):
 
 
 class BaseQuantizer(nn.Module):
+    def forward(self, x: torch.Tensor, frame_rate: int) -> QuantizedResult:
+        raise NotImplementedError()
+
     def encode(self, x: torch.Tensor) -> torch.Tensor:
         raise NotImplementedError()
 
@@ -79,6 +93,16 @@ class ResidualVectorQuantizer(BaseQuantizer):
             cb = torch.stack([layer._codebook.embed.detach().float() for layer in self.vq.layers]).contiguous()
             self._prep = (cb, _C.rvq_codebook_norms(cb))
         return self._prep
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, frame_rate: int) -> QuantizedResult:
+        """vq.py:76-85 in eval mode: the quantized latents (sum of the selected codebook entries), the codes [B, K, T], the
+        bandwidth n_q log2(bins) frame_rate / 1000 kb/s and a zero penalty (the commitment loss only exists while training,
+        core_vq.py:347-364); no q_dropout, no straight-through estimator, no EMA updates."""
+        assert not self.training, "audiocraft_amd quantizers run in eval mode only (no EMA / k-means / dropout)"
+        codes = self.encode(x)
+        bw = torch.tensor(self.n_q * math.log2(self.bins) * frame_rate / 1000).to(x)
+        return QuantizedResult(self.decode(codes), codes, bw, penalty=torch.zeros((), device=x.device, dtype=x.dtype))
 
     def encode(self, x: torch.Tensor) -> torch.Tensor:
         """latents [B, D, T] -> codes [B, K, T] int64 (reference vq.py:87-96, core_vq.py:386-396)."""

@@ -188,3 +188,47 @@ def test_kv_repeat_state_dict_survives_release_of_the_masters():
     assert torch.equal(lm.forward_steps(a['tf_sequence'].cuda(), ct).cpu(), before)
     lm2 = build(cfg, {k: v.cpu() for k, v in back.items()})
     assert rel(lm2.forward_steps(a['tf_sequence'].cuda(), ct).cpu(), a['tf_logits']) < 1e-4
+
+
+def test_lm_fuser_sum_in_two_step_and_double_cfg_vs_oracle():
+    """The 'sum' / 'input_interpolate' table in the other two CFG modes (lm.py:362-390): two_step_cfg encodes the conditional
+    and the null conditions separately (two row groups, each with its own table rows), double CFG runs three row groups."""
+    cfg, sd, a = load_golden('lm_fuser_sum')
+    c = lm_cfg(cfg)
+    lm = build(cfg, sd)
+    B = 3
+    full = condition_tensors('lm_fuser_sum', a)
+    half = lambda lo: {k: (e[lo:lo + B].contiguous(), m[lo:lo + B].contiguous()) for k, (e, m) in full.items()}  # noqa: E731
+    cond, null = half(0), half(B)
+    cross, ops = options_inputs('lm_fuser_sum', cfg, a)
+    part = lambda lo: [(op, t[lo:lo + B]) for op, t in ops]  # noqa: E731
+    prompt = a['prompt']
+    for p in (None, prompt):
+        toks = lm.generate(None if p is None else p.cuda(), [], num_samples=B, max_gen_len=11, use_sampling=False,
+                           condition_tensors=(cond, null), check=True)
+        ref = olm.generate(sd, c, p, B, cross[:B], max_gen_len=11, use_sampling=False, null_cross_src=cross[B:],
+                           input_ops=part(0), null_input_ops=part(B))
+        assert torch.equal(toks.cpu(), ref)
+    # double CFG: rows [text + wav; wav; null] -- here the middle group carries the conditional rows once more
+    tri = {k: (torch.cat([e[:B], e[:B], e[B:]]).contiguous(), torch.cat([m[:B], m[:B], m[B:]]).contiguous())
+           for k, (e, m) in full.items()}
+    toks, lg = lm.generate(None, [], num_samples=B, max_gen_len=11, use_sampling=False, condition_tensors=tri,
+                           cfg_coef_beta=2.5, return_logits=True, check=True)
+    cat3 = lambda t: torch.cat([t[:B], t[:B], t[B:]])  # noqa: E731
+    ref, rlg = olm.generate(sd, c, None, B, cat3(cross), max_gen_len=11, use_sampling=False, cfg_coef_beta=2.5,
+                            input_ops=[(op, cat3(t)) for op, t in ops], return_logits=True)
+    assert torch.equal(toks.cpu(), ref) and rel(lg.cpu(), rlg) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['codec_noncausal', 'codec_causal'])
+def test_quantizer_forward_is_the_reference_eval_forward(name):
+    """ResidualVectorQuantizer.forward (vq.py:76-85) in eval mode on the reference's own latents: its quantized latents and
+    codes (goldens of the unmodified reference), the bandwidth, a zero penalty."""
+    import math
+    from test_gpu_models import build_codec
+    cfg, sd, a = load_golden(name)
+    m = build_codec(cfg, sd)
+    q = m.quantizer(a['latents'].cuda(), cfg['frame_rate'])
+    assert torch.equal(q.codes.cpu(), a['codes']) and torch.equal(q.x.cpu(), a['quantized_latents'])
+    assert abs(float(q.bandwidth) - cfg['n_q'] * math.log2(cfg['bins']) * cfg['frame_rate'] / 1000) < 1e-6
+    assert float(q.penalty) == 0.0

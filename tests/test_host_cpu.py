@@ -488,6 +488,24 @@ def test_genmodel_reads_experiment_config_of_the_lm():
         MusicGen('no-duration', builders.get_debug_compression_model('cpu'), lm)
     ag = AudioGen('plain', builders.get_debug_compression_model('cpu', sample_rate=16000), lm, max_duration=10)
     assert ag.sample_rate == 16000 and ag.duration == 5 and ag.extend_stride == 2
+    # MusicGen-Style's parameter setter (musicgen.py:134-153): forwarded to a `self_wav` conditioner that offers set_params,
+    # the reference's assertion otherwise
+    plain = MusicGen('plain', builders.get_debug_compression_model('cpu'), lm, max_duration=30)
+    with pytest.raises(AssertionError, match='MusicGen-Style'):
+        plain.set_style_conditioner_params(eval_q=2)
+    assert not hasattr(ag, 'set_style_conditioner_params')    # a MusicGen method only, as in the reference
+    seen = {}
+
+    class Style(torch.nn.Module):
+        def set_params(self, **kw):
+            seen.update(kw)
+    lm.condition_provider.conditioners['self_wav'] = Style()
+    try:
+        mg2 = MusicGen('style-stub', builders.get_debug_compression_model('cpu'), lm, max_duration=30)
+        mg2.set_style_conditioner_params(eval_q=2, excerpt_length=1.5)
+        assert seen == dict(eval_q=2, excerpt_length=1.5, ds_factor=None, encodec_n_q=None)
+    finally:
+        del lm.condition_provider.conditioners['self_wav']
     assert builders.ENCODEC_16KHZ['seanet']['ratios'] == [8, 5, 4, 2] and builders.audiogen_lm_cfg()['dim'] == 1536
 
 
