@@ -7,6 +7,7 @@ The HF / DAC / stereo-interleave wrappers of the reference are outside this path
 """
 import math
 import os
+import re
 import typing as tp
 from abc import ABC, abstractmethod
 
@@ -54,16 +55,33 @@ class CompressionModel(ABC, nn.Module):
 
     @staticmethod
     def get_pretrained(name: str, device='cuda') -> 'CompressionModel':
-        """reference encodec.py:88-122.  `debug_compression_model`, a path (file / directory holding a
-        `compression_state_dict.bin` written by `audiocraft.utils.export`), or a released name resolved on disk under
-        $AUDIOCRAFT_CACHE_DIR (there is no network here; the DAC / HuggingFace-EnCodec wrappers are third-party codecs
-        outside the path and raise)."""
+        """reference encodec.py:88-122.  `debug_compression_model`; a path (file / directory holding a
+        `compression_state_dict.bin` written by `audiocraft.utils.export`) or a released name resolved on disk under
+        $AUDIOCRAFT_CACHE_DIR; else -- like the reference's last branch -- a HuggingFace EnCodec (`facebook/encodec_24khz`, or a
+        directory in HuggingFace's format) through `transformers.EncodecModel.from_pretrained`, whose weights are re-keyed into
+        this package's EncodecModel (`HFEncodecCompressionModel`).  There is no network here: HuggingFace resolves names in
+        its local cache only.  The DAC wrappers (third-party codecs outside the path) raise."""
         from . import builders, loaders
         if name in ('dac_44khz', 'dac_24khz'):
             raise NotImplementedError("DAC codecs are third-party models outside the MusicGen path")
         if name == 'debug_compression_model':
             return builders.get_debug_compression_model(device).eval()
-        return loaders.load_compression_model(name, device=device).eval()
+        hf_dir = os.path.isdir(name) and os.path.isfile(os.path.join(name, 'config.json')) and \
+            not os.path.isfile(os.path.join(name, 'compression_state_dict.bin'))
+        if not hf_dir:
+            try:
+                return loaders.load_compression_model(name, device=device).eval()
+            except FileNotFoundError as exc:
+                not_on_disk = exc
+        else:
+            not_on_disk = None
+        try:
+            from transformers import EncodecModel as HFEncodecModel
+            hf_model = HFEncodecModel.from_pretrained(name)
+        except Exception as exc:   # no transformers, not in the HuggingFace cache, not an EnCodec: say what was tried
+            raise FileNotFoundError(f"compression model '{name}': not an audiocraft export on disk ({not_on_disk}) and not "
+                                    f"loadable as a HuggingFace EnCodec ({type(exc).__name__}: {exc})") from exc
+        return HFEncodecCompressionModel(hf_model, device).eval()
 
 
 class EncodecModel(CompressionModel):
@@ -189,6 +207,137 @@ class EncodecModel(CompressionModel):
         assert out.shape[-1] >= x.shape[-1], (out.shape[-1], x.shape[-1])
         kbps = codes.shape[1] * math.log2(self.cardinality) * self.frame_rate / 1000
         return QuantizedResult(out[..., :x.shape[-1]], codes, torch.tensor(kbps).to(out))
+
+
+def hf_encodec_cfg(config) -> dict:
+    """`transformers.EncodecConfig` -> builders.get_compression_model cfg.  HuggingFace's EnCodec (modeling_encodec.py) is the
+    same SEANet / RVQ as the reference's own (`modules/seanet.py`, `quantization/vq.py`) under other names: the layer lists
+    of encoder and decoder line up index by index (activations included), `use_conv_shortcut` is `not true_skip`,
+    `dilation_growth_rate` is `dilation_base`, `normalize` is `renormalize`."""
+    def get(name, default=None):
+        return getattr(config, name, default) if not isinstance(config, dict) else config.get(name, default)
+    if get('norm_type', 'weight_norm') != 'weight_norm':
+        raise NotImplementedError(f"HF EnCodec norm_type {get('norm_type')!r} (only 'weight_norm': facebook/encodec_24khz)")
+    if get('chunk_length_s') is not None:
+        raise NotImplementedError("HF EnCodec with chunked encoding (chunk_length_s: the 48 kHz model) is not on the MusicGen path")
+    if get('codebook_dim', get('hidden_size')) != get('hidden_size'):
+        raise NotImplementedError("HF EnCodec with codebook_dim != hidden_size")
+    ratios = list(get('upsampling_ratios'))
+    hop = 1
+    for r in ratios:
+        hop *= r
+    sr = get('sampling_rate')
+    frame_rate = sr / hop
+    bins = get('codebook_size')
+    # EncodecConfig.num_quantizers: the codebooks the largest target bandwidth needs (configuration_encodec.py)
+    n_q = int(1000 * get('target_bandwidths')[-1] // (math.ceil(frame_rate) * 10)) if bins == 1024 else \
+        int(get('target_bandwidths')[-1] * 1000 / (math.ceil(frame_rate) * math.log2(bins)))
+    n_q = int(get('num_quantizers', n_q) or n_q)
+    seanet = dict(channels=get('audio_channels'), dimension=get('hidden_size'), n_filters=get('num_filters'),
+                  n_residual_layers=get('num_residual_layers'), ratios=ratios, activation='ELU', activation_params={'alpha': 1.0},
+                  norm='weight_norm', norm_params={}, kernel_size=get('kernel_size'), last_kernel_size=get('last_kernel_size'),
+                  residual_kernel_size=get('residual_kernel_size'), dilation_base=get('dilation_growth_rate'),
+                  causal=bool(get('use_causal_conv')), pad_mode=get('pad_mode'), true_skip=not get('use_conv_shortcut'),
+                  compress=get('compress'), lstm=get('num_lstm_layers'), disable_norm_outer_blocks=0)
+    return dict(seanet=seanet, rvq=dict(n_q=n_q, bins=bins), sample_rate=sr, frame_rate=frame_rate,
+                channels=get('audio_channels'), causal=bool(get('use_causal_conv')), renormalize=bool(get('normalize')),
+                trim_right_ratio=get('trim_right_ratio', 1.0))
+
+
+def convert_hf_encodec_state_dict(hf_state: tp.Dict[str, torch.Tensor], native_keys: tp.Iterable[str]) -> tp.Dict[str, torch.Tensor]:
+    """State dict of `transformers.EncodecModel` -> the reference's EnCodec key names (what `EncodecModel.load_state_dict` of
+    this package takes): `encoder.layers.{i}.[block.{j}. | shortcut.]conv.{parametrizations.weight.original0 | original1 |
+    weight_g | weight_v | bias}` -> `encoder.model.{i}...conv.conv.{weight_g | weight_v | bias}` (`convtr.convtr.` where the
+    native model holds a transposed convolution at that index), LSTMs unchanged, `quantizer.layers.{q}.codebook.*` ->
+    `quantizer.vq.layers.{q}._codebook.*`.  No tensor is touched."""
+    native = set(native_keys)
+    leaf = {'parametrizations.weight.original0': 'weight_g', 'parametrizations.weight.original1': 'weight_v',
+            'weight_g': 'weight_g', 'weight_v': 'weight_v', 'weight': 'weight', 'bias': 'bias'}
+    out: tp.Dict[str, torch.Tensor] = {}
+    for k, v in hf_state.items():
+        m = re.match(r'^(encoder|decoder)\.layers\.(\d+)\.(.*)$', k)
+        if m:
+            side, idx, rest = m.groups()
+            base = f'{side}.model.{idx}.'
+            if rest.startswith('lstm.'):
+                new = base + rest
+            else:
+                cm = re.match(r'^((?:block\.\d+\.|shortcut\.)?)conv\.(.*)$', rest)
+                if cm is None or cm.group(2) not in leaf:
+                    raise KeyError(f"unexpected HF EnCodec key {k!r}")
+                sub, name = cm.group(1), leaf[cm.group(2)]
+                new = base + sub + 'conv.conv.' + name
+                if new not in native:
+                    new = base + sub + 'convtr.convtr.' + name
+        else:
+            qm = re.match(r'^quantizer\.layers\.(\d+)\.codebook\.(.*)$', k)
+            if qm is None:
+                raise KeyError(f"unexpected HF EnCodec key {k!r}")
+            new = f'quantizer.vq.layers.{qm.group(1)}._codebook.{qm.group(2)}'
+        if new not in native:
+            raise KeyError(f"HF EnCodec key {k!r} has no counterpart ({new!r}) in the native model")
+        out[new] = v
+    return out
+
+
+class HFEncodecCompressionModel(CompressionModel):
+    """The reference's wrapper around HuggingFace EnCodec (audiocraft/models/encodec.py:323-394: `facebook/encodec_24khz`, the
+    codec of `MultiBandDiffusion.get_mbd_24khz`) -- same constructor argument (a `transformers.EncodecModel`), methods and
+    properties; `set_num_codebooks` only takes the codebook counts of `config.target_bandwidths`, `forward` raises.
+    The wrapped HF module is NOT what runs: its weights are re-keyed (`convert_hf_encodec_state_dict`) into this package's
+    `EncodecModel` of the same geometry (`hf_encodec_cfg`), i.e. the SEANet / LSTM / RVQ kernels of libacmi."""
+
+    def __init__(self, model, device=None):
+        super().__init__()
+        from . import builders
+        config = model.config
+        if device is None:
+            p = next(iter(model.parameters()), None)
+            device = p.device if p is not None else 'cpu'
+        cfg = hf_encodec_cfg(config)
+        self.config = config
+        self.model = builders.get_compression_model(cfg, device)
+        self.model.load_state_dict(convert_hf_encodec_state_dict(model.state_dict(), self.model.state_dict().keys()))
+        self._sample_rate, self._channels, self._frame_rate = cfg['sample_rate'], cfg['channels'], cfg['frame_rate']
+        self._cardinality = cfg['rvq']['bins']
+        bws = list(getattr(config, 'target_bandwidths'))
+        num_codebooks = [bw * 1000 / (self.frame_rate * math.log2(self.cardinality)) for bw in bws]
+        deltas = [nc - int(nc) for nc in num_codebooks]
+        assert all(d <= 1e-3 for d in deltas), deltas   # "we indeed have integers"
+        self.possible_num_codebooks = [int(nc) for nc in num_codebooks]
+        assert max(self.possible_num_codebooks) <= self.model.total_codebooks
+        self.set_num_codebooks(max(self.possible_num_codebooks))
+        self.eval()
+
+    def forward(self, x: torch.Tensor) -> QuantizedResult:
+        raise NotImplementedError("Forward and training with HF EncodecModel not supported.")
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
+        self.model.set_num_codebooks(self.num_codebooks)
+        return self.model.encode(x)     # (codes [B, K, T], scale [B, 1] | None): what `res[0][0], res[1][0]` are in the reference
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
+        # (with a scale the reference hands `scale` to HF as its per-frame list, i.e. it applies scale[0] to every item of the
+        # batch; here every item gets its own -- identical for `normalize: false` codecs such as facebook/encodec_24khz)
+        return self.model.decode(codes, scale)
+
+    @torch.no_grad()
+    def decode_latent(self, codes: torch.Tensor):
+        return self.model.decode_latent(codes)
+
+    channels = property(lambda self: self._channels)
+    frame_rate = property(lambda self: self._frame_rate)
+    sample_rate = property(lambda self: self._sample_rate)
+    cardinality = property(lambda self: self._cardinality)
+    num_codebooks = property(lambda self: self._num_codebooks)
+    total_codebooks = property(lambda self: max(self.possible_num_codebooks))
+
+    def set_num_codebooks(self, n: int):
+        if n not in self.possible_num_codebooks:
+            raise ValueError(f"Allowed values for num codebooks: {self.possible_num_codebooks}")
+        self._num_codebooks = n
 
 
 class InterleaveStereoCompressionModel(CompressionModel):

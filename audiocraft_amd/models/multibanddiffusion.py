@@ -63,8 +63,9 @@ class MultiBandDiffusion:
     def get_mbd_24khz(bw: float = 3.0, device: tp.Optional[tp.Union[torch.device, str]] = None, n_q: tp.Optional[int] = None):
         """The diffusion decoders for EnCodec 24 kHz at 1.5 / 3 / 6 kbps (mbd_comp_{n_q}.pt).  The reference resolves the codec
         through `CompressionSolver.model_from_checkpoint('//pretrained/facebook/encodec_24khz')`, i.e. the HuggingFace
-        EncodecModel wrapper (a third-party model outside this path); here the 24 kHz codec must be on disk in the reference's
-        own export format (`compression_state_dict.bin` of an `EncodecModel`, looked up like every other checkpoint)."""
+        EncodecModel wrapper: `CompressionModel.get_pretrained` does the same here (an audiocraft export on disk if there is
+        one, else `transformers.EncodecModel.from_pretrained` from HuggingFace's local cache, its weights re-keyed into the
+        SEANet / RVQ kernels of this package: `HFEncodecCompressionModel`)."""
         device = device or 'cuda'
         assert bw in [1.5, 3.0, 6.0], f"bandwidth {bw} not available"
         if n_q is not None:

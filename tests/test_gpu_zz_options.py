@@ -232,3 +232,62 @@ def test_quantizer_forward_is_the_reference_eval_forward(name):
     assert torch.equal(q.codes.cpu(), a['codes']) and torch.equal(q.x.cpu(), a['quantized_latents'])
     assert abs(float(q.bandwidth) - cfg['n_q'] * math.log2(cfg['bins']) * cfg['frame_rate'] / 1000) < 1e-6
     assert float(q.penalty) == 0.0
+
+
+def test_hf_encodec_wrapper_vs_transformers_golden():
+    """HFEncodecCompressionModel on the device against what `transformers` itself computed (tests/golden/
+    make_hf_encodec_golden.py: a causal, reflect-padded, conv-shortcut EnCodec): latents, codes at every target bandwidth
+    (end to end: any differing index must be a provable near tie), decoded audio."""
+    import types
+    from audiocraft_amd.models.encodec import HFEncodecCompressionModel
+    from parity_utils import assert_codes_near_tie
+    from test_oracle_golden import hf_native, ocodec
+    cfg, sd, a = load_golden('hf_encodec_small')
+    hf = types.SimpleNamespace(config=types.SimpleNamespace(**cfg), state_dict=lambda: sd, parameters=lambda: iter(()))
+    m = HFEncodecCompressionModel(hf, 'cuda')
+    _, conv, c = hf_native(cfg, sd)
+    books = ocodec.codebooks_from_state(conv, c.n_q)
+    wav = a['wav'].cuda()
+    lat = m.model.encoder(wav).cpu()
+    assert torch.allclose(lat, a['latents'], atol=3e-5, rtol=1e-4)
+    for bw, k in zip(cfg['target_bandwidths'], (1, 2, 4)):
+        m.set_num_codebooks(k)
+        codes, scale = m.encode(wav)
+        assert scale is None and codes.shape == a[f'codes_bw{bw}'].shape
+        assert_codes_near_tie(codes, a[f'codes_bw{bw}'], lat, a['latents'], books[:k], what=f'HF EnCodec golden, {k} codebooks')
+        dec = m.decode(a[f'codes_bw{bw}'].cuda(), None).cpu()
+        assert dec.shape == a[f'decoded_bw{bw}'].shape
+        assert (dec - a[f'decoded_bw{bw}']).abs().max().item() < 1e-4
+    assert torch.equal(m.decode_latent(a['codes_bw2.4'].cuda()).cpu(), a['quantized'])
+
+
+def test_hf_encodec_24khz_configuration_vs_transformers_run_here():
+    """The configuration of facebook/encodec_24khz itself (EncodecConfig's defaults: 32 x 1024 codebooks, ratios 8 5 4 2, 75 fps)
+    with seeded random weights: `transformers` runs on the host, the wrapper on the device, on the same 0.4 s of audio."""
+    transformers = pytest.importorskip('transformers')
+    from audiocraft_amd.models.encodec import HFEncodecCompressionModel
+    from parity_utils import assert_codes_near_tie
+    torch.manual_seed(3)
+    hf = transformers.EncodecModel(transformers.EncodecConfig()).eval()
+    with torch.no_grad():
+        for layer in hf.quantizer.layers:       # HF initialises the codebooks with zeros
+            layer.codebook.embed.copy_(torch.randn_like(layer.codebook.embed) * 0.3)
+    m = HFEncodecCompressionModel(hf, 'cuda')
+    assert m.possible_num_codebooks == [2, 4, 8, 16, 32] and m.frame_rate == 75.0 and m.sample_rate == 24000
+    wav = 0.3 * torch.randn(2, 1, 9611, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        lat_ref = hf.encoder(wav)
+        enc = hf.encode(wav, None, 24.0)
+        codes_ref = enc[0][0]
+        dec_ref = hf.decode(codes_ref[None], [None])[0]
+        enc6 = hf.encode(wav, None, 6.0)[0][0]
+    lat = m.model.encoder(wav.cuda()).cpu()
+    assert torch.allclose(lat, lat_ref, atol=3e-5, rtol=1e-4)
+    codes, _ = m.encode(wav.cuda())
+    books = torch.stack([layer.codebook.embed for layer in hf.quantizer.layers])
+    assert_codes_near_tie(codes, codes_ref, lat, lat_ref, books, what='HF EnCodec-24k configuration, 32 codebooks')
+    m.set_num_codebooks(8)     # 6 kb/s
+    codes8, _ = m.encode(wav.cuda())
+    assert codes8.shape == enc6.shape == (2, 8, 31)
+    dec = m.decode(codes_ref.cuda(), None).cpu()
+    assert dec.shape == dec_ref.shape and (dec - dec_ref).abs().max().item() < 1e-4

@@ -403,3 +403,83 @@ def test_loudness_oracle_pinned_to_bs1770():
     assert ol.loudness(1e-5 * tone, sr) == -math.inf           # everything below the absolute gate
     # the clamp of torchaudio's biquads: a full-scale tone, boosted by the shelf, is clipped and reads lower than -3.01
     assert ol.loudness(tone, sr) < -3.01
+
+
+def hf_native(cfg, sd):
+    """(native cfg, reference-format state dict, oracle CodecConfig) of the HF EnCodec golden (make_hf_encodec_golden.py)."""
+    from audiocraft_amd.models import builders
+    from audiocraft_amd.models.encodec import convert_hf_encodec_state_dict, hf_encodec_cfg
+    ncfg = hf_encodec_cfg(cfg)
+    native = builders.get_compression_model(ncfg, 'cpu')
+    conv = convert_hf_encodec_state_dict(sd, native.state_dict().keys())
+    native.load_state_dict(conv)       # strict: every HF tensor has exactly one home
+    sk = ncfg['seanet']
+    c = ocodec.CodecConfig(channels=sk['channels'], dimension=sk['dimension'], n_filters=sk['n_filters'],
+                           n_residual_layers=sk['n_residual_layers'], ratios=sk['ratios'], kernel_size=sk['kernel_size'],
+                           last_kernel_size=sk['last_kernel_size'], residual_kernel_size=sk['residual_kernel_size'],
+                           dilation_base=sk['dilation_base'], causal=sk['causal'], pad_mode=sk['pad_mode'],
+                           true_skip=sk['true_skip'], compress=sk['compress'], lstm=sk['lstm'], norm=sk['norm'],
+                           n_q=ncfg['rvq']['n_q'], bins=ncfg['rvq']['bins'], sample_rate=ncfg['sample_rate'],
+                           frame_rate=int(ncfg['frame_rate']), renormalize=ncfg['renormalize'])
+    return ncfg, conv, c
+
+
+def test_hf_encodec_rekeyed_into_the_reference_layout_matches_transformers():
+    """HuggingFace's EnCodec (what `facebook/encodec_24khz` is to the reference, encodec.py:323-394) IS the reference's SEANet /
+    RVQ under other parameter names: its state dict, re-keyed without touching a tensor, through the oracle (pinned to the
+    reference's own EnCodec goldens) reproduces what `transformers` itself computed (fixture made by running it)."""
+    cfg, sd, a = load_golden('hf_encodec_small')
+    ncfg, conv, c = hf_native(cfg, sd)
+    assert c.causal and c.pad_mode == 'reflect' and not c.true_skip and c.lstm == 2 and c.n_q == cfg['num_quantizers']
+    lat = ocodec.seanet_encoder(conv, c, a['wav'])
+    assert torch.allclose(lat, a['latents'], atol=2e-5, rtol=1e-4)
+    books = ocodec.codebooks_from_state(conv, c.n_q)
+    full = ocodec.rvq_encode(a['latents'], books)
+    for bw, k in zip(cfg['target_bandwidths'], (1, 2, 4)):      # a bandwidth is a number of codebooks (600 bit/s each here)
+        assert torch.equal(full[:, :k], a[f'codes_bw{bw}'])
+        dec = ocodec.encodec_decode(conv, c, a[f'codes_bw{bw}'], None)
+        assert torch.allclose(dec, a[f'decoded_bw{bw}'], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(ocodec.rvq_decode(a['codes_bw2.4'], books), a['quantized'], atol=1e-6)
+
+
+def test_hf_encodec_wrapper_api_host_side():
+    """HFEncodecCompressionModel keeps the reference wrapper's surface: codebook counts of the target bandwidths only,
+    properties from the HF config, forward refuses."""
+    import types
+    from audiocraft_amd.models.encodec import HFEncodecCompressionModel, hf_encodec_cfg
+    cfg, sd, _ = load_golden('hf_encodec_small')
+    hf = types.SimpleNamespace(config=types.SimpleNamespace(**cfg), state_dict=lambda: sd, parameters=lambda: iter(()))
+    m = HFEncodecCompressionModel(hf, 'cpu')
+    assert m.possible_num_codebooks == [1, 2, 4] and m.num_codebooks == 4 and m.total_codebooks == 4
+    assert (m.sample_rate, m.frame_rate, m.channels, m.cardinality) == (2400, 100.0, 1, 64)
+    m.set_num_codebooks(2)
+    assert m.num_codebooks == 2
+    with pytest.raises(ValueError):
+        m.set_num_codebooks(3)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 1, 48))
+    with pytest.raises(NotImplementedError):
+        hf_encodec_cfg(dict(cfg, norm_type='time_group_norm'))
+    with pytest.raises(NotImplementedError):
+        hf_encodec_cfg(dict(cfg, chunk_length_s=1.0))
+
+
+def test_get_pretrained_reads_a_huggingface_encodec_directory(tmp_path):
+    """CompressionModel.get_pretrained's last branch (reference encodec.py:117-121): a name that is no audiocraft export goes
+    to `transformers.EncodecModel.from_pretrained`; here a directory in HuggingFace's own format (config.json +
+    model.safetensors written by `save_pretrained` from the golden's state dict)."""
+    transformers = pytest.importorskip('transformers')
+    from audiocraft_amd.models.encodec import CompressionModel, HFEncodecCompressionModel
+    cfg, sd, _ = load_golden('hf_encodec_small')
+    keys = {k: v for k, v in cfg.items() if k not in ('transformers_version', 'num_quantizers')}
+    hf = transformers.EncodecModel(transformers.EncodecConfig(**keys))
+    hf.load_state_dict(sd)
+    hf.save_pretrained(str(tmp_path))
+    m = CompressionModel.get_pretrained(str(tmp_path), 'cpu')
+    assert isinstance(m, HFEncodecCompressionModel) and m.possible_num_codebooks == [1, 2, 4] and not m.training
+    own = m.model.state_dict()
+    assert torch.equal(own['encoder.model.0.conv.conv.weight_v'], sd['encoder.layers.0.conv.parametrizations.weight.original1'])
+    assert torch.equal(own['decoder.model.3.convtr.convtr.weight_g'], sd['decoder.layers.3.conv.parametrizations.weight.original0'])
+    assert torch.equal(own['quantizer.vq.layers.2._codebook.embed'], sd['quantizer.layers.2.codebook.embed'])
+    with pytest.raises(FileNotFoundError, match='HuggingFace'):
+        CompressionModel.get_pretrained(str(tmp_path / 'nothing-here'), 'cpu')
