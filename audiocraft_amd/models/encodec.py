@@ -229,10 +229,9 @@ def hf_encodec_cfg(config) -> dict:
     sr = get('sampling_rate')
     frame_rate = sr / hop
     bins = get('codebook_size')
-    # EncodecConfig.num_quantizers: the codebooks the largest target bandwidth needs (configuration_encodec.py)
-    n_q = int(1000 * get('target_bandwidths')[-1] // (math.ceil(frame_rate) * 10)) if bins == 1024 else \
-        int(get('target_bandwidths')[-1] * 1000 / (math.ceil(frame_rate) * math.log2(bins)))
-    n_q = int(get('num_quantizers', n_q) or n_q)
+    # EncodecConfig.num_quantizers (a property there, a plain entry in a dict): the codebooks the largest target bandwidth
+    # needs, 1000 * bandwidth // (ceil(frame rate) * bits per codebook)
+    n_q = get('num_quantizers') or int(1000 * get('target_bandwidths')[-1] // (math.ceil(frame_rate) * int(math.log2(bins))))
     seanet = dict(channels=get('audio_channels'), dimension=get('hidden_size'), n_filters=get('num_filters'),
                   n_residual_layers=get('num_residual_layers'), ratios=ratios, activation='ELU', activation_params={'alpha': 1.0},
                   norm='weight_norm', norm_params={}, kernel_size=get('kernel_size'), last_kernel_size=get('last_kernel_size'),
