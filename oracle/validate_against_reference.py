@@ -202,6 +202,113 @@ def check_rope():
     print(f"rope    ok: full forward rel-L2 {r:.1e}, greedy + continuation tokens identical (rope+xpos+window+LayerScale, sin_rope+window, rope)")
 
 
+class _Frames(TextConditioner):
+    """A text-keyed condition of `frames` frames through the real output_proj (zeros for null conditions)."""
+    def __init__(self, dim, output_dim, frames, seed):
+        super().__init__(dim, output_dim)
+        self.frames, self.seed = frames, seed
+
+    def tokenize(self, x):
+        return x
+
+    def forward(self, x):
+        g = torch.Generator().manual_seed(self.seed)
+        mask = torch.tensor([[1] * self.frames if xi is not None else [0] * self.frames for xi in x])
+        e = torch.randn(len(x), self.frames, self.dim, generator=g)
+        return self.output_proj(e) * mask.unsqueeze(-1), mask
+
+
+def check_options():
+    """kv_repeat, qk_layer_norm (+ cross), fuser 'sum' / 'input_interpolate' + cross_attention_pos_emb at d 256 / 8 heads /
+    4 layers against the imported reference (its custom attention): full forward, greedy tokens, continuation from a 9-step
+    prompt (the interpolated condition is resampled to that first call's length)."""
+    cross_only = {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpolate': []}
+    for extra in (dict(kv_repeat=4), dict(kv_repeat=2, positional_embedding='sin_rope'),
+                  dict(qk_layer_norm=True, qk_layer_norm_cross=True)):
+        lm = _build_lm(256, 8, 4, 4, 2048, [0, 1, 2, 3], {'description': _Text(64, 256, 7)}, cross_only, seed=41, **extra)
+        with torch.no_grad():
+            for k, p in lm.named_parameters():
+                if '_layer_norm.' in k:
+                    p.add_(0.1 * torch.randn_like(p))
+        sd = {k: v.detach() for k, v in lm.state_dict().items()}
+        oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True, **extra)
+        conds = [ConditioningAttributes(text={'description': f't{i}'}) for i in range(2)]
+        null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+        ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+        seq = torch.randint(0, 2049, (4, 4, 30), generator=torch.Generator().manual_seed(5))
+        with torch.no_grad():
+            ref = lm(seq, [], ct)
+        r = rel(olm.lm_forward(sd, oc, seq, ct['description'][0]), ref)
+        assert r < 1e-5, (extra, r)
+        toks = lm.generate(None, conds, max_gen_len=24, use_sampling=False)
+        assert torch.equal(toks, olm.generate(sd, oc, None, 2, ct['description'][0], max_gen_len=24, use_sampling=False)), extra
+    # the fuser's additive methods
+    fuse = {'cross': ['description'], 'prepend': [], 'sum': ['genre'], 'input_interpolate': ['curve']}
+    torch.manual_seed(43)
+    cds = {'description': _Text(64, 256, 7), 'genre': _Frames(64, 256, 1, 77), 'curve': _Frames(64, 256, 11, 78)}
+    torch.manual_seed(42)
+    lm = LMModel(DelayedPatternProvider(4, delays=[0, 1, 2, 3]), ConditioningProvider(cds),
+                 ConditionFuser(fuse, cross_attention_pos_emb=True, cross_attention_pos_emb_scale=0.6),
+                 n_q=4, card=2048, dim=256, num_heads=8, hidden_scale=4, norm='layer_norm', norm_first=True, bias_proj=False,
+                 weight_init='gaussian', depthwise_init='current', zero_bias_init=True, cfg_coef=3.0, num_layers=4, dropout=0.,
+                 activation='gelu', bias_ff=False, bias_attn=False, causal=True, attention_as_float32=False,
+                 cross_attention=True, custom=False, memory_efficient=True, positional_embedding='sin').eval()
+    sd = {k: v.detach() for k, v in lm.state_dict().items()}
+    oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True)
+    conds = [ConditioningAttributes(text={'description': f't{i}', 'genre': f'g{i}', 'curve': f'c{i}'}) for i in range(2)]
+    null = ClassifierFreeGuidanceDropout(p=1.0)(conds)
+    ct = lm.condition_provider(lm.condition_provider.tokenize(conds + null))
+    cross = olm.cross_pos_emb(ct['description'][0], 0.6)
+    ops = [('sum', ct['genre'][0]), ('input_interpolate', ct['curve'][0])]
+    seq = torch.randint(0, 2049, (4, 4, 30), generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        ref = lm(seq, [], ct)
+    r2 = rel(olm.lm_forward(sd, oc, seq, cross, input_ops=ops), ref)
+    assert r2 < 1e-5, r2
+    toks = lm.generate(None, conds, max_gen_len=24, use_sampling=False)
+    assert torch.equal(toks, olm.generate(sd, oc, None, 2, cross, max_gen_len=24, use_sampling=False, input_ops=ops))
+    prompt = torch.randint(0, 2048, (2, 4, 9), generator=torch.Generator().manual_seed(7))
+    toks = lm.generate(prompt, conds, max_gen_len=24, use_sampling=False)
+    assert torch.equal(toks, olm.generate(sd, oc, prompt, 2, cross, max_gen_len=24, use_sampling=False, input_ops=ops))
+    print(f"options ok: kv_repeat 4 / 2 + sin_rope / qk_layer_norm (+ cross): forward rel-L2 {r:.1e}, greedy tokens identical; "
+          f"fuser sum + input_interpolate + cross pos emb: forward rel-L2 {r2:.1e}, greedy + continuation tokens identical")
+
+
+def check_hf_encodec():
+    """HuggingFace EnCodec at EncodecConfig's defaults (= facebook/encodec_24khz: causal, reflect padding, conv shortcuts, 32 x
+    1024 codebooks) with seeded random weights, run by `transformers` itself, vs the oracle on the re-keyed state dict (what
+    HFEncodecCompressionModel loads): the third party on this path that IS installed here."""
+    import transformers
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    from test_oracle_golden import hf_native
+    torch.manual_seed(3)
+    hf = transformers.EncodecModel(transformers.EncodecConfig()).eval()
+    with torch.no_grad():
+        for layer in hf.quantizer.layers:
+            layer.codebook.embed.copy_(torch.randn_like(layer.codebook.embed) * 0.3)
+    wav = 0.3 * torch.randn(2, 1, 24000, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        lat_ref = hf.encoder(wav)
+        codes_ref = hf.encode(wav, None, 24.0)[0][0]
+        dec_ref = hf.decode(codes_ref[None], [None])[0]
+    cfg = {k: getattr(hf.config, k) for k in ('audio_channels', 'sampling_rate', 'target_bandwidths', 'hidden_size', 'codebook_dim',
+                                              'num_filters', 'num_residual_layers', 'upsampling_ratios', 'codebook_size',
+                                              'kernel_size', 'last_kernel_size', 'residual_kernel_size', 'dilation_growth_rate',
+                                              'use_causal_conv', 'pad_mode', 'compress', 'num_lstm_layers', 'trim_right_ratio',
+                                              'use_conv_shortcut', 'norm_type', 'normalize', 'chunk_length_s', 'num_quantizers')}
+    _, conv, c = hf_native(cfg, {k: v.detach() for k, v in hf.state_dict().items()})
+    lat = ocodec.seanet_encoder(conv, c, wav)
+    r = rel(lat, lat_ref)
+    assert r < 1e-5, r
+    codes = ocodec.rvq_encode(lat_ref, ocodec.codebooks_from_state(conv, c.n_q))
+    assert torch.equal(codes, codes_ref)
+    dec = ocodec.encodec_decode(conv, c, codes_ref, None)
+    e = (dec - dec_ref).abs().max().item()
+    assert e < 2e-5, e
+    print(f"hf      ok: transformers {transformers.__version__} EncodecModel (24 kHz configuration) vs the oracle on re-keyed weights: "
+          f"latents rel-L2 {r:.1e}, {tuple(codes.shape)} codes bit exact, waveform max abs {e:.1e}")
+
+
 def check_melody():
     fuse = {'cross': [], 'prepend': ['self_wav', 'description'], 'sum': [], 'input_interpolate': []}
     torch.manual_seed(3)
@@ -359,7 +466,7 @@ def check_mbd():
     print(f"mbd     ok: NoiseSchedule.generate (6 steps, beta_tilde, clip, rescale, noise_scale) max abs {(cur * 0.9 - ref).abs().max().item():.1e}")
 
 
-CHECKS = {'epic': check_epic, 'mbd': check_mbd, 'lm': check_lm, 'bias': check_bias, 'rope': check_rope, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
+CHECKS = {'epic': check_epic, 'mbd': check_mbd, 'lm': check_lm, 'bias': check_bias, 'rope': check_rope, 'options': check_options, 'hf': check_hf_encodec, 'melody': check_melody, 'stereo': check_stereo, 'codec': check_codec}
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
