@@ -164,7 +164,7 @@ class LMModel(nn.Module):
         assert dim % num_heads == 0 and dim % 8 == 0
         self.kv_repeat = int(kwargs.get('kv_repeat', 1))
         self.qk_layer_norm = bool(kwargs.get('qk_layer_norm', False))
-        self.qk_layer_norm_cross = bool(kwargs.get('qk_layer_norm_cross', False))
+        self.qk_layer_norm_cross = bool(kwargs.get('qk_layer_norm_cross', False)) and cross_attention   # (only exists with one)
         assert self.kv_repeat >= 1 and num_heads % self.kv_repeat == 0, "kv_repeat must divide num_heads (transformer.py:197)"
         assert not self.qk_layer_norm or self.kv_repeat == 1, "qk_layer_norm needs kv_repeat == 1 (transformer.py:219)"
         if dim > 2048 and (self.qk_layer_norm or self.qk_layer_norm_cross):
@@ -197,7 +197,7 @@ class LMModel(nn.Module):
             rope = _Rope(dim // num_heads, max_period, self.xpos, device)
         kv_dim = (dim // num_heads) * (num_heads // self.kv_repeat)
         self.transformer = _Transformer(dim, self.ffn_dim, num_layers, cross_attention, bias_ff, bias_attn, device, layer_scale,
-                                        rope, kv_dim, self.qk_layer_norm, self.qk_layer_norm_cross and cross_attention)
+                                        rope, kv_dim, self.qk_layer_norm, self.qk_layer_norm_cross)
         self.out_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
         self.linears = nn.ModuleList([nn.Linear(dim, card, bias=bias_proj, device=device) for _ in range(n_q)])
         self._init_weights(weight_init, depthwise_init, zero_bias_init)
