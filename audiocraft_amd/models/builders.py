@@ -60,12 +60,15 @@ def get_compression_model(cfg: dict, device='cuda') -> EncodecModel:
 
 
 def get_codebooks_pattern_provider(n_q: int, cfg: tp.Optional[dict] = None):
+    """reference builders.py:240-254: `cfg['modeling']` names the provider, `cfg[<that name>]` holds its arguments."""
+    from ..modules import codebooks_patterns as cp
+    providers = {'parallel': cp.ParallelPatternProvider, 'delay': cp.DelayedPatternProvider, 'unroll': cp.UnrolledPatternProvider,
+                 'coarse_first': cp.CoarseFirstPattern, 'musiclm': cp.MusicLMPattern}
     cfg = cfg or {'modeling': 'delay', 'delay': {'delays': list(range(n_q))}}
-    if cfg.get('modeling', 'delay') != 'delay':
-        raise NotImplementedError("only the 'delay' codebook pattern is on the MusicGen path")
-    d = cfg.get('delay', {})
-    return DelayedPatternProvider(n_q, delays=d.get('delays'), flatten_first=d.get('flatten_first', 0),
-                                  empty_initial=d.get('empty_initial', 0))
+    name = cfg.get('modeling', 'delay')
+    if name not in providers:
+        raise KeyError(f"unknown codebooks pattern '{name}' (one of {sorted(providers)})")
+    return providers[name](n_q, **dict(cfg.get(name) or {}))
 
 
 def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype=None) -> LMModel:

@@ -162,9 +162,8 @@ def test_pattern_matches_naive_loops(T, delays):
     back_t, _, bm_t = p.revert_pattern_sequence(v[..., :T], -1)
     b3, bm3 = opat.revert_pattern_sequence(v2[..., :T], -1, T, delays)
     assert torch.equal(back_t, b3) and torch.equal(bm_t, bm3)
-    for t in range(T):
+    for t in range(T + 1):   # t == T: the coordinates the layout's max_delay tail still holds (as the reference's layout does)
         assert p.get_first_step_with_timesteps(t) == opat.first_step_with_timestep(K, T, t, delays)
-    assert p.get_first_step_with_timesteps(T) is None
     # layout view agrees with the closed form
     lay = opat.delayed_layout(K, T, delays)
     assert [[tuple(c) for c in s] for s in p.layout] == lay
@@ -179,6 +178,42 @@ def test_pattern_matches_naive_loops(T, delays):
                 assert lm[q, t] == (t + dl[q] < S)
                 if lm[q, t]:
                     assert torch.equal(lv[:, :, q, t], logits[:, :, q, t + dl[q]])
+
+
+def test_pattern_providers_match_reference_golden():
+    """Every provider of the reference's builder (`delay` incl. flatten_first / empty_initial, `parallel`, `unroll`,
+    `coarse_first`, `musiclm`): layouts, build / revert values + indexes + masks (all steps and valid steps only, full and
+    truncated sequences), the logits maps and first steps, against what the unmodified reference recorded
+    (tests/golden/make_pattern_golden.py; the reference's own checks: tests/modules/test_codebooks_patterns.py)."""
+    import json
+    from audiocraft_amd.models import builders
+    recs = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'patterns.json')))
+    assert len(recs) >= 60 and {r['provider'] for r in recs} == {'delay', 'parallel', 'unroll', 'coarse_first', 'musiclm'}
+    for r in recs:
+        what = (r['provider'], r['kwargs'], r['n_q'], r['timesteps'])
+        prov = builders.get_codebooks_pattern_provider(r['n_q'], {'modeling': r['provider'], r['provider']: r['kwargs']})
+        p = prov.get_pattern(r['timesteps'])
+        assert [[[c.t, c.q] for c in s] for s in p.layout] == r['layout'], what
+        assert (p.num_sequence_steps, p.max_delay, len(p.valid_layout)) == (r['num_sequence_steps'], r['max_delay'], r['valid_steps']), what
+        assert p.starts_with_special_token()
+        firsts = [[p.get_first_step_with_timesteps(t, q) for q in [None] + list(range(r['n_q']))] for t in range(r['timesteps'] + 1)]
+        assert firsts == r['first_steps'], what
+        z = torch.tensor(r['z'], dtype=torch.long).reshape(2, r['n_q'], r['timesteps'])
+        for m in r['maps']:
+            v, i, k = p.build_pattern_sequence(z, 99, m['keep'])
+            assert v.tolist() == m['values'] and i.tolist() == m['indexes'] and k.int().tolist() == m['mask'], what
+            for rv in m['revert']:
+                s = torch.tensor(rv['s'], dtype=torch.long)
+                v, i, k = p.revert_pattern_sequence(s, -1, m['keep'])
+                assert v.tolist() == rv['values'] and i.tolist() == rv['indexes'] and k.int().tolist() == rv['mask'], (what, rv['S'])
+                lv, li, lk = p.revert_pattern_logits(torch.arange(float(2 * 3 * r['n_q'] * rv['S'])).reshape(2, 3, r['n_q'], rv['S']),
+                                                     float('nan'), m['keep'])
+                assert li.tolist() == rv['logits_indexes'] and lk.int().tolist() == rv['logits_mask'], (what, rv['S'])
+                assert torch.isnan(lv[:, :, ~lk]).all() and not torch.isnan(lv[:, :, lk]).any()
+    with pytest.raises(KeyError):
+        builders.get_codebooks_pattern_provider(4, {'modeling': 'spiral'})
+    with pytest.raises(AssertionError):    # two codebooks of one inner step must share their delay (codebooks_patterns.py:441-445)
+        builders.get_codebooks_pattern_provider(3, {'modeling': 'unroll', 'unroll': {'flattening': [0, 1, 1], 'delays': [0, 1, 2]}})
 
 
 def test_pattern_valid_steps_only():
