@@ -40,6 +40,8 @@ class LMConfig:
     kv_repeat: int = 1                      # H / kv_repeat key / value heads (transformer.py:196-200, 373-386, 398-400)
     qk_layer_norm: bool = False             # LayerNorm on the projected queries / keys (transformer.py:216-222, 388-392)
     qk_layer_norm_cross: bool = False       # same in the cross-attention (transformer.py:358-360, 526-529)
+    # codebook pattern other than the delay rule: (provider name, its kwargs) of builders.get_codebooks_pattern_provider
+    pattern: tp.Optional[tp.Tuple[str, dict]] = None
 
 
 def create_sin_embedding(positions: torch.Tensor, dim: int, max_period: float = 10000.) -> torch.Tensor:
@@ -323,8 +325,9 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
     assert T0 < max_gen_len
     gen_codes = torch.full((B, K, max_gen_len), unknown, dtype=torch.long)
     gen_codes[..., :T0] = prompt
-    gen_sequence, mask = patterns.build_pattern_sequence(gen_codes, special, cfg.delays)
-    start = patterns.first_step_with_timestep(K, max_gen_len, T0, cfg.delays)
+    layout = None if cfg.pattern is None else patterns.provider_layout(cfg.pattern[0], K, max_gen_len, **cfg.pattern[1])
+    gen_sequence, mask = patterns.build_pattern_sequence(gen_codes, special, cfg.delays, layout)
+    start = patterns.first_step_with_timestep(K, max_gen_len, T0, cfg.delays, layout)
     assert start is not None
     state = LMState(cfg.num_layers)
     S = gen_sequence.shape[-1]
@@ -360,7 +363,7 @@ def generate(sd: dict, cfg: LMConfig, prompt: tp.Optional[torch.Tensor], num_sam
     if max_steps is not None:
         return gen_sequence, (torch.stack(all_logits, dim=2) if return_logits else None)
     assert not (gen_sequence == unknown).any()
-    out_codes, out_mask = patterns.revert_pattern_sequence(gen_sequence, unknown, max_gen_len, cfg.delays)
+    out_codes, out_mask = patterns.revert_pattern_sequence(gen_sequence, unknown, max_gen_len, cfg.delays, layout)
     assert (out_codes != unknown).all() and out_mask.all()
     out = out_codes[..., (T0 if remove_prompts else 0):max_gen_len]
     assert (out >= 0).all() and (out <= cfg.card).all()

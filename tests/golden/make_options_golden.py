@@ -12,6 +12,10 @@
 
 The reference runs with custom=True (kv_repeat / qk_layer_norm assert the custom attention, transformer.py:210-219).
 
+  lm_patterns.npz    one model generating through the other codebook patterns of the reference's builder
+                     (codebooks_patterns.py:359-552): parallel, unroll (partly flattened, delayed), coarse_first, musiclm,
+                     delay with flatten_first / empty_initial -- greedy tokens and per-step logits of each
+
 Run in the build container only:   python tests/golden/make_options_golden.py
 """
 import os
@@ -112,3 +116,29 @@ if __name__ == '__main__':
     conds3 = [ConditioningAttributes(text={'description': f'p{i}', 'genre': f'g{i}', 'curve': f'c{i}'}) for i in range(3)]
     lm = build(cfg, cds, fuse, {}, dict(cross_attention_pos_emb=True, cross_attention_pos_emb_scale=0.7))
     run('lm_fuser_sum', cfg, lm, conds3)
+
+    # ---- codebook patterns: the provider is an attribute of the LM, the weights do not depend on it
+    import audiocraft.modules.codebooks_patterns as cbp
+    PATTERNS = [('parallel', {}), ('unroll', dict(flattening=[0, 1, 1, 2], delays=[0, 0, 0, 1])), ('coarse_first', dict(delays=[0, 1, 1])),
+                ('musiclm', dict(group_by=2)), ('delay', dict(delays=[0, 1, 2, 3], flatten_first=2, empty_initial=1))]
+    klass = {'parallel': cbp.ParallelPatternProvider, 'unroll': cbp.UnrolledPatternProvider, 'coarse_first': cbp.CoarseFirstPattern,
+             'musiclm': cbp.MusicLMPattern, 'delay': cbp.DelayedPatternProvider}
+    cfg = dict(BASE, seed=24, patterns=[[n, k] for n, k in PATTERNS])
+    torch.manual_seed(3003)
+    text = {'description': mg.SynthText(cfg['cond_dim'], cfg['dim'], cfg['Lc'])}
+    lm = build(cfg, text, CROSS_ONLY, {})
+    arrays = {}
+    g = torch.Generator().manual_seed(9)
+    prompt = torch.randint(0, cfg['card'], (3, cfg['n_q'], 3), generator=g)
+    arrays['prompt'] = prompt
+    for i, (name, kw) in enumerate(PATTERNS):
+        lm.pattern_provider = klass[name](cfg['n_q'], **kw)
+        tokens, rec, ct = mg.run_lm(lm, conds, None, 7, use_sampling=False)
+        arrays['cond_description'] = ct['description'][0]
+        arrays[f'tokens_{i}'] = tokens
+        arrays[f'step_logits_{i}'] = torch.stack([r[:, :, -1] for r in rec], dim=2)
+        if name != 'coarse_first':   # (a prompt shorter than the sequence makes coarse_first's first call span every coarse step)
+            tokens, _, _ = mg.run_lm(lm, conds, prompt, 7, use_sampling=False)
+            arrays[f'cont_tokens_{i}'] = tokens
+    mg.save('lm_patterns', cfg, lm.state_dict(), **arrays)
+    print('lm_patterns', [n for n, _ in PATTERNS])

@@ -135,6 +135,23 @@ def test_lm_options_oracle_matches_reference(name):
     assert torch.equal(toks, a['cont_tokens'])
 
 
+def test_lm_other_codebook_patterns_oracle_matches_reference():
+    """One model generating through the other codebook patterns of the reference's builder (parallel, partly flattened +
+    delayed unroll, coarse_first, musiclm, delay with flatten_first / empty_initial; codebooks_patterns.py:359-552): greedy
+    tokens and per-step logits of the unmodified reference, without and with a 3-step prompt."""
+    import dataclasses
+    cfg, sd, a = load_golden('lm_patterns')
+    base = lm_cfg(cfg)
+    for i, (name, kw) in enumerate(cfg['patterns']):
+        c = dataclasses.replace(base, pattern=(name, kw))
+        toks, lg = olm.generate(sd, c, None, 3, a['cond_description'], max_gen_len=7, use_sampling=False, return_logits=True)
+        assert torch.equal(toks, a[f'tokens_{i}']), name
+        assert torch.allclose(lg, olm.cfg_mix(a[f'step_logits_{i}'], c.cfg_coef), atol=1e-4, rtol=1e-4), name
+        if f'cont_tokens_{i}' in a:
+            toks = olm.generate(sd, c, a['prompt'], 3, a['cond_description'], max_gen_len=7, use_sampling=False)
+            assert torch.equal(toks, a[f'cont_tokens_{i}']), name
+
+
 def test_lm_melody_oracle_matches_reference():
     cfg, sd, a = load_golden('lm_melody')
     c = lm_cfg(cfg)
