@@ -13,7 +13,6 @@ import typing as tp
 
 import torch
 
-from ..modules.codebooks_patterns import DelayedPatternProvider
 from ..modules.conditioners import (ChromaStemConditioner, ConditionFuser, ConditioningProvider,
                                     SyntheticChromaEmbedder, SyntheticTextEmbedder, T5Conditioner)
 from ..modules.seanet import SEANetDecoder, SEANetEncoder

@@ -44,7 +44,9 @@ class Pattern:
 
     @property
     def max_delay(self) -> int:
-        return max(self.delays)
+        # the reference's definition (codebooks_patterns.py:84-90): how far the layout's timesteps run past `timesteps`.  The
+        # layout has timesteps + max(delays) steps after the special one, its last holds timestep T + max - 1 - min(delays)
+        return max(self.delays) - min(self.delays)
 
     @property
     def valid_layout(self):
@@ -58,13 +60,13 @@ class Pattern:
         assert t <= self.timesteps, "provided timesteps is greater than the pattern's number of timesteps"
         # (t == timesteps: the layout runs max_delay steps past the last timestep and holds the coordinates (timesteps, q) of
         # the codebooks delayed by less than max_delay, codebooks_patterns.py:347-353)
-        last = self.timesteps + self.max_delay
+        last = self.num_sequence_steps
         steps = [t + 1 + d for d in (self.delays if q is None else [self.delays[q]]) if t + 1 + d <= last]
         return min(steps) if steps else None
 
     # -- index maps --------------------------------------------------------------------------------
     def _seq_len(self, keep_only_valid_steps: bool) -> int:
-        return self.timesteps + 1 + (0 if keep_only_valid_steps else self.max_delay)
+        return self.num_sequence_steps + 1 - (self.max_delay if keep_only_valid_steps else 0)
 
     def sequence_map(self, timesteps: int, keep_only_valid_steps: bool = False, device='cpu'):
         """-> (t_index [K, S] int64 clamped, mask [K, S] bool) with t_index[q, s] = s - 1 - delays[q]."""

@@ -25,6 +25,7 @@ def cases():
         out += [('delay', dict(delays=list(range(n_q))), n_q, T), ('delay', dict(delays=[0] * n_q, flatten_first=2), n_q, T),
                 ('delay', dict(delays=list(range(n_q)), flatten_first=3, empty_initial=2), n_q, T),
                 ('delay', dict(empty_initial=1), n_q, T), ('delay', dict(delays=[0, 0] + [2] * (n_q - 2)), n_q, T),
+                ('delay', dict(delays=[1] + [3] * (n_q - 1)), n_q, T),     # no codebook without delay: max_delay < max(delays)
                 ('parallel', dict(), n_q, T), ('parallel', dict(empty_initial=2), n_q, T), ('unroll', dict(), n_q, T),
                 ('coarse_first', dict(), n_q, T), ('coarse_first', dict(delays=list(range(n_q - 1))), n_q, T)]
         if n_q % 2 == 0:

@@ -4,8 +4,6 @@ qk_layer_norm (+ cross), the fuser's 'sum' / 'input_interpolate' methods and cro
 goldens of the unmodified reference (tests/golden/make_options_golden.py) and the CPU oracle at a larger size.
 
 (File name: sorts after the suites of the released configurations, which the driver's `-x` run therefore finishes first.)"""
-import dataclasses
-
 import pytest
 import torch
 

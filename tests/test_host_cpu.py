@@ -188,7 +188,7 @@ def test_pattern_providers_match_reference_golden():
     import json
     from audiocraft_amd.models import builders
     recs = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'patterns.json')))
-    assert len(recs) >= 60 and {r['provider'] for r in recs} == {'delay', 'parallel', 'unroll', 'coarse_first', 'musiclm'}
+    assert len(recs) >= 70 and {r['provider'] for r in recs} == {'delay', 'parallel', 'unroll', 'coarse_first', 'musiclm'}
     for r in recs:
         what = (r['provider'], r['kwargs'], r['n_q'], r['timesteps'])
         prov = builders.get_codebooks_pattern_provider(r['n_q'], {'modeling': r['provider'], r['provider']: r['kwargs']})
@@ -214,6 +214,39 @@ def test_pattern_providers_match_reference_golden():
         builders.get_codebooks_pattern_provider(4, {'modeling': 'spiral'})
     with pytest.raises(AssertionError):    # two codebooks of one inner step must share their delay (codebooks_patterns.py:441-445)
         builders.get_codebooks_pattern_provider(3, {'modeling': 'unroll', 'unroll': {'flattening': [0, 1, 1], 'delays': [0, 1, 2]}})
+
+
+def test_delay_pattern_closed_form_equals_its_layout_form():
+    """The closed-form `Pattern` (what MusicGen runs) and the coordinate-array `LayoutPattern` are two implementations of
+    the same delay rule: 300 random (codebooks, timesteps, delays) -- delays that do not start at 0 included, where the
+    reference's max_delay is max - min (codebooks_patterns.py:84-90) -- give identical layouts, maps and first steps."""
+    import random
+    from audiocraft_amd.modules import codebooks_patterns as cp
+    rng = random.Random(0)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(300):
+        K, T = rng.randint(1, 6), rng.randint(1, 12)
+        delays = sorted(rng.randint(0, 4) for _ in range(K))
+        a = cp.Pattern(K, T, delays)
+        st, t, q, used = cp._delayed_coords(K, delays, T, 0, 1)
+        b = cp.LayoutPattern(K, T, 1 + used, st, t, q)
+        what = (K, T, delays)
+        assert [[tuple(c) for c in s] for s in a.layout] == [[tuple(c) for c in s] for s in b.layout], what
+        assert (a.max_delay, a.num_sequence_steps, len(a.valid_layout)) == (b.max_delay, b.num_sequence_steps, len(b.valid_layout)), what
+        z = torch.randint(0, 9, (2, K, T), generator=g)
+        for keep in (False, True):
+            x, y = a.build_pattern_sequence(z, 99, keep), b.build_pattern_sequence(z, 99, keep)
+            assert all(torch.equal(i, j) for i, j in zip(x, y)), (what, keep)
+            for S in {x[0].shape[-1], max(x[0].shape[-1] - 1, 1), 1}:
+                s = torch.randint(0, 9, (2, K, S), generator=g)
+                assert all(torch.equal(i, j) for i, j in zip(a.revert_pattern_sequence(s, -1, keep),
+                                                              b.revert_pattern_sequence(s, -1, keep))), (what, keep, S)
+                lg = torch.randn(1, 2, K, S, generator=g)
+                xa, xb = a.revert_pattern_logits(lg, float('nan'), keep), b.revert_pattern_logits(lg, float('nan'), keep)
+                assert torch.equal(xa[1], xb[1]) and torch.equal(xa[2], xb[2]) and torch.equal(torch.nan_to_num(xa[0]), torch.nan_to_num(xb[0]))
+        for tt in range(T + 1):
+            for qq in [None] + list(range(K)):
+                assert a.get_first_step_with_timesteps(tt, qq) == b.get_first_step_with_timesteps(tt, qq), (what, tt, qq)
 
 
 def test_pattern_valid_steps_only():
