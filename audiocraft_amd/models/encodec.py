@@ -360,9 +360,8 @@ class InterleaveStereoCompressionModel(CompressionModel):
         return self.model.num_codebooks if self.per_timestep else self.model.num_codebooks * 2
 
     def set_num_codebooks(self, n: int):
-        if not self.per_timestep:
-            assert n % 2 == 0
-            n //= 2
+        """reference encodec.py:428-433: `n` is the WRAPPED model's number of codebooks, i.e. before the interleaving (what
+        `compression_model_n_q` of an experiment config means, builders.py:345-348); `num_codebooks` then reads 2 n."""
         self.model.set_num_codebooks(n)
 
     @property

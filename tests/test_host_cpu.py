@@ -535,6 +535,16 @@ def test_stereo_interleave_wrapper():
         assert torch.equal(codes, torch.from_numpy(gold[f'codes_{tag}']))
         assert torch.equal(st.decode(codes), torch.from_numpy(gold[f'wav_{tag}']))
         assert [st.num_codebooks, st.frame_rate, st.channels, st.total_codebooks] == gold[f'meta_{tag}'].tolist()
+    # set_num_codebooks counts the WRAPPED model's codebooks, before the interleaving (reference encodec.py:428-433, as
+    # `compression_model_n_q` is applied by builders.py:345-348); found by running the reference class side by side
+    seen = []
+    mono = Mono()
+    mono.set_num_codebooks = seen.append
+    InterleaveStereoCompressionModel(mono).set_num_codebooks(4)
+    InterleaveStereoCompressionModel(mono, per_timestep=True).set_num_codebooks(3)
+    assert seen == [4, 3]
+    with pytest.raises(NotImplementedError):   # encodec.py:504-506
+        InterleaveStereoCompressionModel(mono).decode_latent(torch.zeros(1, 8, 4, dtype=torch.long))
 
 
 def test_genmodel_reads_experiment_config_of_the_lm():
