@@ -90,6 +90,8 @@ def test_argument_validation_without_gpu():
     d.Cout, d.Cin, d.ksize = 1, 64, 7      # the few-output kernel: raw weights, no scratch
     assert lib.acmi_conv1d_weight_floats(ctypes.byref(d)) == 64 * 7 and lib.acmi_conv1d_work_floats(ctypes.byref(d)) == 0
     assert lib.acmi_lm_step(None, None, 0, None) == -1
+    assert lib.acmi_layer_norm_rows(None, None, None, None, 4, 64, ctypes.c_float(1e-5), None) == -1
+    assert b'acmi_layer_norm_rows' in lib.acmi_last_error()
     assert lib.acmi_ln_tile(None, None, 0, 4, 4096, ctypes.c_float(1e-5), None) == -1
     assert _C.lstm_work_floats(3, 8) == 5 * 3 * 8 + 4   # c + three hidden-state buffers + give-up counter
     # descriptor entry points: null descriptors, contradictory operands, bad placement
