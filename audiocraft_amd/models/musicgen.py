@@ -10,6 +10,7 @@ the previous one, a melody being tiled periodically so every window sees a full-
 (musicgen.py:290-337).
 """
 import typing as tp
+import warnings
 
 import torch
 
@@ -46,7 +47,10 @@ class MusicGen(BaseGenModel):
         model name or a directory holding `state_dict.bin` + `compression_state_dict.bin` in the reference
         export format, resolved on disk only (see `loaders.py`; there is no network here)."""
         device = 'cuda' if device is None else device
-        name = _SHORT_NAMES.get(name, name)
+        if name in _SHORT_NAMES:     # reference musicgen.py:83-87
+            warnings.warn("MusicGen pretrained model relying on deprecated checkpoint mapping. "
+                          f"Please use full pre-trained id instead: facebook/musicgen-{name}")
+            name = _SHORT_NAMES[name]
         if name == 'debug':
             return MusicGen(name, builders.get_debug_compression_model(device), builders.get_debug_lm_model(device),
                             max_duration=30)
