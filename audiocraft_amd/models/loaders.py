@@ -21,6 +21,17 @@ def get_audiocraft_cache_dir() -> tp.Optional[str]:
     return os.environ.get('AUDIOCRAFT_CACHE_DIR', None)
 
 
+def _hub_cache_lookup(repo_id: str, filename: str, cache_dir: tp.Optional[str]) -> tp.Optional[str]:
+    if repo_id.count('/') != 1 or repo_id.startswith(('/', '.')):
+        return None
+    try:
+        from huggingface_hub import try_to_load_from_cache
+        hit = try_to_load_from_cache(repo_id=repo_id, filename=filename, cache_dir=cache_dir)
+    except Exception:   # no huggingface_hub, malformed id: not a hub checkpoint
+        return None
+    return hit if isinstance(hit, str) and os.path.isfile(hit) else None
+
+
 def _find(file_or_id: str, filename: str) -> str:
     if os.path.isfile(file_or_id):
         return file_or_id
@@ -34,6 +45,12 @@ def _find(file_or_id: str, filename: str) -> str:
         cand = os.path.join(cache, file_or_id, filename)
         if os.path.isfile(cand):
             return cand
+    # the reference resolves names through huggingface_hub.hf_hub_download (loaders.py:63-70): a checkpoint fetched by it
+    # earlier sits in the hub's cache layout (<cache>/models--org--name/snapshots/<rev>/<filename>), under
+    # $AUDIOCRAFT_CACHE_DIR if set, else HuggingFace's default cache -- looked up without touching the network
+    hit = _hub_cache_lookup(file_or_id, filename, cache)
+    if hit is not None:
+        return hit
     raise FileNotFoundError(
         f"checkpoint '{file_or_id}' ({filename}) not found on disk; downloading is not possible here. "
         "Pass a directory containing the exported files, or set AUDIOCRAFT_CACHE_DIR. "

@@ -467,6 +467,25 @@ def test_loader_passes_transformer_options_and_bench_tags():
     assert 'not a BASELINE' in bench.config_tag(argparse.Namespace(model='x/y', batch=3, duration=5.0, greedy=False))
 
 
+def test_loader_finds_checkpoints_in_the_huggingface_hub_cache(tmp_path, monkeypatch):
+    """The reference resolves model names with hf_hub_download (loaders.py:63-70), so a checkpoint it fetched earlier sits in
+    the hub's cache layout; the loaders find it there (under $AUDIOCRAFT_CACHE_DIR or HuggingFace's default cache) without
+    any network access."""
+    pytest.importorskip('huggingface_hub')
+    from audiocraft_amd.models import loaders
+    repo = tmp_path / 'models--facebook--musicgen-tiny'
+    (repo / 'snapshots' / 'abc123').mkdir(parents=True)
+    (repo / 'refs').mkdir()
+    (repo / 'refs' / 'main').write_text('abc123')
+    torch.save({'marker': 7}, repo / 'snapshots' / 'abc123' / 'state_dict.bin')
+    monkeypatch.setenv('AUDIOCRAFT_CACHE_DIR', str(tmp_path))
+    assert loaders._get_state_dict('facebook/musicgen-tiny', 'state_dict.bin') == {'marker': 7}
+    with pytest.raises(FileNotFoundError):
+        loaders._get_state_dict('facebook/musicgen-tiny', 'compression_state_dict.bin')
+    with pytest.raises(FileNotFoundError):
+        loaders._get_state_dict('facebook/musicgen-absent', 'state_dict.bin')
+
+
 def test_loader_roundtrip(tmp_path):
     """Reference export format (utils/export.py:58-79) -> loaders.load_lm_model (construction on CPU only)."""
     from audiocraft_amd.models import builders, loaders
