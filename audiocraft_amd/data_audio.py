@@ -124,6 +124,19 @@ def f32_pcm(wav: torch.Tensor) -> torch.Tensor:
     raise ValueError(f"Unsupported wav dtype: {wav.dtype}")
 
 
+def i16_pcm(wav: torch.Tensor) -> torch.Tensor:
+    """reference audio_utils.py:172-192: float samples in [-1, 1] to int16 -- scaled by 2^15, or by 2^15 - 1 when a sample
+    would otherwise land on +32768 (the int16 range is asymmetric); int16 input is returned as it is."""
+    if not wav.dtype.is_floating_point:
+        assert wav.dtype == torch.int16
+        return wav
+    assert wav.abs().max() <= 1
+    scaled = (wav * 2 ** 15).round()
+    if scaled.max() >= 2 ** 15:
+        scaled = (wav * (2 ** 15 - 1)).round()
+    return scaled.short()
+
+
 def _write_wav_s16(path: Path, wav: torch.Tensor, sample_rate: int):
     """What `ffmpeg -f f32le ... -f wav -c:a pcm_s16le` produces: interleaved little-endian int16, samples rounded to
     the nearest step and saturated."""

@@ -218,6 +218,50 @@ def test_pattern_providers_match_reference_golden():
         builders.get_codebooks_pattern_provider(3, {'modeling': 'unroll', 'unroll': {'flattening': [0, 1, 1], 'delays': [0, 1, 2]}})
 
 
+REFERENCE_ROOT = '/root/reference'
+_ALIAS_PATTERNS = """
+import audiocraft_amd.modules.codebooks_patterns as mine
+pkg = types.ModuleType('audiocraft'); pkg.__path__ = []
+mods = types.ModuleType('audiocraft.modules'); mods.__path__ = []
+sys.modules.update({'audiocraft': pkg, 'audiocraft.modules': mods, 'audiocraft.modules.codebooks_patterns': mine})
+mods.codebooks_patterns = mine
+"""
+_ALIAS_AUDIO_UTILS = """
+import audiocraft_amd.data_audio as da, audiocraft_amd.data_audio_utils as du
+m = types.ModuleType('audiocraft.data.audio_utils')
+for src in (da, du):
+    for k in dir(src):
+        if not k.startswith('__'):
+            setattr(m, k, getattr(src, k))
+pkg = types.ModuleType('audiocraft'); pkg.__path__ = []
+data = types.ModuleType('audiocraft.data'); data.__path__ = []
+audio = types.ModuleType('audiocraft.data.audio'); audio.audio_write = da.audio_write
+sys.modules.update({'audiocraft': pkg, 'audiocraft.data': data, 'audiocraft.data.audio_utils': m, 'audiocraft.data.audio': audio,
+                    'julius': types.ModuleType('julius')})
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ROOT), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize('test_file,alias,select,n_min', [
+    ('tests/modules/test_codebooks_patterns.py', _ALIAS_PATTERNS, '', 120),
+    # (the two deselected cases compare with julius' resampler, absent here; resampling itself runs on the device)
+    ('tests/data/test_audio_utils.py', _ALIAS_AUDIO_UTILS, 'not upsample and not resample', 11),
+])
+def test_reference_own_tests_pass_on_this_implementation(test_file, alias, select, n_min):
+    """The reference's OWN test files for host-side pieces of the path -- the codebook patterns (parallel, delayed, unrolled
+    providers, layouts, build / revert maps against its naive loops) and the audio utilities (channel conversion, PCM
+    conversion, the normalisation strategies) -- run unmodified with the `audiocraft.*` module they import aliased to this
+    package's module; in a subprocess, so that the alias does not leak into this session."""
+    import subprocess
+    import sys
+    code = ("import sys, types, pytest\n" + f"sys.path[:0] = [{ROOT!r}, {REFERENCE_ROOT!r}]\n" + alias +
+            f"sys.exit(int(pytest.main(['-q', '-p', 'no:cacheprovider', {os.path.join(REFERENCE_ROOT, test_file)!r}, '-k', {select!r}])))\n")
+    out = subprocess.run([sys.executable, '-c', code], cwd='/tmp', capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r'(\d+) passed', out.stdout)
+    assert m and int(m.group(1)) >= n_min and 'failed' not in out.stdout, out.stdout[-500:]
+
+
 def test_delay_pattern_closed_form_equals_its_layout_form():
     """The closed-form `Pattern` (what MusicGen runs) and the coordinate-array `LayoutPattern` are two implementations of
     the same delay rule: 300 random (codebooks, timesteps, delays) -- delays that do not start at 0 included, where the
