@@ -59,7 +59,10 @@ def init_from_env(backend: tp.Optional[str] = None) -> tp.Tuple[int, int, int]:
             torch.cuda.set_device(idx)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', idx))
         else:
-            if torch.cuda.is_available():
+            # a host-side transport: bind a device only when this rank has one (one per rank, or the shared-device
+            # switch); a rank beyond the node's devices stays on the host instead of failing before the rendezvous.
+            # The strict LOCAL_RANK < device_count check belongs to the RCCL branch only.
+            if torch.cuda.is_available() and (shared_device_allowed() or local_rank < torch.cuda.device_count()):
                 torch.cuda.set_device(device_index(local_rank))
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank

@@ -105,3 +105,31 @@ def test_shard_helpers_single_process():
     assert adist.world_size() == 1 and adist.rank() == 0
     assert adist.gather_rows(e, 12) is e
     assert adist.broadcast_condition_tensors(ct, 'cpu') is ct
+
+
+def test_gloo_rank_beyond_the_nodes_devices_stays_on_the_host(monkeypatch):
+    """A host-side (gloo) run with more ranks than GPUs must reach the rendezvous: only the RCCL branch insists on
+    LOCAL_RANK < device_count (advisor finding, round 4)."""
+    calls = {}
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '1')
+    monkeypatch.setenv('LOCAL_RANK', '1')
+    monkeypatch.delenv('ACMI_ALLOW_SHARED_DEVICE', raising=False)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda i: calls.setdefault('set_device', i))
+    monkeypatch.setattr(dist, 'is_initialized', lambda: False)
+    monkeypatch.setattr(dist, 'init_process_group', lambda backend, **kw: calls.setdefault('init', (backend, kw)))
+    assert adist.init_from_env('gloo') == (1, 2, 1)
+    assert 'set_device' not in calls and calls['init'][0] == 'gloo'
+    # rank 0 of the same node does bind its device
+    calls.clear()
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.setenv('LOCAL_RANK', '0')
+    assert adist.init_from_env('gloo') == (0, 2, 0)
+    assert calls['set_device'] == 0
+    # RCCL keeps the strict check
+    monkeypatch.setenv('RANK', '1')
+    monkeypatch.setenv('LOCAL_RANK', '1')
+    with pytest.raises(RuntimeError, match='LOCAL_RANK=1'):
+        adist.init_from_env('nccl')

@@ -289,3 +289,29 @@ def test_hf_encodec_24khz_configuration_vs_transformers_run_here():
     assert codes8.shape == enc6.shape == (2, 8, 31)
     dec = m.decode(codes_ref.cuda(), None).cpu()
     assert dec.shape == dec_ref.shape and (dec - dec_ref).abs().max().item() < 1e-4
+
+
+def test_lm_other_codebook_patterns_vs_reference_golden():
+    """LM generation through the NON-delay codebook patterns of the reference's builder (`parallel`, `unroll`, `coarse_first`,
+    `musiclm`, `delay` with flatten_first / empty_initial: codebooks_patterns.py:359-548, builders.py:233-254) on the device,
+    against `lm_patterns.npz` (greedy tokens + per-step logits recorded from the unmodified reference, reproduced by the oracle
+    in tests/test_oracle_golden.py).  The kernels only see the [K, S] validity mask and the token sequence."""
+    from audiocraft_amd.models import builders
+    cfg, sd, a = load_golden('lm_patterns')
+    cross = a['cond_description'].cuda()
+    ct = {'description': (cross, torch.ones(cross.shape[:2], dtype=torch.int64).cuda())}
+    for i, (name, kw) in enumerate(cfg['patterns']):
+        lm = builders.get_lm_model(dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'], n_q=cfg['n_q'],
+                                        card=cfg['card'], hidden_scale=cfg['hidden_scale'], cfg_coef=cfg['cfg_coef'],
+                                        conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': cfg['cond_dim'],
+                                                                      'length': cfg['Lc']}},
+                                        fuser={'cross': ['description']}, codebooks_pattern={'modeling': name, name: kw}),
+                                   'cuda', torch.float32)
+        lm.load_state_dict(sd)
+        toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=7, use_sampling=False, condition_tensors=ct,
+                               return_logits=True, check=True)
+        assert torch.equal(toks.cpu(), a[f'tokens_{i}']), name
+        assert rel(lg.cpu(), olm.cfg_mix(a[f'step_logits_{i}'], cfg['cfg_coef'])) < 1e-4, name
+        if f'cont_tokens_{i}' in a:
+            toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=7, use_sampling=False, condition_tensors=ct, check=True)
+            assert torch.equal(toks.cpu(), a[f'cont_tokens_{i}']), name
