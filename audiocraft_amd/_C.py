@@ -110,7 +110,15 @@ class AttnDesc(C.Structure):
                 ('q_shift', vp), ('active_rows', i32), ('pos_minor_rows', i32), ('start_rows', vp)]
 
 
+class FfnEngineDesc(C.Structure):
+    _fields_ = [('w0', vp), ('w1', vp), ('w2', vp), ('b0', vp), ('b1', vp), ('cs1', vp), ('b2', vp), ('a0', vp), ('x', vp),
+                ('xt_mid', vp), ('xt_out', vp), ('xt_rbs', i32), ('hidden', vp), ('shift', vp), ('flags', vp), ('flags_next', vp),
+                ('err', vp), ('M', i32), ('d', i32), ('ffn', i32), ('eps', f32), ('acq_mode', i32), ('waves', i32), ('trace', vp)]
+
+
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
+_ffn_engine = _sig('acmi_ffn_engine', [C.POINTER(FfnEngineDesc), vp])
+_ffn_engine_supported = _sig('acmi_ffn_engine_supported', [i32, i32, i32, i32])
 _linear_pair = _sig('acmi_linear_pair', [C.POINTER(LinearDesc), C.POINTER(LinearDesc), vp])
 _attn_ex = _sig('acmi_attn_decode_ex', [C.POINTER(AttnDesc), vp])
 _ln_tile_reduce = _sig('acmi_ln_tile_reduce', [vp, vp, i32, vp, i32, i32, i32, f32, vp])
@@ -138,13 +146,14 @@ _resample = _sig('acmi_resample_frac', [vp, vp, vp, i32, i32, i32, i32, i32, i32
 EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add', 'acmi_add_cropped', 'acmi_interp_add', 'acmi_ddpm_step',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_layer_ex', 'acmi_lstm_layer_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
-           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex', 'acmi_layer_norm_rows']
+           'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex', 'acmi_layer_norm_rows',
+           'acmi_ffn_engine', 'acmi_ffn_engine_supported']
 
 
 # ctypes mirror -> C type of include/acmi.h (tests/test_host_cpu.py compiles the header with gcc and compares every
 # field's offset: a mirror that drifts from the header would corrupt every call silently)
 STRUCT_MIRRORS = {'acmi_conv_desc': ConvDesc, 'acmi_lm_layer': LMLayer, 'acmi_lm_model': LMModelDesc, 'acmi_lm_state': LMState,
-                  'acmi_linear_desc': LinearDesc, 'acmi_attn_desc': AttnDesc}
+                  'acmi_linear_desc': LinearDesc, 'acmi_attn_desc': AttnDesc, 'acmi_ffn_engine_desc': FfnEngineDesc}
 
 
 def version() -> int:
@@ -393,6 +402,15 @@ def linear_ex(a, w: TiledWeight, out, M, a_mode, out_mode, **kw):
     `colsum` the folded LayerNorm on a raw tiled activation (a [, a_lo]); xt_hi / xt_lo: raw tiled copy of the output."""
     linear_launch(linear_desc(a, w, out, M, a_mode, out_mode, **kw))
     return out
+
+
+def ffn_engine(d: FfnEngineDesc):
+    """cross-out -> linear1 (+ norm2, GELU) -> linear2 of a decode layer as one persistent launch (acmi_ffn_engine)."""
+    check(_ffn_engine(C.byref(d), stream()), 'acmi_ffn_engine')
+
+
+def ffn_engine_supported(M: int, d: int, ffn: int, dtype: torch.dtype) -> bool:
+    return bool(_ffn_engine_supported(M, d, ffn, dtype_code(dtype)))
 
 
 def linear_pair(plain: LinearDesc, xcat: LinearDesc):

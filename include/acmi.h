@@ -452,6 +452,46 @@ int acmi_linear_ex(const acmi_linear_desc* desc, void* stream);
  * folded LayerNorm or the QKV scatter; both must have the same M and wdtype. */
 int acmi_linear_pair(const acmi_linear_desc* plain, const acmi_linear_desc* xcat, void* stream);
 
+/* The tail of a decode layer as ONE persistent launch (0.1.8):
+ *     x2 = x1 + att W0^T + b0                     (cross-attention out projection,  transformer.py:344-361, 563-566)
+ *     h  = gelu(LN(x2) W1'^T + b1)                (norm2 folded + linear1 + GELU,   transformer.py:567-569)
+ *     x3 = x2 + h W2^T + b2                       (linear2 + residual,              transformer.py:570-572)
+ * i.e. three dependent calls of acmi_linear_ex (half-tile / folded-LayerNorm-from-the-fragments / half-tile forms) whose
+ * two inner dependency edges are crossed INSIDE the launch: one workgroup per CU (d / 8 of them, all co-resident) owns 8
+ * features of x2 and x3 and 32 features of h; its compute waves stream their weight slices of ALL THREE matrices into a
+ * per-wave LDS ring (LDS-DMA, non-temporal) from the start, so that by the time an edge resolves the next GEMM's weights are
+ * already on the CU; a control wave reduces the waves' partial tiles in a fixed order (deterministic), applies the epilogues,
+ * publishes x2's / h's fragments with write-through stores + one flag per workgroup, and polls the producers' flags.
+ * bf16 weights, M <= 16 rows, d % 256 == 0, ffn == 4 d.
+ *   w0, w2: half-tile order (acmi_linear_desc.w_half) [d, d] / [d, ffn];  w1: tiled weight [ffn, d] = linear1 diag(gamma);
+ *   b0 / b2: f32 [d] or NULL;  b1, cs1: f32 [ffn] (acmi_lm_layer.b_ff1 / cs_ff1);
+ *   a0: tiled activation [16, d] (the cross-attention output);  x: f32 [M, d], x1 in, x3 out;
+ *   xt_mid / xt_out: raw fragments of x2 / x3, bf16(v - shift[row]) (acmi_linear_desc.xt_hi / xt_shift), xt_rbs K tiles per
+ *   row block (0 = d / 32);  hidden: tiled activation [16, ffn] (written and read inside the launch);
+ *   flags: device uint32[2 * d / 8], ALL ZERO at launch -- the launch leaves them set and zeroes flags_next (same size, a
+ *   different array) for the next engine launch of the stream;  err: device uint32, OR-ed with a code when a bounded wait
+ *   gave up (a workgroup was not resident: another process on the device) -- the outputs are then garbage;
+ *   trace: NULL, or device uint64[(d / 8) * 2 * 16] in-kernel timeline stamps (s_memrealtime) of the control wave and of the
+ *   first compute wave of every workgroup.
+ * acq_mode: how the consumers read what other workgroups published -- 0 plain loads (each line is read once per launch, after
+ *   its flag), 1 one agent-scope acquire by the control wave + plain loads, 2 agent-scope (sc1) loads. */
+typedef struct {
+    const void* w0; const void* w1; const void* w2;
+    const float* b0; const float* b1; const float* cs1; const float* b2;
+    const void* a0; float* x;
+    void* xt_mid; void* xt_out; int xt_rbs;
+    void* hidden;
+    const float* shift;
+    uint32_t* flags; uint32_t* flags_next; uint32_t* err;
+    int M, d, ffn; float eps;
+    int acq_mode;
+    int waves;               /* compute waves per workgroup: 0 = default (4), or 4 / 8 */
+    uint64_t* trace;
+} acmi_ffn_engine_desc;
+int acmi_ffn_engine(const acmi_ffn_engine_desc* desc, void* stream);
+/* 1 when acmi_ffn_engine supports the geometry (else acmi_lm_step keeps the three launches) */
+int acmi_ffn_engine_supported(int M, int d, int ffn, int wdtype);
+
 /* Single-query attention over a [Beff, H, Tcap, hd] cache, positions [0, len): the
  * F.scaled_dot_product_attention call of transformer.py:412-414 for one new step.
  * q [Beff, H*hd] f32 -> out: [Beff, H*hd] f32 row-major (out_mode ACMI_OUT_F32) or a tiled activation
