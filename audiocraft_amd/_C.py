@@ -113,10 +113,11 @@ class AttnDesc(C.Structure):
 class FfnEngineDesc(C.Structure):
     _fields_ = [('w0', vp), ('w1', vp), ('w2', vp), ('b0', vp), ('b1', vp), ('cs1', vp), ('b2', vp), ('a0', vp), ('x', vp),
                 ('xt_mid', vp), ('xt_out', vp), ('xt_rbs', i32), ('hidden', vp), ('shift', vp), ('flags', vp), ('flags_next', vp),
-                ('err', vp), ('M', i32), ('d', i32), ('ffn', i32), ('eps', f32), ('acq_mode', i32), ('waves', i32), ('trace', vp)]
+                ('err', vp), ('M', i32), ('d', i32), ('ffn', i32), ('eps', f32), ('acq_mode', i32), ('waves', i32), ('dma_chunk', i32), ('dma_epi', i32), ('poll_sleep', i32), ('trace', vp)]
 
 
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
+FFN_ENGINE_FLAG_BYTES = 16384
 _ffn_engine = _sig('acmi_ffn_engine', [C.POINTER(FfnEngineDesc), vp])
 _ffn_engine_supported = _sig('acmi_ffn_engine_supported', [i32, i32, i32, i32])
 _linear_pair = _sig('acmi_linear_pair', [C.POINTER(LinearDesc), C.POINTER(LinearDesc), vp])

@@ -35,14 +35,20 @@ struct EngArgs {
     u32x4* xt_mid; u32x4* xt_out;
     u32x4* hid;
     const float* shift;
-    unsigned* flags; unsigned* flags_next; unsigned* err;
+    unsigned char* flags; unsigned char* flags_next; unsigned* err;
     unsigned long long* trace;
     int M, d, nwg; float eps, inv_d;
-    int acq;
+    int acq, chunk, g_epi, sleep;
 };
 
 #define ENG_NSTAMP 16
 #define ENG_TIMEOUT_TICKS 5000000ull   // 50 ms of the 100 MHz s_memrealtime clock
+// Flag layout of a set: ENG_NREP replicas x 2 edges x 1 KB; workgroup j's byte flag of edge e in replica r sits at
+// (r * 2 + e) * 1024 + j.  A producer sets its flag in EVERY replica (one store instruction, one lane per replica); consumer j
+// polls replica j % ENG_NREP only.  One array polled by all d / 8 CUs is a hot spot: every poll and every flag store of the
+// chip queues at ONE memory channel (v2 of this kernel: the slowest workgroup's flag store landed 4.5 us after the median one).
+#define ENG_NREP 8
+#define ENG_FLAG_BYTES (ENG_NREP * 2 * 1024)
 
 __device__ __forceinline__ float eng_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -73,33 +79,45 @@ __device__ __forceinline__ void eng_pin(u32x4 (&v)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]) :: "memory");
 }
 
-__device__ __forceinline__ u32x4 eng_ld(const u32x4* p, __amdgpu_buffer_rsrc_t rs, unsigned byte_off, int acq) {
-    // acq 2: agent-scope (sc1) load -- served by the memory side, never by a stale line of this XCD's L2
-    if (acq == 2) return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
-    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p) + byte_off);
+// words of the workgroup's control block in LDS (written by the control wave, read by the compute waves)
+enum { ENG_GRANT = 0, ENG_EDGE = 1 };
+__device__ __forceinline__ int eng_lds_get(const unsigned* p) {
+    return __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void eng_lds_put(unsigned* p, int v) {
+    __hip_atomic_store(p, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // NW compute waves, KF = K tiles of d per compute wave, RF = ring fragments (1 KB) per compute wave, C2 = chunks op2's
-// activation is fetched in (register budget)
-template <int NW, int KF, int RF, int C2>
+// activation is fetched in (register budget), SC1 = consumers read published fragments with agent-scope (sc1) loads
+//
+// The weight stream is METERED.  A CU's vector-memory path is a FIFO: a flag poll, an activation load or a hand-off store
+// issued behind a burst of weight requests waits for that burst (v1 of this kernel requested a wave's whole ring at once and
+// measured 4.2 us from "own flag stored" to "all flags seen" on every edge -- profiles/r05_engine_v1_burst_dma_*).  So the
+// compute waves only request what the control wave has GRANTED (a cumulative fragment count per wave, in LDS): the weights of
+// op0 at entry, then `chunk` fragments per wave right after every poll has been issued (the poll is ahead of them in the FIFO),
+// and whatever an op still misses once its edge has resolved.
+template <int NW, int KF, int RF, int C2, bool SC1>
 __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs p) {
     constexpr int UF0 = KF / 2;                 // op0: weight units per wave (a unit = 8 features x 2 K tiles)
     constexpr int S1 = UF0, S2 = UF0 + 2 * KF, TOTAL = UF0 + 4 * KF;   // the wave's weight stream: [0, S1) op0, [S1, S2) op1, [S2, TOTAL) op2
     constexpr int NKC = NW * KF;                // K tiles of d
     static_assert(KF % 2 == 0 && RF >= 2 * KF && RF >= UF0 && (4 * KF) % C2 == 0 && ((4 * KF) / C2) % 2 == 0, "engine geometry");
-    constexpr int PA = RF < TOTAL ? RF : TOTAL;                 // phase A: stream fragments [0, PA) (ring full)
-    constexpr int PB = RF + UF0 < TOTAL ? RF + UF0 : TOTAL;     // phase B (op0 consumed): [PA, PB)
+    static_assert(512 % (NW * 64) == 0, "op1's epilogue: 512 outputs over the compute waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: control wave, 1 .. NW: compute waves
     const int j = blockIdx.x;
     float* const red = reinterpret_cast<float*>(smem + (size_t)NW * RF * 1024);          // [NW][4 tiles][256]
     unsigned short* const stage = reinterpret_cast<unsigned short*>(smem + (size_t)NW * RF * 1024 + (size_t)NW * 4096);   // 1 KB
+    unsigned* const ctl = reinterpret_cast<unsigned*>(smem + (size_t)NW * RF * 1024 + (size_t)NW * 4096 + 1024);           // 64 B
     unsigned long long ts[ENG_NSTAMP];
 #pragma unroll
     for (int i = 0; i < ENG_NSTAMP; ++i) ts[i] = 0;
 #define ENG_TS(i) do { if (p.trace != nullptr) ts[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     ENG_TS(0);
+    if (threadIdx.x == 0) { ctl[ENG_GRANT] = S1; ctl[ENG_EDGE] = 0; }
+    eng_bar();                                       // B0: the control block is initialised
 
     if (wv != 0) {
         // ------------------------------------------------------------------------------------------ compute wave
@@ -111,28 +129,40 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
         const u32x4* g1a = p.w1 + ((size_t)(2 * j) * NKC + (size_t)w * KF) * 64;
         const u32x4* g1b = g1a + (size_t)NKC * 64;
         const u32x4* g2 = p.w2 + ((size_t)j * (2 * NKC) + (size_t)w * 2 * KF) * 64;
-        auto issue = [&](auto lo_c, auto hi_c) {
-            constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-#pragma unroll
-            for (int i = LO; i < HI; ++i) {
-                const unsigned dst = ring_lds + (unsigned)((i % RF) * 1024);
-                if (i < S1) eng_dma(g0, voff + (unsigned)(i * 1024), dst);
-                else if (i < S1 + KF) eng_dma(g1a, voff + (unsigned)((i - S1) * 1024), dst);
-                else if (i < S2) eng_dma(g1b, voff + (unsigned)((i - S1 - KF) * 1024), dst);
-                else eng_dma(g2, voff + (unsigned)((i - S2) * 1024), dst);
+        int issued = 0, slot = 0, freed = 0;         // wave-uniform: stream fragments requested / ring slot of the next one / consumed
+        auto pump = [&](int limit) __attribute__((always_inline)) {                 // request stream fragments up to `limit`, as far as the ring has room
+            const int lim = min(min(limit, freed + RF), TOTAL);
+            while (issued < lim) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_lds + (unsigned)(slot * 1024)));
+                if (issued < S1) eng_dma(g0, voff + (unsigned)(issued * 1024), dst);
+                else if (issued < S1 + KF) eng_dma(g1a, voff + (unsigned)((issued - S1) * 1024), dst);
+                else if (issued < S2) eng_dma(g1b, voff + (unsigned)((issued - S1 - KF) * 1024), dst);
+                else eng_dma(g2, voff + (unsigned)((issued - S2) * 1024), dst);
+                ++issued;
+                slot = slot + 1 == RF ? 0 : slot + 1;
             }
         };
-#define ENG_IC(v) std::integral_constant<int, (v)>()
-        // ---- op0: its weights first, then the activation (written by the previous launch), then the rest of the ring
-        issue(ENG_IC(0), ENG_IC(UF0));
+        auto wait_edge = [&](int k) __attribute__((always_inline)) {                // until edge k has resolved: request what the control wave grants
+            for (;;) {
+                pump(eng_lds_get(ctl + ENG_GRANT));
+                if (eng_lds_get(ctl + ENG_EDGE) >= k) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        };
+        // op1's epilogue is shared by the compute waves: 512 / NW outputs each; this lane's: rows rw + (lane >> 5) (+ 2 per
+        // further output), hidden feature 32 j + (lane & 31)
+        constexpr int EO = 512 / (NW * 64);          // outputs per lane
+        const float b1v = p.b1 != nullptr ? p.b1[32 * j + (lane & 31)] : 0.f;
+        const float c1v = p.cs1[32 * j + (lane & 31)];
+        // ---- op0: its weights, then the activation (written by the previous launch)
+        pump(S1);
         u32x4 av[KF];
         {
             const u32x4* a0 = p.a0 + (size_t)(w * KF) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < KF; ++i) av[i] = a0[i * 64];
         }
-        eng_pin(av);           // the activation is back, hence (in-order return) op0's weights have landed in LDS
-        issue(ENG_IC(UF0), ENG_IC(PA));
+        eng_pin(av);              // the activation is back, hence (in-order return) op0's weights have landed in LDS
         ENG_TS(1);
         {
             f32x4 ce = {0.f, 0.f, 0.f, 0.f}, co = {0.f, 0.f, 0.f, 0.f};
@@ -147,16 +177,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
         }
         ENG_TS(2);
         eng_bar();                                   // B1: op0's partial tiles are in LDS
-        issue(ENG_IC(PA), ENG_IC(PB));               // the ring slots of op0 are free
-        eng_bar();                                   // B2: x2 is complete (every producer's flag seen by the control wave)
+        freed = S1;
+        wait_edge(1);                                // x2 is complete (every producer's flag seen by the control wave)
+        ts[9] = (unsigned long long)issued;
+        pump(S2);                                    // what op1 still misses
         ENG_TS(3);
         // ---- op1
         {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xt_mid, 0, -1, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < KF; ++i) av[i] = eng_ld(p.xt_mid, rs, (unsigned)(((w * KF + i) * 64 + lane) * 16), p.acq);
+            for (int i = 0; i < KF; ++i) {
+                const unsigned off = (unsigned)(((w * KF + i) * 64 + lane) * 16);
+                if (SC1) av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+                else av[i] = p.xt_mid[(w * KF + i) * 64 + lane];
+            }
         }
-        eng_pin(av);           // every older request of this wave -- all of op1's weights -- has landed as well
+        eng_pin(av);              // every older request of this wave -- all of op1's weights -- has landed as well
         ENG_TS(4);
         {
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, cs = c0, cg = c0;
@@ -178,9 +214,34 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
             }
         }
         ENG_TS(5);
-        eng_bar();                                   // B3
-        issue(ENG_IC(PB), ENG_IC(TOTAL));            // the ring slots of op1 are free
-        eng_bar();                                   // B4: h is complete
+        eng_bar();                                   // B3: op1's partial tiles are in LDS
+        freed = S2;
+        {   // epilogue of op1: folded LayerNorm (statistics from the fragments), bias, exact GELU -> bf16 in `stage`
+            const float rk = p.inv_d;
+#pragma unroll
+            for (int i = 0; i < EO; ++i) {
+                const int m = w * (2 * EO) + 2 * i + (lane >> 5), f = lane & 31, t = f >> 4, n = f & 15;
+                const int idx = ((((m >> 2) * 16) + n) << 2) + (m & 3);
+                const int idg = ((((m >> 2) * 16) + m) << 2) + (m & 3);
+                float v = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    v += red[(ww * 4 + t) * 256 + idx];
+                    s1 += red[(ww * 4 + 2) * 256 + idx];
+                    s2 += red[(ww * 4 + 3) * 256 + idg];
+                }
+                const float mean_s = s1 * rk;
+                const float rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * rk - mean_s * mean_s, 0.f) + p.eps);
+                v = rstd * (v - mean_s * c1v);
+                v += b1v;
+                v = eng_gelu(v);
+                stage[m * 32 + f] = f32_to_bf16(v);
+            }
+        }
+        eng_bar();                                   // B3b: h's fragment is staged
+        wait_edge(2);                                // h is complete
+        ts[10] = (unsigned long long)issued;
+        pump(TOTAL);
         ENG_TS(6);
         // ---- op2
         {
@@ -191,8 +252,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
             for (int c = 0; c < C2; ++c) {
                 u32x4 ah[AF];
 #pragma unroll
-                for (int i = 0; i < AF; ++i)
-                    ah[i] = eng_ld(p.hid, rs, (unsigned)(((w * 4 * KF + c * AF + i) * 64 + lane) * 16), p.acq);
+                for (int i = 0; i < AF; ++i) {
+                    const int kt = w * 4 * KF + c * AF + i;
+                    if (SC1) ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)((kt * 64 + lane) * 16), 0, 16);
+                    else ah[i] = p.hid[kt * 64 + lane];
+                }
                 eng_pin(ah);
                 if (c == 0) ENG_TS(7);
 #pragma unroll
@@ -218,8 +282,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
     // ---------------------------------------------------------------------------------------------- control wave
     const int M = p.M, d = p.d, nwg = p.nwg;
     // half-tile epilogues (op0, op2): output e = lane + 64 i, i < 2: row e >> 3, feature 8 j + (e & 7)
-    // op1: output e = lane + 64 i, i < 8: n-tile i >> 2, row (lane >> 4) + 4 (i & 3), feature 32 j + 16 (i >> 2) + (lane & 15)
-    float res[2], b0v[2], b2v[2], shv[2], b1v[2], c1v[2];
+    float res[2], b0v[2], b2v[2], shv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int e = lane + 64 * i, m = min(e >> 3, M - 1), f = 8 * j + (e & 7);
@@ -227,34 +290,39 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
         b0v[i] = p.b0 != nullptr ? p.b0[f] : 0.f;
         b2v[i] = p.b2 != nullptr ? p.b2[f] : 0.f;
         shv[i] = p.shift != nullptr ? p.shift[m] : 0.f;
-        const int n = 32 * j + 16 * i + (lane & 15);
-        b1v[i] = p.b1 != nullptr ? p.b1[n] : 0.f;
-        c1v[i] = p.cs1[n];
     }
-    if (lane < 2) __hip_atomic_store(p.flags_next + lane * nwg + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < 2 * ENG_NREP) __hip_atomic_store(p.flags_next + lane * 1024 + j, (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned char* const my_flags = p.flags + (j & (ENG_NREP - 1)) * 2048;   // the replica this workgroup polls
     const __amdgpu_buffer_rsrc_t rs_mid = __builtin_amdgcn_make_buffer_rsrc(p.xt_mid, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_hid = __builtin_amdgcn_make_buffer_rsrc(p.hid, 0, -1, 0x00020000);
-    const int xt_rbs = NKC;   // row block 0 only (M <= 16): the row-block stride never enters
-    (void)xt_rbs;
+    int grant = S1, npoll = 0;
 
-    auto poll = [&](const unsigned* fl, unsigned code) {
+    // all nwg byte flags == 1?  One dword (4 flags) per lane; after every poll's loads are on their way the compute waves
+    // are granted `chunk` more fragments each (behind the poll in the CU's memory FIFO)
+    auto poll = [&](const unsigned char* fl, unsigned code) __attribute__((always_inline)) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned* fw = reinterpret_cast<const unsigned*>(fl);
         for (;;) {
-            bool ok = true;
-            for (int i = lane; i < nwg; i += 64) ok = ok && __hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
-            if (__all(ok)) break;
+            unsigned v = 0x01010101u;
+            if (lane * 4 < nwg) v = __hip_atomic_load(fw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_sched_barrier(0);
+            grant = min(grant + p.chunk, TOTAL);
+            eng_lds_put(ctl + ENG_GRANT, grant);
+            __builtin_amdgcn_sched_barrier(0);
+            ++npoll;
+            if (__all(v == 0x01010101u)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > ENG_TIMEOUT_TICKS) {
                 if (lane == 0) __hip_atomic_fetch_or(p.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            for (int q = 0; q < p.sleep; ++q) __builtin_amdgcn_s_sleep(4);   // 4 x 64 clocks per unit
         }
         if (p.acq == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
 
     // x2 / x3 of this lane's two outputs; half-tile epilogue shared by op0 and op2
     float xv[2];
-    auto half_epilogue = [&](const float (&resv)[2], const float (&bv)[2]) {
+    auto half_epilogue = [&](const float (&resv)[2], const float (&bv)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int e = lane + 64 * i, m = e >> 3, c = e & 7;
@@ -278,56 +346,36 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
         const u32x4 q = *reinterpret_cast<const u32x4*>(stage + m * 8);
         // K tile j >> 2, lane group j & 3 of x2's fragments
         if (lane < 16 && m < M)
-            __builtin_amdgcn_raw_buffer_store_b128(q, rs_mid,
-                                                   (unsigned)((((j >> 2) * 64) + (j & 3) * 16 + m) * 16), 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b128(q, rs_mid, (unsigned)((((j >> 2) * 64) + (j & 3) * 16 + m) * 16), 0, 16 /* sc1 */);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(p.flags + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < ENG_NREP) __hip_atomic_store(p.flags + lane * 2048 + j, (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ENG_TS(2);
-    poll(p.flags, 1u);
+    poll(my_flags, 1u);
+    grant = max(grant, S2);
+    eng_lds_put(ctl + ENG_GRANT, grant);
+    eng_lds_put(ctl + ENG_EDGE, 1);
     ENG_TS(3);
-    eng_bar();                                       // B2
+    ts[9] = (unsigned long long)npoll;
     eng_bar();                                       // B3: op1's partial tiles
+    if (p.g_epi > 0) { grant = min(grant + p.g_epi, TOTAL); eng_lds_put(ctl + ENG_GRANT, grant); }
+    eng_bar();                                       // B3b: K tile j of h is staged as bf16
     ENG_TS(4);
-    // ---- epilogue of op1: folded LayerNorm (statistics from the fragments), bias, exact GELU -> K tile j of h
     {
-        const float rk = p.inv_d;
-        float mean_s[4], rstd[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = (lane >> 4) + 4 * q;
-            const int idx = ((q * 16 + (lane & 15)) << 2) + (lane >> 4);
-            const int idg = ((q * 16 + m) << 2) + (lane >> 4);
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { s1 += red[(w * 4 + 2) * 256 + idx]; s2 += red[(w * 4 + 3) * 256 + idg]; }
-            mean_s[q] = s1 * rk;
-            rstd[q] = __builtin_amdgcn_rsqf(fmaxf(s2 * rk - mean_s[q] * mean_s[q], 0.f) + p.eps);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = i >> 2, q = i & 3, m = (lane >> 4) + 4 * q, n = lane & 15;
-            const int idx = ((q * 16 + n) << 2) + (lane >> 4);
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v += red[(w * 4 + t) * 256 + idx];
-            v = rstd[q] * (v - mean_s[q] * c1v[t]);
-            v += b1v[t];
-            v = eng_gelu(v);
-            stage[m * 32 + t * 16 + n] = f32_to_bf16(v);
-        }
         const int m = lane & 15, kg = lane >> 4;
         const u32x4 q4 = *reinterpret_cast<const u32x4*>(stage + m * 32 + kg * 8);
-        if (m < M)
-            __builtin_amdgcn_raw_buffer_store_b128(q4, rs_hid,
-                                                   (unsigned)((j * 64 + lane) * 16), 0, 16 /* sc1 */);
+        if (m < M) __builtin_amdgcn_raw_buffer_store_b128(q4, rs_hid, (unsigned)((j * 64 + lane) * 16), 0, 16 /* sc1 */);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(p.flags + nwg + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < ENG_NREP) __hip_atomic_store(p.flags + lane * 2048 + 1024 + j, (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ENG_TS(5);
-    poll(p.flags + nwg, 2u);
+    npoll = 0;
+    poll(my_flags + 1024, 2u);
+    grant = TOTAL;
+    eng_lds_put(ctl + ENG_GRANT, grant);
+    eng_lds_put(ctl + ENG_EDGE, 2);
     ENG_TS(6);
-    eng_bar();                                       // B4
+    ts[10] = (unsigned long long)npoll;
     eng_bar();                                       // B5: op2's partial tiles
     ENG_TS(7);
     // ---- epilogue of op2: x3 = x2 + h W2^T + b2 -> x (f32) and the raw fragments for the next layer (plain stores: the
@@ -353,24 +401,28 @@ __global__ __launch_bounds__((NW + 1) * 64) void ffn_engine_kernel(const EngArgs
         for (int i = 0; i < ENG_NSTAMP; ++i) dst[i] = ts[i];
     }
 #undef ENG_TS
-#undef ENG_IC
 }
 
-template <int NW, int KF, int RF, int C2>
-static int eng_launch(const EngArgs& a, hipStream_t st) {
-    constexpr size_t lds = (size_t)NW * RF * 1024 + (size_t)NW * 4096 + 1024;
+template <int NW, int KF, int RF, int C2, bool SC1>
+static int eng_launch_k(const EngArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)NW * RF * 1024 + (size_t)NW * 4096 + 1024 + 64;
     static_assert(lds <= 160 * 1024, "engine LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_engine_kernel<NW, KF, RF, C2>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_engine_kernel<NW, KF, RF, C2, SC1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             acmi_set_error("acmi_ffn_engine: cannot raise the dynamic LDS limit");
             return ACMI_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((ffn_engine_kernel<NW, KF, RF, C2>), dim3(a.nwg), dim3((NW + 1) * 64), lds, st, a);
+    hipLaunchKernelGGL((ffn_engine_kernel<NW, KF, RF, C2, SC1>), dim3(a.nwg), dim3((NW + 1) * 64), lds, st, a);
     return acmi_check_launch("ffn_engine_kernel");
+}
+
+template <int NW, int KF, int RF, int C2>
+static int eng_launch(const EngArgs& a, hipStream_t st) {
+    return a.acq == 2 ? eng_launch_k<NW, KF, RF, C2, true>(a, st) : eng_launch_k<NW, KF, RF, C2, false>(a, st);
 }
 
 extern "C" int acmi_ffn_engine_supported(int M, int d, int ffn, int wdtype) {
@@ -388,8 +440,12 @@ extern "C" int acmi_ffn_engine(const acmi_ffn_engine_desc* c, void* stream) {
     a.w0 = (const u32x4*)c->w0; a.w1 = (const u32x4*)c->w1; a.w2 = (const u32x4*)c->w2;
     a.b0 = c->b0; a.b1 = c->b1; a.cs1 = c->cs1; a.b2 = c->b2;
     a.a0 = (const u32x4*)c->a0; a.x = c->x; a.xt_mid = (u32x4*)c->xt_mid; a.xt_out = (u32x4*)c->xt_out; a.hid = (u32x4*)c->hidden;
-    a.shift = c->shift; a.flags = c->flags; a.flags_next = c->flags_next; a.err = c->err; a.trace = (unsigned long long*)c->trace;
+    a.shift = c->shift; a.flags = (unsigned char*)c->flags; a.flags_next = (unsigned char*)c->flags_next; a.err = c->err; a.trace = (unsigned long long*)c->trace;
     a.M = c->M; a.d = c->d; a.nwg = c->d / 8; a.eps = c->eps; a.inv_d = 1.0f / (float)c->d; a.acq = c->acq_mode;
+    static const int env_chunk = getenv("ACMI_ENGINE_CHUNK") ? atoi(getenv("ACMI_ENGINE_CHUNK")) : 0;
+    a.chunk = c->dma_chunk > 0 ? c->dma_chunk : (env_chunk > 0 ? env_chunk : 4);
+    a.g_epi = c->dma_epi > 0 ? c->dma_epi : 0;
+    a.sleep = c->poll_sleep >= 0 ? c->poll_sleep : 0;
     hipStream_t st = (hipStream_t)stream;
     static const int env_nw = getenv("ACMI_ENGINE_NW") ? atoi(getenv("ACMI_ENGINE_NW")) : 0;
     const int nw = c->waves > 0 ? c->waves : (env_nw > 0 ? env_nw : 4);

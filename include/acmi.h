@@ -468,13 +468,15 @@ int acmi_linear_pair(const acmi_linear_desc* plain, const acmi_linear_desc* xcat
  *   a0: tiled activation [16, d] (the cross-attention output);  x: f32 [M, d], x1 in, x3 out;
  *   xt_mid / xt_out: raw fragments of x2 / x3, bf16(v - shift[row]) (acmi_linear_desc.xt_hi / xt_shift), xt_rbs K tiles per
  *   row block (0 = d / 32);  hidden: tiled activation [16, ffn] (written and read inside the launch);
- *   flags: device uint32[2 * d / 8], ALL ZERO at launch -- the launch leaves them set and zeroes flags_next (same size, a
- *   different array) for the next engine launch of the stream;  err: device uint32, OR-ed with a code when a bounded wait
+ *   flags: ACMI_FFN_ENGINE_FLAG_BYTES device bytes (byte flags, replicated so that no single line is polled by every CU), ALL
+ *   ZERO at launch -- the launch leaves them set and zeroes flags_next (same size, a different array) for the next engine
+ *   launch of the stream;  err: device uint32, OR-ed with a code when a bounded wait
  *   gave up (a workgroup was not resident: another process on the device) -- the outputs are then garbage;
  *   trace: NULL, or device uint64[(d / 8) * 2 * 16] in-kernel timeline stamps (s_memrealtime) of the control wave and of the
  *   first compute wave of every workgroup.
  * acq_mode: how the consumers read what other workgroups published -- 0 plain loads (each line is read once per launch, after
  *   its flag), 1 one agent-scope acquire by the control wave + plain loads, 2 agent-scope (sc1) loads. */
+#define ACMI_FFN_ENGINE_FLAG_BYTES 16384
 typedef struct {
     const void* w0; const void* w1; const void* w2;
     const float* b0; const float* b1; const float* cs1; const float* b2;
@@ -482,10 +484,14 @@ typedef struct {
     void* xt_mid; void* xt_out; int xt_rbs;
     void* hidden;
     const float* shift;
-    uint32_t* flags; uint32_t* flags_next; uint32_t* err;
+    void* flags; void* flags_next; uint32_t* err;
     int M, d, ffn; float eps;
     int acq_mode;
     int waves;               /* compute waves per workgroup: 0 = default (4), or 4 / 8 */
+    int dma_chunk;           /* weight fragments (1 KB) every compute wave may request per flag poll of the control wave (the
+                                stream is metered: a CU's memory path is a FIFO, polls wait behind bursts); 0 = default */
+    int dma_epi;             /* ... and when an epilogue starts (ahead of its hand-off stores); 0 = none */
+    int poll_sleep;          /* pause between two flag polls, in units of 256 clocks; 0 = none */
     uint64_t* trace;
 } acmi_ffn_engine_desc;
 int acmi_ffn_engine(const acmi_ffn_engine_desc* desc, void* stream);

@@ -65,7 +65,7 @@ def launch_chain(L, b, M, d, F, eps):
     return (d0, d1, d2)
 
 
-def engine_desc(L, b, M, d, F, eps, flags, flags_next, err, acq, waves, trace=None):
+def engine_desc(L, b, M, d, F, eps, flags, flags_next, err, acq, waves, trace=None, chunk=0, epi=0, sleep=0):
     e = _C.FfnEngineDesc()
     e.w0, e.w1, e.w2 = L.t_w0h.data_ptr(), L.t_w1.data_ptr(), L.t_w2h.data_ptr()
     e.b0, e.b1, e.cs1, e.b2 = _C.ptr(L.b0), _C.ptr(L.b1), _C.ptr(L.cs1), _C.ptr(L.b2)
@@ -73,6 +73,7 @@ def engine_desc(L, b, M, d, F, eps, flags, flags_next, err, acq, waves, trace=No
     e.xt_mid, e.xt_out, e.xt_rbs, e.hidden = _C.ptr(b.xt[0]), _C.ptr(b.xt[1]), 0, _C.ptr(b.hidden)
     e.shift, e.flags, e.flags_next, e.err = _C.ptr(b.shift), flags.data_ptr(), flags_next.data_ptr(), _C.ptr(err)
     e.M, e.d, e.ffn, e.eps, e.acq_mode, e.waves = M, d, F, eps, acq, waves
+    e.dma_chunk, e.dma_epi, e.poll_sleep = chunk, epi, sleep
     e.trace = None if trace is None else trace.data_ptr()
     return e
 
@@ -99,6 +100,9 @@ def main():
     ap.add_argument('--modes', default='0,1,2')
     ap.add_argument('--waves', default='4,8')
     ap.add_argument('--trace', default=None)
+    ap.add_argument('--chunks', default='4')
+    ap.add_argument('--epi', default='0')
+    ap.add_argument('--sleep', default='0')
     ap.add_argument('--check-reps', type=int, default=50)
     args = ap.parse_args()
     dev = torch.device('cuda')
@@ -167,12 +171,14 @@ def main():
 
     # ------------------------------------------------------------ the engine
     results = {}
-    for waves in [int(v) for v in args.waves.split(',')]:
-        for acq in [int(v) for v in args.modes.split(',')]:
-            tag = f"engine w{waves} acq{acq}"
+    import itertools
+    ints = lambda v: [int(q) for q in v.split(',')]   # noqa: E731
+    for waves, acq, chunk, epi, sleep in itertools.product(ints(args.waves), ints(args.modes), ints(args.chunks), ints(args.epi), ints(args.sleep)):
+        if True:
+            tag = f"engine w{waves} acq{acq} chunk{chunk} epi{epi} sleep{sleep}"
             be = Bufs(M, d, F, dev)
             be.shift.copy_(shift)
-            flags = torch.zeros(3, 2 * nwg, dtype=torch.int32, device=dev)
+            flags = torch.zeros(3, _C.FFN_ENGINE_FLAG_BYTES, dtype=torch.uint8, device=dev)
             err = torch.zeros(1, dtype=torch.int32, device=dev)
             set_of = lambda li: 2 if (li == NL - 1 and NL % 2 == 1) else li & 1   # noqa: E731
             descs = []
@@ -181,7 +187,7 @@ def main():
                 be.x.copy_(x_init)
                 for li, L in enumerate(layers):
                     tr = None if trace is None else trace[li]
-                    e = engine_desc(L, be, M, d, F, eps, flags[set_of(li)], flags[set_of((li + 1) % NL)], err, acq, waves, tr)
+                    e = engine_desc(L, be, M, d, F, eps, flags[set_of(li)], flags[set_of((li + 1) % NL)], err, acq, waves, tr, chunk, epi, sleep)
                     descs.append(e)
                     _C.ffn_engine(e)
             try:
@@ -191,7 +197,7 @@ def main():
                 for li, (xi, xo, hid, xt0, xt1) in enumerate(per_layer):
                     flags.zero_()
                     be.x.copy_(xi)
-                    e = engine_desc(layers[li], be, M, d, F, eps, flags[0], flags[1], err, acq, waves)
+                    e = engine_desc(layers[li], be, M, d, F, eps, flags[0], flags[1], err, acq, waves, None, chunk, epi, sleep)
                     _C.ffn_engine(e)
                     torch.cuda.synchronize()
                     worst[0] = max(worst[0], (be.x - xo).abs().max().item())
@@ -227,14 +233,14 @@ def main():
                 print(f"{tag}: {t_e / NL * 1e6:7.2f} us per layer (1 launch) = {t_e / t_chain:.3f} x the chain, "
                       f"{wbytes / (t_e / NL) / 1e12:.2f} TB/s; after {NL} layers max abs diff to the chain {drift:.3e}; "
                       f"{bad}/{args.check_reps} replays differ from the first; err word {int(err.item())}", flush=True)
-                if args.trace and acq == int(args.modes.split(',')[0]):
+                if args.trace:
                     trace = torch.zeros(NL, nwg * 2 * 16, dtype=torch.int64, device=dev)
                     flags.zero_()
                     gt = graph_of(lambda: run_engine(trace))
                     for _ in range(5):
                         gt.replay()
                     torch.cuda.synchronize()
-                    dump_trace(trace.cpu(), NL, nwg, f"{args.trace}.w{waves}.csv")
+                    dump_trace(trace.cpu(), NL, nwg, f"{args.trace}.w{waves}_acq{acq}_chunk{chunk}_epi{epi}_sleep{sleep}.csv")
             except _C.AcmiError as ex:
                 print(f"{tag}: {ex}", flush=True)
 
@@ -243,10 +249,10 @@ def dump_trace(tr, NL, nwg, path):
     """per layer: stamps relative to the launch's earliest stamp 0; rows = (layer, stamp): min / median / max over workgroups"""
     import numpy as np
     t = tr.numpy().reshape(NL, nwg, 2, 16).astype(np.int64)
-    names_c = ['entry', 'B1 passed (partials of op0)', 'flag 1 stored', 'all flags 1 seen', 'B3 passed (partials of op1)',
+    names_c = ['entry', 'B1 passed (partials of op0)', 'flag 1 stored', 'all flags 1 seen', 'B3b passed (h staged)',
                'flag 2 stored', 'all flags 2 seen', 'B5 passed (partials of op2)', 'x3 stored']
-    names_w = ['entry', 'ring full + act0 back', 'op0 MFMAs done', 'B2 passed (x2 complete)', 'act1 back', 'op1 MFMAs done',
-               'B4 passed (h complete)', 'act2 back (first chunk)', 'op2 MFMAs done']
+    names_w = ['entry', 'act0 back', 'op0 MFMAs done', 'edge 1 seen, rest of op1 requested', 'act1 back', 'op1 MFMAs done',
+               'edge 2 seen, rest of op2 requested', 'act2 back (first chunk)', 'op2 MFMAs done']
     with open(path, 'w') as f:
         f.write('wave,stamp,name,min_us,median_us,max_us\n')
         for which, names in ((0, names_c), (1, names_w)):
@@ -259,6 +265,19 @@ def dump_trace(tr, NL, nwg, path):
                 v = rel[:, :, i]
                 f.write(f"{'control' if which == 0 else 'compute0'},{i},{nm},{np.median(v.min(axis=1)):.2f},{np.median(v):.2f},"
                         f"{np.median(v.max(axis=1)):.2f}\n")
+        # skew: per XCD (control wave's XCC_ID in stamp 15) and per workgroup index, 'B1 passed' and 'flag 2 stored'
+        xcc = (t[2, :, 0, 15] >> 32) & 0xf
+        for i, nm in ((1, 'B1 passed'), (5, 'flag 2 stored')):
+            v = np.stack([(t[li, :, 0, i] - t[li, :, :, 0].min()) / 100.0 for li in range(2, NL)])   # [layers, nwg]
+            per_x = [float(np.median(v[:, xcc == x])) for x in range(8)]
+            per_j = np.median(v, axis=0)
+            f.write(f"skew,{i},{nm}: median by XCD," + ' '.join(f'{q:.2f}' for q in per_x) + ",-,-\n")
+            f.write(f"skew,{i},{nm}: per-workgroup medians (min / median / max over workgroups) and same-workgroup spread over layers (median of max - min),"
+                    f"{per_j.min():.2f},{np.median(per_j):.2f},{per_j.max():.2f} / {np.median(v.max(axis=0) - v.min(axis=0)):.2f}\n")
+        cnt = t[2:, :, :, 9:11]
+        f.write(f"control,9,polls of edge 1 / edge 2 (median),{np.median(cnt[:, :, 0, 0]):.1f},{np.median(cnt[:, :, 0, 1]):.1f},-\n")
+        f.write(f"compute0,9,stream fragments requested when edge 1 / edge 2 resolved (median),{np.median(cnt[:, :, 1, 0]):.1f},"
+                f"{np.median(cnt[:, :, 1, 1]):.1f},-\n")
         # launch-to-launch: entry of layer l+1 minus x3 stored of layer l (slowest workgroup)
         gaps = [(t[li + 1, :, :, 0].min() - t[li, :, 0, 8].max()) / 100.0 for li in range(2, NL - 1)]
         spans = [(t[li, :, 0, 8].max() - t[li, :, :, 0].min()) / 100.0 for li in range(2, NL)]
