@@ -23,7 +23,7 @@ def available() -> bool:
     return os.path.isdir(os.path.join(REF_ROOT, 'audiocraft'))
 
 
-def build_reference_lm(sd: dict, dim: int, num_heads: int, num_layers: int, n_q: int, card: int, cross_attention: bool):
+def build_reference_lm(sd: tp.Optional[dict], dim: int, num_heads: int, num_layers: int, n_q: int, card: int, cross_attention: bool):
     """The reference `LMModel` with MusicGen's configuration (config/model/lm/musicgen_lm.yaml over default.yaml) and the
     given reference-format state dict (transformer / embeddings / heads; conditioner weights are not on the timed path)."""
     from . import refstubs  # noqa: F401  (installs the import stubs; needs the reference tree)
@@ -46,6 +46,8 @@ def build_reference_lm(sd: dict, dim: int, num_heads: int, num_layers: int, n_q:
                  num_layers=num_layers, dropout=0., activation='gelu', bias_ff=False, bias_attn=False, causal=True,
                  custom=False, memory_efficient=True, attention_as_float32=False, cross_attention=cross_attention,
                  positional_embedding='sin').eval()
+    if sd is None:    # the reference's own random initialisation (calibration runs: scripts/cpu_calibration.py)
+        return lm
     own = lm.state_dict()
     missing = [k for k in own if k not in sd and not k.startswith('condition_provider.')]
     assert not missing, f"state dict lacks {missing[:4]}"

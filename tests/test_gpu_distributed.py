@@ -181,7 +181,7 @@ def test_sharded_path_fake_two_ranks_real_kernels(monkeypatch):
 # broadcasts of the conditioning, the sharded generate + decode with the real kernels in two processes, gather_rows, the
 # all_reduce(MAX) of the clock and rank 0's JSON line.
 # ----------------------------------------------------------------------------------------------------------------------
-def _run_bench(tmp_path, gpus, batch, tag):
+def _run_bench(tmp_path, gpus, batch, tag, model='facebook/musicgen-small', greedy=True, duration='1'):
     import json
     import subprocess
     import sys
@@ -190,9 +190,10 @@ def _run_bench(tmp_path, gpus, batch, tag):
     env = dict(os.environ, ACMI_DIST_BACKEND='gloo', ACMI_ALLOW_SHARED_DEVICE='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '1', '--warmup', '0', '--duration', '1',
-           '--model', 'facebook/musicgen-small', '--batch', str(batch), '--greedy', '--no-cpu-baseline', '--no-roofline',
-           '--dump-tokens', str(tok)]
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '1', '--warmup', '0', '--duration', duration,
+           '--model', model, '--batch', str(batch), '--no-cpu-baseline', '--no-roofline', '--dump-tokens', str(tok)]
+    if greedy:
+        cmd.append('--greedy')
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -211,3 +212,21 @@ def test_bench_two_processes_on_one_device(tmp_path):
     assert line1['n_gpus'] == 1 and line1['config']['global_batch'] == 4
     assert tok2.shape == tok1.shape == (4, 4, 50)
     assert torch.equal(tok2, tok1), "gathered greedy tokens of the 2-rank run differ from the unsharded run"
+
+
+def test_bench_configs3_flags_two_processes_sampled(tmp_path):
+    """`bench.py --gpus N --model facebook/musicgen-large --batch 8` is how the driver's scaling run starts BASELINE.json
+    configs[3]; here with 2 ranks on one device, 2 prompts per rank and 0.4 s, SAMPLED (the mode of that configuration).
+    Checks the line, and the per-rank sampling seeds of generate_sharded (base_seed + rank, cf. reference utils/utils.py:203-223):
+    rank 0's shard reproduces the first rows of the unsharded run (same seed, same per-sample counters: a fixed (seed, rank)
+    reproduces), rank 1's shard does not reproduce the unsharded run's rows 2-3 (another seed)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    line2, tok2 = _run_bench(tmp_path, 2, 2, 'l2', model='facebook/musicgen-large', greedy=False, duration='0.4')
+    assert line2['n_gpus'] == 2 and line2['config']['global_batch'] == 4 and line2['scaling'] == 'weak' and line2['dtype'] == 'bf16'
+    assert 'musicgen-large' in line2['config']['workload'] and 'top-k 250' in line2['config']['workload']
+    assert 'not a BASELINE.json configuration' in line2['config']['workload']    # shortened: the tag says so
+    line1, tok1 = _run_bench(tmp_path, 1, 4, 'l1', model='facebook/musicgen-large', greedy=False, duration='0.4')
+    assert tok2.shape == tok1.shape == (4, 4, 20)
+    assert torch.equal(tok2[:2], tok1[:2]), "rank 0's shard (seed, rank fixed) must reproduce the unsharded rows"
+    assert not torch.equal(tok2[2:], tok1[2:]), "rank 1 samples with its own seed"

@@ -891,3 +891,55 @@ def test_attn_prefill_vs_torch(C, kvdt, Beff, H, hd, npos, pos0, window):
         r = rel(got[:, :npos], ref)
         assert r < tol, f"out {odt}: rel-L2 {r}"
         assert got[:, npos:].abs().sum() == 0                  # pad rows are not written
+
+
+@pytest.mark.parametrize('model,waves', [('small', 4), ('medium', 4), ('medium', 8)])
+@pytest.mark.parametrize('rows', [16, 5])
+def test_ffn_engine_vs_launch_chain_and_f64(model, waves, rows):
+    """acmi_ffn_engine (cross-out -> linear1 + norm2 + GELU -> linear2 of a decode layer as ONE persistent launch, transformer.py
+    :344-361, :563-572) against the three launches acmi_lm_step runs for the same sub-chain and against an f64 restatement from the
+    logical weights; every consumer-load mode; bit-reproducible from launch to launch.  (Measured 1.2x SLOWER than the three
+    launches on MI355X -- DESIGN.md section 5.8 -- so acmi_lm_step does not use it; the op stays as the evidence's kernel.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from audiocraft_amd import _C
+    from scripts import engine_lab as el
+    d, F = el.GEOM[model]
+    dev, eps, M = torch.device('cuda'), 1e-5, rows
+    g = torch.Generator().manual_seed(77)
+    L = el.Layer(d, F, g, dev)
+    x1 = (torch.randn(M, d, generator=g) * 1.5 + 0.7 * torch.randn(M, 1, generator=g)).to(dev)
+    L.att = _C.tile_matrix(torch.randn(M, d, generator=g).to(dev).bfloat16(), torch.bfloat16)   # rows >= M of the fragments are zero
+    shift = torch.zeros(16)
+    shift[:M] = x1.mean(dim=1).cpu()
+    bc, be = el.Bufs(M, d, F, dev), el.Bufs(M, d, F, dev)
+    bc.shift.copy_(shift)
+    be.shift.copy_(shift)
+    bc.x.copy_(x1)
+    el.launch_chain(L, bc, M, d, F, eps)
+    x2r, hr, x3r = el.reference_layer0(L, x1, shift, M, d, F, eps)
+    scale = x3r.abs().max().item()
+    assert (bc.x.double().cpu() - x3r).abs().max().item() < 2e-3 * scale
+    flags = torch.zeros(2, _C.FFN_ENGINE_FLAG_BYTES, dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    outs = []
+    for acq in (0, 1, 2, 2):
+        flags.zero_()
+        be.x.copy_(x1)
+        be.hidden.zero_()
+        _C.ffn_engine(el.engine_desc(L, be, M, d, F, eps, flags[0], flags[1], err, acq, waves, None, 4, 0, 1))
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0
+        assert bool((flags[1] == 0).all()) and int(flags[0].sum().item()) == 8 * 2 * (d // 8)   # own set raised, next set zeroed
+        assert (be.x.double().cpu() - x3r).abs().max().item() < 2e-3 * scale
+        assert (_C.untile_matrix(be.hidden, 16, F)[:M].double().cpu() - hr).abs().max().item() < 2e-2
+        assert (be.x - bc.x).abs().max().item() < 2e-3 * scale
+        assert (be.xt[1].float() - bc.xt[1].float()).abs().max().item() <= 0.0625      # bf16 fragments: an ulp of flips at most
+        if M < 16:   # rows beyond M are never written
+            assert bool((_C.untile_matrix(be.hidden, 16, F)[M:] == 0).all())
+        outs.append((be.x.clone(), be.hidden.clone(), be.xt[1].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[2], outs[3])), "two launches on the same inputs differ"
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[2])), "consumer-load modes differ"
+    with pytest.raises(_C.AcmiError):
+        _C.ffn_engine(el.engine_desc(L, be, 17, d, F, eps, flags[0], flags[1], err, 0, waves))
+    assert not _C.ffn_engine_supported(16, 1536, 6144, torch.float32) and _C.ffn_engine_supported(16, 1536, 6144, torch.bfloat16)

@@ -930,3 +930,32 @@ def test_mbd_cfg_resolves_only_what_the_loader_reads():
                dora=Node(_poison=True, dir='${oc.env:USER}'), datasource=Node(_poison=True))
     out = _pick_mbd_cfg(cfg, lambda n: isinstance(n, Node), to_container)
     assert out == {'channels': 1, 'schedule': {'num_steps': 10}, 'diffusion_unet': {'hidden': 8}, 'processor': {'use': False}}
+
+
+def test_philox_restatement_known_answers():
+    """oracle/sampler.py against the published known-answer vectors of Philox4x32-10 (Random123 kat_vectors): the host replay
+    of the device sampler's random stream is pinned to the generator's definition, not to the device."""
+    import numpy as np
+    from oracle.sampler import philox4x32_10, race, uniforms
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, want in kats:
+        got = philox4x32_10(*[np.uint32(v) for v in c], k[0], k[1])
+        assert tuple(int(v) for v in got) == want
+    u = uniforms(2048, 5, 77, 0x1234567890abcdef)
+    assert u.min() > 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.03
+    # the race is torch.multinomial's algorithm: over many independent positions it samples the top-k renormalised distribution
+    rng = np.random.default_rng(0)
+    p = rng.dirichlet(np.ones(16) * 0.7)
+    kth = np.sort(p)[-5]
+    counts = np.zeros(16)
+    for step in range(4000):
+        tok, margin, _ = race(p, 5, 3, step, 99)
+        counts[tok] += 1
+        assert 0 <= margin <= 1
+    exp = np.where(p >= kth, p, 0) / p[p >= kth].sum() * 4000
+    assert counts[p < kth].sum() == 0
+    chi2 = ((counts[p >= kth] - exp[p >= kth]) ** 2 / exp[p >= kth]).sum()
+    assert chi2 < 20, chi2
