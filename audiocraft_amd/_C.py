@@ -254,8 +254,23 @@ def lstm_layer(gates_in, w_hh, skip, y, work, B, H, T):
         check(_lstm_layer(ptr(gates_in), ptr(w_hh), ptr(skip), ptr(y), ptr(work), B, H, T, stream()), 'acmi_lstm_layer')
 
 
+_lstm_xcd_enabled = True
+
+
+def disable_lstm_xcd(why: str):
+    """The XCD-local LSTM form (one recurrence per XCD, acmi_lstm_layer_ex) depends on every workgroup being resident and on
+    the dispatcher's round-robin workgroup -> XCD placement; on a shared or partitioned device its bounded waits give up and
+    set the err word.  From then on this process runs the all-CU form (what ACMI_LSTM_XCD=0 selects): slower, not unavailable."""
+    global _lstm_xcd_enabled
+    if _lstm_xcd_enabled:
+        import warnings
+        warnings.warn(f"libacmi: the XCD-local LSTM recurrence is disabled for this process ({why}); using the all-CU form")
+    _lstm_xcd_enabled = False
+
+
 def lstm_layer_work_floats(B, H, T) -> int:
-    return int(_lstm_layer_work(B, H, T))
+    """Work floats of one LSTM layer; the legacy size (5 B H + 4) selects the all-CU form in lstm_layer."""
+    return int(_lstm_layer_work(B, H, T)) if _lstm_xcd_enabled else int(_lstm_work(B, H))
 
 
 _lstm2 = _sig('acmi_lstm_stack2', [vp] * 8 + [i32] * 3 + [vp])
@@ -273,13 +288,17 @@ def defer_lstm_checks(sink):
     _lstm_tls.sink = sink
 
 
+def lstm_failed(err_word: torch.Tensor) -> bool:
+    return int(err_word.view(torch.int32)[0]) != 0
+
+
 def lstm_check(err_word: torch.Tensor, what: str):
     """err_word: the [1+] int32/f32 view whose first word counts the persistent kernels' bounded-spin give-ups."""
     sink = getattr(_lstm_tls, 'sink', None)
     if sink is not None:
         sink.append((err_word, what))
         return
-    if int(err_word.view(torch.int32)[0]) != 0:
+    if lstm_failed(err_word):
         raise AcmiError(f"{what}: the persistent LSTM kernel gave up waiting for a workgroup or found it on another XCD than expected (set "
                         "ACMI_LSTM_XCD=0 for the all-CU form at H = 1024, ACMI_LSTM_WAVE=0 for one launch per layer, ACMI_LSTM_PERSISTENT=0 for one "
                         "per time step)")

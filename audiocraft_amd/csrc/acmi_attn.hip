@@ -225,6 +225,151 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* hq, const
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// cross_q_kernel: the decode step's cross-attention (transformer.py:344-361) as its own kernel -- one wave per (row, head),
+// a host-known source length of at most NI * 8 positions (one chunk), head size 64, the LayerNorm hook on the query.
+// Same arithmetic, in the same order, as attn_decode_kernel<KT, 64, true> run with one wave (bit-identical results); what
+// differs is WHEN things are requested.  This launch is pure latency (16 keys x 8 active rows at the headline configuration:
+// 5.2 us per layer, 10 % of a decode position, for ~0.4 MB): its critical path is the round trip of what the PREVIOUS launch
+// has just written -- the statistics partials of x1 and the raw query r -- so those requests go out first, from preloaded
+// arguments (q, caches, q_stats, out + four packed words = 14 dwords), before any scalar load; the constant operands
+// (column sums, bias, shift: L2-warm) follow once the argument block is in; only NI (2 for <= 16 keys) K / V positions per lane
+// are requested instead of the generic kernel's 8 + 8 (clamped re-reads of the last position otherwise); one wave needs no LDS
+// combine, no barrier: the eight lanes of position group 0 hold the 64 outputs and store them as 16-byte fragments.
+//   g0 = H | Tcap << 16   g1 = len | q_np << 16   g2 = q_cnt | out_rbs << 16   g3 = flags: bit 0 tiled, bit 1 bf16 output
+struct CrossQArgs {
+    const float* q_colsum; const float* q_bias; const float* q_shift; const int* len_rows;
+    float q_eps, scale; int out_col0, q_K;
+};
+#define ACMI_CROSSQ_ARGS_OFF 56
+__device__ __forceinline__ void crossq_load_args(CrossQArgs& p, int z) {
+    const char ACMI_AS4* ka = (const char ACMI_AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+    __builtin_memcpy(&p, (const void ACMI_AS4*)__builtin_assume_aligned((const void ACMI_AS4*)(ka + (ACMI_CROSSQ_ARGS_OFF + z)), 8),
+                     sizeof(CrossQArgs));
+}
+template <typename KT, int NI>
+__global__ __launch_bounds__(64) void cross_q_kernel(const float* hq, const void* hkc, const void* hvc, const float* hstats, void* hout,
+                                                     unsigned g0, unsigned g1, unsigned g2, unsigned g3, const CrossQArgs) {
+    constexpr int HD = 64, DPL = 8, LPP = 8, PPI = 8;
+    typedef KT rawv __attribute__((ext_vector_type(DPL)));
+    const int H = (int)(g0 & 0xffffu), Tcap = (int)(g0 >> 16), hlen = (int)(g1 & 0xffffu), q_np = (int)(g1 >> 16);
+    const int q_cnt = (int)(g2 & 0xffffu), out_rbs = (int)(g2 >> 16);
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, c = lane % LPP, pp = lane / LPP;
+    // 1. what the previous launch wrote: statistics partials of row b, the raw query
+    float spm[2], spq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float2 t = *reinterpret_cast<const float2*>(hstats + ((size_t)b * q_np + min(lane + 64 * i, q_np - 1)) * 2);
+        spm[i] = t.x; spq[i] = t.y;
+    }
+    float qv[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) qv[e] = hq[((size_t)b * H + h) * HD + c * DPL + e];
+    // 2. keys / values of the (constant) cross-attention cache: NI positions per lane, clamped to the host-side length bound
+    const KT* kb = reinterpret_cast<const KT*>(hkc) + ((size_t)b * H + h) * Tcap * HD + c * DPL;
+    const KT* vb = reinterpret_cast<const KT*>(hvc) + ((size_t)b * H + h) * Tcap * HD + c * DPL;
+    rawv kr[NI], vr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int t = min(i * PPI + pp, hlen - 1);
+        kr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(kb + (size_t)t * HD));
+        vr[i] = __builtin_nontemporal_load(reinterpret_cast<const rawv*>(vb + (size_t)t * HD));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // 3. the argument block (scalar loads behind the requests above), then the constant operands
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    opaque0 = __builtin_amdgcn_readfirstlane(opaque0);
+    CrossQArgs p;
+    crossq_load_args(p, opaque0);
+    float qcs[DPL], qb[DPL];
+    const float qsh = *(p.q_shift != nullptr ? p.q_shift + b : hstats);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+        qcs[e] = p.q_colsum[h * HD + c * DPL + e];
+        qb[e] = p.q_bias[h * HD + c * DPL + e];
+    }
+    const int len = p.len_rows ? max(1, min(p.len_rows[b], hlen)) : hlen;
+    __builtin_amdgcn_sched_barrier(0);
+    {   // Chan combination of the partials -> mean, rstd of row b; then the affine map of q (as attn_decode_kernel<.., true>)
+        const bool v0 = lane < q_np, v1 = lane + 64 < q_np;
+        const float mean = wave_sum((v0 ? spm[0] : 0.f) + (v1 ? spm[1] : 0.f)) / (float)q_np;
+        const float d0 = spm[0] - mean, d1 = spm[1] - mean;
+        const float q2 = (v0 ? spq[0] + (float)q_cnt * d0 * d0 : 0.f) + (v1 ? spq[1] + (float)q_cnt * d1 * d1 : 0.f);
+        const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)p.q_K + p.q_eps);
+        const float meff = mean - (p.q_shift != nullptr ? qsh : 0.f);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) qv[e] = rstd * (qv[e] - meff * qcs[e]) + qb[e];
+    }
+    float s[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int t = i * PPI + pp;
+        if (t >= len) {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) vr[i][e] = (KT)0;
+        }
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) part = fmaf(qv[e], raw_to_f32(kr[i][e]), part);
+        part = group_sum<LPP>(part);
+        s[i] = (t < len) ? part * p.scale : -INFINITY;
+    }
+    float cmax = s[0];
+#pragma unroll
+    for (int i = 1; i < NI; ++i) cmax = fmaxf(cmax, s[i]);
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) cmax = fmaxf(cmax, off == 8 ? dpp_f32<0x128>(cmax) : __shfl_xor(cmax, off, 64));
+    float l = 0.f, o[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) o[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int t = i * PPI + pp;
+        const float pr = (t < len) ? expf(s[i] - cmax) : 0.f;
+        l += pr;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] = fmaf(pr, raw_to_f32(vr[i][e]), o[e]);
+    }
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) {
+        const bool dpp8 = off == 8;
+        l += dpp8 ? dpp_f32<0x128>(l) : __shfl_xor(l, off, 64);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) o[e] += dpp8 ? dpp_f32<0x128>(o[e]) : __shfl_xor(o[e], off, 64);
+    }
+    if (lane < LPP) {   // position group 0: lane c holds output dims [8 c, 8 c + 8) of head h
+        float r[DPL];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) r[e] = l > 0.f ? (1.0f * o[e]) / (1.0f * l) : 0.f;
+        const int f = h * HD + c * DPL;
+        if (!(g3 & 1u)) {
+            float* dst = reinterpret_cast<float*>(hout) + (size_t)b * H * HD + f;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) dst[e] = r[e];
+        } else if (g3 & 2u) {   // 8 consecutive features of one row = one lane's 16 bytes of a bf16 A-fragment
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(r[2 * e], r[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(hout) + tiled_index<bf16_t>(b, p.out_col0 + f, out_rbs)) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) reinterpret_cast<float*>(hout)[tiled_index<float>(b, p.out_col0 + f + e, out_rbs)] = r[e];
+        }
+    }
+}
+
+template <typename KT, int NI>
+static int launch_cross_q(const AttnArgs& a, int rows, hipStream_t st) {
+    CrossQArgs c = {};
+    c.q_colsum = a.q_colsum; c.q_bias = a.q_bias; c.q_shift = a.q_shift; c.len_rows = a.len_rows;
+    c.q_eps = a.q_eps; c.scale = a.scale; c.out_col0 = a.out_col0; c.q_K = a.q_K;
+    const unsigned g0 = (unsigned)a.H | ((unsigned)a.Tcap << 16), g1 = (unsigned)a.len | ((unsigned)a.q_np << 16);
+    const unsigned g2 = (unsigned)a.q_cnt | ((unsigned)a.out_rbs << 16), g3 = (a.out_tiled ? 1u : 0u) | (a.out_bf16 ? 2u : 0u);
+    hipLaunchKernelGGL((cross_q_kernel<KT, NI>), dim3(a.H, rows), dim3(64), 0, st, a.q, a.kc, a.vc, a.q_stats, a.out, g0, g1, g2, g3, c);
+    return acmi_check_launch("cross_q_kernel");
+}
+
 template <typename KT>
 static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     static int attn_nw = -1;
@@ -239,6 +384,16 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     }
     // rows past active_rows do nothing: with one position per call (query row == cache row) they are not even launched
     const int rows = (a.active_rows > 0 && Beff == a.rpp) ? a.active_rows : Beff;
+    // the decode step's cross-attention: a kernel of its own (see cross_q_kernel); ACMI_CROSSQ=0 keeps the generic one (A/B)
+    static const bool crossq_ok = !(getenv("ACMI_CROSSQ") != nullptr && getenv("ACMI_CROSSQ")[0] == '0');
+    constexpr int PPC = 8;   // positions per load instruction at head size 64
+    if (crossq_ok && a.q_colsum != nullptr && a.len_dev == nullptr && hd == 64 && a.past_context <= 0 && a.start_rows == nullptr &&
+        a.pm_n == 0 && Beff == a.rpp && a.len <= PPC * (sizeof(KT) == 2 ? 8 : 4) && a.Tcap <= 0xffff && a.q_np <= 0xffff &&
+        a.q_cnt <= 0xffff && a.out_rbs <= 0xffff && a.H <= 0xffff) {
+        if (a.len <= 2 * PPC) return launch_cross_q<KT, 2>(a, rows, st);
+        if (a.len <= 4 * PPC) return launch_cross_q<KT, 4>(a, rows, st);
+        if (sizeof(KT) == 2) return launch_cross_q<KT, 8>(a, rows, st);
+    }
     dim3 grid(a.H, rows), block(64 * nwv);
     ACMI_REQUIRE(a.H <= 0xffff && a.Tcap <= 0xffff && a.rpp <= 0xffff && a.pm_n <= 0xffff && a.active_rows <= 0xffff,
                  "acmi_attn_decode: geometry beyond the packed launch words (H %d, Tcap %d, rows %d)", a.H, a.Tcap, a.rpp);

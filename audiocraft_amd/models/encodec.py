@@ -78,7 +78,8 @@ class CompressionModel(ABC, nn.Module):
         try:
             from transformers import EncodecModel as HFEncodecModel
             hf_model = HFEncodecModel.from_pretrained(name)
-        except Exception as exc:   # no transformers, not in the HuggingFace cache, not an EnCodec: say what was tried
+        except (OSError, ImportError) as exc:   # no transformers / not in the HuggingFace cache: say what was tried.  Anything
+            # else (a config or version incompatibility of a model that IS there) propagates as what it is
             raise FileNotFoundError(f"compression model '{name}': not an audiocraft export on disk ({not_on_disk}) and not "
                                     f"loadable as a HuggingFace EnCodec ({type(exc).__name__}: {exc})") from exc
         return HFEncodecCompressionModel(hf_model, device).eval()
@@ -142,6 +143,12 @@ class EncodecModel(CompressionModel):
         graph.replay()
         out = static_out.clone()
         if checks and bool(torch.stack([w.view(torch.int32)[0] for w, _ in checks]).any()):
+            if _C._lstm_xcd_enabled:
+                # the XCD-local recurrence lost residency / placement (shared device): drop the captured passes, keep the all-CU
+                # form for the rest of the process and run this call again, eagerly (its own check raises if that fails too)
+                _C.disable_lstm_xcd("its bounded waits gave up inside a captured codec pass")
+                graphs.clear()
+                return net(x)
             raise _C.AcmiError(f"{checks[0][1]}: the persistent LSTM kernel gave up waiting for a workgroup "
                                "(set ACMI_LSTM_WAVE=0 / ACMI_LSTM_PERSISTENT=0)")
         return out

@@ -510,6 +510,11 @@ class LMModel(nn.Module):
         dev = self.device
         Beff = B * (use_cfg + 1)
         H, hd, d = self.num_heads, self.dim // self.num_heads, self.dim
+        # the decode kernels take their geometry in packed 16-bit launch words (include/acmi.h: acmi_attn_desc / acmi_linear_desc)
+        if max(Tmax, Lc, Beff * self.PREFILL_CHUNK) > 65535:
+            raise ValueError(f"stream of {Tmax} positions / {Lc} condition rows / {Beff * self.PREFILL_CHUNK} activation rows: libacmi's "
+                             f"decode kernels address at most 65535 cache positions and rows (packed launch words); generate "
+                             f"longer audio through MusicGen's windowed generation (extend_stride)")
         f32 = dict(device=dev, dtype=torch.float32)
         run: dict = {'key': key, 'Beff': Beff, 'graphs': {}}
         run['k'] = torch.zeros(self.num_layers, Beff, H, Tmax, hd, device=dev, dtype=self.kv_dtype)

@@ -200,7 +200,8 @@ class StreamableLSTM(nn.Module):
         self.lstm = _LSTMParams(dimension, num_layers, device)
         self._prep = None
 
-    def run(self, x: torch.Tensor) -> torch.Tensor:
+    def _run_once(self, x: torch.Tensor):
+        """-> (y, err word of the per-layer recurrence kernels or None)"""
         B, C, T = x.shape
         H = self.dimension
         if self._prep is None:
@@ -228,7 +229,7 @@ class StreamableLSTM(nn.Module):
             _C.conv1d_tiled(d, x, p0[3], p0[2], None, gates)
             out = torch.empty(B, H, T, device=x.device, dtype=torch.float32)
             _C.lstm_stack2(gates, p0[1], p1[0], p1[1], p1[2], x if self.skip else None, out, B, H, T)
-            return out
+            return out, None
         y = x
         for layer, prep in enumerate(self._prep):
             w_ih, w_hh, bias = prep[:3]
@@ -242,8 +243,21 @@ class StreamableLSTM(nn.Module):
             y = out
         # the persistent recurrence kernel counts bounded-spin give-ups of its all-gather in the last words of `work`
         # (never seen on an otherwise idle device; a non-zero count means the result is not to be trusted)
-        _C.lstm_check(work[5 * B * H:5 * B * H + 4], 'acmi_lstm_layer')
+        return y, work[5 * B * H:5 * B * H + 4]
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        y, err = self._run_once(x)
+        if err is None:
+            return y
+        deferred = getattr(_C._lstm_tls, 'sink', None) is not None   # inside a capture: the owner checks after each replay
+        if not deferred and _C._lstm_xcd_enabled and _C.lstm_failed(err):
+            # the XCD-local form lost residency / placement (shared or partitioned device): degrade in speed, not in
+            # availability -- once, on the all-CU form, which this process keeps from now on
+            _C.disable_lstm_xcd("its bounded waits gave up")
+            y, err = self._run_once(x)
+        _C.lstm_check(err, 'acmi_lstm_layer')
         return y
+
 
 
 class _ELU(nn.Module):

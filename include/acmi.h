@@ -537,6 +537,9 @@ typedef struct {
     const int* start_rows;  /* device int32[cache_rows] or NULL: keys before start_rows[cache row] are not attended
                                (acmi_lm_state.row_off) */
 } acmi_attn_desc;
+/* Limits (the kernels' leading arguments are packed 16-bit words, preloaded into SGPRs): Tcap, cache_rows, pos_minor_rows,
+ * active_rows and H at most 65535 -- larger values are rejected with ACMI_EINVAL.  acmi_linear_ex / acmi_linear_pair with a
+ * tiled activation likewise: M, K tiles, a_rbs and ksplit at most 65535. */
 int acmi_attn_decode_ex(const acmi_attn_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -172,6 +172,39 @@ def test_lstm_vs_oracle(C, B, H, T, layers, wave, monkeypatch):
     assert err < 2e-5, f"max abs err {err}"
 
 
+def test_lstm_xcd_form_degrades_to_the_all_cu_form_when_it_gives_up(C, monkeypatch):
+    """A give-up of the XCD-local recurrence (lost residency / placement on a shared or partitioned device) costs speed, not
+    availability (advisor, round 4): the layer stack is run again on the all-CU form, which the process keeps from then on."""
+    import warnings
+    from audiocraft_amd.modules.seanet import StreamableLSTM
+    monkeypatch.setattr(C, 'lstm_stack2_supported', lambda *a: False)
+    monkeypatch.setattr(C, '_lstm_xcd_enabled', True)
+    B, H, T = 8, 1024, 24
+    g = torch.Generator().manual_seed(3)
+    m = StreamableLSTM(H, 2, device='cuda')
+    sd = {}
+    for k_, p in m.lstm.named_parameters():
+        with torch.no_grad():
+            p.copy_(torch.empty_like(p).cpu().uniform_(-1 / math.sqrt(H), 1 / math.sqrt(H), generator=g))
+        sd['l.lstm.' + k_] = p.detach().cpu()
+    x = torch.randn(B, H, T, generator=g)
+    ref = ocodec.lstm_stack(x, sd, 'l.lstm', 2)
+    assert C.lstm_layer_work_floats(B, H, T) > C.lstm_work_floats(B, H)       # the XCD-local form is what would run
+    real_failed, calls = C.lstm_failed, []
+
+    def failed_once(err_word):      # the first check reports a give-up
+        calls.append(1)
+        return True if len(calls) == 1 else real_failed(err_word)
+    monkeypatch.setattr(C, 'lstm_failed', failed_once)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = m.run(x.cuda()).cpu()
+    assert any('XCD-local LSTM' in str(q.message) for q in w)
+    assert (got - ref).abs().max().item() < 2e-5
+    assert not C._lstm_xcd_enabled and C.lstm_layer_work_floats(B, H, T) == C.lstm_work_floats(B, H)
+    assert (m.run(x.cuda()).cpu() - ref).abs().max().item() < 2e-5           # and stays usable
+
+
 @pytest.mark.parametrize('B,H,T', [(8, 1024, 40), (3, 512, 64), (12, 1024, 17)])
 def test_lstm_layer_forms_agree(C, B, H, T, monkeypatch):
     """acmi_lstm_layer_ex: the XCD-local form (default), the same kernel on memory-side stores / loads (ACMI_LSTM_XCD=2) and
