@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* hq, const
     // (Round 3 tried a second register set -- the next chunk in flight while one is multiplied, with exact vmcnt counts in
     // the steady state: 27.4 us at t = 1500 either way, +0.4 ... 0.8 us at every length from the longer prologue and the
     // 214 VGPRs.  The slope of this kernel, 0.0159 us per position = 6.2 TB/s, IS the copy bandwidth of the chip: what is
-    // left is the fixed 3.6 us, 1.55 of them the kernel boundary.  profiles/r03_attn_microbench.log)
+    // left is the fixed 3.6 us, 1.55 of them the kernel boundary.  profiles/archive/r03_attn_microbench.log)
     int start = p.past_context > 0 ? max(0, len - 1 - p.past_context) : 0;   // bounded receptive field
     if (p.start_rows != nullptr) start = max(start, __builtin_amdgcn_readfirstlane(p.start_rows[b0]));   // left-padded stream
     lim = len;

@@ -1,6 +1,6 @@
 """dev tool: the self-attention kernel at the headline shape (16 rows x 24 heads x 64, bf16 cache) at a few context
 lengths, cycling over distinct caches (cold, like in a real decode position); also the command the rocprofv3 --pmc
-passes of profiles/r02_attn_pmc_* run."""
+passes of profiles/archive/r02_attn_pmc_* run."""
 import os
 import sys
 
