@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 170 /* 0.1.7: qk_layer_norm (acmi_lm_layer.q_ln_g .. cq_ln_b, acmi_layer_norm_rows), fuser 'sum' / 'input_interpolate'
+#define ACMI_VERSION 180 /* 0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
+                            acmi_lm_step), the decode step's cross-attention as a kernel of its own (cross_q_kernel, inside acmi_attn_decode_ex).  0.1.7: qk_layer_norm (acmi_lm_layer.q_ln_g .. cq_ln_b, acmi_layer_norm_rows), fuser 'sum' / 'input_interpolate'
                             (acmi_lm_state.input_add).  0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
                             colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
                             with prepended conditions of different lengths).  0.1.4: acmi_conv1d takes pre-tiled weights + a work buffer (acmi_conv1d_tile_weights /
