@@ -66,7 +66,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float* hq, const
     constexpr int DPL = HD >= 8 ? 8 : HD;  // dims per lane
     constexpr int LPP = HD / DPL;          // lanes per position
     constexpr int PPI = 64 / LPP;          // positions covered by one load instruction of a wave
-    constexpr int NI = sizeof(KT) == 2 ? 8 : 4;  // positions per lane per chunk (K and V loads in flight: 2 * NI)
+#ifndef ACMI_ATTN_NI
+#define ACMI_ATTN_NI 8   // experiment switch (round 5): 16 with 2 waves per (row, head) = the same bytes in flight from half the waves
+#endif
+    constexpr int NI = sizeof(KT) == 2 ? ACMI_ATTN_NI : 4;  // positions per lane per chunk (K and V loads in flight: 2 * NI)
     typedef KT rawv __attribute__((ext_vector_type(DPL)));
     constexpr int CH = NI * PPI;
     const int h = blockIdx.x, b = blockIdx.y;
@@ -378,7 +381,7 @@ static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
     // it has 64-position chunks (bf16 cache, hd 64) -- idle waves still cost dispatch time
     int nwv = attn_nw;
     if (a.len_dev == nullptr) {
-        const int dpl = hd >= 8 ? 8 : hd, chunk = (sizeof(KT) == 2 ? 8 : 4) * (64 / (hd / dpl));
+        const int dpl = hd >= 8 ? 8 : hd, chunk = (sizeof(KT) == 2 ? ACMI_ATTN_NI : 4) * (64 / (hd / dpl));
         const int need = (a.len + chunk - 1) / chunk;
         while (nwv > 1 && nwv / 2 >= need) nwv /= 2;
     }
