@@ -16,6 +16,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'facebook/musicgen-medium'
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 duration = float(sys.argv[3]) if len(sys.argv) > 3 else 8.0
 model = MusicGen.get_random_init(name, 'cuda', torch.bfloat16, text_len=16, seed=0)
+model.set_generation_params(use_sampling=True, top_k=250, duration=2.0)
+model.generate([f"synthetic prompt {i}" for i in range(batch)])   # warm-up: clocks, allocator, first graph capture
 model.set_generation_params(use_sampling=True, top_k=250, duration=duration)
 wav = model.generate([f"synthetic prompt {i}" for i in range(batch)])
 torch.cuda.synchronize()
