@@ -451,6 +451,7 @@ struct RopeArgs {
     float* q; void* kc; int kv_bf16; int H, hd, Tcap, d, rpp; const int* pos;
     const float* freq; const float* decay; float scale, base; int first, shift;
     int npos_pad, npos;   // > 0: position-minor rows (see EmbedArgs); pad rows are skipped
+    const int* row_off;   // left padding of each cache row's stream (acmi_lm_state.row_off) or NULL: the rotary position is the row's OWN
 };
 
 __global__ __launch_bounds__(1024) void rope_qk_kernel(const RopeArgs p) {
@@ -460,7 +461,10 @@ __global__ __launch_bounds__(1024) void rope_qk_kernel(const RopeArgs p) {
     if (p.npos_pad > 0) { brow = gm / p.npos_pad; pidx = gm - brow * p.npos_pad; if (pidx >= p.npos) return; }
     else { pidx = gm / p.rpp; brow = gm - pidx * p.rpp; }
     const int tpos = *p.pos + pidx;
-    const int rp = tpos >= p.first ? tpos - p.shift : tpos;     // rotary position (acmi_lm_state.rope_first / rope_shift)
+    // rotary position (acmi_lm_state.rope_first / rope_shift); of a left-padded stream: counted from the row's own first position
+    // (the reference keeps one streaming state per pass, lm.py:378-390) -- the cache slot stays the stream position tpos
+    const int own = tpos - (p.row_off != nullptr ? p.row_off[brow] : 0);
+    const int rp = own >= p.first ? own - p.shift : own;
     float sn, cs;
     sincosf((float)rp * p.freq[i], &sn, &cs);
     float dq = 1.0f, dk = 1.0f;
@@ -761,7 +765,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     ACMI_REQUIRE(s->Beff == s->B * (s->use_cfg + 1), "acmi_lm_step: Beff=%d is not B=%d x %d row groups", s->Beff, s->B,
                  s->use_cfg + 1);
     ACMI_REQUIRE(mode == ACMI_STEP_PREFILL || s->n_pos <= 1, "acmi_lm_step: n_pos=%d only with ACMI_STEP_PREFILL", s->n_pos);
-    ACMI_REQUIRE(s->row_off == nullptr || m->rope_freq == nullptr, "acmi_lm_step: row_off (left-padded streams) with rotary positions");
+    ACMI_REQUIRE(s->row_off == nullptr || m->rope_freq == nullptr || (m->past_context <= 0 && s->rope_shift == 0),
+                 "acmi_lm_step: row_off (left-padded streams) with rotary positions needs an unbounded context (past_context <= 0)");
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
     int rc;
 
@@ -837,7 +842,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 RopeArgs ra = {};
                 ra.q = s->q; ra.kc = L.k_cache; ra.kv_bf16 = kvbf; ra.H = H; ra.hd = hd; ra.Tcap = s->Tmax; ra.d = d; ra.rpp = s->Beff;
                 ra.pos = s->pos; ra.freq = m->rope_freq; ra.decay = m->rope_decay; ra.scale = m->rope_scale; ra.base = m->rope_base;
-                ra.first = s->rope_first > 0 ? s->rope_first : 0x7fffffff; ra.shift = s->rope_shift;
+                ra.first = s->rope_first > 0 ? s->rope_first : 0x7fffffff; ra.shift = s->rope_shift; ra.row_off = s->row_off;
                 hipLaunchKernelGGL(rope_qk_kernel, dim3(M), dim3(d / 2), 0, st, ra);
                 if ((rc = acmi_check_launch("rope_qk_kernel"))) return rc;
             }

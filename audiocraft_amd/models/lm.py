@@ -574,8 +574,10 @@ class LMModel(nn.Module):
             run.pop('input_add', None)
             st.input_add, st.n_add = None, 0
         if row_off is not None:      # left padding of the rows' streams (two_step_cfg with unequal prepend lengths)
-            if self.positional_embedding in ('rope', 'sin_rope'):
-                raise NotImplementedError("two_step_cfg with prepended conditions of different lengths on a rotary model")
+            if self.positional_embedding in ('rope', 'sin_rope') and self.past_context is not None and self.past_context > 0:
+                # (the rotary lag after a first call longer than past_context would differ per row group: rope_first / rope_shift)
+                raise NotImplementedError("two_step_cfg with prepended conditions of different lengths on a rotary model "
+                                          "with a bounded context (past_context)")
             run['row_off'] = row_off.to(device=self.device, dtype=torch.int32).contiguous()
             st.row_off = run['row_off'].data_ptr()
         else:
@@ -770,11 +772,18 @@ class LMModel(nn.Module):
             prepend, cross_src, cross_lens, row_off = self._fuse_two_step(*cfg_conditions)
             ops_groups = [self.fuser.input_ops(c) for c in cfg_conditions]
         else:
-            prepend, cross_src = self.fuser.fuse(cfg_conditions)
+            mixed = self.fuser.mixed_order(cfg_conditions)
+            prepend, cross_src = self.fuser.fuse(cfg_conditions, allow_mixed=mixed)
             ops_groups = [self.fuser.input_ops(cfg_conditions)]
         # 'sum' / 'input_interpolate' conditions: the reference's first call covers the steps before the first generated one,
         # every later call is one step (lm.py:536-543)
-        input_add = self._input_add_table(ops_groups, [start_offset_sequence, 1])
+        if not two_step and mixed:
+            # such a condition after a 'prepend' one in the provider's order: the reference's loop adds it to the prepended rows
+            # of the first call too, and resamples an interpolated condition over prepend + token positions
+            prepend, add_first = self.fuser.first_call_inputs(cfg_conditions, start_offset_sequence)
+            input_add = torch.cat([add_first, ConditionFuser.input_add_rows(ops_groups[0], 1)], dim=1)
+        else:
+            input_add = self._input_add_table(ops_groups, [start_offset_sequence, 1])
         if self.has_cross_attention:
             assert cross_src is not None, "this model cross-attends to a condition but none was given"
         else:

@@ -419,8 +419,43 @@ class ConditionFuser(nn.Module):
             f"given conditions contain unknown attributes for fuser, expected {self.cond2fuse.keys()}, " \
             f"got {conditions.keys()}"
 
-    def fuse(self, conditions: tp.Dict[str, ConditionType]) -> tp.Tuple[tp.Optional[torch.Tensor],
-                                                                          tp.Optional[torch.Tensor]]:
+    def mixed_order(self, conditions: tp.Dict[str, ConditionType]) -> bool:
+        """True when a 'sum' / 'input_interpolate' condition comes AFTER a 'prepend' one in the dict order: the reference's
+        loop then adds it to the prepended rows as well (`first_call_inputs`)."""
+        seen_prepend = False
+        for cond_type in conditions:
+            op = self.cond2fuse[cond_type]
+            if op == 'prepend':
+                seen_prepend = True
+            elif op in ('sum', 'input_interpolate') and seen_prepend:
+                return True
+        return False
+
+    def first_call_inputs(self, conditions: tp.Dict[str, ConditionType], T: int):
+        """The reference's loop (conditioners.py:1730-1748) for the FIRST streaming call of T token steps, replayed on a zero
+        input -- every op is additive or a concatenation, so the result splits into what is prepended and what is added:
+        -> (prepend [B, P, d] f32 INCLUDING what later 'sum' / 'input_interpolate' conditions add to the prepended rows,
+            add [B, T, d] f32 for the call's token steps).  Later (one-step) calls see no prepend: `input_add_rows(ops, 1)`."""
+        self._check_known(conditions)
+        inp, P = None, 0
+        for cond_type, (cond, _mask) in conditions.items():
+            op = self.cond2fuse[cond_type]
+            if op not in ('sum', 'input_interpolate', 'prepend'):
+                continue
+            cond = cond.float()
+            if inp is None:
+                inp = torch.zeros(cond.shape[0], T, cond.shape[2], device=cond.device)
+            if op == 'prepend':
+                inp = torch.cat([cond, inp], dim=1)
+                P += cond.shape[1]
+            else:
+                inp = inp + self.input_add_rows([(op, cond)], P + T)
+        if inp is None:
+            return None, None
+        return (inp[:, :P].contiguous() if P else None), inp[:, P:].contiguous()
+
+    def fuse(self, conditions: tp.Dict[str, ConditionType], allow_mixed: bool = False) -> tp.Tuple[tp.Optional[torch.Tensor],
+                                                                                                    tp.Optional[torch.Tensor]]:
         """-> (prepend [B, P, d] | None, cross_src [B, Lc, d] | None).
 
         Same ordering as the reference loop (conditioners.py:1730-1748): 'cross' conditions are
@@ -437,9 +472,10 @@ class ConditionFuser(nn.Module):
             elif op == 'cross':
                 cross = cond if cross is None else torch.cat([cross, cond], dim=1)
             elif op in ('sum', 'input_interpolate'):
-                if prepend is not None:
-                    # the reference would add this condition to the already prepended rows as well (its loop works on the
-                    # concatenated input); the provider's dict order (text, then wav, then joint conditions) decides
+                if prepend is not None and not allow_mixed:
+                    # the reference adds this condition to the already prepended rows as well (its loop works on the
+                    # concatenated input); the provider's dict order (text, then wav, then joint conditions) decides.
+                    # LMModel.generate handles it (first_call_inputs); the streaming / teacher-forced entry points do not
                     raise NotImplementedError(f"'{op}' condition {cond_type!r} after a 'prepend' condition in the provider's order")
             elif op == 'ignore':
                 continue

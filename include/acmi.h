@@ -315,8 +315,9 @@ typedef struct {
                                prepended condition rows (two_step_cfg on a prepend fuser, reference lm.py:378-390: the conditional
                                and the unconditional pass keep separate streaming states): the shorter streams are padded on the
                                left -- `prepend` holds zeros there -- so that every row reaches its first token at the same stream
-                               position and one sampler launch serves all of them.  Not with rotary positions, not with the
-                               one-forward prefill (pf_xn) */
+                               position and one sampler launch serves all of them.  With rotary positions (0.1.8) the rotary
+                               position of a row is its OWN position as well; not with a bounded context (past_context) then, and
+                               not with the one-forward prefill (pf_xn) */
     const float* input_add; /* device f32 [Beff, n_add, d] or NULL: what the fuser's 'sum' / 'input_interpolate' conditions add to
                                the embedded input (conditioners.py:1733-1737: `input += cond` before the positional embedding).
                                Token step t of cache row b (t = stream position - n_prepend; prepended rows take nothing) adds

@@ -211,23 +211,29 @@ def lm_forward(sd: dict, cfg: LMConfig, sequence: torch.Tensor, cross_src: tp.Op
     sequence [B, K, S] int64 -> logits [B, K, S, card].  `prepend_src` [B, P, C] is concatenated
     before the tokens on the first (or non-streaming) call only (ConditionFuser.forward,
     conditioners.py:1739-1741) and the logits are cropped back to the last S steps (lm.py:265-266).
-    `input_ops`: the fuser's 'sum' / 'input_interpolate' conditions in dict order, applied to the embedded input of EVERY
+    `input_ops`: the fuser's 'sum' / 'input_interpolate' conditions in dict order (and, when a prepend condition precedes one of
+    them in that order, ('prepend', cond) entries instead of `prepend_src`), applied to the embedded input of EVERY
     call before `prepend_src` joins it (conditioners.py:1733-1737): ('sum', cond [B, 1 | T, C]) is added (broadcast like
     the reference's in-place `input += cond`), ('input_interpolate', cond [B, Tc, C]) is nearest-resampled to the call's
     length first -- a one-step streaming call therefore always receives its frame 0."""
     B, K, S = sequence.shape
     x = sum(F.embedding(sequence[:, k], sd[f'emb.{k}.weight']) for k in range(K))
-    for op, cond in input_ops:
+    first = state.first_step if state is not None else True
+    # the reference walks the conditions in dict order (conditioners.py:1730-1748): an op that comes AFTER a 'prepend' one sees
+    # the prepended rows as part of the input.  ('prepend', cond) entries in `input_ops` keep that order; `prepend_src` (the
+    # common case: every prepend after every sum / interpolate) is the last entry.
+    ops = list(input_ops) + ([('prepend', prepend_src)] if prepend_src is not None else [])
+    for op, cond in ops:
         if op == 'sum':
             assert cond.shape[1] in (1, x.shape[1]), "the reference's in-place add cannot broadcast this"
             x = x + cond
         elif op == 'input_interpolate':
             x = x + F.interpolate(cond.transpose(1, 2), size=x.shape[1]).transpose(1, 2)
+        elif op == 'prepend':
+            if first:
+                x = torch.cat([cond, x], dim=1)
         else:
             raise ValueError(op)
-    first = state.first_step if state is not None else True
-    if prepend_src is not None and first:
-        x = torch.cat([prepend_src, x], dim=1)
     if state is not None:
         state.first_step = False
     out = transformer_forward(sd, cfg, x, cross_src, state)

@@ -12,6 +12,11 @@
 
 The reference runs with custom=True (kv_repeat / qk_layer_norm assert the custom attention, transformer.py:210-219).
 
+  lm_fuser_prepend_sum.npz  fuser {'prepend': ['description'], 'sum': ['genre'], 'input_interpolate': ['curve']}: in the provider's
+                     dict order the prepend comes FIRST, so the reference adds the later conditions to the prepended rows as
+                     well (its loop works on the concatenated input, conditioners.py:1730-1748): the one-frame condition to all
+                     P + T rows of the first call, the 5-frame condition resampled over P + T positions
+
   lm_patterns.npz    one model generating through the other codebook patterns of the reference's builder
                      (codebooks_patterns.py:359-552): parallel, unroll (partly flattened, delayed), coarse_first, musiclm,
                      delay with flatten_first / empty_initial -- greedy tokens and per-step logits of each
@@ -47,7 +52,7 @@ class SynthFrames(TextConditioner):
         return self.output_proj(e) * mask.unsqueeze(-1), mask
 
 
-def build(cfg, conditioners, fuse, extra, fuser_kw=None):
+def build(cfg, conditioners, fuse, extra, fuser_kw=None, cross_attention=True):
     torch.manual_seed(cfg['seed'])
     lm = LMModel(DelayedPatternProvider(cfg['n_q'], delays=cfg['delays']), ConditioningProvider(conditioners),
                  ConditionFuser(fuse, **(fuser_kw or {})),
@@ -56,7 +61,7 @@ def build(cfg, conditioners, fuse, extra, fuser_kw=None):
                  weight_init='gaussian', depthwise_init='current', zero_bias_init=True, cfg_coef=cfg['cfg_coef'],
                  num_layers=cfg['num_layers'], dropout=0., activation='gelu', bias_ff=cfg.get('bias_ff', False),
                  bias_attn=cfg.get('bias_attn', False), causal=True, custom=True, memory_efficient=False,
-                 attention_as_float32=False, cross_attention=True, **extra).eval()
+                 attention_as_float32=False, cross_attention=cross_attention, **extra).eval()
     with torch.no_grad():
         for k, p in lm.named_parameters():
             if '.norm' in k or k.startswith('out_norm') or '_layer_norm.' in k:
@@ -94,18 +99,21 @@ CROSS_ONLY = {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpo
 
 if __name__ == '__main__':
     conds = [ConditioningAttributes(text={'description': f'p{i}'}) for i in range(3)]
+    ONLY = len(sys.argv) > 1 and sys.argv[1] == 'prepend_sum_only'   # regenerate just the newest fixture
 
     extra = dict(kv_repeat=2)
     cfg = dict(BASE, seed=21, bias_attn=True, bias_ff=True, **extra)
     torch.manual_seed(3000)
     text = {'description': mg.SynthText(cfg['cond_dim'], cfg['dim'], cfg['Lc'])}
-    run('lm_kv_repeat', cfg, build(cfg, text, CROSS_ONLY, extra), conds)
+    if not ONLY:
+        run('lm_kv_repeat', cfg, build(cfg, text, CROSS_ONLY, extra), conds)
 
     extra = dict(qk_layer_norm=True, qk_layer_norm_cross=True)
     cfg = dict(BASE, seed=22, bias_attn=True, **extra)
     torch.manual_seed(3001)
     text = {'description': mg.SynthText(cfg['cond_dim'], cfg['dim'], cfg['Lc'])}
-    run('lm_qk_ln', cfg, build(cfg, text, CROSS_ONLY, extra), conds)
+    if not ONLY:
+        run('lm_qk_ln', cfg, build(cfg, text, CROSS_ONLY, extra), conds)
 
     cfg = dict(BASE, seed=23, curve_frames=5, cross_attention_pos_emb=True, cross_attention_pos_emb_scale=0.7)
     torch.manual_seed(3002)
@@ -114,8 +122,21 @@ if __name__ == '__main__':
            'curve': SynthFrames(cfg['cond_dim'], cfg['dim'], cfg['curve_frames'], 78)}
     fuse = {'cross': ['description'], 'prepend': [], 'sum': ['genre'], 'input_interpolate': ['curve']}
     conds3 = [ConditioningAttributes(text={'description': f'p{i}', 'genre': f'g{i}', 'curve': f'c{i}'}) for i in range(3)]
-    lm = build(cfg, cds, fuse, {}, dict(cross_attention_pos_emb=True, cross_attention_pos_emb_scale=0.7))
-    run('lm_fuser_sum', cfg, lm, conds3)
+    if not ONLY:
+        lm = build(cfg, cds, fuse, {}, dict(cross_attention_pos_emb=True, cross_attention_pos_emb_scale=0.7))
+        run('lm_fuser_sum', cfg, lm, conds3)
+
+    cfg = dict(BASE, seed=24, curve_frames=5, cross_attention=False)
+    torch.manual_seed(3003)
+    cds = {'description': mg.SynthText(cfg['cond_dim'], cfg['dim'], cfg['Lc']),
+           'genre': SynthFrames(cfg['cond_dim'], cfg['dim'], 1, 79),
+           'curve': SynthFrames(cfg['cond_dim'], cfg['dim'], cfg['curve_frames'], 80)}
+    fuse = {'cross': [], 'prepend': ['description'], 'sum': ['genre'], 'input_interpolate': ['curve']}
+    lm = build(cfg, cds, fuse, {}, cross_attention=False)
+    assert list(lm.condition_provider.conditioners.keys()) == ['description', 'genre', 'curve']   # the order that matters
+    run('lm_fuser_prepend_sum', cfg, lm, conds3)
+    if len(sys.argv) > 1 and sys.argv[1] == 'prepend_sum_only':
+        sys.exit(0)
 
     # ---- codebook patterns: the provider is an attribute of the LM, the weights do not depend on it
     import audiocraft.modules.codebooks_patterns as cbp

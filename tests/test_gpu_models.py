@@ -537,6 +537,28 @@ def test_lm_two_step_cfg_unequal_prepend_vs_reference_golden():
     assert torch.equal(toks_eq, toks_one)
 
 
+def test_lm_two_step_cfg_unequal_prepend_on_a_rotary_model_vs_reference_golden():
+    """The same two left-padded streams on a ROTARY model (round 5; raised NotImplementedError before): the rotary position
+    of a row is its OWN position (stream position - row_off), as in the reference, where each pass has its own streaming
+    state (lm.py:378-390, transformer.py:300-313).  Golden from the unmodified reference (`make_rope_golden.py two_step`)."""
+    cfg, sd, a = load_golden('lm_rope_two_step_prepend')
+    lm = build_lm(cfg, sd)
+    ones = lambda t: torch.ones(t.shape[:2], dtype=torch.int64).cuda()  # noqa: E731
+    ct = {'description': (a['prepend_src'].cuda(), ones(a['prepend_src']))}
+    nt = {'description': (a['null_prepend_src'].cuda(), ones(a['null_prepend_src']))}
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=11, use_sampling=False, condition_tensors=(ct, nt),
+                           return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
+    assert rel(lg.cpu(), ref) < 1e-4
+    toks_p = lm.generate(a['prompt'].cuda(), [], max_gen_len=12, use_sampling=False, condition_tensors=(ct, nt))
+    assert torch.equal(toks_p.cpu(), a['greedy_tokens_prompt'])
+    # with a bounded context the rotary lag would differ per row group: still refused, with a message that says so
+    lm_pc = build_lm(dict(cfg, past_context=6), sd)
+    with pytest.raises(NotImplementedError, match='past_context'):
+        lm_pc.generate(None, [], num_samples=3, max_gen_len=11, use_sampling=False, condition_tensors=(ct, nt))
+
+
 def test_lm_double_cfg_vs_reference_golden(prefill_mode):
     """cfg_coef_beta (MusicGen-Style double CFG, lm.py:362-376): 3B rows [text + wav; wav; null]."""
     cfg, sd, a = load_golden('lm_double_cfg')

@@ -315,3 +315,23 @@ def test_lm_other_codebook_patterns_vs_reference_golden():
         if f'cont_tokens_{i}' in a:
             toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=7, use_sampling=False, condition_tensors=ct, check=True)
             assert torch.equal(toks.cpu(), a[f'cont_tokens_{i}']), name
+
+
+def test_lm_fuser_sum_after_prepend_vs_reference_golden():
+    """A 'sum' and an 'input_interpolate' condition AFTER a 'prepend' one in the provider's order (round 5; raised
+    NotImplementedError before): the reference adds them to the prepended rows of the first call as well
+    (conditioners.py:1730-1748); golden from the unmodified reference, greedy tokens + step logits, with and without a prompt."""
+    cfg, sd, a = load_golden('lm_fuser_prepend_sum')
+    lm = build(cfg, sd)
+    ones = lambda t: torch.ones(t.shape[:2], dtype=torch.int64).cuda()  # noqa: E731
+    ct = {k: (a['cond_' + k].cuda(), ones(a['cond_' + k])) for k in ('description', 'genre', 'curve')}   # the provider's order
+    toks, lg = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct,
+                           return_logits=True, check=True)
+    assert torch.equal(toks.cpu(), a['greedy_tokens'])
+    assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
+    toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=11, use_sampling=False, condition_tensors=ct, check=True)
+    assert torch.equal(toks.cpu(), a['cont_tokens'])
+    # the other order (sum / interpolate first) is a different model output: the order is honoured, not normalised
+    ct2 = {k: ct[k] for k in ('genre', 'curve', 'description')}
+    toks2 = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct2)
+    assert not torch.equal(toks2.cpu(), a['greedy_tokens'])

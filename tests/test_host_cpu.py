@@ -404,7 +404,7 @@ OPTION_KEYS = ('kv_repeat', 'qk_layer_norm', 'qk_layer_norm_cross', 'bias_attn',
 
 def options_lm_cfg(cfg):
     """builders.get_lm_model cfg of an options golden (tests/golden/make_options_golden.py)."""
-    fuser = {'cross': ['description']}
+    fuser = {'cross': ['description']} if cfg.get('cross_attention', True) else {'prepend': ['description']}
     if 'curve_frames' in cfg:
         fuser.update({'sum': ['genre'], 'input_interpolate': ['curve']})
     return dict(dim=cfg['dim'], num_heads=cfg['num_heads'], num_layers=cfg['num_layers'], n_q=cfg['n_q'], card=cfg['card'],
@@ -959,3 +959,46 @@ def test_philox_restatement_known_answers():
     assert counts[p < kth].sum() == 0
     chi2 = ((counts[p >= kth] - exp[p >= kth]) ** 2 / exp[p >= kth]).sum()
     assert chi2 < 20, chi2
+
+
+def test_fuser_first_call_inputs_is_the_reference_loop():
+    """ConditionFuser.first_call_inputs against a literal replay of the reference's fuser loop (conditioners.py:1730-1748) on
+    a random input: conditions in dict order, `input += cond` / F.interpolate to the CURRENT input length / prepend in front."""
+    import torch.nn.functional as F
+    from audiocraft_amd.modules.conditioners import ConditionFuser
+    g = torch.Generator().manual_seed(4)
+    B, d = 3, 8
+    for order in (['description', 'genre', 'curve'], ['genre', 'description', 'curve'], ['curve', 'wav', 'genre', 'description'],
+                  ['genre', 'curve', 'description']):
+        fuser = ConditionFuser({'prepend': ['description', 'wav'], 'sum': ['genre'], 'input_interpolate': ['curve']})
+        conds = {'description': torch.randn(B, 5, d, generator=g), 'wav': torch.randn(B, 3, d, generator=g),
+                 'genre': torch.randn(B, 1, d, generator=g), 'curve': torch.randn(B, 7, d, generator=g)}
+        ct = {k: (conds[k], torch.ones(B, conds[k].shape[1], dtype=torch.int64)) for k in order}
+        for T in (1, 4, 9):
+            x = torch.randn(B, T, d, generator=g)
+            ref = x.clone()
+            for k in order:                       # the reference's loop, first streaming call
+                op, cond = fuser.cond2fuse[k], conds[k]
+                if op == 'sum':
+                    ref += cond
+                elif op == 'input_interpolate':
+                    ref += F.interpolate(cond.transpose(1, 2), size=ref.shape[1]).transpose(1, 2)
+                else:
+                    ref = torch.cat([cond, ref], dim=1)
+            prepend, add = fuser.first_call_inputs(ct, T)
+            P = sum(conds[k].shape[1] for k in order if fuser.cond2fuse[k] == 'prepend')
+            assert prepend.shape == (B, P, d) and add.shape == (B, T, d)
+            got = torch.cat([prepend, x + add], dim=1)
+            assert torch.allclose(got, ref, atol=1e-6), (order, T)
+            seen, mixed = False, False
+            for k in order:
+                seen = seen or fuser.cond2fuse[k] == 'prepend'
+                mixed = mixed or (seen and fuser.cond2fuse[k] != 'prepend')
+            assert fuser.mixed_order(ct) == mixed
+            if not mixed:                          # the common order: the plain concatenation + the token additions
+                p0, _ = fuser.fuse(ct)
+                assert torch.equal(prepend, p0.float())
+                assert torch.allclose(add, ConditionFuser.input_add_rows(fuser.input_ops(ct), T))
+            else:
+                with pytest.raises(NotImplementedError):
+                    fuser.fuse(ct)

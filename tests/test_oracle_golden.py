@@ -135,6 +135,25 @@ def test_lm_options_oracle_matches_reference(name):
     assert torch.equal(toks, a['cont_tokens'])
 
 
+def test_lm_fuser_sum_after_prepend_oracle_matches_reference():
+    """A 'sum' and an 'input_interpolate' condition that come AFTER a 'prepend' one in the provider's dict order: the
+    reference's loop (conditioners.py:1730-1748) then works on the concatenated input -- the one-frame condition is added
+    to the prepended rows too, the 5-frame one is resampled over P + T positions (first call) / 1 position (later calls)."""
+    cfg, sd, a = load_golden('lm_fuser_prepend_sum')
+    c = lm_cfg(cfg)
+    ops = [('prepend', a['cond_description']), ('sum', a['cond_genre']), ('input_interpolate', a['cond_curve'])]
+    logits = olm.lm_forward(sd, c, a['tf_sequence'], None, input_ops=ops)
+    assert torch.allclose(logits, a['tf_logits'], atol=2e-5, rtol=1e-4)
+    # the order matters: with the prepend LAST (what `prepend_src` means) the logits are different
+    other = olm.lm_forward(sd, c, a['tf_sequence'], None, a['cond_description'], input_ops=ops[1:])
+    assert not torch.allclose(other, a['tf_logits'], atol=1e-3)
+    toks, lg = olm.generate(sd, c, None, 3, None, max_gen_len=12, use_sampling=False, return_logits=True, input_ops=ops)
+    assert torch.equal(toks, a['greedy_tokens'])
+    assert torch.allclose(lg, olm.cfg_mix(a['greedy_step_logits'], c.cfg_coef), atol=1e-4, rtol=1e-4)
+    toks = olm.generate(sd, c, a['prompt'], 3, None, max_gen_len=11, use_sampling=False, input_ops=ops)
+    assert torch.equal(toks, a['cont_tokens'])
+
+
 def test_lm_other_codebook_patterns_oracle_matches_reference():
     """One model generating through the other codebook patterns of the reference's builder (parallel, partly flattened +
     delayed unroll, coarse_first, musiclm, delay with flatten_first / empty_initial; codebooks_patterns.py:359-552): greedy
@@ -198,6 +217,23 @@ def test_lm_oracle_two_step_cfg_with_unequal_prepend_matches_reference():
     c = lm_cfg(cfg)
     assert a['prepend_src'].shape[1] == 5 and a['null_prepend_src'].shape[1] == 1
     toks, logits = olm.generate(sd, c, None, 3, None, a['prepend_src'], max_gen_len=11, use_sampling=False, cfg_coef=7.0,
+                                null_prepend_src=a['null_prepend_src'], return_logits=True)
+    assert torch.equal(toks, a['greedy_tokens'])
+    ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
+    assert torch.allclose(logits, ref, atol=2e-5, rtol=1e-5)
+    toks_p = olm.generate(sd, c, a['prompt'], 3, None, a['prepend_src'], max_gen_len=12, use_sampling=False,
+                          null_prepend_src=a['null_prepend_src'])
+    assert torch.equal(toks_p, a['greedy_tokens_prompt'])
+
+
+def test_lm_oracle_two_step_cfg_with_unequal_prepend_on_a_rotary_model_matches_reference():
+    """The same two streams on a ROTARY model (positional_embedding 'rope'): each pass has its own streaming state, hence
+    its own rotary positions -- the same token is rotated by different angles in the two streams (reference lm.py:378-390,
+    transformer.py:300-313, rope.py:75-114); with and without a prompt."""
+    cfg, sd, a = load_golden('lm_rope_two_step_prepend')
+    c = lm_cfg(cfg)
+    assert c.positional_embedding == 'rope' and a['prepend_src'].shape[1] == 5 and a['null_prepend_src'].shape[1] == 1
+    toks, logits = olm.generate(sd, c, None, 3, None, a['prepend_src'], max_gen_len=11, use_sampling=False,
                                 null_prepend_src=a['null_prepend_src'], return_logits=True)
     assert torch.equal(toks, a['greedy_tokens'])
     ref = a['uncond_step_logits'] + (a['cond_step_logits'] - a['uncond_step_logits']) * cfg['cfg_coef']
