@@ -25,9 +25,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--wgs', default='16,32,64')
 ap.add_argument('--frac', type=float, default=1.0)
 ap.add_argument('--reps', type=int, default=5)
+ap.add_argument('--paced', default='', help='persistent time-paced prefetcher: comma list of wgs:lead, wgs:lead:percent, e.g. 32:3:100,64:3:50')
 args = ap.parse_args()
 lab = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lab', 'libprefetch_lab.so'))
 lab.lab_touch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+lab.lab_paced_touch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 sink = torch.zeros(4, dtype=torch.int32, device='cuda')
 
 model = MusicGen.get_random_init('facebook/musicgen-medium', 'cuda', torch.bfloat16)
@@ -48,6 +50,13 @@ def hook(ws):
         return
     k = state['k']
     state['k'] += 1
+    if state['mode'] == 'paced' and k == 0:
+        main, side = torch.cuda.current_stream(), state['side']
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        lab.lab_paced_touch(state['table'].data_ptr(), len(state['seq_flat']), state['period'], state['lead'], state['wgs'],
+                            state['pct'], sink.data_ptr(), side.cuda_stream)
     if state['mode'] == 'prefetch' and k + 1 < len(state['seq']):
         main, side = torch.cuda.current_stream(), state['side']
         ev = torch.cuda.Event()
@@ -114,8 +123,23 @@ state['seq'] = state['seq'][:n]
 print(f"{n} GEMM launches per position", flush=True)
 base = run('plain')
 print(f"plain chain            : {base['avg_us']:.3f} us per launch", flush=True)
-for wgs in [int(v) for v in args.wgs.split(',')]:
+for wgs in [int(v) for v in args.wgs.split(',') if v]:
     r = run('prefetch', wgs)
     print(f"prefetch, {wgs:3d} workgroups: {r['avg_us']:.3f} us per launch ({r['avg_us'] / base['avg_us']:.3f} x)", flush=True)
+if args.paced:
+    import struct
+    flat = [w for ws in state['seq'] for w in ws]          # one entry per weight matrix, in launch order
+    per_launch = [len(ws) for ws in state['seq']]
+    # pace per ENTRY: entries of one launch share its due time -> expand the period table by repeating (lead counts entries ~ launches)
+    raw = b''.join(struct.pack('<QQ', w.data.data_ptr(), w.data.numel() * w.data.element_size()) for w in flat)
+    state['table'] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    state['seq_flat'] = flat
+    total_us = base['avg_us'] * n
+    state['period'] = max(1, int(total_us / len(flat) * 100))      # ticks of 10 ns per table entry
+    for spec in args.paced.split(','):
+        wgs, lead, pct = (int(v) for v in spec.split(':'))
+        state['lead'], state['pct'] = lead, pct
+        r = run('paced', wgs)
+        print(f"paced prefetcher, {wgs:3d} workgroups, {lead} entries ahead, {pct:3d} % of every matrix: {r['avg_us']:.3f} us per launch ({r['avg_us'] / base['avg_us']:.3f} x)", flush=True)
 base2 = run('plain')
 print(f"plain chain (again)    : {base2['avg_us']:.3f} us per launch", flush=True)
