@@ -10,6 +10,13 @@
 // (its K range of the workgroup's output features) through a private ring in LDS with LDS-DMA (`global_load_lds_dwordx4 nt`:
 // no registers in flight), so the two inner dependency edges are crossed with the next GEMM's weights already on the CU.
 //
+// RESULT (round 5, MI355X, scripts/engine_lab.py, profiles/r05_engine_*): parity-green, bit-reproducible, and SLOWER than the
+// launches -- 21.9 us per layer against 18.1 us at d = 1536 (1.21 x; d = 1024: 1.23 x, d = 2048: 1.28 x).  The prefetch credit is
+// real (the FFN1 stage shrinks from 5.8 to 3.6 us, the FFN2 stage from 6.5 to 2.5 us) but an in-launch all-to-all edge costs
+// ~4.2 us here (2.4 us waiting for the slowest of 192 producers, 1.8 us flag propagation + poll) plus ~1 us to pull the fresh
+// activation, against 1.3 us for a kernel boundary; DESIGN.md section 5.8 has the timeline.  acmi_lm_step therefore keeps the
+// three launches; this file stays as an exported, tested op and as the kernel behind that evidence.
+//
 // Work split (NWG = d / 8 workgroups, one per CU, all co-resident; NW compute waves + 1 control wave each):
 //   op0  x2 = x1 + att W0^T          workgroup j owns features [8j, 8j + 8)          (half-tile order, K = d)
 //   op1  h  = gelu(LN(x2) W1'^T)     workgroup j owns hidden features [32j, 32j + 32) = K tile j of h (tiled order, K = d)
