@@ -966,9 +966,13 @@ class LMModel(nn.Module):
     def reset_streaming(self):
         self._stream = None
 
-    def _stream_begin(self, B: int, condition_tensors: ConditionTensors):
+    def _stream_begin(self, B: int, condition_tensors: ConditionTensors, first_len: int = 1):
         dev = self.device
-        prepend, cross_src = self.fuser.fuse(condition_tensors)
+        mixed = self.fuser.mixed_order(condition_tensors)
+        prepend, cross_src = self.fuser.fuse(condition_tensors, allow_mixed=mixed)
+        add_first = None
+        if mixed:   # a 'sum' / 'input_interpolate' condition after a 'prepend' one: the first call's length shapes the prepended rows
+            prepend, add_first = self.fuser.first_call_inputs(condition_tensors, first_len)
         P = 0 if prepend is None else prepend.shape[1]
         Lc = 0 if cross_src is None else cross_src.shape[1]
         cap = self.streaming_capacity
@@ -989,14 +993,15 @@ class LMModel(nn.Module):
         if cross_src is not None:
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
         self._prefill(desc, state, P)   # the fuser prepends on the first call only (conditioners.py:1722-1741)
-        self._stream = {'run': run, 'state': state, 'desc': desc, 'prepend': prepend, 'P': P, 'steps': 0, 'B': B, 'ops': ops}
+        self._stream = {'run': run, 'state': state, 'desc': desc, 'prepend': prepend, 'P': P, 'steps': 0, 'B': B, 'ops': ops,
+                        'add_first': add_first}
         return self._stream
 
     def _streaming_forward(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
         B, K, S = sequence.shape
         st = getattr(self, '_stream', None)
         if st is None:
-            st = self._stream_begin(B, condition_tensors)
+            st = self._stream_begin(B, condition_tensors, S)
             self._set_first_call(st['state'], st['P'] + S)   # the first call's length fixes the rotary offsets
             st['first_len'] = st['P'] + S
         assert st['B'] == B, "the batch size of a stream cannot change"
@@ -1004,7 +1009,8 @@ class LMModel(nn.Module):
         run, off = st['run'], st['steps']
         run['gen_sequence'][:, :, off:off + S] = sequence.to(self.device)
         if st.get('ops'):
-            run['input_add'][:, off:off + S] = ConditionFuser.input_add_rows(st['ops'], S).to(self.device)
+            add = st.pop('add_first', None) if off == 0 else None    # (mixed order: what the first call adds to its token rows)
+            run['input_add'][:, off:off + S] = (add if add is not None else ConditionFuser.input_add_rows(st['ops'], S)).to(self.device)
         outs = []
         for _ in range(S):
             _C.lm_step(st['desc'], st['state'], _C.STEP_DECODE)
@@ -1086,14 +1092,18 @@ class LMModel(nn.Module):
         returns logits [B, K, S, card] like `LMModel.forward` (lm.py:221-268)."""
         dev = self.device
         B, K, S = sequence.shape
-        prepend, cross_src = self.fuser.fuse(condition_tensors)
+        mixed = self.fuser.mixed_order(condition_tensors)
+        prepend, cross_src = self.fuser.fuse(condition_tensors, allow_mixed=mixed)
+        # the reference's forward is ONE call of S steps: that is the length its fuser interpolates a condition to
+        if mixed:   # ... and, for a condition that follows a 'prepend' one in the provider's order, the prepended rows count too
+            prepend, input_add = self.fuser.first_call_inputs(condition_tensors, S)
+        else:
+            input_add = self._input_add_table([self.fuser.input_ops(condition_tensors)], [S])
         P = 0 if prepend is None else prepend.shape[1]
         Lc = 0 if cross_src is None else cross_src.shape[1]
         run = self._prepare_run(B, _C.CFG_NONE, P + S + 1, Lc, S + 1)
         if prepend is not None:
             prepend = prepend.to(device=dev, dtype=torch.float32).contiguous()
-        # the reference's forward is ONE call of S steps: that is the length its fuser interpolates a condition to
-        input_add = self._input_add_table([self.fuser.input_ops(condition_tensors)], [S])
         state = self._make_state(run, B, _C.CFG_NONE, P + S + 1, Lc, S + 1, prepend, True, False, 1.0, 0, 0.0, 1.0, 0,
                                  input_add=input_add)
         desc = self._packed['desc']

@@ -475,7 +475,7 @@ class ConditionFuser(nn.Module):
                 if prepend is not None and not allow_mixed:
                     # the reference adds this condition to the already prepended rows as well (its loop works on the
                     # concatenated input); the provider's dict order (text, then wav, then joint conditions) decides.
-                    # LMModel.generate handles it (first_call_inputs); the streaming / teacher-forced entry points do not
+                    # LMModel handles it through first_call_inputs (generate, forward, streaming; not two_step_cfg)
                     raise NotImplementedError(f"'{op}' condition {cond_type!r} after a 'prepend' condition in the provider's order")
             elif op == 'ignore':
                 continue

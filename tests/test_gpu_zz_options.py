@@ -331,6 +331,18 @@ def test_lm_fuser_sum_after_prepend_vs_reference_golden():
     assert rel(lg.cpu(), olm.cfg_mix(a['greedy_step_logits'], cfg['cfg_coef'])) < 1e-4
     toks = lm.generate(a['prompt'].cuda(), [], max_gen_len=11, use_sampling=False, condition_tensors=ct, check=True)
     assert torch.equal(toks.cpu(), a['cont_tokens'])
+    # the teacher-forced forward (one call of S steps: the reference golden) and the streaming protocol (a first call of 4 steps,
+    # whose length shapes what is added to the prepended rows, then single steps: against the oracle on the same split)
+    c = lm_cfg(cfg)
+    seq = a['tf_sequence']
+    assert rel(lm.forward_steps(seq.cuda(), ct).cpu(), a['tf_logits']) < 1e-4
+    ops = [('prepend', a['cond_description']), ('sum', a['cond_genre']), ('input_interpolate', a['cond_curve'])]
+    st = olm.LMState(c.num_layers)
+    ref = [olm.lm_forward(sd, c, seq[..., :4], None, None, st, ops)]
+    ref += [olm.lm_forward(sd, c, seq[..., i:i + 1], None, None, st, ops) for i in range(4, 7)]
+    with lm.streaming():
+        got = [lm(seq[..., :4].cuda(), [], ct).cpu()] + [lm(seq[..., i:i + 1].cuda(), [], ct).cpu() for i in range(4, 7)]
+    assert rel(torch.cat(got, dim=2), torch.cat(ref, dim=2)) < 1e-4
     # the other order (sum / interpolate first) is a different model output: the order is honoured, not normalised
     ct2 = {k: ct[k] for k in ('genre', 'curve', 'description')}
     toks2 = lm.generate(None, [], num_samples=3, max_gen_len=12, use_sampling=False, condition_tensors=ct2)
