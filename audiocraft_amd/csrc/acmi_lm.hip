@@ -650,8 +650,6 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
                  s->pf_tcap, npos);
     ACMI_REQUIRE(m->layers[0].w_qkv != nullptr && m->layers[0].b_qkv != nullptr && m->layers[0].b_ff1 != nullptr,
                  "acmi_lm_step: the tiled prefill needs the folded-LayerNorm matrices");
-    ACMI_REQUIRE(m->layers[0].q_ln_g == nullptr && m->layers[0].k_ln_g == nullptr && m->layers[0].cq_ln_g == nullptr,
-                 "acmi_lm_step: qk_layer_norm models prefill through the decode kernels (no pf_xn)");
     int rc;
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
@@ -686,6 +684,14 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             b.H = H; b.hd = hd; b.Tcap = s->Tmax; b.d = d; b.npos = npos; b.npos_pad = npp; b.vt_tcap = s->pf_tcap; b.pos = s->pos;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
         }
+        if (L.q_ln_g != nullptr || L.k_ln_g != nullptr) {   // qk_layer_norm on the q rows and the K rows just stored (before the rotary positions)
+            ACMI_REQUIRE(L.q_ln_g != nullptr && L.k_ln_g != nullptr, "acmi_lm_step: q_ln_g and k_ln_g come together");
+            QkLnArgs qa = {};
+            qa.q = s->q; qa.kc = L.k_cache; qa.kv_bf16 = kvbf; qa.H = H; qa.hd = hd; qa.Tcap = s->Tmax; qa.d = d; qa.rpp = s->Beff;
+            qa.pos = s->pos; qa.qg = L.q_ln_g; qa.qb = L.q_ln_b; qa.kg = L.k_ln_g; qa.kb = L.k_ln_b; qa.eps = m->eps;
+            qa.npos_pad = npp; qa.npos = npos;
+            if ((rc = launch_qk_ln(qa, M, true, st))) return rc;
+        }
         if (m->rope_freq != nullptr) {
             RopeArgs ra = {};
             ra.q = s->q; ra.kc = L.k_cache; ra.kv_bf16 = kvbf; ra.H = H; ra.hd = hd; ra.Tcap = s->Tmax; ra.d = d; ra.rpp = s->Beff;
@@ -714,6 +720,11 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             BigArgs b = big(s->pf_xn, L.w_cq, L.b_cq, d, d, ACMI_BIG_F32);
             b.out = s->q; b.ldo = d;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
+            if (L.cq_ln_g != nullptr) {   // qk_layer_norm_cross on the queries (the keys were normalised when the cache was filled)
+                QkLnArgs qa = {};
+                qa.q = s->q; qa.d = d; qa.rpp = s->Beff; qa.qg = L.cq_ln_g; qa.qb = L.cq_ln_b; qa.eps = m->eps;
+                if ((rc = launch_qk_ln(qa, M, false, st))) return rc;
+            }
             if (L.cvt_cache != nullptr && s->cvt_tcap >= s->Lc) {
                 // the same MFMA attention kernel, non-causal over the Lc source positions (V time-minor: built once per generate)
                 PrefillAttnArgs pa = {};

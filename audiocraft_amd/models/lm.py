@@ -889,7 +889,7 @@ class LMModel(nn.Module):
         fits its tiles; ACMI_PREFILL=chunk forces the decode kernels on PREFILL_CHUNK positions per call (A/B, tests)."""
         import os
         mode = os.environ.get('ACMI_PREFILL', '')
-        if mode == 'chunk' or self.qk_layer_norm or self.qk_layer_norm_cross:   # qk_layer_norm: decode kernels only
+        if mode == 'chunk':
             return False
         kt = _C._tile_params(self.weight_dtype)[1]
         hd = self.dim // self.num_heads

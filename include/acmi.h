@@ -212,7 +212,7 @@ typedef struct {
      * the full model dimension of the projected queries and of the projected keys, f32 [d] weight / bias each, applied by a
      * launch of its own right after the QKV GEMM (before the rotary positions): q in place in state->q, k in place in the
      * cache row the GEMM has just appended (a bf16 cache therefore rounds k twice; exact with an f32 cache).  All four NULL =
-     * off.  Not with the one-forward prefill (pf_xn). */
+     * off.  (0.1.8: also through the one-forward prefill.) */
     const float* q_ln_g; const float* q_ln_b; const float* k_ln_g; const float* k_ln_b;
     /* qk_layer_norm_cross (transformer.py:358-360, 526-529): the same on the cross-attention's queries, f32 [d] each or NULL.
      * The step then runs the cross query as a projection of its own (the split of w_qkvx / w_mq needs a query that is linear
