@@ -44,7 +44,8 @@ class LMLayer(C.Structure):
                 ('k_cache', vp), ('v_cache', vp), ('ck_cache', vp), ('cv_cache', vp),
                 ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp),
                 ('b_out', vp), ('b_cout', vp), ('b_ff2', vp), ('b_mq', vp), ('cvt_cache', vp),
-                ('q_ln_g', vp), ('q_ln_b', vp), ('k_ln_g', vp), ('k_ln_b', vp), ('cq_ln_g', vp), ('cq_ln_b', vp)]
+                ('q_ln_g', vp), ('q_ln_b', vp), ('k_ln_g', vp), ('k_ln_b', vp), ('cq_ln_g', vp), ('cq_ln_b', vp),
+                ('n1_g', vp), ('n1_b', vp), ('nc_g', vp), ('nc_b', vp), ('n2_g', vp), ('n2_b', vp)]
 
 
 class LMModelDesc(C.Structure):
@@ -52,7 +53,7 @@ class LMModelDesc(C.Structure):
                 ('card', i32), ('wdtype', i32), ('kvdtype', i32), ('cross_attention', i32), ('eps', f32),
                 ('positional_scale', f32), ('layers', C.POINTER(LMLayer)), ('emb', C.POINTER(vp)),
                 ('pos_table', vp), ('w_head', vp), ('b_head', vp), ('cs_head', vp), ('rope_freq', vp), ('rope_decay', vp),
-                ('rope_scale', f32), ('rope_base', f32), ('past_context', i32)]
+                ('rope_scale', f32), ('rope_base', f32), ('past_context', i32), ('post_norm', i32)]
 
 
 class LMState(C.Structure):

@@ -134,19 +134,24 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(float* __restrict__ x, WT*
             if (k < K) *reinterpret_cast<float4*>(x + (size_t)m * K + k) = v[j];
         }
     }
-    float s = 0.f;
+    // eps < 0: no standardisation, the rows go into fragment order as they are (post-norm layers, acmi_lm_model.post_norm:
+    // the GEMMs there consume x itself; (v - 0) * 1 is exact)
+    float mean = 0.f, rstd = 1.0f;
+    if (eps >= 0.f) {
+        float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    const float mean = wave_sum(s) / (float)K;
-    float s2 = 0.f;
+        for (int j = 0; j < ACMI_STAGE_JMAX; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        mean = wave_sum(s) / (float)K;
+        float s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
-        if ((lane + 64 * j) * 4 < K) {
-            const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
-            s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
+            if ((lane + 64 * j) * 4 < K) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
         }
+        rstd = 1.0f / sqrtf(wave_sum(s2) / (float)K + eps);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)K + eps);
 #pragma unroll
     for (int j = 0; j < ACMI_STAGE_JMAX; ++j) {
         const int k = (lane + 64 * j) * 4;

@@ -603,11 +603,18 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
         p.a_stats = c.gram ? nullptr : s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
         p.a_shift = c.xsh;
     } else {
-        int rc = acmi_launch_ln_tile(s->x, c.xh, m->wdtype, c.rows, m->dim, m->eps, nullptr, 0, c.st);
+        // post-norm layers consume x itself (eps < 0: fragment order, no standardisation); pre-norm: the standardised rows
+        int rc = acmi_launch_ln_tile(s->x, c.xh, m->wdtype, c.rows, m->dim, m->post_norm ? -1.0f : m->eps, nullptr, 0, c.st);
         if (rc) return rc;
         p.a = c.xh;
     }
     return acmi_launch_lin(p, m->wdtype, c.st);
+}
+
+// post-norm layers (acmi_lm_model.post_norm; transformer.py:567-573): x <- LayerNorm(x) in place after a block's residual add
+static int post_ln(StepCtx& c, const float* g, const float* b) {
+    ACMI_REQUIRE(g != nullptr && b != nullptr, "acmi_lm_step: post_norm needs n1_g .. n2_b on every layer");
+    return acmi_layer_norm_rows(c.s->x, g, b, c.s->x, c.rows, c.m->dim, c.m->eps, (void*)c.st);
 }
 
 // describes x <- x + a W^T (in place on the f32 copy), also emitted as fragments into (xh, xl) + statistics
@@ -675,9 +682,17 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
         b.a = a; b.w = w; b.bias = bias; b.M = M; b.N = N; b.K = K; b.epi = epi;
         return b;
     };
+    // post-norm layers (acmi_lm_model.post_norm): the GEMMs read x itself (raw fragments), each block's LayerNorm follows its
+    // residual add as a launch of its own, and the cross-attention's query is projected from the LAYER INPUT
+    const bool post = m->post_norm != 0;
+    const float tile_eps = post ? -1.0f : m->eps;
+    auto post_ln = [&](const float* g, const float* bta) {
+        ACMI_REQUIRE(g != nullptr && bta != nullptr, "acmi_lm_step: post_norm needs n1_g .. n2_b on every layer");
+        return acmi_layer_norm_rows(s->x, g, bta, s->x, M, d, m->eps, (void*)st);
+    };
     for (int li = 0; li < m->num_layers; ++li) {
         const acmi_lm_layer& L = m->layers[li];
-        if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
+        if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, tile_eps, nullptr, 0, st))) return rc;
         {
             BigArgs b = big(s->pf_xn, L.w_qkv, L.b_qkv, 3 * d, d, ACMI_BIG_QKV);
             b.q_out = s->q; b.k_cache = L.k_cache; b.v_cache = L.v_cache; b.vt = s->pf_vt; b.kv_bf16 = kvbf;
@@ -714,9 +729,11 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             b.out = s->x; b.ldo = d;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
         }
+        if (post && (rc = post_ln(L.n1_g, L.n1_b))) return rc;
         if (m->cross_attention) {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache && L.w_cq && L.b_cq, "acmi_lm_step: cross-attention operands missing");
-            if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
+            // post-norm: pf_xn still holds the layer input's fragments, which is what the reference projects the query from
+            if (!post && (rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
             BigArgs b = big(s->pf_xn, L.w_cq, L.b_cq, d, d, ACMI_BIG_F32);
             b.out = s->q; b.ldo = d;
             if ((rc = acmi_launch_big(b, m->wdtype, st))) return rc;
@@ -742,8 +759,9 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             BigArgs c = big(s->att, L.w_cout, L.b_cout, d, d, ACMI_BIG_RESID);
             c.out = s->x; c.ldo = d;
             if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;
+            if (post && (rc = post_ln(L.nc_g, L.nc_b))) return rc;
         }
-        if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, m->eps, nullptr, 0, st))) return rc;
+        if ((rc = acmi_launch_ln_tile(s->x, s->pf_xn, m->wdtype, M, d, tile_eps, nullptr, 0, st))) return rc;
         {
             BigArgs b = big(s->pf_xn, L.w_ff1, L.b_ff1, F, d, ACMI_BIG_TILED);
             b.out_t = s->hidden; b.out_rbs = F / kt; b.act = 1;
@@ -752,6 +770,7 @@ static int lm_prefill_big(const acmi_lm_model* m, const acmi_lm_state* s, hipStr
             c.out = s->x; c.ldo = d;
             if ((rc = acmi_launch_big(c, m->wdtype, st))) return rc;
         }
+        if (post && (rc = post_ln(L.n2_g, L.n2_b))) return rc;
     }
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, s->pos, npos);
     return acmi_check_launch("advance_kernel");
@@ -781,8 +800,11 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     const int wbf = m->wdtype == ACMI_BF16, kvbf = m->kvdtype == ACMI_BF16;
     int rc;
 
+    const bool post = m->post_norm != 0;
+    ACMI_REQUIRE(!post || (m->cs_head == nullptr && m->layers[0].cs_qkv == nullptr && m->layers[0].w_qkvx == nullptr),
+                 "acmi_lm_step: post_norm takes the plain matrices (cs_* / w_qkvx NULL)");
     StepCtx c = {};
-    c.m = m; c.s = s; c.st = st; c.lnm = ln_mode_of(m, s);
+    c.m = m; c.s = s; c.st = st; c.lnm = post ? (int)LN_TILE : ln_mode_of(m, s);
     c.kt = wbf ? 32 : 16; c.nkc_d = (d + c.kt - 1) / c.kt;
     c.rbs = s->x_rbs > 0 ? s->x_rbs : c.nkc_d;
     ACMI_REQUIRE(c.rbs >= c.nkc_d, "acmi_lm_step: x_rbs=%d < %d K tiles of d", c.rbs, c.nkc_d);
@@ -871,6 +893,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
 
         if (!m->cross_attention) {
             if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
+            if (post && (rc = post_ln(c, L.n1_g, L.n1_b))) return rc;
         } else {
             ACMI_REQUIRE(s->Lc > 0 && L.ck_cache && L.cv_cache, "acmi_lm_step: cross-attention caches missing");
             acmi_attn_desc ca = {};
@@ -893,10 +916,19 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 ca.q = s->r; ca.q_stats = s->stats; ca.q_stats_np = c.np; ca.q_stats_cnt = c.cnt; ca.eps = m->eps;
                 ca.q_colsum = L.cs_cq; ca.q_bias = L.b_cq; ca.q_shift = sh_l;
             } else {
-                if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
                 LinArgs a = {};
                 a.out = s->q; a.out_mode = ACMI_OUT_F32;
-                if ((rc = gemm_ln_x(c, a, L.w_cq, L.b_cq, L.cs_cq, d))) return rc;
+                if (post) {
+                    // the reference's post-norm layer takes the cross-attention's query from the LAYER INPUT (`src`,
+                    // transformer.py:569-572): its fragments are still in xh (the QKV launch's), s->q is free (self-attention done)
+                    a.a = c.xh; a.a_tiled = 1; a.w = L.w_cq; a.bias = L.b_cq; a.M = c.rows; a.N = d; a.K = d;
+                    if ((rc = acmi_launch_lin(a, m->wdtype, st))) return rc;
+                    if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
+                    if ((rc = post_ln(c, L.n1_g, L.n1_b))) return rc;
+                } else {
+                    if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
+                    if ((rc = gemm_ln_x(c, a, L.w_cq, L.b_cq, L.cs_cq, d))) return rc;
+                }
                 if (L.cq_ln_g != nullptr) {   // qk_layer_norm_cross on the queries (the keys were normalised when the cache was filled)
                     QkLnArgs qa = {};
                     qa.q = s->q; qa.d = d; qa.rpp = s->Beff; qa.qg = L.cq_ln_g; qa.qb = L.cq_ln_b; qa.eps = m->eps;
@@ -906,6 +938,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             }
             if ((rc = acmi_attn_decode_ex(&ca, stream))) return rc;
             if ((rc = gemm_produce_x(c, s->att, L.w_cout, d, false, L.b_cout))) return rc;
+            if (post && (rc = post_ln(c, L.nc_g, L.nc_b))) return rc;
         }
         {   // norm2 -> linear1 + GELU -> hidden (A-fragment order) ; linear2 -> x
             LinArgs a = {};
@@ -917,6 +950,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             const bool half = half_ok && L.w_ff2h != nullptr && c.lnm == LN_FOLD && M <= 32 && d % 8 == 0 && d / 8 <= 256 &&
                               F % (2 * c.kt) == 0;
             if ((rc = gemm_produce_x(c, s->hidden, half ? L.w_ff2h : L.w_ff2, F, half, L.b_ff2))) return rc;
+            if (post && (rc = post_ln(c, L.n2_g, L.n2_b))) return rc;
         }
     }
     if (mode == ACMI_STEP_DECODE) {

@@ -104,7 +104,8 @@ def get_lm_model(cfg: dict, device='cuda', weight_dtype=torch.bfloat16, kv_dtype
     n_q = cfg.get('n_q', 4)
     lm = LMModel(get_codebooks_pattern_provider(n_q, cfg.get('codebooks_pattern')), provider, fuser, n_q=n_q,
                  card=cfg.get('card', 2048), dim=dim, num_heads=cfg['num_heads'],
-                 hidden_scale=cfg.get('hidden_scale', 4), norm='layer_norm', norm_first=True, bias_proj=cfg.get('bias_proj', False),
+                 hidden_scale=cfg.get('hidden_scale', 4), norm='layer_norm', norm_first=cfg.get('norm_first', True),
+                 bias_proj=cfg.get('bias_proj', False),
                  weight_init=cfg.get('weight_init', 'gaussian'), depthwise_init=cfg.get('depthwise_init', 'current'),
                  zero_bias_init=True, cfg_coef=cfg.get('cfg_coef', 3.0), num_layers=cfg['num_layers'],
                  cross_attention=bool(fuse['cross']), bias_ff=cfg.get('bias_ff', False), bias_attn=cfg.get('bias_attn', False),

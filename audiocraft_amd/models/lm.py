@@ -138,8 +138,10 @@ class LMModel(nn.Module):
     Beyond the MusicGen configuration the decode step also implements the transformer options no release uses
     (config/model/lm/default.yaml:25-46): positional_embedding 'rope' / 'sin_rope' (+ xpos), past_context, layer_scale,
     kv_repeat (the shared key / value heads are laid out per query head when the weights are packed: no kernel knows),
-    qk_layer_norm / qk_layer_norm_cross (a launch of their own after the projections).  Unsupported reference options
-    raise: norm_first=False, norms other than 'layer_norm', non-causal / non-GELU transformers.
+    qk_layer_norm / qk_layer_norm_cross (a launch of their own after the projections), and post-norm layers
+    (norm_first=False, the constructor default here as in the reference; transformer.py:567-573 -- a correctness path: plain
+    matrices, every LayerNorm a launch of its own, no out_norm, see include/acmi.h acmi_lm_model.post_norm).  Unsupported
+    reference options raise: norms other than 'layer_norm', non-causal / non-GELU transformers.
     """
 
     def __init__(self, pattern_provider: CodebooksPatternProvider, condition_provider: ConditioningProvider,
@@ -155,8 +157,11 @@ class LMModel(nn.Module):
                  weight_dtype: torch.dtype = torch.bfloat16, kv_dtype: tp.Optional[torch.dtype] = None,
                  device=None, **kwargs):
         super().__init__()
-        if not norm_first or norm != 'layer_norm':
-            raise NotImplementedError("only pre-norm LayerNorm transformers (the MusicGen configuration)")
+        if norm != 'layer_norm':
+            raise NotImplementedError("only LayerNorm transformers (norm='layer_norm', the MusicGen configuration)")
+        if not norm_first and dim > 2048:
+            raise NotImplementedError("norm_first=False for dim > 2048 (acmi_layer_norm_rows)")
+        self.norm_first = bool(norm_first)
         if positional_embedding not in ('sin', 'rope', 'sin_rope'):
             raise ValueError(f"positional_embedding {positional_embedding!r} (transformer.py:632)")
         if activation != 'gelu' or not causal:
@@ -198,7 +203,8 @@ class LMModel(nn.Module):
         kv_dim = (dim // num_heads) * (num_heads // self.kv_repeat)
         self.transformer = _Transformer(dim, self.ffn_dim, num_layers, cross_attention, bias_ff, bias_attn, device, layer_scale,
                                         rope, kv_dim, self.qk_layer_norm, self.qk_layer_norm_cross)
-        self.out_norm = nn.LayerNorm(dim, eps=1e-5, device=device)
+        # lm.py:171-173: out_norm only exists on pre-norm models (a post-norm stack ends with its last layer's norm2)
+        self.out_norm: tp.Optional[nn.LayerNorm] = nn.LayerNorm(dim, eps=1e-5, device=device) if norm_first else None
         self.linears = nn.ModuleList([nn.Linear(dim, card, bias=bias_proj, device=device) for _ in range(n_q)])
         self._init_weights(weight_init, depthwise_init, zero_bias_init)
         self._packed: tp.Optional[dict] = None
@@ -301,10 +307,17 @@ class LMModel(nn.Module):
             keep.append(t)
             return t
 
+        post = not self.norm_first
+
         def folded(w, norm, own_bias=None):
             """LN(x) W^T = standardise(x) W'^T + W beta, W' = W diag(gamma)  ->  (tiled W', f32 bias W beta,
-            f32 column sums of the dtype-rounded W': standardise(x) W'^T = rstd (x W'^T - mean colsum))."""
+            f32 column sums of the dtype-rounded W': standardise(x) W'^T = rstd (x W'^T - mean colsum)).
+            Post-norm models (norm_first=False): the GEMM consumes x itself -> (tiled W, the projection's own bias or zeros,
+            no column sums: acmi_lm_step then runs the unfolded form)."""
             w32 = w.detach().to(device=dev, dtype=torch.float32)
+            if post:
+                own = torch.zeros(w32.shape[0], device=dev) if own_bias is None else own_bias
+                return W(w32), Fp(own), None
             g = norm.weight.detach().to(device=dev, dtype=torch.float32)
             b = norm.bias.detach().to(device=dev, dtype=torch.float32)
             bias = w32 @ b
@@ -361,6 +374,8 @@ class LMModel(nn.Module):
                     # its own (no w_qkvx / w_mq); the keys are normalised when the cross-attention caches are filled
                     ent['cq_ln_g'], ent['cq_ln_b'] = Fp(ca.q_layer_norm.weight), Fp(ca.q_layer_norm.bias)
                     ent['ck_ln_g'], ent['ck_ln_b'] = Fp(ca.k_layer_norm.weight), Fp(ca.k_layer_norm.bias)
+                if self.qk_layer_norm_cross or post:
+                    pass    # (post-norm: the query is projected from the layer input by a launch of its own as well)
                 else:
                     # x1 W_cq'^T = x0 W_cq'^T + att (W_cq' W_out)^T with x1 = x0 + att W_out^T: the x0 part is a fourth block of
                     # output features of the QKV launch (raw, no LayerNorm epilogue), the att part rides in the out-projection
@@ -380,10 +395,15 @@ class LMModel(nn.Module):
                     ent['b_cout'] = sb
                 ent.update({'w_ck': W(ipw[d:2 * d]), 'w_cv': W(ipw[2 * d:]),
                             'w_cout': W(scaled(ca.out_proj.weight, 'layer_scale_cross'))})
+            if post:   # the LayerNorms themselves: applied in place after each block's residual add
+                for key, mod in (('n1', layer.norm1), ('n2', layer.norm2)) + \
+                        ((('nc', layer.norm_cross),) if layer.cross_attention is not None else ()):
+                    ent[key + '_g'], ent[key + '_b'] = Fp(mod.weight), Fp(mod.bias)
+            ent = {k: v for k, v in ent.items() if v is not None}
             L = layers[li]
             for k in ('w_qkv', 'w_out', 'w_cq', 'w_cout', 'w_xcq', 'w_ff1', 'w_ff2', 'b_qkv', 'b_cq', 'b_ff1', 'cs_qkv',
                       'cs_cq', 'cs_ff1', 'w_qkvx', 'b_qkvx', 'cs_qkvx', 'w_mq', 'w_ff2h', 'b_out', 'b_cout', 'b_ff2', 'b_mq',
-                      'q_ln_g', 'q_ln_b', 'k_ln_g', 'k_ln_b', 'cq_ln_g', 'cq_ln_b'):
+                      'q_ln_g', 'q_ln_b', 'k_ln_g', 'k_ln_b', 'cq_ln_g', 'cq_ln_b', 'n1_g', 'n1_b', 'nc_g', 'nc_b', 'n2_g', 'n2_b'):
                 setattr(L, k, ent[k].data_ptr() if k in ent else None)
             pk['per_layer'].append(ent)
         embs = [E(e.weight) for e in self.emb]
@@ -392,6 +412,7 @@ class LMModel(nn.Module):
         if self.linears[0].bias is not None:
             head_bias = torch.cat([lin.bias for lin in self.linears], dim=0)
         w_head, b_head, cs_head = folded(torch.cat([lin.weight for lin in self.linears], dim=0), self.out_norm, head_bias)
+        desc_post = int(post)
         half = d // 2
         # divisor table of create_sin_embedding, computed exactly like the reference does
         # (transformer.py:83-88: f32 tensor ops on the host); cos/sin are evaluated on the device
@@ -407,6 +428,7 @@ class LMModel(nn.Module):
         desc.rope_freq = desc.rope_decay = None
         desc.rope_scale, desc.rope_base = float(self.positional_scale), 512.0
         desc.past_context = int(self.past_context or 0)
+        desc.post_norm = desc_post
         if self.positional_embedding in ('rope', 'sin_rope'):
             # the tables of RotaryEmbedding / XPos: buffers computed like the reference does (rope.py:26-30, 59-61)
             pk['rope_freq'] = Fp(self.transformer.rope.frequencies)
@@ -417,7 +439,8 @@ class LMModel(nn.Module):
         desc.layers = C.cast(layers, C.POINTER(_C.LMLayer))
         desc.emb = C.cast(emb_arr, C.POINTER(_C.vp))
         desc.pos_table = None
-        desc.w_head, desc.b_head, desc.cs_head = w_head.data_ptr(), b_head.data_ptr(), cs_head.data_ptr()
+        desc.w_head, desc.b_head = w_head.data_ptr(), b_head.data_ptr()
+        desc.cs_head = None if cs_head is None else cs_head.data_ptr()
         pk.update({'desc': desc, 'emb_arr': emb_arr, 'w_head': w_head, 'b_head': b_head, 'cs_head': cs_head,
                    'pos_freq': pos_freq, 'embs': embs})
         self._packed = pk
@@ -453,8 +476,8 @@ class LMModel(nn.Module):
             m = _C.untile_matrix(tw.data, tw.N, tw.K).float()
             return m if rows is None else m[rows]
 
-        def norm_w(mod):
-            return mod.weight.detach().float()
+        def norm_w(mod):   # the LayerNorm gain folded into the consuming matrix (post-norm models fold nothing)
+            return mod.weight.detach().float() if self.norm_first else torch.ones(d, device=self.device)
 
         parts = name.split('.')
         if parts[0] == 'emb':

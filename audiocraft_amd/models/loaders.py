@@ -92,7 +92,8 @@ def parse_cfg(text_or_dict) -> dict:
 
 TRANSFORMER_OPTIONS = ('positional_embedding', 'xpos', 'past_context', 'layer_scale', 'positional_scale', 'max_period',
                        'bias_ff', 'bias_attn', 'bias_proj',   # biases: true in config/model/lm/default.yaml, false in the releases
-                       'kv_repeat', 'qk_layer_norm', 'qk_layer_norm_cross')   # config/model/lm/default.yaml:43-46
+                       'kv_repeat', 'qk_layer_norm', 'qk_layer_norm_cross',   # config/model/lm/default.yaml:43-46
+                       'norm_first')                                          # default.yaml:21 (false there, true in every release)
 
 
 def lm_cfg_from_xp(cfg: dict) -> dict:

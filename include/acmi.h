@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 180 /* 0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
+#define ACMI_VERSION 190 /* 0.1.9: post-norm layers (acmi_lm_model.post_norm, acmi_lm_layer.n1_g .. n2_b; acmi_ln_tile with eps < 0 = raw rows).  0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
                             acmi_lm_step), the decode step's cross-attention as a kernel of its own (cross_q_kernel, inside acmi_attn_decode_ex).  0.1.7: qk_layer_norm (acmi_lm_layer.q_ln_g .. cq_ln_b, acmi_layer_norm_rows), fuser 'sum' / 'input_interpolate'
                             (acmi_lm_state.input_add).  0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
                             colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
@@ -218,6 +218,10 @@ typedef struct {
      * The step then runs the cross query as a projection of its own (the split of w_qkvx / w_mq needs a query that is linear
      * in x1).  The cross-attention KEYS are normalised by the caller when it fills ck_cache (acmi_layer_norm_rows). */
     const float* cq_ln_g; const float* cq_ln_b;
+    /* Post-norm layers (acmi_lm_model.post_norm; transformer.py:567-573, norm_first=False): norm1 / norm_cross / norm2 with
+     * their affine parts, f32 [d] each, applied IN PLACE to x after the residual add of the block (acmi_layer_norm_rows); the
+     * matrices above are then the plain ones (nothing folded: cs_* NULL, b_* = the projections' own biases or zeros). */
+    const float* n1_g; const float* n1_b; const float* nc_g; const float* nc_b; const float* n2_g; const float* n2_b;
 } acmi_lm_layer;
 
 typedef struct {
@@ -244,6 +248,13 @@ typedef struct {
     const float* rope_decay;        /* [hd / 2] f32: (i / (hd/2) + 0.4) / 1.4, or NULL */
     float rope_scale, rope_base;    /* RotaryEmbedding.scale (the transformer's positional_scale); XPos.base_scale (512) */
     int past_context;               /* self-attention sees keys p - past_context .. p (transformer.py:249-264, 286-293); <= 0: all */
+    /* 0.1.9: post-norm layers -- norm_first=False, the CONSTRUCTOR DEFAULT of the reference's LMModel / StreamingTransformer
+     * (lm.py:147, config/model/lm/default.yaml:21), which every release overrides with norm_first: true:
+     *     x = norm1(x + sa(x));  x = norm_cross(x + ca(q from the LAYER INPUT, transformer.py:569-572));  x = norm2(x + ff(x))
+     * and no out_norm in front of the heads (lm.py:171-173).  Correctness path: every GEMM reads x through acmi_ln_tile's raw
+     * form, every LayerNorm is a launch of its own (acmi_lm_layer.n1_g ..); w_head / b_head are the plain stacked heads.
+     * dim <= 2048.  0 = pre-norm (everything above). */
+    int post_norm;
 } acmi_lm_model;
 
 typedef struct {
@@ -355,7 +366,8 @@ int acmi_pos_table(const float* freq, float* table, int T, int d, void* stream);
 /* Row standardisation ((x - mean) / sqrt(var + eps), two-pass statistics, no affine part) of a
  * row-major f32 matrix x [M, K] into a zero-initialised tiled activation in `wdtype`: the LayerNorm
  * prologue of the decode step's GEMMs (nn.LayerNorm, transformer.py:54-67), whose affine part is
- * folded into the consuming matrix.  K % 4 == 0, K <= 2048. */
+ * folded into the consuming matrix.  K % 4 == 0, K <= 2048.  eps < 0 (0.1.9): no standardisation, the rows are only
+ * converted and laid out in fragment order (the GEMM inputs of post-norm layers). */
 int acmi_ln_tile(const float* x, void* out, int wdtype, int M, int K, float eps, void* stream);
 
 /* Same, preceded by the deterministic (fixed-order) reduction of a split-K producer:

@@ -42,6 +42,9 @@ class LMConfig:
     qk_layer_norm_cross: bool = False       # same in the cross-attention (transformer.py:358-360, 526-529)
     # codebook pattern other than the delay rule: (provider name, its kwargs) of builders.get_codebooks_pattern_provider
     pattern: tp.Optional[tp.Tuple[str, dict]] = None
+    # post-norm layers (transformer.py:567-573; the constructor default of LMModel / StreamingTransformer, lm.py:147; every
+    # release sets norm_first: true): x = norm1(x + sa(x)); x = norm_cross(x + ca(layer INPUT)); x = norm2(x + ff(x)); no out_norm
+    norm_first: bool = True
 
 
 def create_sin_embedding(positions: torch.Tensor, dim: int, max_period: float = 10000.) -> torch.Tensor:
@@ -124,8 +127,9 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
         return sd.get(f'{name}.scale', 1.0)
     for li in range(cfg.num_layers):
         p = f'transformer.layers.{li}'
-        # --- self attention (pre-norm)
-        h = _ln(x, sd, p + '.norm1', cfg.eps)
+        # --- self attention (pre-norm: on norm1(x); post-norm: on x itself, norm1 follows the residual add)
+        src = x
+        h = _ln(x, sd, p + '.norm1', cfg.eps) if cfg.norm_first else x
         proj = F.linear(h, sd[p + '.self_attn.in_proj_weight'], sd.get(p + '.self_attn.in_proj_bias'))
         if cfg.kv_repeat == 1:
             packed = proj.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)  # "b t (p h d) -> p b h t d"
@@ -168,11 +172,14 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
         a = _attention(q, k, v, causal, cfg.past_context)
         a = a.permute(0, 2, 1, 3).reshape(B, T, C)
         x = x + ls(p + '.layer_scale_1') * F.linear(a, sd[p + '.self_attn.out_proj.weight'], sd.get(p + '.self_attn.out_proj.bias'))
+        if not cfg.norm_first:
+            x = _ln(x, sd, p + '.norm1', cfg.eps)
         # --- cross attention: q/k/v projections with the three slices of in_proj_weight, k/v
         # re-projected at every call, no key-padding mask (transformer.py:344-361, 542-548)
         if cfg.cross_attention:
             assert cross_src is not None
-            h = _ln(x, sd, p + '.norm_cross', cfg.eps)
+            # post-norm: the reference passes `src`, the LAYER INPUT, as the query source (transformer.py:569-572), not norm1's output
+            h = _ln(x, sd, p + '.norm_cross', cfg.eps) if cfg.norm_first else src
             w = sd[p + '.cross_attention.in_proj_weight']
             bq = bk = bv = None
             if p + '.cross_attention.in_proj_bias' in sd:
@@ -187,10 +194,14 @@ def transformer_forward(sd: dict, cfg: LMConfig, x: torch.Tensor, cross_src: tp.
             a = _attention(qc, kc, vc, False).transpose(1, 2).reshape(B, T, C)
             x = x + ls(p + '.layer_scale_cross') * F.linear(a, sd[p + '.cross_attention.out_proj.weight'],
                                                             sd.get(p + '.cross_attention.out_proj.bias'))
+            if not cfg.norm_first:
+                x = _ln(x, sd, p + '.norm_cross', cfg.eps)
         # --- feed forward, exact (erf) GELU
-        h = _ln(x, sd, p + '.norm2', cfg.eps)
+        h = _ln(x, sd, p + '.norm2', cfg.eps) if cfg.norm_first else x
         h = F.gelu(F.linear(h, sd[p + '.linear1.weight'], sd.get(p + '.linear1.bias')))
         x = x + ls(p + '.layer_scale_2') * F.linear(h, sd[p + '.linear2.weight'], sd.get(p + '.linear2.bias'))
+        if not cfg.norm_first:
+            x = _ln(x, sd, p + '.norm2', cfg.eps)
     if state is not None:
         state.offset = offset + T
     return x
@@ -237,7 +248,8 @@ def lm_forward(sd: dict, cfg: LMConfig, sequence: torch.Tensor, cross_src: tp.Op
     if state is not None:
         state.first_step = False
     out = transformer_forward(sd, cfg, x, cross_src, state)
-    out = _ln(out, sd, 'out_norm', cfg.eps)
+    if cfg.norm_first:   # lm.py:171-173, 260-261: out_norm only exists on pre-norm models
+        out = _ln(out, sd, 'out_norm', cfg.eps)
     logits = torch.stack([F.linear(out, sd[f'linears.{k}.weight'], sd.get(f'linears.{k}.bias'))
                           for k in range(K)], dim=1)
     return logits[:, :, -S:]

@@ -17,6 +17,10 @@ The reference runs with custom=True (kv_repeat / qk_layer_norm assert the custom
                      well (its loop works on the concatenated input, conditioners.py:1730-1748): the one-frame condition to all
                      P + T rows of the first call, the 5-frame condition resampled over P + T positions
 
+  lm_post_norm.npz   norm_first=False -- the constructor default of LMModel / StreamingTransformer (lm.py:147, default.yaml:21), which
+                     every release overrides: x = norm1(x + sa(x)); x = norm_cross(x + ca(src)) with the LAYER INPUT `src` as the
+                     query source (transformer.py:567-573); x = norm2(x + ff(x)); no out_norm (lm.py:171-173).  Biases on
+
   lm_patterns.npz    one model generating through the other codebook patterns of the reference's builder
                      (codebooks_patterns.py:359-552): parallel, unroll (partly flattened, delayed), coarse_first, musiclm,
                      delay with flatten_first / empty_initial -- greedy tokens and per-step logits of each
@@ -52,12 +56,12 @@ class SynthFrames(TextConditioner):
         return self.output_proj(e) * mask.unsqueeze(-1), mask
 
 
-def build(cfg, conditioners, fuse, extra, fuser_kw=None, cross_attention=True):
+def build(cfg, conditioners, fuse, extra, fuser_kw=None, cross_attention=True, norm_first=True):
     torch.manual_seed(cfg['seed'])
     lm = LMModel(DelayedPatternProvider(cfg['n_q'], delays=cfg['delays']), ConditioningProvider(conditioners),
                  ConditionFuser(fuse, **(fuser_kw or {})),
                  n_q=cfg['n_q'], card=cfg['card'], dim=cfg['dim'], num_heads=cfg['num_heads'],
-                 hidden_scale=cfg['hidden_scale'], norm='layer_norm', norm_first=True, bias_proj=False,
+                 hidden_scale=cfg['hidden_scale'], norm='layer_norm', norm_first=norm_first, bias_proj=cfg.get('bias_proj', False),
                  weight_init='gaussian', depthwise_init='current', zero_bias_init=True, cfg_coef=cfg['cfg_coef'],
                  num_layers=cfg['num_layers'], dropout=0., activation='gelu', bias_ff=cfg.get('bias_ff', False),
                  bias_attn=cfg.get('bias_attn', False), causal=True, custom=True, memory_efficient=False,
@@ -99,7 +103,15 @@ CROSS_ONLY = {'cross': ['description'], 'prepend': [], 'sum': [], 'input_interpo
 
 if __name__ == '__main__':
     conds = [ConditioningAttributes(text={'description': f'p{i}'}) for i in range(3)]
-    ONLY = len(sys.argv) > 1 and sys.argv[1] == 'prepend_sum_only'   # regenerate just the newest fixture
+    ONLY = len(sys.argv) > 1 and sys.argv[1] == 'prepend_sum_only'   # regenerate just that fixture
+    if len(sys.argv) > 1 and sys.argv[1] == 'post_norm_only':
+        cfg = dict(BASE, seed=25, bias_attn=True, bias_ff=True, bias_proj=True, norm_first=False)
+        torch.manual_seed(3004)
+        text = {'description': mg.SynthText(cfg['cond_dim'], cfg['dim'], cfg['Lc'])}
+        lm = build(cfg, text, CROSS_ONLY, {}, norm_first=False)
+        assert lm.out_norm is None and not lm.transformer.layers[0].norm_first
+        run('lm_post_norm', cfg, lm, conds)
+        sys.exit(0)
 
     extra = dict(kv_repeat=2)
     cfg = dict(BASE, seed=21, bias_attn=True, bias_ff=True, **extra)

@@ -67,9 +67,11 @@ def prefill_mode(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum'])
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum', 'lm_post_norm'])
 def test_lm_options_vs_reference_golden(name, prefill_mode):
-    """Teacher-forced logits, greedy tokens + per-step CFG logits without and with a 4-step prompt (the first call then spans
+    """(lm_post_norm: norm_first=False, the reference's constructor default -- transformer.py:567-573, the cross-attention's
+    query from the layer input, no out_norm -- through the decode step, the chunked and the one-forward prefill.)
+    Teacher-forced logits, greedy tokens + per-step CFG logits without and with a 4-step prompt (the first call then spans
     several positions: the multi-position prefill, and the length an interpolated condition is resampled to), graph replay ==
     eager launches, bf16 packs."""
     cfg, sd, a = load_golden(name)
@@ -93,7 +95,7 @@ def test_lm_options_vs_reference_golden(name, prefill_mode):
     assert rel(lm16.forward_steps(a['tf_sequence'].cuda(), ct).cpu(), a['tf_logits']) < 3e-2
 
 
-@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_fuser_sum'])
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_fuser_sum', 'lm_post_norm'])
 def test_lm_options_streaming_calls_vs_oracle(name):
     """The StreamingModule protocol on these options: a first call of 4 steps, then single steps, against the oracle run on the
     same split (every call resamples an 'input_interpolate' condition to ITS length; a kv_repeat stream lists the stored
@@ -131,7 +133,8 @@ def test_lm_options_midsize_vs_oracle(wdt, tol, B):
     from audiocraft_amd.models import builders
     for extra in (dict(qk_layer_norm=True, qk_layer_norm_cross=True, bias_attn=True,
                        fuser={'cross': ['description'], 'sum': ['genre'], 'input_interpolate': ['curve']}),
-                  dict(kv_repeat=4, positional_embedding='sin_rope', bias_attn=True, fuser={'cross': ['description']})):
+                  dict(kv_repeat=4, positional_embedding='sin_rope', bias_attn=True, fuser={'cross': ['description']}),
+                  dict(norm_first=False, bias_attn=True, bias_ff=True, fuser={'cross': ['description']})):
         torch.manual_seed(1)
         cfg = dict(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0,
                    conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 64, 'length': 6}}, **extra)
@@ -140,7 +143,7 @@ def test_lm_options_midsize_vs_oracle(wdt, tol, B):
             for k, p in lm.named_parameters():
                 if 'norm' in k:
                     p.add_(0.1 * torch.randn_like(p))
-                if k.endswith('in_proj_bias') or k.endswith('out_proj.bias'):
+                if k.endswith('in_proj_bias') or k.endswith('out_proj.bias') or k.endswith('linear1.bias') or k.endswith('linear2.bias'):
                     p.add_(0.05 * torch.randn_like(p))
         sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
         if wdt == torch.bfloat16:   # the oracle sees the same bf16-rounded matrices; activations stay f32 there
@@ -148,7 +151,7 @@ def test_lm_options_midsize_vs_oracle(wdt, tol, B):
         oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True,
                           kv_repeat=extra.get('kv_repeat', 1), qk_layer_norm=extra.get('qk_layer_norm', False),
                           qk_layer_norm_cross=extra.get('qk_layer_norm_cross', False),
-                          positional_embedding=extra.get('positional_embedding', 'sin'))
+                          positional_embedding=extra.get('positional_embedding', 'sin'), norm_first=extra.get('norm_first', True))
         g = torch.Generator().manual_seed(5)
         cross = torch.randn(2 * B, 6, 256, generator=g)
         cross[B:] = 0

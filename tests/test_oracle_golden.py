@@ -20,7 +20,7 @@ def codec_cfg(cfg):
 
 
 LM_OPT_KEYS = ['positional_embedding', 'xpos', 'past_context', 'positional_scale', 'kv_repeat', 'qk_layer_norm',
-               'qk_layer_norm_cross']
+               'qk_layer_norm_cross', 'norm_first']
 
 
 def lm_cfg(cfg):
@@ -112,14 +112,17 @@ def options_inputs(name, cfg, a):
     return cross, ops
 
 
-@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum'])
+@pytest.mark.parametrize('name', ['lm_kv_repeat', 'lm_qk_ln', 'lm_fuser_sum', 'lm_post_norm'])
 def test_lm_options_oracle_matches_reference(name):
     """kv_repeat, qk_layer_norm (+ cross), the fuser's 'sum' / 'input_interpolate' methods and cross_attention_pos_emb
-    (transformer.py:196-222, 358-400; conditioners.py:1733-1757) against goldens of the unmodified reference."""
+    (transformer.py:196-222, 358-400; conditioners.py:1733-1757), post-norm layers (norm_first=False, transformer.py:567-573:
+    the cross-attention's query comes from the layer INPUT; no out_norm) against goldens of the unmodified reference."""
     cfg, sd, a = load_golden(name)
     c = lm_cfg(cfg)
     cross, ops = options_inputs(name, cfg, a)
-    assert (c.kv_repeat, c.qk_layer_norm, bool(ops)) != (1, False, False)
+    assert (c.kv_repeat, c.qk_layer_norm, bool(ops), c.norm_first) != (1, False, False, True)
+    if not c.norm_first:
+        assert not any(k.startswith('out_norm') for k in sd)
     logits = olm.lm_forward(sd, c, a['tf_sequence'], cross, input_ops=ops)
     assert torch.allclose(logits, a['tf_logits'], atol=2e-5, rtol=1e-4)
     if c.kv_repeat > 1:     # the in-projection really is narrower, and the cache keeps the un-repeated heads
