@@ -141,7 +141,7 @@ class LMModel(nn.Module):
     qk_layer_norm / qk_layer_norm_cross (a launch of their own after the projections), and post-norm layers
     (norm_first=False, the constructor default here as in the reference; transformer.py:567-573 -- a correctness path: plain
     matrices, every LayerNorm a launch of its own, no out_norm, see include/acmi.h acmi_lm_model.post_norm).  Unsupported
-    reference options raise: norms other than 'layer_norm', non-causal / non-GELU transformers.
+    reference options raise: non-causal / non-GELU transformers (and, like the reference, norms other than 'layer_norm').
     """
 
     def __init__(self, pattern_provider: CodebooksPatternProvider, condition_provider: ConditioningProvider,
@@ -158,7 +158,7 @@ class LMModel(nn.Module):
                  device=None, **kwargs):
         super().__init__()
         if norm != 'layer_norm':
-            raise NotImplementedError("only LayerNorm transformers (norm='layer_norm', the MusicGen configuration)")
+            raise ValueError(f"Unknown norm type: {norm}")   # create_norm_fn, transformer.py:54-67: the reference knows no other
         if not norm_first and dim > 2048:
             raise NotImplementedError("norm_first=False for dim > 2048 (acmi_layer_norm_rows)")
         self.norm_first = bool(norm_first)
@@ -885,7 +885,9 @@ class LMModel(nn.Module):
         s.wait_stream(torch.cuda.current_stream())
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
-            g.capture_begin()
+            # thread-local capture mode: another host thread (a second model generating on its own stream) may synchronise or
+            # allocate meanwhile; the capturing thread itself only enqueues acmi kernels
+            g.capture_begin(capture_error_mode='thread_local')
             try:
                 _C.lm_step(desc, state, _C.STEP_DECODE)
             finally:
