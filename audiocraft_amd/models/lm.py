@@ -885,9 +885,7 @@ class LMModel(nn.Module):
         s.wait_stream(torch.cuda.current_stream())
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s):
-            # thread-local capture mode: another host thread (a second model generating on its own stream) may synchronise or
-            # allocate meanwhile; the capturing thread itself only enqueues acmi kernels
-            g.capture_begin(capture_error_mode='thread_local')
+            g.capture_begin()   # (global capture mode: one generate at a time per process -- see DESIGN.md section 7.1, two-stream lab)
             try:
                 _C.lm_step(desc, state, _C.STEP_DECODE)
             finally:

@@ -20,6 +20,10 @@ models = [MusicGen.get_random_init('facebook/musicgen-medium', 'cuda', torch.bfl
 for m in models:
     m.set_generation_params(use_sampling=True, top_k=250, duration=D)
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+# the product captures in the default (global) mode, in which one thread's capture makes the other thread's synchronisations
+# illegal; the lab switches to thread-local capture (not robust: a two-thread test of it crashed once in ten runs)
+_begin = torch.cuda.CUDAGraph.capture_begin
+torch.cuda.CUDAGraph.capture_begin = lambda self, *a, **kw: _begin(self, *a, **dict(kw, capture_error_mode='thread_local'))
 
 
 def gen(i, n):

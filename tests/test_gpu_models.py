@@ -413,37 +413,6 @@ def test_lm_sampling_generate_is_well_formed():
     assert not torch.equal(toks, toks3)
 
 
-def test_two_models_generate_concurrently_from_two_host_threads():
-    """Two LM replicas, each generating on its own HIP stream from its own host thread (a server holding two models in one
-    process): the hipGraph capture of one must not make the other's synchronisations illegal (thread-local capture mode),
-    and every thread's tokens equal what it generates alone."""
-    import threading
-    from audiocraft_amd.models import builders
-    from audiocraft_amd.modules.conditioners import ConditioningAttributes
-    lms = [builders.get_debug_lm_model('cuda') for _ in range(2)]
-    conds = [ConditioningAttributes(text={'description': 'a b c'}), ConditioningAttributes(text={'description': 'd e'})]
-    alone = [lm.generate(None, conds, max_gen_len=60, use_sampling=True, top_k=50, seed=11 + i).cpu() for i, lm in enumerate(lms)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    got, errors = [None, None], []
-
-    def work(i):
-        try:
-            with torch.cuda.stream(streams[i]):
-                for _ in range(3):   # several generates each: captures and replays of the two threads interleave
-                    t = lms[i].generate(None, conds, max_gen_len=60, use_sampling=True, top_k=50, seed=11 + i)
-                streams[i].synchronize()
-            got[i] = t.cpu()
-        except Exception as e:   # noqa: BLE001
-            errors.append(e)
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    assert not errors, errors
-    assert torch.equal(got[0], alone[0]) and torch.equal(got[1], alone[1])
-
-
 def test_compute_predictions_matches_oracle():
     """LMModel.compute_predictions (lm.py:270-321): logits re-aligned with the codes + validity mask."""
     cfg, sd, a = load_golden('lm_text')
