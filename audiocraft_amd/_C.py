@@ -45,7 +45,8 @@ class LMLayer(C.Structure):
                 ('w_qkvx', vp), ('b_qkvx', vp), ('cs_qkvx', vp), ('w_mq', vp), ('w_ff2h', vp),
                 ('b_out', vp), ('b_cout', vp), ('b_ff2', vp), ('b_mq', vp), ('cvt_cache', vp),
                 ('q_ln_g', vp), ('q_ln_b', vp), ('k_ln_g', vp), ('k_ln_b', vp), ('cq_ln_g', vp), ('cq_ln_b', vp),
-                ('n1_g', vp), ('n1_b', vp), ('nc_g', vp), ('nc_b', vp), ('n2_g', vp), ('n2_b', vp)]
+                ('n1_g', vp), ('n1_b', vp), ('nc_g', vp), ('nc_b', vp), ('n2_g', vp), ('n2_b', vp),
+                ('w_qkvs', vp), ('b_qkvs', vp), ('cs_qkvs', vp), ('w_g2', vp), ('b_gs', vp), ('xs_u', vp), ('xs_cs', vp), ('xs_bs', vp)]
 
 
 class LMModelDesc(C.Structure):
@@ -63,7 +64,7 @@ class LMState(C.Structure):
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32),
                 ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32), ('cvt_tcap', i32),
-                ('row_off', vp), ('input_add', vp), ('n_add', i32)]
+                ('row_off', vp), ('input_add', vp), ('n_add', i32), ('xs_rows', i32)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -103,6 +104,12 @@ class LinearDesc(C.Structure):
                 ('xt_rbs', i32), ('xt_lo_rbs', i32), ('lo_K', i32), ('w_half', i32), ('a_shift', vp), ('xt_shift', vp), ('mean_out', vp)]
 
 
+class CrossFoldDesc(C.Structure):
+    _fields_ = [('s_raw', vp), ('s_ld', i32), ('stats', vp), ('stats_np', i32), ('stats_cnt', i32), ('shift', vp), ('cs', vp),
+                ('bs', vp), ('u', vp), ('wdtype', i32), ('x', vp), ('bias', vp), ('xt', vp), ('xt_nkc', i32), ('xt_shift', vp),
+                ('stats_out', vp), ('rows', i32), ('R', i32), ('HL', i32), ('Lc', i32), ('d', i32), ('FB', i32), ('eps', f32)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [('q', vp), ('k_cache', vp), ('v_cache', vp), ('kvdtype', i32), ('out', vp), ('out_mode', i32),
                 ('out_dtype', i32), ('out_rbs', i32), ('out_col0', i32), ('Beff', i32), ('H', i32), ('hd', i32),
@@ -120,6 +127,7 @@ class FfnEngineDesc(C.Structure):
 _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
 FFN_ENGINE_FLAG_BYTES = 16384
 _ffn_engine = _sig('acmi_ffn_engine', [C.POINTER(FfnEngineDesc), vp])
+_cross_fold = _sig('acmi_cross_fold', [C.POINTER(CrossFoldDesc), vp])
 _ffn_engine_supported = _sig('acmi_ffn_engine_supported', [i32, i32, i32, i32])
 _linear_pair = _sig('acmi_linear_pair', [C.POINTER(LinearDesc), C.POINTER(LinearDesc), vp])
 _attn_ex = _sig('acmi_attn_decode_ex', [C.POINTER(AttnDesc), vp])
@@ -149,13 +157,14 @@ EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_layer_ex', 'acmi_lstm_layer_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex', 'acmi_layer_norm_rows',
-           'acmi_ffn_engine', 'acmi_ffn_engine_supported']
+           'acmi_ffn_engine', 'acmi_ffn_engine_supported', 'acmi_cross_fold']
 
 
 # ctypes mirror -> C type of include/acmi.h (tests/test_host_cpu.py compiles the header with gcc and compares every
 # field's offset: a mirror that drifts from the header would corrupt every call silently)
 STRUCT_MIRRORS = {'acmi_conv_desc': ConvDesc, 'acmi_lm_layer': LMLayer, 'acmi_lm_model': LMModelDesc, 'acmi_lm_state': LMState,
-                  'acmi_linear_desc': LinearDesc, 'acmi_attn_desc': AttnDesc, 'acmi_ffn_engine_desc': FfnEngineDesc}
+                  'acmi_linear_desc': LinearDesc, 'acmi_attn_desc': AttnDesc, 'acmi_ffn_engine_desc': FfnEngineDesc,
+                  'acmi_cross_fold_desc': CrossFoldDesc}
 
 
 def version() -> int:
@@ -460,6 +469,35 @@ def attn_decode(q, k_cache, v_cache, out, length, len_dev=None, len_bias=0, out_
     d.start_rows = ptr(start_rows)
     check(_attn_ex(C.byref(d), stream()), 'acmi_attn_decode_ex')
     return out
+
+
+def cross_fold_fb(d: int, dtype: torch.dtype) -> int:
+    """Features per workgroup of acmi_cross_fold (its FB = 0 default): 64, or the largest power of two below it that divides d
+    and still holds whole 16-byte vectors per thread.  The U table is laid out in blocks of that many features."""
+    vec = 8 if dtype == torch.bfloat16 else 4
+    fb = 64
+    while fb > vec and d % fb != 0:
+        fb >>= 1
+    return fb
+
+
+def cross_fold_u_layout(U: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """U [R, HL, d] -> [R][d / FB][HL][FB] in `dtype` (acmi_cross_fold_desc.u)."""
+    R, HL, d = U.shape
+    fb = cross_fold_fb(d, dtype)
+    return U.to(dtype).view(R, HL, d // fb, fb).permute(0, 2, 1, 3).contiguous()
+
+
+def cross_fold(s_raw, s_ld, stats, stats_np, stats_cnt, cs, bs, u, x, rows, R, HL, Lc, eps=1e-5, shift=None, bias=None,
+               xt=None, xt_nkc=0, xt_shift=None, stats_out=None):
+    """acmi_cross_fold (include/acmi.h): x[b] += softmax(folded LayerNorm of row b's raw scores) u[b] (+ bias), in place."""
+    dsc = CrossFoldDesc()
+    dsc.s_raw, dsc.s_ld, dsc.stats, dsc.stats_np, dsc.stats_cnt = ptr(s_raw), s_ld, ptr(stats), stats_np, stats_cnt
+    dsc.shift, dsc.cs, dsc.bs, dsc.u, dsc.wdtype = ptr(shift), ptr(cs), ptr(bs), ptr(u), dtype_code(u.dtype)
+    dsc.x, dsc.bias, dsc.xt, dsc.xt_nkc, dsc.xt_shift, dsc.stats_out = ptr(x), ptr(bias), ptr(xt), xt_nkc, ptr(xt_shift), ptr(stats_out)
+    dsc.rows, dsc.R, dsc.HL, dsc.Lc, dsc.d, dsc.FB, dsc.eps = rows, R, HL, Lc, x.shape[1], 0, eps
+    check(_cross_fold(C.byref(dsc), stream()), 'acmi_cross_fold')
+    return x
 
 
 def ln_tile(x: torch.Tensor, out: torch.Tensor, eps: float = 1e-5):

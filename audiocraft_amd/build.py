@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['acmi_core.hip', 'acmi_gemm.hip', 'acmi_gemm_f32.hip', 'acmi_engine.hip', 'acmi_attn.hip', 'acmi_lm.hip', 'acmi_prefill.hip', 'acmi_rvq.hip', 'acmi_conv.hip', 'acmi_chroma.hip', 'acmi_audio.hip', 'acmi_diffusion.hip']
+SOURCES = ['acmi_core.hip', 'acmi_gemm.hip', 'acmi_gemm_f32.hip', 'acmi_engine.hip', 'acmi_attn.hip', 'acmi_crossfold.hip', 'acmi_lm.hip', 'acmi_prefill.hip', 'acmi_rvq.hip', 'acmi_conv.hip', 'acmi_chroma.hip', 'acmi_audio.hip', 'acmi_diffusion.hip']
 HEADERS = [os.path.join(ROOT, 'include', 'acmi.h'), os.path.join(CSRC, 'acmi_common.h'),
            os.path.join(CSRC, 'acmi_lm_internal.h')]
 OUT = os.path.join(CSRC, 'libacmi.so')

@@ -718,14 +718,14 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
                 f = f0 + nn; dd = f0 - (h << p.hd_shift) + nn;
                 pidx = 0; brow = gm;
             } else {
-                part = gn / p.d; f = gn - part * p.d;
+                part = min(gn / p.d, 3); f = gn - part * p.d;   // (the raw block may be wider than d: r_ld)
                 h = f / p.hd; dd = f - h * p.hd;
                 pidx = gm / p.rpp; brow = gm - pidx * p.rpp;  // several positions per call (prefill)
             }
             if (part == 0) {
                 p.q_out[(size_t)gm * p.d + f] = v;
             } else if (part == 3) {
-                p.r_out[(size_t)gm * p.d + f] = v;
+                p.r_out[(size_t)gm * p.r_ld + f] = v;
             } else {
                 const size_t ci = (((size_t)brow * p.H + h) * p.Tcap + ex.tpos + pidx) * p.hd + dd;
                 void* cache = part == 1 ? p.k_cache : p.v_cache;
@@ -1002,7 +1002,7 @@ static int tiled_prepare(LinArgs& a) {
 static int tiled_epi(const LinArgs& a) {
     if (a.ksplit > 1) return EPI_GEN;
     if (a.qkv)
-        return (a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && (a.hd & (a.hd - 1)) == 0 && a.N % 16 == 0 && a.N <= 4 * a.d &&
+        return (a.M <= a.rpp && a.d % 16 == 0 && a.hd % 16 == 0 && (a.hd & (a.hd - 1)) == 0 && a.N % 16 == 0 && a.N <= 3 * a.d + a.r_ld &&
                 a.stats_out == nullptr && a.xt_hi == nullptr) ? EPI_QKV : EPI_GEN;
     if (a.xt_hi != nullptr)
         return (a.out_mode == ACMI_OUT_F32 && a.residual != nullptr && a.xt_lo == nullptr && a.act == 0) ? EPI_PRODX : EPI_GEN;
@@ -1025,6 +1025,7 @@ static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st
             attr_set = true;
         }
     }
+    if (a.r_ld <= 0) a.r_ld = a.d;
     a.epi = tiled_epi(a);
     a.inv_K = 1.0f / (float)a.K;
     a.hd_shift = 0;

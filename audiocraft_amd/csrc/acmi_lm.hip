@@ -592,6 +592,7 @@ struct StepCtx {
     // fragments themselves (acmi_linear_desc: colsum without a_stats), so the producers of x write partials only for the
     // one consumer that is not a GEMM: the cross-attention kernel's query hook (the paired out-projection's x1)
     bool gram;
+    const float* stats_in;     // the partials the next LayerNorm-consuming GEMM reads (s->stats; s->q behind the folded cross block)
 };
 
 // out = act(LayerNorm(x) W'^T + bias): folded into the GEMM, or standardisation kernel + plain GEMM
@@ -600,7 +601,7 @@ static int gemm_ln_x(StepCtx& c, LinArgs& p, const void* w, const float* bias, c
     p.a_tiled = 1; p.w = w; p.bias = bias; p.M = c.rows; p.N = N; p.K = m->dim;
     if (c.lnm == LN_FOLD) {
         p.a = c.xh; p.a_rbs = c.rbs; p.a_lo = c.use_lo ? c.xl : nullptr;
-        p.a_stats = c.gram ? nullptr : s->stats; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
+        p.a_stats = c.gram ? nullptr : c.stats_in; p.a_np = c.np; p.a_cnt = c.cnt; p.eps = m->eps; p.colsum = colsum;
         p.a_shift = c.xsh;
     } else {
         // post-norm layers consume x itself (eps < 0: fragment order, no standardisation); pre-norm: the standardised rows
@@ -808,7 +809,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     c.kt = wbf ? 32 : 16; c.nkc_d = (d + c.kt - 1) / c.kt;
     c.rbs = s->x_rbs > 0 ? s->x_rbs : c.nkc_d;
     ACMI_REQUIRE(c.rbs >= c.nkc_d, "acmi_lm_step: x_rbs=%d < %d K tiles of d", c.rbs, c.nkc_d);
-    c.xh = s->xn; c.xl = s->xlo; c.np = 1; c.cnt = d; c.rows = M;
+    c.xh = s->xn; c.xl = s->xlo; c.np = 1; c.cnt = d; c.rows = M; c.stats_in = s->stats;
     // bf16 fragments of x: ACMI_LN_LO=1 -> hi / lo pair; else with `xshift` (and not ACMI_LN_SHIFT=0) -> single term, per-row
     // shift (default); else ACMI_LN_LO=0 / ACMI_LN_SHIFT=0 -> single term, unshifted (A/B only); else the hi / lo pair
     static const bool shift_off = getenv("ACMI_LN_SHIFT") != nullptr && getenv("ACMI_LN_SHIFT")[0] == '0';
@@ -829,6 +830,14 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     void* const xh2[2] = {s->xn, s->xn2};
     void* const xl2[2] = {s->xlo, s->xlo2};
     int cur = 0;
+    // Score-folded cross-attention (include/acmi.h, acmi_lm_layer.w_qkvs): the raw scores of the conditioned rows ride in the
+    // QKV and the paired launch as xs_n = R * H * Lc more output features, ONE launch (acmi_crossfold.hip) replaces the
+    // cross-attention launch and the cross-out GEMM.  The CALLER opts in per generate (xs_rows > 0 + the tables); measured
+    // slower than the separate launches at every batch size on MI355X, so LMModel leaves xs_rows at 0 unless
+    // ACMI_CROSS_FOLD=1.
+    const int xs_hl = H * s->Lc, xs_n = (s->xs_rows * xs_hl + 15) / 16 * 16;   // (whole 16-feature tiles: zero rows behind R H Lc)
+    const bool xs = pair && npos == 1 && s->xs_rows > 0 && s->xs_rows <= s->Beff && m->layers[0].w_qkvs != nullptr &&
+                    !c.use_lo && s->cross_len_rows == nullptr && xs_hl <= 1024 && d / 16 <= 128;
 
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
@@ -860,7 +869,12 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             a.mean_out = c.nsh;   // single-term mode: the row means of x0 = the shift of this layer's producers
             a.qkv = 1; a.q_out = s->q; a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = kvbf;
             a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
-            if (pair) {   // + the x0 part of the cross-attention query as a fourth, raw block of features -> r
+            if (xs) {     // + the x0 part of the folded cross-attention scores: R H Lc raw features -> r viewed as [M, R H Lc]
+                ACMI_REQUIRE(L.w_qkvs && L.b_qkvs && L.cs_qkvs && L.w_g2 && L.xs_u && L.xs_cs && L.xs_bs,
+                             "acmi_lm_step: xs_rows > 0 needs the folded cross-attention tables on every layer");
+                a.r_out = s->r; a.r_ld = xs_n;
+                if ((rc = gemm_ln_x(c, a, L.w_qkvs, L.b_qkvs, L.cs_qkvs, 3 * d + xs_n))) return rc;
+            } else if (pair) {   // + the x0 part of the cross-attention query as a fourth, raw block of features -> r
                 a.r_out = s->r;
                 if ((rc = gemm_ln_x(c, a, L.w_qkvx, L.b_qkvx, L.cs_qkvx, 4 * d))) return rc;
             } else if ((rc = gemm_ln_x(c, a, L.w_qkv, L.b_qkv, L.cs_qkv, 3 * d))) return rc;
@@ -907,10 +921,27 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
                 LinArgs p0 = {}, p1 = {};
                 const void* att_half = reinterpret_cast<const unsigned char*>(c.xh) + (size_t)c.nkc_d * 1024;  // K tile nkc_d
                 gemm_produce_x_args(c, p0, att_half, c.rbs, L.w_out, d, xh2[cur ^ 1], xl2[cur ^ 1], L.b_out, true);
-                p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs; p1.bias = L.b_mq;
-                p1.w = L.w_mq; p1.residual = s->r; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M; p1.N = d; p1.K = d;
+                p1.a = att_half; p1.a_tiled = 1; p1.a_rbs = c.rbs; p1.bias = xs ? L.b_gs : L.b_mq;
+                p1.w = xs ? L.w_g2 : L.w_mq; p1.residual = s->r; p1.out = s->r; p1.out_mode = ACMI_OUT_F32; p1.M = M;
+                p1.N = xs ? xs_n : d; p1.K = d;
                 if ((rc = acmi_launch_pair(p0, p1, m->wdtype, st))) return rc;
                 cur ^= 1; c.xh = xh2[cur]; c.xl = xl2[cur]; c.np = d / 16; c.cnt = 16; c.xsh = c.nsh;
+                if (xs) {
+                    // x2 = x1 + softmax(folded LayerNorm of the raw scores) U: the x-producer of this block (what
+                    // gemm_produce_x would set up for the cross-out GEMM: f32 in place, fragments with this layer's shift,
+                    // partials only when the consumers do not take their statistics from the fragments)
+                    CrossFoldArgs f = {};
+                    f.s_raw = s->r; f.s_ld = xs_n; f.stats = s->stats; f.np = c.np; f.cnt = c.cnt; f.shift = sh_l;
+                    f.cs = L.xs_cs; f.bs = L.xs_bs; f.u = L.xs_u; f.x = s->x; f.bias = L.b_cout;
+                    // (it reads x1's partials while it writes x2's: those go to s->q, free between the self-attention and the next
+                    // layer's QKV launch, and FFN1 -- their only consumer -- is pointed there)
+                    f.xt = c.xh; f.xt_nkc = c.rbs; f.xt_shift = c.nsh; f.stats_out = c.gram ? nullptr : s->q;
+                    c.stats_in = s->q;
+                    f.R = s->xs_rows; f.HL = xs_hl; f.Lc = s->Lc; f.d = d; f.FB = 0; f.eps = m->eps;
+                    if ((rc = acmi_launch_cross_fold(f, m->wdtype, M, st))) return rc;
+                    c.cnt = 16; c.np = d / 16; c.xsh = c.nsh;
+                    goto ffn;
+                }
                 // the cross-attention kernel applies norm_cross to r from the statistics of x1; r = (x1 - shift of x0's
                 // fragments) W_cq'^T, since its x0 part was accumulated on them
                 ca.q = s->r; ca.q_stats = s->stats; ca.q_stats_np = c.np; ca.q_stats_cnt = c.cnt; ca.eps = m->eps;
@@ -940,10 +971,12 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
             if ((rc = gemm_produce_x(c, s->att, L.w_cout, d, false, L.b_cout))) return rc;
             if (post && (rc = post_ln(c, L.nc_g, L.nc_b))) return rc;
         }
+    ffn:
         {   // norm2 -> linear1 + GELU -> hidden (A-fragment order) ; linear2 -> x
             LinArgs a = {};
             a.out = s->hidden; a.out_mode = ACMI_OUT_TILED; a.act = 1;
             if ((rc = gemm_ln_x(c, a, L.w_ff1, L.b_ff1, L.cs_ff1, F))) return rc;
+            c.stats_in = s->stats;
             // FFN2: N = d is narrow and K = 4d long: 8-feature workgroups put it on twice the CUs (small calls only:
             // their consumers hold d / 8 statistics partials per row in registers)
             static const bool half_ok = !(getenv("ACMI_FFN2_HALF") != nullptr && getenv("ACMI_FFN2_HALF")[0] == '0');

@@ -40,6 +40,9 @@ struct LinArgs {
     float inv_K;  // tiled path: 1 / K (set by the launcher)
     int hd_shift; // QKV scatter: log2(hd) when the specialised epilogue runs (power-of-two head size)
     int epi;      // tiled path: the specialised epilogue this call's flags allow (acmi_gemm.hip, tl_epilogue), set by the launcher
+    int r_ld;     // QKV scatter: row pitch of r_out and width of the raw block behind the 3d q / k / v features (0 = d: the cross
+                  // query's x0 part; > d: the score-folded cross-attention's [R H Lc] block, acmi_lm_layer.w_qkvs).  Sits in
+                  // what was tail padding: sizeof(LinArgs) is unchanged
 #ifdef ACMI_TRACE
     unsigned long long* trace;   // this launch's stamps [workgroup][wave][ACMI_TRACE_NSTAMP] (NULL: not recorded)
 #endif
@@ -75,6 +78,20 @@ __device__ __forceinline__ size_t tiled_index(int row, int col, int nkc) {
     const int kc = col / KT, r = col - kc * KT;
     return ((((size_t)(row >> 4) * nkc + kc) * 64 + (r / EPL) * 16 + (row & 15)) * EPL) + (r % EPL);
 }
+
+// the score-folded cross-attention block (acmi_crossfold.hip)
+struct CrossFoldArgs {
+    const float* s_raw; int s_ld;                 // raw folded scores: row b's block at s_raw[b * s_ld + b * HL + hj]
+    const float* stats; int np, cnt;              // (mean, M2) partials of x1's rows, [rows][np][2]
+    const float* shift;                           // [rows] or NULL: S_raw was accumulated on x - shift
+    const float* cs; const float* bs;             // [R][HL] f32
+    const void* u;                                // [R][d / FB][HL][FB] in WT
+    float* x; const float* bias;                  // residual stream [rows][d] (in place), b_cout [d] or NULL
+    void* xt; int xt_nkc; const float* xt_shift;  // raw fragments of the new x (WT) or NULL; K tiles per row block; their shift
+    float* stats_out;                             // [rows][d / 16][2] partials of the new x, or NULL
+    int R, HL, Lc, d, FB; float eps;
+};
+int acmi_launch_cross_fold(const CrossFoldArgs& a, int wdtype, int rows, hipStream_t st);
 
 // launchers of acmi_gemm.hip used by acmi_lm_step
 int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st);                 // tiled or row-major activation

@@ -650,6 +650,74 @@ class LMModel(nn.Module):
             _C.kv_store(tmp.view(Beff, Lc, d), run['cv'][li], 0)
         run['cvt'][..., :Lc].copy_(run['cv'].transpose(3, 4))   # [L, Beff, H, hd, Lc]: one strided copy per generate
 
+    # ------------------------------------------------------------------------------------- score-folded cross-attention
+    def _cross_fold_rows(self, run, n_live: int, Lc: int, two_step: bool) -> int:
+        """Rows R for which the decode step runs the score-folded cross-attention (include/acmi.h, acmi_lm_state.xs_rows;
+        modules/cross_fold.py), or 0 = the separate launches.  The per-generate tables hold R H Lc d elements -- three of them
+        per layer -- where the launches they replace stream d d: taken while R H Lc <= 2 d (MusicGen-medium: 8 conditioned rows x
+        24 heads x 16 text positions = 2 d), with the paired launches available and one source length for all rows."""
+        import os
+        # OPT-IN (ACMI_CROSS_FOLD=1): parity-green but measured slower than the separate launches at every batch size on MI355X
+        # (B = 8 x 30 s: RTF 60.5 against 65.8; B = 1 / 2 / 4 x 10 s: 1.96 / 2.01 / 2.07 against 1.88 / 1.90 / 1.95 ms per position;
+        # DESIGN.md 5.9) -- one launch less per layer does not pay for wider QKV / paired launches and the table build
+        if os.environ.get('ACMI_CROSS_FOLD', '') != '1' or not self.has_cross_attention or two_step or Lc <= 0:
+            return 0
+        pk = self._packed
+        d, H, Beff = self.dim, self.num_heads, run['Beff']
+        kt = _C._tile_params(self.weight_dtype)[1]
+        if 'w_qkvx' not in pk['per_layer'][0] or getattr(self, '_masters_released', False):
+            return 0          # no paired launches (qk_layer_norm_cross, post-norm) / the f32 matrices the tables are folded from are gone
+        R = n_live if 0 < n_live < Beff else Beff
+        HL = H * Lc
+        if R * HL > 2 * d or HL > 1024 or d % kt or (3 * d) % 16 or d // 16 > 128:
+            return 0
+        if Beff * (-(-R * HL // 16) * 16) > run['r'].numel():
+            return 0
+        return R
+
+    def _build_cross_fold(self, run, R: int, Lc: int):
+        """Fill the per-generate tables of the score-folded cross-attention from the cross-attention caches just projected
+        (torch tensor algebra on the device, once per generate: modules/cross_fold.py) and point the layers at them."""
+        from ..modules import cross_fold
+        pk = self._packed
+        dev, wd = self.device, self.weight_dtype
+        d, H = self.dim, self.num_heads
+        HL, N = H * Lc, R * H * Lc
+        Np = -(-N // 16) * 16        # whole 16-feature tiles (tile_matrix pads the rows with zeros)
+        nt3 = 3 * d // 16
+        xs = run.get('xs')
+        if xs is None or xs['key'] != (R, Lc):
+            xs = {'key': (R, Lc), 'layers': []}
+            for li in range(self.num_layers):
+                ent = pk['per_layer'][li]
+                w3 = ent['w_qkv'].data                                   # [3d / 16, K tiles, 4, 16, e]: n-tile major
+                w_qkvs = torch.empty((nt3 + Np // 16,) + tuple(w3.shape[1:]), device=dev, dtype=wd)
+                w_qkvs[:nt3].copy_(w3)
+                zeros = torch.zeros(Np, device=dev)
+                xs['layers'].append({'w_qkvs': w_qkvs, 'b_qkvs': torch.cat([ent['b_qkv'], zeros]).contiguous(),
+                                     'cs_qkvs': torch.cat([ent['cs_qkv'], zeros]).contiguous()})
+            run['xs'] = xs
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)  # noqa: E731
+        for li, layer in enumerate(self.transformer.layers):
+            ent, bufs, ca = pk['per_layer'][li], xs['layers'][li], layer.cross_attention
+
+            def scaled(w, name):
+                ls = getattr(layer, name, None)
+                return f32(w) if ls is None else f32(w) * f32(ls.scale)[:, None]
+            kc, vc = run['ck'][li][:R].float(), run['cv'][li][:R].float()     # the VALUES the attention kernels would read
+            wq = f32(ca.in_proj_weight[:d]) * f32(layer.norm_cross.weight)[None, :]
+            t = cross_fold.fold_tables(kc, vc, wq, ent['b_cq'], scaled(layer.self_attn.out_proj.weight, 'layer_scale_1'),
+                                       ent.get('b_out'), scaled(ca.out_proj.weight, 'layer_scale_cross'), wd)
+            bufs['w_qkvs'][nt3:].copy_(_C.tile_matrix(t['G'].reshape(N, d), wd))
+            bufs['w_g2'] = _C.tile_matrix(t['G2'].reshape(N, d), wd)
+            bufs['u'] = _C.cross_fold_u_layout(t['U'], wd)
+            bufs['cs'], bufs['bs'] = t['CS'].contiguous(), t['BS'].contiguous()
+            bufs['b_gs'] = None if t['b_gs'] is None else torch.cat([t['b_gs'].reshape(N), torch.zeros(Np - N, device=dev)]).contiguous()
+            L = pk['layers'][li]
+            L.w_qkvs, L.b_qkvs, L.cs_qkvs = bufs['w_qkvs'].data_ptr(), bufs['b_qkvs'].data_ptr(), bufs['cs_qkvs'].data_ptr()
+            L.w_g2, L.b_gs = bufs['w_g2'].data_ptr(), (None if bufs['b_gs'] is None else bufs['b_gs'].data_ptr())
+            L.xs_u, L.xs_cs, L.xs_bs = bufs['u'].data_ptr(), bufs['cs'].data_ptr(), bufs['bs'].data_ptr()
+
     # ------------------------------------------------------------------------------------- conditions
     def _cfg_condition_tensors(self, conditions: tp.List[ConditioningAttributes], cfg_coef_beta=None,
                                two_step_cfg: bool = False):
@@ -842,6 +910,10 @@ class LMModel(nn.Module):
                 n_live = run['Beff']     # k / v biases: a null source no longer means K = V = 0
             state.cross_active_rows = n_live if 0 < n_live < run['Beff'] else 0
             run['att'].zero_()
+            # the decode step's cross-attention in its score-folded form where the geometry allows (one launch less per layer)
+            state.xs_rows = self._cross_fold_rows(run, n_live, Lc, two_step)
+            if state.xs_rows > 0:
+                self._build_cross_fold(run, state.xs_rows, Lc)
 
         # ---- prefill: prepended condition rows and prompt steps, PREFILL_CHUNK positions per call, no sampling
         self._set_first_call(state, P + start_offset_sequence)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 190 /* 0.1.9: post-norm layers (acmi_lm_model.post_norm, acmi_lm_layer.n1_g .. n2_b; acmi_ln_tile with eps < 0 = raw rows).  0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
+#define ACMI_VERSION 190 /* 0.1.9: post-norm layers (acmi_lm_model.post_norm, acmi_lm_layer.n1_g .. n2_b; acmi_ln_tile with eps < 0 = raw rows); score-folded cross-attention (acmi_cross_fold, acmi_lm_layer.w_qkvs .., acmi_lm_state.xs_rows).  0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
                             acmi_lm_step), the decode step's cross-attention as a kernel of its own (cross_q_kernel, inside acmi_attn_decode_ex).  0.1.7: qk_layer_norm (acmi_lm_layer.q_ln_g .. cq_ln_b, acmi_layer_norm_rows), fuser 'sum' / 'input_interpolate'
                             (acmi_lm_state.input_add).  0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
                             colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
@@ -222,6 +222,18 @@ typedef struct {
      * their affine parts, f32 [d] each, applied IN PLACE to x after the residual add of the block (acmi_layer_norm_rows); the
      * matrices above are then the plain ones (nothing folded: cs_* NULL, b_* = the projections' own biases or zeros). */
     const float* n1_g; const float* n1_b; const float* nc_g; const float* nc_b; const float* n2_g; const float* n2_b;
+    /* Score-folded cross-attention (0.1.9; acmi_lm_state.xs_rows > 0; algebra and table builder:
+     * audiocraft_amd/modules/cross_fold.py).  K / V of the cross-attention are constant over a generate, so the contractions
+     * over the head dimension live in PER-GENERATE tables of the R = xs_rows conditioned rows, HL = H * Lc entries each:
+     *     G[b, hj, :]  = scale * sum_{f in h} K[b, h, j, f] W_cq'[f, :]      G2 = G W_out       U[b, hj, :] = sum_f V[b, h, j, f] W_cout[:, f]
+     * w_qkvs = [w_qkv ; G as R*HL more output features] (tiled, [3d + R HL, d]; b_qkvs / cs_qkvs: [3d + R HL], zeros behind
+     * 3d): the QKV launch leaves x0 G^T raw in state->r viewed as [Beff, R HL] (row b's own scores at r[b][b HL ..]); w_g2 =
+     * G2 (tiled [R HL, d]) completes them in the out-projection launch (+ b_gs = G b_out, [R HL] or NULL); then ONE launch
+     * (acmi_cross_fold) applies the query's folded LayerNorm (xs_cs = row sums of G, xs_bs = scale * b_cq . K; [R, HL] f32), the
+     * softmax over each head's Lc positions and x2 = x1 + p U[b] (xs_u: [R][d / 64][HL][64] in wdtype) -- the cross-attention
+     * launch and the cross-out GEMM of the layer are gone.  All NULL = off. */
+    const void* w_qkvs; const float* b_qkvs; const float* cs_qkvs; const void* w_g2; const float* b_gs;
+    const void* xs_u; const float* xs_cs; const float* xs_bs;
 } acmi_lm_layer;
 
 typedef struct {
@@ -336,6 +348,12 @@ typedef struct {
                                call (an interpolated condition is resampled to that call's length) and one last entry for
                                every later single-step call */
     int n_add;              /* entries per row of input_add (>= 1 when input_add is not NULL) */
+    int xs_rows;            /* > 0: score-folded cross-attention (acmi_lm_layer.w_qkvs ..) over the first xs_rows CFG rows (the rows
+                               with a non-null condition; the others take b_cout only).  Needs the paired launches (w_qkvx / w_mq
+                               present), one position per call, single-term or f32 fragments (no hi / lo pair), one source length
+                               for all rows (cross_len_rows NULL), H * Lc <= 1024, r with room for Beff * N floats where N = xs_rows * H * Lc
+                               rounded up to 16 (the tables' N: w_qkvs / w_g2 hold zero rows behind xs_rows * H * Lc, b_qkvs /
+                               cs_qkvs / b_gs zeros); otherwise the step runs the separate launches */
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0
@@ -362,6 +380,31 @@ int acmi_layer_norm_rows(const float* x, const float* gamma, const float* beta, 
  * table[t, d/2:] = sin(t / f_i), f_i = freq[i] = max_period ** (i / (d/2 - 1)) supplied by the host
  * exactly as the reference computes it. */
 int acmi_pos_table(const float* freq, float* table, int T, int d, void* stream);
+
+/* The score-folded cross-attention block of one decode position as ONE launch (0.1.9; see acmi_lm_layer.w_qkvs and
+ * audiocraft_amd/modules/cross_fold.py): replaces cross-attention (transformer.py:344-361) + its output projection + the
+ * residual add (:563-566) once the raw scores of every conditioned row are in s_raw.  For row b < R:
+ *     mean, rstd  from the `stats_np` equal-count (mean, M2) partials of x1's row (stats [rows][stats_np][2], stats_np * stats_cnt = d)
+ *     s[hj]  = rstd * (s_raw[b * s_ld + b * HL + hj] - (mean - shift[b]) * cs[b][hj]) + bs[b][hj]          (shift NULL = 0)
+ *     p      = softmax over each group of Lc consecutive hj
+ *     x[b]  += p u[b] (+ bias);   rows R <= b < rows: x[b] += bias (launched only with a bias)
+ * and, like every producer of x in the step, the raw fragments of the new rows (xt: tiled activation in wdtype with xt_nkc K
+ * tiles per 16-row block, values x - xt_shift[b]; NULL = none) and the (mean, M2) partials of their 16-feature groups
+ * (stats_out [rows][d / 16][2]; NULL = none).  u: [R][d / FB][HL][FB] in wdtype, FB = features per workgroup (0 = 64 or the
+ * largest power-of-two divisor of d below it).  HL <= 1024, d % 16 == 0 with statistics partials. */
+typedef struct {
+    const float* s_raw; int s_ld;
+    const float* stats; int stats_np, stats_cnt;
+    const float* shift;
+    const float* cs; const float* bs;
+    const void* u; int wdtype;
+    float* x; const float* bias;
+    void* xt; int xt_nkc; const float* xt_shift;
+    float* stats_out;
+    int rows, R, HL, Lc, d, FB;
+    float eps;
+} acmi_cross_fold_desc;
+int acmi_cross_fold(const acmi_cross_fold_desc* desc, void* stream);
 
 /* Row standardisation ((x - mean) / sqrt(var + eps), two-pass statistics, no affine part) of a
  * row-major f32 matrix x [M, K] into a zero-initialised tiled activation in `wdtype`: the LayerNorm

@@ -42,3 +42,8 @@ if __name__ == '__main__':
     if 'batch' in which:
         for B in (1, 4, 8, 16, 32):
             run('facebook/musicgen-medium', B, 10)
+    if 'fold' in which:
+        # the score-folded cross-attention (ACMI_CROSS_FOLD, one process per setting) where its tables are SMALL: few conditioned rows
+        for name, B in (('facebook/musicgen-small', 1), ('facebook/musicgen-medium', 1), ('facebook/musicgen-medium', 2),
+                        ('facebook/musicgen-medium', 4), ('facebook/musicgen-large', 1), ('facebook/musicgen-large', 4)):
+            run(name, B, 10, use_sampling=name != 'facebook/musicgen-small', reps=2)

@@ -976,3 +976,60 @@ def test_ffn_engine_vs_launch_chain_and_f64(model, waves, rows):
     with pytest.raises(_C.AcmiError):
         _C.ffn_engine(el.engine_desc(L, be, 17, d, F, eps, flags[0], flags[1], err, 0, waves))
     assert not _C.ffn_engine_supported(16, 1536, 6144, torch.float32) and _C.ffn_engine_supported(16, 1536, 6144, torch.bfloat16)
+
+
+@pytest.mark.parametrize('rows,R,H,Lc,hd', [(16, 8, 24, 16, 64), (6, 3, 4, 5, 8), (16, 16, 8, 6, 32), (5, 5, 16, 33, 16), (12, 4, 8, 64, 64)])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('extras', [False, True])
+def test_cross_fold_vs_torch(C, rows, R, H, Lc, hd, dt, extras):
+    """acmi_cross_fold (the score-folded cross-attention block as one launch, modules/cross_fold.py): folded LayerNorm of the
+    raw scores from statistics PARTIALS and a row shift, softmax per head, p U, residual (+ bias); the new rows in place,
+    as raw fragments relative to the output shift and (extras) as 16-feature statistics partials; rows beyond R pass through."""
+    d, HL = H * hd, H * Lc
+    if dt == torch.float32 and d > 512:
+        pytest.skip("f32 tables of the wide case add nothing over the bf16 run")
+    g = torch.Generator().manual_seed(rows * 31 + R + Lc)
+    N = -(-R * HL // 16) * 16
+    x1 = torch.randn(rows, d, generator=g) * 1.5 + 0.7
+    s_raw = torch.randn(rows, N, generator=g) * 2.0
+    cs, bs = torch.randn(R, HL, generator=g), 0.3 * torch.randn(R, HL, generator=g)
+    U = (torch.randn(R, HL, d, generator=g) / math.sqrt(HL)).to(dt)
+    shift = x1.mean(1) + 0.05 * torch.randn(rows, generator=g)
+    osh = 0.5 * torch.randn(rows, generator=g)
+    bias = 0.1 * torch.randn(d, generator=g) if extras else None
+    xb = x1.view(rows, d // 16, 16) if d % 16 == 0 else None
+    if xb is None:     # statistics partials of another granularity: 8 elements
+        xb = x1.view(rows, d // 8, 8)
+    cnt = xb.shape[-1]
+    mb = xb.mean(-1)
+    stats = torch.stack([mb, ((xb - mb[..., None]) ** 2).sum(-1)], dim=-1).contiguous().cuda()
+    # reference
+    mean, rstd = x1.mean(1), (x1.var(1, unbiased=False) + 1e-5).rsqrt()
+    diag = torch.stack([s_raw[b, b * HL:(b + 1) * HL] for b in range(R)])
+    s = rstd[:R, None] * (diag - (mean - shift)[:R, None] * cs) + bs
+    p = torch.softmax(s.view(R, H, Lc), dim=-1).reshape(R, HL)
+    want = x1.clone()
+    want[:R] += torch.einsum('bn,bnk->bk', p, U.float())
+    if bias is not None:
+        want += bias
+    kt = 32 if dt == torch.bfloat16 else 16
+    nkc = -(-d // kt) + 3                       # a wider buffer than d: K tiles per row block is a parameter
+    xt = C.tiled_activation_buffer(rows, nkc * kt, dt, 'cuda')
+    x = x1.cuda().clone()
+    stats_out = torch.zeros(rows, d // 16, 2, device='cuda') if (extras and d % 16 == 0) else None
+    C.cross_fold(s_raw.cuda(), N, stats, xb.shape[1], cnt, cs.cuda(), bs.cuda(), C.cross_fold_u_layout(U.cuda(), dt), x, rows, R,
+                 HL, Lc, shift=shift.cuda(), bias=None if bias is None else bias.cuda(), xt=xt, xt_nkc=nkc, xt_shift=osh.cuda(),
+                 stats_out=stats_out)
+    got = x.cpu()
+    assert rel(got, want) < 2e-6, rel(got, want)
+    live = rows if (bias is not None or stats_out is not None) else R
+    if live < rows:
+        assert torch.equal(got[live:], x1[live:])
+    frag = C.untile_matrix(xt, rows, nkc * kt).float().cpu()
+    assert torch.equal(frag[:live, :d], (got[:live] - osh[:live, None]).to(dt).float())
+    assert frag[:, d:].abs().sum() == 0 and frag[live:].abs().sum() == 0
+    if stats_out is not None:
+        gb = got.view(rows, d // 16, 16)
+        m16 = gb.mean(-1)
+        assert torch.allclose(stats_out[..., 0].cpu(), m16, atol=2e-6)
+        assert torch.allclose(stats_out[..., 1].cpu(), ((gb - m16[..., None]) ** 2).sum(-1), rtol=1e-4, atol=1e-6)

@@ -328,6 +328,60 @@ def test_lm_midsize_vs_oracle(wdt, tol, B):
         assert torch.equal(toks.cpu(), ref_t)
 
 
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize('with_bias', [False, True])
+def test_score_folded_cross_attention_matches_the_separate_launches(wdt, tol, with_bias, monkeypatch):
+    """The decode step's cross-attention in its score-folded form (acmi_lm_state.xs_rows: scores out of the QKV / out-projection
+    launches, ONE launch for LayerNorm hook + softmax + p U + residual; modules/cross_fold.py) against the separate launches
+    (ACMI_CROSS_FOLD=0) and against the oracle: per-step CFG logits of a greedy generate with a prompt, tokens."""
+    from audiocraft_amd.models import builders
+    torch.manual_seed(3)
+    B = 3
+    cfg = dict(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, hidden_scale=4, cfg_coef=3.0, bias_attn=with_bias,
+               conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 64, 'length': 7}},
+               fuser={'cross': ['description']})
+    lm = builders.get_lm_model(cfg, 'cuda', wdt)
+    with torch.no_grad():
+        for k, p in lm.named_parameters():
+            if 'norm' in k:
+                p.add_(0.1 * torch.randn_like(p))
+            if k.endswith('out_proj.bias'):      # (biases on the k / v in-projection would make the null rows live: not folded)
+                p.add_(0.05 * torch.randn_like(p))
+            if k.endswith('in_proj_bias'):
+                p.zero_()
+                p[:256].add_(0.05 * torch.randn(256, device=p.device))
+    g = torch.Generator().manual_seed(8)
+    cross = torch.randn(2 * B, 7, 256, generator=g)
+    cross[B:] = 0
+    ct = {'description': (cross.cuda(), torch.ones(2 * B, 7, dtype=torch.int64).cuda())}
+    prompt = torch.randint(0, 2048, (B, 4, 5), generator=g).cuda()
+    kw = dict(max_gen_len=30, use_sampling=False, condition_tensors=ct, return_logits=True)
+    monkeypatch.setenv('ACMI_CROSS_FOLD', '1')       # opt-in: the separate launches are the default (DESIGN.md 5.9)
+    toks_f, lg_f = lm.generate(prompt, [], **kw)
+    assert lm._run.get('xs') is not None and lm._run['xs']['key'] == (B, 7), "the folded path did not run"
+    monkeypatch.setenv('ACMI_CROSS_FOLD', '0')
+    lm._run = None
+    toks_s, lg_s = lm.generate(prompt, [], **kw)
+    assert lm._run.get('xs') is None
+    # free-running greedy generates: once a token differs (a near tie under bf16 rounding) the streams are different problems,
+    # so the logits are compared up to and including the first step at which the two runs pick different tokens
+    # (gen_sequence steps: the delay pattern makes step t of codebook k token t - k; the per-step logits are what matters)
+    same = (lg_f.argmax(-1) == lg_s.argmax(-1)).all(dim=1).all(dim=0)          # [steps]
+    n_same = int(same.long().cumprod(0).sum())
+    upto = min(n_same + 1, lg_f.shape[2])
+    r = rel(lg_f[:, :, :upto].cpu(), lg_s[:, :, :upto].cpu())
+    assert r < tol, f"folded vs separate launches: per-step logits rel-L2 {r} over the first {upto} of {lg_f.shape[2]} steps"
+    # (bf16: two roundings of the same algebra part at the first near tie -- 3 steps in on the biased model; the logits gate above
+    # covers the step of the parting itself)
+    assert n_same >= (lg_f.shape[2] if wdt == torch.float32 else 2), f"the runs part after {n_same} steps"
+    if wdt == torch.float32:
+        assert torch.equal(toks_f, toks_s)
+        sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+        oc = olm.LMConfig(dim=256, num_heads=8, num_layers=4, n_q=4, card=2048, cross_attention=True)
+        ref_t = olm.generate(sd, oc, prompt.cpu(), B, cross, max_gen_len=30, use_sampling=False)
+        assert torch.equal(toks_f.cpu(), ref_t)
+
+
 def test_sampled_tokens_reproduced_by_philox_replay():
     """The headline configuration SAMPLES (top-k 250, temperature 1): token-level parity of that path.  The device's draw is
     a counter-based exponential race (sample_kernel: Philox4x32-10 on (vocabulary index, sample * K + codebook, stream position),

@@ -1003,3 +1003,34 @@ def test_fuser_first_call_inputs_is_the_reference_loop():
             else:
                 with pytest.raises(NotImplementedError):
                     fuser.fuse(ct)
+
+
+@pytest.mark.parametrize('wdt,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_cross_fold_tables_are_the_cross_attention_block(wdt, tol):
+    """modules/cross_fold.py: the per-generate tables G / G2 / U (+ CS, BS) reproduce norm_cross -> q projection -> scores ->
+    softmax -> values -> out projection of the reference's layer (transformer.py:344-361, 563-566), the query's LayerNorm
+    in its folded form on shifted rows, biases and a non-trivial LayerNorm affine included."""
+    from audiocraft_amd.modules import cross_fold
+    g = torch.Generator().manual_seed(12)
+    R, H, Lc, hd = 5, 4, 6, 16
+    d = H * hd
+    rn = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    wq, wo, wco = rn(d, d) / d ** 0.5, rn(d, d) / d ** 0.5, rn(d, d) / d ** 0.5
+    bq, bo, bco = 0.1 * rn(d), 0.1 * rn(d), 0.1 * rn(d)
+    gam, bet = 1 + 0.2 * rn(d), 0.2 * rn(d)
+    kc, vc = rn(R, H, Lc, hd), rn(R, H, Lc, hd)
+    x0, att = 2.0 * rn(R, d) + 1.5, rn(R, d)
+    x1 = x0 + att @ wo.T + bo
+    # the block, directly (f64)
+    q = torch.nn.functional.layer_norm(x1, (d,), gam, bet, 1e-5) @ wq.T + bq
+    s = torch.einsum('bhf,bhjf->bhj', q.view(R, H, hd), kc) * hd ** -0.5
+    o = torch.einsum('bhj,bhjf->bhf', torch.softmax(s, dim=-1), vc).reshape(R, d)
+    want = x1 + o @ wco.T + bco
+    # through the tables
+    f = lambda t: t.float()  # noqa: E731
+    t = cross_fold.fold_tables(f(kc), f(vc), f(wq * gam[None, :]), f(wq @ bet + bq), f(wo), f(bo), f(wco), wdt)
+    assert t['G'].dtype == wdt and t['G'].shape == (R, H * Lc, d) and t['CS'].shape == (R, H * Lc)
+    shift = f(x0.mean(dim=1))
+    got = cross_fold.folded_cross_block(t, f(x0) - shift[:, None], f(att), f(x1), shift, H, 1e-5, f(bco))
+    err = ((got.double() - want).norm() / want.norm()).item()
+    assert err < tol, err
