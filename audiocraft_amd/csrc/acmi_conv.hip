@@ -889,7 +889,7 @@ __global__ __launch_bounds__(LxCfg<HH>::THREADS, 1) void lstm_xcd_kernel(const f
     const size_t hx_bytes = (size_t)B * T * H * 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hx, 0, (int)hx_bytes, 0x00020000);
     // MEM 0: plain stores (write-through L1 -> the XCD's L2) and `nt` polling loads, which are served by the L2 every time
-    // (measured, profiles/r04_session33_lstm.log: an `sc0` load keeps returning the CU's stale L1 line; `buffer_inv sc1` before a plain
+    // (measured, profiles/archive/r04_session33_lstm.log: an `sc0` load keeps returning the CU's stale L1 line; `buffer_inv sc1` before a plain
     // load works at 29 us per step); MEM 1: write-through stores, agent-scope loads (memory side)
     constexpr int LD_AUX = MEM == 1 ? 16 : 2, ST_AUX = MEM == 1 ? 16 : 0;
 
@@ -1223,7 +1223,7 @@ extern "C" size_t acmi_lstm_work_floats(int B, int H) { return (size_t)5 * B * H
 
 // The recurrence kernels' work areas are armed by a KERNEL, not by hipMemset*Async: inside a replayed hipGraph a large memset
 // node was seen to take effect late (replay >= 1 of a captured 8 x 1024 x 200 layer found the previous replay's words,
-// profiles/r04_session36_lstm_graph.log); a kernel node is ordered like every other launch of the pass.
+// profiles/archive/r04_session36_lstm_graph.log); a kernel node is ordered like every other launch of the pass.
 __global__ __launch_bounds__(256) void lstm_fill_kernel(unsigned* a, size_t na, unsigned va, unsigned* b, size_t nb, unsigned vb) {
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
     for (size_t i = i0; i < na; i += step) a[i] = va;
@@ -1442,7 +1442,7 @@ extern "C" int acmi_lstm_stack2_supported(int B, int H, int T) {
     // 32 KB gathers per layer-1 step, each in two rounds (register budget of two workgroups per CU), do not pay
     if (want == 1 && H > 512) return 0;
     // two launches of the XCD-local form (2 T steps of 1.4 us at H = 512) beat the wavefront's T + 1 steps: EnCodec-24k geometry,
-    // 1 x 10 s: decode 4.58 -> 3.29 ms, encode 4.95 -> 3.63 ms (profiles/r04_session37_lstm.log)
+    // 1 x 10 s: decode 4.58 -> 3.29 ms, encode 4.95 -> 3.63 ms (profiles/archive/r04_session37_lstm.log)
     if (want == 1 && lstm_xcd_would_run(B, H, T)) return 0;
     return lstm_wave2_can(B, H, T, lstm_wave2_lds(H)) ? 1 : 0;
 }

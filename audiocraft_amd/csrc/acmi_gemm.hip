@@ -341,7 +341,7 @@ int launch_rowmajor(LinArgs& a, hipStream_t st) {
 //         activation fragment a -- a x ones (row sums) and a x a^T (Gram matrix: its diagonal holds the rows' sums of
 //         squares; the A and B operands of the 16x16 MFMA share one register layout, so `a` serves as both) -- give
 //         mean and variance of exactly the values the GEMM multiplies, and the consumer loads no partials at all.
-//         The in-kernel timeline (profiles/r04_lin_timeline*.csv) priced the partials: 16 dwordx2 requests per lane
+//         The in-kernel timeline (profiles/archive/r04_lin_timeline*.csv) priced the partials: 16 dwordx2 requests per lane
 //         (24 KB per workgroup, freshly written by the previous launch) through the same per-CU address pipe as the
 //         weight stream, plus Chan's combination in front of the barrier.  The fragments are bf16(x - shift) with the
 //         shift near the row mean, so the one-pass variance sum(a^2) / K - mean^2 does not cancel.

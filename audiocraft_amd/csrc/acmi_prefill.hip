@@ -62,7 +62,7 @@ __device__ __forceinline__ float big_gelu_bf16(float x) {
 // epilogue's, behind a vmcnt(0)).
 //
 // K loop (the second half of round 4; timelines by scripts/big_gemm_bench.py --trace with a -DACMI_BIG_TRACE build,
-// profiles/r04_session14 .. 22_prefill_gemm.log; cycles per K step of the 256 x 256 tile, ideal = 1024: the SIMD's 64
+// profiles/archive/r04_session14 .. 22_prefill_gemm.log; cycles per K step of the 256 x 256 tile, ideal = 1024: the SIMD's 64
 // MFMAs of 16 cycles):
 //   1735  every wave requests, then reads its 12 fragments from LDS, then multiplies: 96 KB of reads per CU at the top
 //         of the step starve the matrix pipes, the waves meet again at the barrier (no wait for memory at all: 24 cycles)
@@ -462,7 +462,7 @@ extern "C" int acmi_linear_big(const void* a, int a_rbs, const void* w, int wdty
 // k slot (kg, j = tt * 4 + r) means key t0 + tt * 16 + kg * 4 + r -- which is how the A operand is fetched from the
 // time-minor V: lane (kg, m = d) reads keys t0 + tt * 16 + kg * 4 .. + 3 of row d (8 bytes per tt in bf16).
 // What bounds it (round 4, rocprofv3 counters of the kernel alone at 16 rows x 24 heads x 600 positions,
-// profiles/r04_session25_prefill_attn.log): not the fragment loads -- halving them (two query blocks per wave) bought 9 % and
+// profiles/archive/r04_session25_prefill_attn.log): not the fragment loads -- halving them (two query blocks per wave) bought 9 % and
 // prefetching the next key block nothing -- but the vector ALU: 360 VALU instructions per key block and query block (8
 // libm expf, a hand-rolled bf16 rounding per probability, 64-bit address arithmetic per load, the 16 multiplies of the
 // running output by alpha) against 8 MFMAs, the VALU 60 % busy.  Hence: scores kept in log2 units (scale * log2 e folded

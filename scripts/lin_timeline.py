@@ -1,10 +1,10 @@
-"""In-kernel timeline of the decode step's GEMM launches (dev tool; writes profiles/r04_lin_timeline*.csv).
+"""In-kernel timeline of the decode step's GEMM launches (dev tool; writes profiles/archive/r04_lin_timeline*.csv).
 
 Needs the trace build of the library (every wave of lin_tiled_kernel / lin_pair_kernel stamps s_memrealtime at nine
 phases, acmi_lm_internal.h):
 
     python -c "from audiocraft_amd import build as b; b.build(out=b.OUT.replace('libacmi.so', 'libacmi_trace.so'), defines=['ACMI_TRACE'])"
-    ACMI_LIB=audiocraft_amd/csrc/libacmi_trace.so python scripts/lin_timeline.py --out profiles/r04_lin_timeline.csv
+    ACMI_LIB=audiocraft_amd/csrc/libacmi_trace.so python scripts/lin_timeline.py --out profiles/archive/r04_lin_timeline.csv
 
 One generate of the headline workload (MusicGen-medium, bf16, 8 prompts, CFG rows 16, top-k 250) is run for --frames
 positions; the hipGraph of one position is captured right after the trace buffer is armed, so every GEMM launch of the graph
@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--frames', type=int, default=300)
     ap.add_argument('--clock-mhz', type=float, default=100.0, help='s_memrealtime rate (hipDeviceAttributeWallClockRate)')
-    ap.add_argument('--out', default='profiles/r04_lin_timeline.csv')
+    ap.add_argument('--out', default='profiles/archive/r04_lin_timeline.csv')
     ap.add_argument('--raw', default='', help='also dump the raw stamps (npz)')
     args = ap.parse_args()
     if not hasattr(_C.lib, 'acmi_trace_config'):
