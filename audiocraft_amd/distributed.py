@@ -125,7 +125,7 @@ def broadcast_condition_tensors(ct: tp.Optional[ConditionTensors], device, src: 
     """Broadcast {name: (emb [rows, L, d] f32, mask [rows, L] int64)} from `src`; other ranks pass None.
     TWO collectives whatever the number of conditions: a fixed-layout int64 header (names, shapes) and one f32 payload
     (embeddings and masks back to back) -- no pickling (`broadcast_object_list`) on the path."""
-    if world_size() == 1:
+    if not dist.is_initialized():      # (a process group of ONE rank still runs its collectives: the 1-GPU RCCL test)
         assert ct is not None
         return ct
     if rank() == src:
@@ -173,7 +173,7 @@ def shard_condition_tensors(ct: ConditionTensors, B_global: int, rk: int, world:
 def gather_rows(local: torch.Tensor, B_global: int) -> torch.Tensor:
     """All-gather per-prompt rows [B_local, ...] -> [B_global, ...] in prompt order (uneven shards padded)."""
     world = world_size()
-    if world == 1:
+    if not dist.is_initialized():
         return local
     rk = rank()
     max_rows = -(-B_global // world)

@@ -230,3 +230,64 @@ def test_bench_configs3_flags_two_processes_sampled(tmp_path):
     assert tok2.shape == tok1.shape == (4, 4, 20)
     assert torch.equal(tok2[:2], tok1[:2]), "rank 0's shard (seed, rank fixed) must reproduce the unsharded rows"
     assert not torch.equal(tok2[2:], tok1[2:]), "rank 1 samples with its own seed"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RCCL itself on the 1-GPU box: a process group of ONE rank on the 'nccl' backend.  It cannot show scaling, but it executes
+# every torch.distributed call of the sharded path against the real RCCL library with the real tensors -- the group
+# creation with `device_id`, the int64 header and f32 payload broadcasts, the int64 token and f32 waveform all-gathers, the
+# barrier and the float64 MAX all-reduce of bench.py's clock -- so a dtype / device / argument RCCL rejects fails HERE and
+# not on the first 8-GPU run.  (gloo accepts host tensors and dtypes RCCL does not; the CPU tests cannot see that.)
+# ----------------------------------------------------------------------------------------------------------------------
+_RCCL_ONE_RANK = r'''
+import os, sys, time, torch
+import torch.distributed as dist
+os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1])
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+from audiocraft_amd import distributed as adist
+from audiocraft_amd.models.musicgen import MusicGen
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))   # as init_from_env does for N > 1
+assert dist.get_backend() == 'nccl' and adist.world_size() == 1
+calls = []
+for name in ('broadcast', 'all_gather', 'barrier', 'all_reduce'):
+    def wrap(fn, name=name):
+        def f(*a, **k):
+            t = a[1] if name == 'all_gather' else (a[0] if a else None)
+            calls.append((name, None if t is None else (str(t.dtype), t.device.type, tuple(t.shape))))
+            return fn(*a, **k)
+        return f
+    setattr(dist, name, wrap(getattr(dist, name)))
+torch.manual_seed(0)
+model = MusicGen.get_pretrained('debug', 'cuda')
+B, T = 3, 20
+desc = [f'prompt {i}' * (1 + i % 3) for i in range(B)]
+tok, wav = adist.generate_sharded(model, desc, B, T, decode=True, gather_audio=True, generation_params={'use_sampling': False})
+dist.barrier(); torch.cuda.synchronize()
+t = torch.tensor([1.25], device='cuda', dtype=torch.float64)            # bench.py's max-over-ranks clock
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.25
+dist.barrier()
+dist.destroy_process_group()
+assert not dist.is_initialized()
+tok0, wav0 = adist.generate_sharded(model, desc, B, T, decode=True, gather_audio=True, generation_params={'use_sampling': False})
+assert torch.equal(tok, tok0) and torch.equal(wav, wav0), "through RCCL != without a group"
+kinds = [c[0] for c in calls]
+assert kinds.count('broadcast') == 2 and kinds.count('all_gather') == 2, kinds
+assert all(c[1] is None or c[1][1] == 'cuda' for c in calls), calls       # RCCL only ever saw device tensors
+print('RCCL_ONE_RANK_OK', calls, flush=True)
+'''
+
+
+def test_rccl_single_rank_group_runs_every_collective_of_the_sharded_path(tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'rccl_one_rank.py'
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'ACMI_DIST_BACKEND', 'ACMI_ALLOW_SHARED_DEVICE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script), str(_free_port())], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_ONE_RANK_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    print(r.stdout.strip().splitlines()[-1])
