@@ -288,7 +288,7 @@ def in_situ_kernel_stats(model_name: str, batch: int, timeout_s: int = 240):
                 n = row['Name']
                 key = ('gemm' if ('lin_tiled_kernel' in n or 'lin_pair_kernel' in n) else
                        'self_attn' if 'attn_decode_kernel' in n and ', false>' in n else
-                       'cross_attn' if 'attn_decode_kernel' in n and ', true>' in n else None)
+                       'cross_attn' if ('cross_q_kernel' in n or ('attn_decode_kernel' in n and ', true>' in n)) else None)
                 if key is None:
                     continue
                 c, tot = fam.get(key, (0, 0.0))
