@@ -354,6 +354,25 @@ def pmc_traffic_live(timeout_s: int = 150):
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
+def attn_traffic_committed(context: int):
+    """HBM bytes per self-attention launch from the COMMITTED PMC passes (profiles/r05_attn_pmc_t751.txt: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate passes, over scripts/attn_bench.py --contexts 751 at the configs[2] geometry; same
+    gfx950 arithmetic as pmc_traffic_per_launch) -- not measured live; None for another context."""
+    path = os.path.join(ROOT, 'profiles', 'r05_attn_pmc_t751.txt')
+    try:
+        vals = {}
+        for line in open(path):
+            if 'attn_decode_kernel' in line:
+                f = line.strip().split(',')
+                vals[f[-3]] = float(f[-2])
+        if context != 751 or 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
+            return {"traffic": None, "traffic_source": f"the committed PMC passes are of context 751 (this run: {context})"}
+        return {"traffic": int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024),
+                "traffic_source": "committed passes (round 5, profiles/r05_attn_pmc_t751.txt): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/attn_bench.py --contexts 751"}
+    except OSError:
+        return {"traffic": None, "traffic_source": "profiles/r05_attn_pmc_t751.txt not found"}
+
+
 def cpu_baseline(model, B: int, duration: float, Lc: int, top_k: int, early_steps: int = 16, late_steps: int = 14,
                  late_context: int = 1400):
     """The reference's CPU path on the host cores, on a bounded sample of the same workload, as SURVEY.md section 8(d)
@@ -636,6 +655,7 @@ def main():
                                     "bytes_per_launch": int(ra['bytes_per_launch']), "avg_launch_us": round(ra['avg_us'], 3),
                                     "context": ra['context'], "launches": ra['launches'],
                                     "note": "one launch per layer at the mean context of the generate, every layer's own (cold) cache"}
+            out["roofline_attn"].update(attn_traffic_committed(ra['context']))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, B, args.duration, args.text_len, args.top_k)
         print(json.dumps(out), flush=True)

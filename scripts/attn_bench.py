@@ -19,6 +19,7 @@ ap.add_argument('--rows', type=int, default=16)
 ap.add_argument('--heads', type=int, default=24)
 ap.add_argument('--layers', type=int, default=48)
 ap.add_argument('--tcap', type=int, default=1504)
+ap.add_argument('--contexts', default='1,32,64,128,256,512,750,1024,1500', help='comma-separated context lengths')
 args = ap.parse_args()
 B, H, hd, L, Tcap = args.rows, args.heads, 64, args.layers, args.tcap
 k = torch.randn(L, B, H, Tcap, hd, device='cuda').bfloat16()
@@ -26,7 +27,7 @@ v = torch.randn(L, B, H, Tcap, hd, device='cuda').bfloat16()
 q = torch.randn(B, H * hd, device='cuda')
 out = _C.tiled_activation_buffer(B, H * hd, torch.bfloat16, 'cuda')
 res = {}
-for t in (1, 32, 64, 128, 256, 512, 750, 1024, 1500):
+for t in [int(c) for c in args.contexts.split(',')]:
     def launch_all():
         for li in range(L):
             _C.attn_decode(q, k[li], v[li], out, t, out_tiled=True)
