@@ -249,6 +249,7 @@ from audiocraft_amd.models.musicgen import MusicGen
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))   # as init_from_env does for N > 1
 assert dist.get_backend() == 'nccl' and adist.world_size() == 1
+print('RCCL_GROUP_UP', flush=True)
 calls = []
 for name in ('broadcast', 'all_gather', 'barrier', 'all_reduce'):
     def wrap(fn, name=name):
@@ -289,5 +290,7 @@ def test_rccl_single_rank_group_runs_every_collective_of_the_sharded_path(tmp_pa
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'ACMI_DIST_BACKEND', 'ACMI_ALLOW_SHARED_DEVICE'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(script), str(_free_port())], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    if 'RCCL_GROUP_UP' not in r.stdout:      # the box could not create the communicator at all: environment, not this package
+        pytest.skip("RCCL could not create a one-rank group here: " + r.stderr[-400:])
     assert r.returncode == 0 and 'RCCL_ONE_RANK_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     print(r.stdout.strip().splitlines()[-1])
