@@ -60,57 +60,107 @@ def loudness(wav: torch.Tensor, sample_rate: int) -> float:
     return float(-0.691 + 10 * np.log10(np.sum(g[:, 0] * e)))
 
 
-def normalize_loudness(wav: torch.Tensor, sample_rate: int, loudness_headroom_db: float = 14,
-                       loudness_compressor: bool = False, energy_floor: float = 2e-3) -> torch.Tensor:
-    """reference audio_utils.py:62-88"""
-    energy = wav.pow(2).mean().sqrt().item()
-    if energy < energy_floor:
-        return wav
-    input_loudness_db = loudness(wav, sample_rate)
-    gain = 10.0 ** ((-loudness_headroom_db - input_loudness_db) / 20.0)
-    output = gain * wav
-    if loudness_compressor:
-        output = torch.tanh(output)
-    assert output.isfinite().all(), (input_loudness_db, energy)
-    return output
+class _Gain(tp.NamedTuple):
+    """What a normalisation strategy decides for one clip: ONE multiplier, ONE symmetric ceiling, applied in one pass."""
+    gain: tp.Optional[float] = None      # None: samples are not scaled
+    ceiling: tp.Optional[float] = None   # None: samples are not clamped
+    soft: bool = False                   # tanh between the gain and the ceiling ('loudness' with its compressor)
+    report: bool = False                 # overshoot beyond the ceiling is reported on stderr when asked for
+
+
+def _db_to_amplitude(db: float) -> float:
+    return 10.0 ** (db / 20.0)
+
+
+def _root_mean_square(x: torch.Tensor) -> float:
+    return math.sqrt(x.double().square().mean().item())
+
+
+def _loudness_gain(wav: torch.Tensor, sample_rate: int, headroom_db: float, energy_floor: float) -> tp.Optional[float]:
+    """Multiplier that brings `wav` to -headroom_db LKFS; None for a clip too quiet to measure (left as it is)."""
+    if _root_mean_square(wav) < energy_floor:
+        return None
+    return _db_to_amplitude(-headroom_db - loudness(wav, sample_rate))
+
+
+def _plan_peak(wav, o) -> _Gain:
+    g = _db_to_amplitude(-o['peak_clip_headroom_db']) / wav.abs().max().item()
+    return _Gain(gain=g if (o['normalize'] or g < 1) else None)
+
+
+def _plan_clip(wav, o) -> _Gain:
+    return _Gain(ceiling=_db_to_amplitude(-o['peak_clip_headroom_db']))
+
+
+def _plan_rms(wav, o) -> _Gain:
+    g = _db_to_amplitude(-o['rms_headroom_db']) / _root_mean_square(wav.mean(dim=0))   # level of the mono downmix
+    return _Gain(gain=g if (o['normalize'] or g < 1) else None, ceiling=1.0, report=True)
+
+
+def _plan_loudness(wav, o) -> _Gain:
+    if o['sample_rate'] is None:
+        raise AssertionError("Loudness normalization requires sample rate.")
+    g = _loudness_gain(wav, o['sample_rate'], o['loudness_headroom_db'], energy_floor=2e-3)
+    return _Gain(gain=g, ceiling=1.0, soft=o['loudness_compressor'] and g is not None, report=True)
+
+
+def _plan_none(wav, o) -> _Gain:
+    if not wav.abs().max().item() < 1:
+        raise AssertionError("un-normalised audio must stay inside (-1, 1)")
+    return _Gain()
+
+
+_PLANS: tp.Dict[str, tp.Callable[[torch.Tensor, dict], _Gain]] = {
+    'peak': _plan_peak, 'clip': _plan_clip, 'rms': _plan_rms, 'loudness': _plan_loudness, '': _plan_none, 'none': _plan_none}
+
+
+def _apply_gain(wav: torch.Tensor, plan: _Gain, log_clipping: bool, stem_name: tp.Optional[str]) -> torch.Tensor:
+    out = wav if plan.gain is None else wav * plan.gain
+    if plan.soft:
+        out = torch.tanh(out)
+    if plan.ceiling is None:
+        return out
+    if plan.report and log_clipping:
+        over = out.abs() > plan.ceiling
+        if bool(over.any()):
+            print(f"[normalize_audio] {stem_name or 'clip'}: {over.float().mean().item():.4%} of the samples exceed full scale "
+                  f"(largest {out.abs().max().item():.4f}); they are clamped", file=sys.stderr)
+    return out.clamp(-plan.ceiling, plan.ceiling)
 
 
 def _clip_wav(wav: torch.Tensor, log_clipping: bool = False, stem_name: tp.Optional[str] = None) -> None:
-    max_scale = wav.abs().max()
-    if log_clipping and max_scale > 1:
-        clamp_prob = (wav.abs() > 1).float().mean().item()
-        print(f"CLIPPING {stem_name or ''} happening with proba (a bit of clipping is okay):", clamp_prob,
-              "maximum scale: ", max_scale.item(), file=sys.stderr)
-    wav.clamp_(-1, 1)
+    """In-place clamp to full scale (the reference's helper of this name, audio_utils.py:91-101, imported by its tests)."""
+    wav.copy_(_apply_gain(wav, _Gain(ceiling=1.0, report=True), log_clipping, stem_name))
+
+
+def normalize_loudness(wav: torch.Tensor, sample_rate: int, loudness_headroom_db: float = 14,
+                       loudness_compressor: bool = False, energy_floor: float = 2e-3) -> torch.Tensor:
+    """`wav` scaled to -loudness_headroom_db LKFS (BS.1770-4), optionally soft-limited by tanh; a clip whose RMS is below
+    `energy_floor` is returned unchanged.  Behaviour of reference audio_utils.py:62-88 (no clamp at this level)."""
+    g = _loudness_gain(wav, sample_rate, loudness_headroom_db, energy_floor)
+    out = _apply_gain(wav, _Gain(gain=g, soft=loudness_compressor and g is not None), False, None)
+    if not bool(out.isfinite().all()):
+        raise AssertionError(f"loudness normalisation produced non-finite samples (gain {g})")
+    return out
 
 
 def normalize_audio(wav: torch.Tensor, normalize: bool = True, strategy: str = 'peak', peak_clip_headroom_db: float = 1,
                     rms_headroom_db: float = 18, loudness_headroom_db: float = 14, loudness_compressor: bool = False,
                     log_clipping: bool = False, sample_rate: tp.Optional[int] = None,
                     stem_name: tp.Optional[str] = None) -> torch.Tensor:
-    """reference audio_utils.py:104-152: 'peak' | 'clip' | 'rms' | 'loudness' | '' / 'none'."""
-    scale_peak = 10 ** (-peak_clip_headroom_db / 20)
-    scale_rms = 10 ** (-rms_headroom_db / 20)
-    if strategy == 'peak':
-        rescaling = (scale_peak / wav.abs().max())
-        if normalize or rescaling < 1:
-            wav = wav * rescaling
-    elif strategy == 'clip':
-        wav = wav.clamp(-scale_peak, scale_peak)
-    elif strategy == 'rms':
-        mono = wav.mean(dim=0)
-        rescaling = scale_rms / mono.pow(2).mean().sqrt()
-        if normalize or rescaling < 1:
-            wav = wav * rescaling
-        _clip_wav(wav, log_clipping=log_clipping, stem_name=stem_name)
-    elif strategy == 'loudness':
-        assert sample_rate is not None, "Loudness normalization requires sample rate."
-        wav = normalize_loudness(wav, sample_rate, loudness_headroom_db, loudness_compressor)
-        _clip_wav(wav, log_clipping=log_clipping, stem_name=stem_name)
-    else:
-        assert wav.abs().max() < 1
-        assert strategy == '' or strategy == 'none', f"Unexpected strategy: '{strategy}'"
-    return wav
+    """Level control in front of the file writer; same strategies and results as reference audio_utils.py:104-152:
+    'peak' (largest sample to -peak_clip_headroom_db dBFS), 'clip' (clamp at that level), 'rms' (mono RMS to -rms_headroom_db,
+    then clamp to full scale), 'loudness' (BS.1770 loudness to -loudness_headroom_db LKFS, then clamp), '' / 'none' (must
+    already fit).  With normalize=False a gain is only applied when it attenuates.  Each strategy reduces to one `_Gain`."""
+    if strategy not in _PLANS:
+        raise AssertionError(f"Unexpected strategy: '{strategy}'")
+    opts = dict(normalize=normalize, peak_clip_headroom_db=peak_clip_headroom_db, rms_headroom_db=rms_headroom_db,
+                loudness_headroom_db=loudness_headroom_db, loudness_compressor=loudness_compressor, sample_rate=sample_rate)
+    plan = _PLANS[strategy](wav, opts)
+    out = _apply_gain(wav, plan, log_clipping, stem_name)
+    if strategy == 'loudness' and not bool(out.isfinite().all()):
+        raise AssertionError(f"loudness normalisation produced non-finite samples (gain {plan.gain})")
+    return out
 
 
 def f32_pcm(wav: torch.Tensor) -> torch.Tensor:

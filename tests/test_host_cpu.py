@@ -842,6 +842,46 @@ def test_audio_write_and_normalisation(tmp_path):
         audio_write(tmp_path / 'x', torch.zeros(1, 1, 10), sr)
 
 
+def test_normalize_audio_vs_reference_golden(capsys):
+    """normalize_audio / i16_pcm / f32_pcm against arrays recorded from the unmodified reference
+    (tests/golden/make_audio_norm_golden.py; reference data/audio_utils.py:104-192): every strategy that needs no third-party
+    meter, normalize on and off, two headroom settings, a quiet, a hot and a two-channel clip."""
+    import numpy as np
+    from audiocraft_amd.data_audio import f32_pcm, i16_pcm, normalize_audio
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'audio_norm.npz'))
+    n = 0
+    for key in z.files:
+        if key.count('|') != 4:
+            continue
+        name, strategy, normalize, hp, hr = key.split('|')
+        wav = torch.tensor(z[f'in_{name}'])
+        keep = wav.clone()
+        y = normalize_audio(wav, normalize=bool(int(normalize)), strategy=strategy, peak_clip_headroom_db=float(hp),
+                            rms_headroom_db=float(hr))
+        np.testing.assert_allclose(y.numpy(), z[key], rtol=2e-6, atol=1e-7, err_msg=key)
+        assert torch.equal(wav, keep), f"{key}: the input was modified"
+        n += 1
+    assert n == 36
+    np.testing.assert_array_equal(normalize_audio(torch.tensor(z['in_none']), strategy='none').numpy(), z['none'])
+    with pytest.raises(AssertionError):
+        normalize_audio(torch.tensor(z['in_hot']), strategy='none')
+    with pytest.raises(AssertionError):
+        normalize_audio(torch.tensor(z['in_quiet']), strategy='loud')
+    with pytest.raises(AssertionError):
+        normalize_audio(torch.tensor(z['in_quiet']), strategy='loudness')      # needs the sample rate
+    # the overshoot report (stderr) appears only when asked for and only when something is clamped
+    capsys.readouterr()
+    normalize_audio(torch.tensor(z['in_hot']), strategy='rms', rms_headroom_db=3.0, log_clipping=True, stem_name='take7')
+    assert 'take7' in capsys.readouterr().err
+    normalize_audio(torch.tensor(z['in_hot']), strategy='rms', rms_headroom_db=3.0)
+    normalize_audio(torch.tensor(z['in_quiet']), strategy='rms', rms_headroom_db=30.0, log_clipping=True)
+    assert capsys.readouterr().err == ''
+    pcm = torch.tensor(z['pcm_in'])
+    np.testing.assert_array_equal(i16_pcm(pcm).numpy(), z['pcm_i16'])
+    np.testing.assert_array_equal(i16_pcm(pcm[:, :4]).numpy(), z['pcm_i16_noplus'])
+    np.testing.assert_array_equal(f32_pcm(torch.tensor([[0, 16384, -32768, 32767]], dtype=torch.int16)).numpy(), z['pcm_f32_from_i16'])
+
+
 def test_bench_cpu_baseline_imports_without_the_reference_tree():
     """bench.py's cpu_baseline leg imports oracle.ref_baseline on every box; where /root/reference does not exist (the GPU
     box) that import must succeed and report `available() == False` (kind "port"), not raise."""
