@@ -23,6 +23,30 @@ class AcmiError(RuntimeError):
     pass
 
 
+# ---- one device-side call sequence at a time per process ------------------------------------------------------------------
+# The generation path mutates per-model run state (KV caches, the device-side position counter, sampler state) and captures
+# hipGraphs in the runtime's GLOBAL capture mode, in which another host thread's synchronisation or allocation during the
+# capture window is an error for BOTH threads.  The reference is "not re-entrant" (lm.py:536-566) and its demo serves one
+# request at a time through a queue (demos/musicgen_app.py:384); here the same contract is enforced instead of assumed: every
+# public entry that touches the device (LMModel.generate / forward / streaming steps, EncodecModel.encode / decode,
+# MultiBandDiffusion) runs under this re-entrant lock, so a second host thread SERIALISES behind the first -- whatever
+# model it uses: the capture mode is process-wide -- and results are what each thread computes alone
+# (tests/test_gpu_models.py::test_two_host_threads_generate_serialised).  Throughput across requests comes from batching and
+# from one process per GPU (bench.py --gpus N), not from threads.
+device_lock = threading.RLock()
+
+
+def exclusive(fn):
+    """Decorator: run `fn` holding the process-wide device lock (re-entrant: entries may nest)."""
+    import functools
+
+    @functools.wraps(fn)
+    def locked(*args, **kwargs):
+        with device_lock:
+            return fn(*args, **kwargs)
+    return locked
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: the MI355X kernel library has not been built. "

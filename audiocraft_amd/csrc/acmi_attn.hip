@@ -375,8 +375,8 @@ static int launch_cross_q(const AttnArgs& a, int rows, hipStream_t st) {
 
 template <typename KT>
 static int launch_attn_t(const AttnArgs& a, int Beff, int hd, hipStream_t st) {
-    static int attn_nw = -1;
-    if (attn_nw < 0) { const char* e = getenv("ACMI_ATTN_NW"); attn_nw = e ? atoi(e) : 4; if (attn_nw != 1 && attn_nw != 2) attn_nw = 4; }
+    // (function-local statics with an initialiser are set once, thread safe: no check-then-write on a plain static)
+    static const int attn_nw = [] { const char* e = getenv("ACMI_ATTN_NW"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
     // waves per (row, head): 4 by default; a host-known short length (cross-attention) needs no more waves than
     // it has 64-position chunks (bf16 cache, hd 64) -- idle waves still cost dispatch time
     int nwv = attn_nw;

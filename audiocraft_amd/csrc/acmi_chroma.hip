@@ -130,14 +130,11 @@ extern "C" int acmi_chroma(const float* wav, int B, int T, int wav_stride, int r
     a.inv_wsum2 = 1.0f / (0.375f * (float)N);
     a.n_frames = 1 + a.Tv / (N >> 2); a.out = out; a.raw = raw_out; a.argmax = argmax;
     const size_t lds = (size_t)M * sizeof(float2) + 16 * ACMI_CHROMA_MAXC * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&chroma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess) {
-            acmi_set_error("acmi_chroma: cannot raise the dynamic LDS limit");
-            return ACMI_ELAUNCH;
-        }
-        attr_set = true;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&chroma_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;   // once, thread safe
+    if (!attr_ok) {
+        acmi_set_error("acmi_chroma: cannot raise the dynamic LDS limit");
+        return ACMI_ELAUNCH;
     }
     const int threads = M >= 2048 ? 1024 : (M >= 512 ? 256 : 64);
     hipLaunchKernelGGL(chroma_kernel, dim3(a.n_frames, B), dim3(threads), lds, (hipStream_t)stream, a);

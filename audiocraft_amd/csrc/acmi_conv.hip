@@ -1263,8 +1263,7 @@ static bool lstm_grid_resident(KernelT kernel, int grid, size_t lds_bytes, int t
 }
 
 static int lstm_persistent_ok(int B, int H) {
-    static int want = -1;
-    if (want < 0) { const char* e = getenv("ACMI_LSTM_PERSISTENT"); want = (e && e[0] == '0') ? 0 : 1; }
+    static const int want = [] { const char* e = getenv("ACMI_LSTM_PERSISTENT"); return (e && e[0] == '0') ? 0 : 1; }();
     return want && H <= 1024 && H % 4 == 0 && B >= 1;
 }
 
@@ -1296,13 +1295,10 @@ static int lstm_launch_xcd(int mode, const float* gates_in, const float* w_hh, c
                            unsigned* xcc_of_group, unsigned* err, int B, int T, hipStream_t st, bool* launched) {
     constexpr size_t lds = LxCfg<HH>::LDS;
     const int grid = 8 * 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<HH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ACMI_OK;   // the other forms remain
-        attr_set = true;
-    }
+    static const bool attr_ok =   // once per instantiation, thread safe
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<HH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_xcd_kernel<HH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!attr_ok) return ACMI_OK;   // the other forms remain
     if (!lstm_grid_resident(lstm_xcd_kernel<HH, 0>, grid, lds, LxCfg<HH>::THREADS)) return ACMI_OK;
     {
         const size_t n4 = (size_t)B * T * HH / 4;   // (hx is 16-byte aligned: 5 B H + 16 words into a 256-byte aligned area, H % 4 == 0)
@@ -1432,8 +1428,8 @@ static bool lstm_wave2_can(int B, int H, int T, size_t lds) {
 
 // ... and should it (the advice acmi_lstm_stack2_supported gives the host)
 extern "C" int acmi_lstm_stack2_supported(int B, int H, int T) {
-    static int want = -1;   // ACMI_LSTM_WAVE: 0 never, 1 (default) where it was measured to win (H <= 512), 2 wherever it can run
-    if (want < 0) { const char* e = getenv("ACMI_LSTM_WAVE"); want = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1; }
+    // ACMI_LSTM_WAVE: 0 never, 1 (default) where it was measured to win (H <= 512), 2 wherever it can run
+    static const int want = [] { const char* e = getenv("ACMI_LSTM_WAVE"); return e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1; }();
     if (!want || B <= 0 || H <= 0) return 0;
     // more than LSTM_BB rows: one launch per layer with the passes spread over copies of the grid wins (16 x 10 s, H = 512:
     // encode 17.7 vs 22.5 ms)

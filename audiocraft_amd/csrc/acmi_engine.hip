@@ -414,14 +414,11 @@ template <int NW, int KF, int RF, int C2, bool SC1>
 static int eng_launch_k(const EngArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)NW * RF * 1024 + (size_t)NW * 4096 + 1024 + 64;
     static_assert(lds <= 160 * 1024, "engine LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_engine_kernel<NW, KF, RF, C2, SC1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            acmi_set_error("acmi_ffn_engine: cannot raise the dynamic LDS limit");
-            return ACMI_ELAUNCH;
-        }
-        attr_set = true;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_engine_kernel<NW, KF, RF, C2, SC1>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;   // once, thread safe
+    if (!attr_ok) {
+        acmi_set_error("acmi_ffn_engine: cannot raise the dynamic LDS limit");
+        return ACMI_ELAUNCH;
     }
     hipLaunchKernelGGL((ffn_engine_kernel<NW, KF, RF, C2, SC1>), dim3(a.nwg), dim3((NW + 1) * 64), lds, st, a);
     return acmi_check_launch("ffn_engine_kernel");

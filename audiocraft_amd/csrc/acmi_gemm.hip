@@ -312,14 +312,11 @@ int launch_rowmajor(LinArgs& a, hipStream_t st) {
     if (nw < 4) nw = 4;
     a.RS = a.NKC * KT * (int)sizeof(WT) + 16;
     const size_t lds = (size_t)nw * 1024 + (size_t)16 * a.RS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_rowmajor_kernel<WT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-            acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
-            return ACMI_ELAUNCH;
-        }
-        attr_set = true;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_rowmajor_kernel<WT>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;   // once, thread safe
+    if (!attr_ok) {
+        acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
+        return ACMI_ELAUNCH;
     }
     hipLaunchKernelGGL((lin_rowmajor_kernel<WT>), dim3((a.N + 15) / 16), dim3(nw * 64), lds, st, a);
     return acmi_check_launch("lin_rowmajor_kernel");
@@ -1015,14 +1012,11 @@ static int tiled_epi(const LinArgs& a) {
 template <typename WT, int MT, int LN, int NT, int NS, bool HT>
 static int launch_tiled_k(LinArgs& a, int gx, int nw, size_t lds, hipStream_t st) {
     if (lds > 64 * 1024) {  // 2 n-tiles x 4 row blocks x 8 waves: just above the default dynamic LDS limit
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
-                return ACMI_ELAUNCH;
-            }
-            attr_set = true;
+        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_tiled_kernel<WT, MT, LN, NT, NS, HT>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;   // once, thread safe
+        if (!attr_ok) {
+            acmi_set_error("acmi_linear: cannot raise the dynamic LDS limit");
+            return ACMI_ELAUNCH;
         }
     }
     if (a.r_ld <= 0) a.r_ld = a.d;

@@ -419,11 +419,7 @@ __global__ void advance_kernel(int* pos, int n) { if (threadIdx.x == 0 && blockI
 enum { LN_TILE = 0, LN_FOLD = 2 };
 enum { LN_X = 100 };  // step_lin: the activation is LayerNorm(x)
 static int ln_mode_of(const acmi_lm_model* m, const acmi_lm_state* s) {
-    static int want = -1;
-    if (want < 0) {
-        const char* e = getenv("ACMI_LN_MODE");
-        want = (e && e[0] == 't') ? LN_TILE : LN_FOLD;
-    }
+    static const int want = [] { const char* e = getenv("ACMI_LN_MODE"); return (e && e[0] == 't') ? (int)LN_TILE : (int)LN_FOLD; }();
     if (want == LN_FOLD) {
         const bool have = m->cs_head != nullptr && m->layers[0].cs_qkv != nullptr && m->layers[0].cs_ff1 != nullptr &&
                           (m->wdtype != ACMI_BF16 || s->xlo != nullptr || s->xshift != nullptr) && m->dim / 16 <= 128 &&
@@ -435,8 +431,7 @@ static int ln_mode_of(const acmi_lm_model* m, const acmi_lm_state* s) {
 // bf16 weights: the raw x fragments are single-term with a per-row shift when the state carries `xshift` (default), the
 // hi / lo pair of 0.1.2 otherwise or with ACMI_LN_LO=1 (A/B switch); ACMI_LN_LO=0 without xshift = hi only, unshifted.
 static int fold_lo_env() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("ACMI_LN_LO"); v = e == nullptr ? -1 : (e[0] == '0' ? 0 : 1); }
+    static const int v = [] { const char* e = getenv("ACMI_LN_LO"); return e == nullptr ? -1 : (e[0] == '0' ? 0 : 1); }();
     return v;
 }
 

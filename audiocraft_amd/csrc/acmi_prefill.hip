@@ -369,14 +369,11 @@ __global__ __launch_bounds__(BigTile<BIG>::NW * 64, BIG ? 1 : 2) void lin_big_ke
 template <typename WT, int E, int BIG>
 static int launch_big_k(const BigArgs& a, int tiles, hipStream_t st) {
     constexpr size_t lds = 4 * BigTile<BIG>::SLOT * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E, BIG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            acmi_set_error("acmi_linear_big: cannot set the dynamic LDS limit");
-            return ACMI_ELAUNCH;
-        }
-        attr_set = true;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_big_kernel<WT, E, BIG>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;   // once, thread safe
+    if (!attr_ok) {
+        acmi_set_error("acmi_linear_big: cannot set the dynamic LDS limit");
+        return ACMI_ELAUNCH;
     }
     hipLaunchKernelGGL((lin_big_kernel<WT, E, BIG>), dim3(tiles), dim3(BigTile<BIG>::NW * 64), lds, st, a);
     return ACMI_OK;

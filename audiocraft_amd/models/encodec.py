@@ -191,21 +191,25 @@ class EncodecModel(CompressionModel):
         assert self.renormalize
         return x * scale.view(-1, 1, 1)
 
+    @_C.exclusive
     @torch.no_grad()
     def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
         assert x.dim() == 3
         x, scale = self.preprocess(x)
         return self.quantizer.encode(self._seanet('enc', self.encoder, x)), scale
 
+    @_C.exclusive
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor):
         return self.quantizer.decode(codes)
 
+    @_C.exclusive
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
         # the result keeps the encoder's extra right padding; callers trim to the length they expect
         return self.postprocess(self._seanet('dec', self.decoder, self.decode_latent(codes)), scale)
 
+    @_C.exclusive
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> QuantizedResult:
         assert x.dim() == 3
@@ -318,17 +322,20 @@ class HFEncodecCompressionModel(CompressionModel):
     def forward(self, x: torch.Tensor) -> QuantizedResult:
         raise NotImplementedError("Forward and training with HF EncodecModel not supported.")
 
+    @_C.exclusive
     @torch.no_grad()
     def encode(self, x: torch.Tensor) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
         self.model.set_num_codebooks(self.num_codebooks)
         return self.model.encode(x)     # (codes [B, K, T], scale [B, 1] | None): what `res[0][0], res[1][0]` are in the reference
 
+    @_C.exclusive
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, scale: tp.Optional[torch.Tensor] = None):
         # (with a scale the reference hands `scale` to HF as its per-frame list, i.e. it applies scale[0] to every item of the
         # batch; here every item gets its own -- identical for `normalize: false` codecs such as facebook/encodec_24khz)
         return self.model.decode(codes, scale)
 
+    @_C.exclusive
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor):
         return self.model.decode_latent(codes)

@@ -11,6 +11,7 @@ from abc import ABC, abstractmethod
 
 import torch
 
+from .. import _C
 from ..modules.conditioners import ConditioningAttributes
 from .encodec import CompressionModel, InterleaveStereoCompressionModel
 from .lm import LMModel
@@ -140,6 +141,7 @@ class BaseGenModel(ABC):
         return torch.cat(pieces, dim=-1)
 
     # -- single driver ------------------------------------------------------------------------------
+    @_C.exclusive   # one request at a time per process: conditioning, token generation and decode are not interleaved with another thread's
     def _run(self, descriptions, prompt_wav, progress: bool, return_tokens: bool, expect_prompt: bool, **prep_kw):
         with torch.no_grad():
             attributes, prompt_tokens = self._prepare_tokens_and_attributes(descriptions, prompt_wav, **prep_kw)

@@ -780,6 +780,7 @@ class LMModel(nn.Module):
         return torch.cat(per_call, dim=1)
 
     # ------------------------------------------------------------------------------------- generate
+    @_C.exclusive
     @torch.no_grad()
     def generate(self,
                  prompt: tp.Optional[torch.Tensor] = None,
@@ -1180,6 +1181,7 @@ class LMModel(nn.Module):
         run['gen_sequence'][:, :, st['steps']:].fill_(-1)
 
     # ------------------------------------------------------------------------------------- teacher forcing
+    @_C.exclusive
     @torch.no_grad()
     def forward_steps(self, sequence: torch.Tensor, condition_tensors: ConditionTensors) -> torch.Tensor:
         """Teacher-forced streaming forward for parity tests: runs the pattern `sequence` [B, K, S]
@@ -1222,6 +1224,7 @@ class LMModel(nn.Module):
         return outs
 
     # ------------------------------------------------------------------------------------- reference forward API
+    @_C.exclusive
     @torch.no_grad()
     def forward(self, sequence: torch.Tensor, conditions: tp.List[ConditioningAttributes] = [],
                 condition_tensors: tp.Optional[ConditionTensors] = None, stage: int = -1) -> torch.Tensor:
@@ -1238,6 +1241,7 @@ class LMModel(nn.Module):
             return self._streaming_forward(sequence, condition_tensors)
         return self.forward_steps(sequence, condition_tensors)
 
+    @_C.exclusive
     @torch.no_grad()
     def compute_predictions(self, codes: torch.Tensor, conditions: tp.List[ConditioningAttributes] = [],
                             condition_tensors: tp.Optional[ConditionTensors] = None, stage: int = -1,

@@ -90,6 +90,7 @@ class MultiBandDiffusion:
     def get_emb(self, codes: torch.Tensor):
         return self.codec_model.decode_latent(codes)
 
+    @_C.exclusive
     @torch.no_grad()
     def generate(self, emb: torch.Tensor, size: tp.Optional[torch.Size] = None, step_list: tp.Optional[tp.List[int]] = None):
         """Waveform from the latent embeddings: the sum over the bands' reverse processes."""

@@ -467,6 +467,64 @@ def test_lm_sampling_generate_is_well_formed():
     assert not torch.equal(toks, toks3)
 
 
+def test_two_host_threads_generate_serialised():
+    """Concurrency is a DEFINED behaviour (audiocraft_amd/_C.py, device_lock): two host threads, each with its own LM replica
+    and its own HIP stream, call generate / codec decode at the same time; the process-wide lock serialises them around
+    hipGraph capture + replay (global capture mode: one thread's capture would otherwise make the other's synchronisations
+    illegal), nothing raises, and every thread's tokens and audio equal what it computes alone.  A third thread hammers the
+    codec meanwhile (another graph-capturing entry)."""
+    import threading
+    from audiocraft_amd import _C
+    from audiocraft_amd.models import builders
+    from audiocraft_amd.modules.conditioners import ConditioningAttributes
+    lms = [builders.get_debug_lm_model('cuda') for _ in range(2)]
+    codec = builders.get_debug_compression_model('cuda')
+    conds = [ConditioningAttributes(text={'description': 'a b c'}), ConditioningAttributes(text={'description': 'd e'})]
+    kw = dict(max_gen_len=60, use_sampling=True, top_k=50)
+    alone = [lm.generate(None, conds, seed=11 + i, **kw).cpu() for i, lm in enumerate(lms)]
+    K = codec.num_codebooks
+    codes = torch.randint(0, codec.cardinality, (2, K, 50), device='cuda', generator=torch.Generator('cuda').manual_seed(3))
+    codec.decode(codes)                       # first sight of the shape (eager); the next call captures
+    wav_alone = codec.decode(codes).cpu()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    got, wavs, errors = [None, None], [], []
+    start = threading.Barrier(3)
+
+    def work(i):
+        try:
+            start.wait()
+            with torch.cuda.stream(streams[i]):
+                for _ in range(4):   # several generates each: captures and replays of the two threads interleave
+                    t = lms[i].generate(None, conds, seed=11 + i, **kw)
+                streams[i].synchronize()
+            got[i] = t.cpu()
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    def work_codec():
+        try:
+            start.wait()
+            with torch.cuda.stream(streams[2]):
+                for _ in range(12):
+                    codec.__dict__.pop('_graphs', None)     # force eager + capture + replay again and again
+                    codec.decode(codes)
+                    codec.decode(codes)
+                    wavs.append(codec.decode(codes).cpu())
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)] + [threading.Thread(target=work_codec)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck behind the device lock"
+    assert not errors, errors
+    assert torch.equal(got[0], alone[0]) and torch.equal(got[1], alone[1])
+    assert len(wavs) == 12 and all(torch.equal(w, wav_alone) for w in wavs)
+    assert _C.device_lock.acquire(blocking=False)    # released by everyone
+    _C.device_lock.release()
+
+
 def test_compute_predictions_matches_oracle():
     """LMModel.compute_predictions (lm.py:270-321): logits re-aligned with the codes + validity mask."""
     cfg, sd, a = load_golden('lm_text')
