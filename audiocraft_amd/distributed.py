@@ -41,6 +41,15 @@ def device_index(local_rank: int) -> int:
     return local_rank
 
 
+def require_own_device():
+    """The generation path runs on a device: a rank that was started beyond the node's devices (a host-side transport lets it
+    through the rendezvous) must not silently share device 0 with another rank -- that is device sharing without
+    ACMI_ALLOW_SHARED_DEVICE and skews the max-over-ranks clock.  Raises with the remedy; no-op for a single process."""
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1 or not torch.cuda.is_available():
+        return
+    device_index(int(os.environ.get('LOCAL_RANK', '0')))   # raises "LOCAL_RANK=r but this node shows n device(s)" unless the switch is on
+
+
 def init_from_env(backend: tp.Optional[str] = None) -> tp.Tuple[int, int, int]:
     """-> (rank, world_size, local_rank); initialises the default process group when WORLD_SIZE > 1.
     Backend: the argument, else ACMI_DIST_BACKEND, else "nccl" (= RCCL) with a GPU and "gloo" without."""
@@ -199,6 +208,7 @@ def generate_sharded(model, descriptions: tp.Optional[tp.Sequence[tp.Optional[st
     Returns (tokens [B_global, K, T] on every rank, wav for the local shard or, with gather_audio, global).
     Sampling seeds are per rank (base_seed + rank, cf. reference utils/utils.py:203-223)."""
     rk, world = rank(), world_size()
+    require_own_device()
     device = model.device
     # every rank needs at least one prompt: a rank with an empty shard would skip generate() and leave the others
     # blocked in the all-gather

@@ -75,13 +75,17 @@ class CompressionModel(ABC, nn.Module):
                 not_on_disk = exc
         else:
             not_on_disk = None
-        try:
+        tried = f"compression model '{name}': not an audiocraft export on disk ({not_on_disk})"
+        try:   # the optional dependency itself: absent, or broken (transformers' lazy import raises RuntimeError then)
             from transformers import EncodecModel as HFEncodecModel
+        except (ImportError, RuntimeError) as exc:
+            raise FileNotFoundError(f"{tried} and transformers' EncodecModel cannot be imported "
+                                    f"({type(exc).__name__}: {exc})") from exc
+        try:   # not in the HuggingFace cache (OSError), or a repository that is not an EnCodec (ValueError)
             hf_model = HFEncodecModel.from_pretrained(name)
-        except (OSError, ImportError) as exc:   # no transformers / not in the HuggingFace cache: say what was tried.  Anything
-            # else (a config or version incompatibility of a model that IS there) propagates as what it is
-            raise FileNotFoundError(f"compression model '{name}': not an audiocraft export on disk ({not_on_disk}) and not "
-                                    f"loadable as a HuggingFace EnCodec ({type(exc).__name__}: {exc})") from exc
+        except (OSError, ValueError) as exc:
+            raise FileNotFoundError(f"{tried} and not loadable as a HuggingFace EnCodec "
+                                    f"({type(exc).__name__}: {exc})") from exc
         return HFEncodecCompressionModel(hf_model, device).eval()
 
 

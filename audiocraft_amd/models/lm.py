@@ -530,6 +530,8 @@ class LMModel(nn.Module):
         if self._run is not None and self._run['key'] == key:
             return self._run
         self._stream = None   # a stream holds pointers into the buffers replaced below
+        for L in pk['layers']:   # ... and so do the layer descriptors' score-folded cross-attention tables (ACMI_CROSS_FOLD)
+            L.w_qkvs = L.b_qkvs = L.cs_qkvs = L.w_g2 = L.b_gs = L.xs_u = L.xs_cs = L.xs_bs = None
         dev = self.device
         Beff = B * (use_cfg + 1)
         H, hd, d = self.num_heads, self.dim // self.num_heads, self.dim
@@ -615,6 +617,7 @@ class LMModel(nn.Module):
             st.cross_len_rows = None
         st.Beff, st.B, st.use_cfg, st.Tmax, st.Lc = run['Beff'], B, int(use_cfg), Tmax, Lc
         st.n_prepend = 0 if prepend is None else prepend.shape[1]
+        self._last_n_prepend = st.n_prepend   # (bench.py: the prefix rows a generate put in front of the token stream)
         st.S = S
         st.gen_sequence, st.seq_mask = run['gen_sequence'].data_ptr(), run['seq_mask'].data_ptr()
         st.prepend = None if prepend is None else prepend.data_ptr()

@@ -250,6 +250,11 @@ class StreamableLSTM(nn.Module):
         if err is None:
             return y
         deferred = getattr(_C._lstm_tls, 'sink', None) is not None   # inside a capture: the owner checks after each replay
+        if not deferred and x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # somebody else's capture (EncodecModel._seanet runs plain launches there) and no sink to defer to: reading the
+            # give-up word would synchronise and invalidate that capture -- refuse with the remedy instead
+            raise _C.AcmiError("StreamableLSTM inside a foreign stream capture: the persistent kernel's give-up word cannot be read "
+                               "there; wrap the capture in audiocraft_amd._C.defer_lstm_checks(list) and check the list after replays")
         if not deferred and _C._lstm_xcd_enabled and _C.lstm_failed(err):
             # the XCD-local form lost residency / placement (shared or partitioned device): degrade in speed, not in
             # availability -- once, on the all-CU form, which this process keeps from now on

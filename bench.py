@@ -182,7 +182,7 @@ def measure_lin_kernel(model, B_eff: int, reps: int = 3):
     return dict(avg_us=ms * 1e3 / (launches * reps), bytes_per_launch=nbytes / launches, launches_per_position=launches)
 
 
-def measure_attn_kernel(model, B_eff: int, T: int, reps: int = 3):
+def measure_attn_kernel(model, B_eff: int, T: int, reps: int = 3, prefix: int = 0):
     """Average duration of the self-attention decode launch at the MEAN context of a T-frame generate: one launch per layer on
     that layer's own KV cache (cold, as in a decode position), captured into a hipGraph, HIP events on the launch stream.
     Algorithmic bytes: K and V rows [0, context) of every (row, head), each read once."""
@@ -191,7 +191,7 @@ def measure_attn_kernel(model, B_eff: int, T: int, reps: int = 3):
     run = lm._run
     k, v = run['k'], run['v']                     # [L, Beff, H, Tmax, hd], what the last generate left
     L, _, H, Tmax, hd = k.shape
-    ctx = max(1, min(Tmax, (T + 3) // 2))
+    ctx = max(1, min(Tmax, prefix + (T + 3) // 2))
     q = torch.randn(B_eff, H * hd, device=k.device)
     out = _C.tiled_activation_buffer(B_eff, H * hd, lm.weight_dtype, k.device)
     pos = torch.tensor([ctx - 1, 0, 0, 0], dtype=torch.int32, device=k.device)   # the length is a device word, as in generate()
@@ -253,7 +253,27 @@ def pmc_traffic_per_launch():
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
-def in_situ_kernel_stats(model_name: str, batch: int, timeout_s: int = 240):
+def _run_child(cmd, env, timeout_s: int):
+    """Run a profiler child in its OWN process group and end the whole group on a time-out (rocprofv3 forks the python
+    process: killing only the parent would leave a grandchild on the GPU during the measurements that follow)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        rc = p.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.wait()
+        raise
+    if rc != 0:
+        raise subprocess.CalledProcessError(rc, cmd)
+
+
+def in_situ_kernel_stats(model_name: str, batch: int, timeout_s: int = 420, duration: float = 8.0, greedy: bool = False,
+                         melody_seconds: float = 0.0):
     """-> ({family: (calls, avg_us)}, source) of the decode kernels INSIDE a real generate: a `rocprofv3 --kernel-trace --stats`
     child process over scripts/short_generate.py (the bench model, one 8 s generate: every GEMM launch sits between its real
     neighbours -- attention kernels, sampler -- in the captured decode graph).  `measure_lin_kernel` times the GEMM launches of a
@@ -277,8 +297,9 @@ def in_situ_kernel_stats(model_name: str, batch: int, timeout_s: int = 240):
     try:
         env = dict(os.environ, TMPDIR='/tmp')
         cmd = [exe, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '--', sys.executable,
-               os.path.join(ROOT, 'scripts', 'short_generate.py'), model_name, str(batch), '8']
-        subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+               os.path.join(ROOT, 'scripts', 'short_generate.py'), model_name, str(batch), str(duration), '1' if greedy else '0',
+               str(melody_seconds)]
+        _run_child(cmd, env, timeout_s)
         files = glob.glob(os.path.join(tmp, '**', '*kernel_stats.csv'), recursive=True)
         if not files:
             return None, 'the kernel-trace pass wrote no kernel_stats.csv'
@@ -299,15 +320,15 @@ def in_situ_kernel_stats(model_name: str, batch: int, timeout_s: int = 240):
         if keep:
             shutil.copyfile(files[0], keep)
         out = {k: (c, tot / c / 1e3) for k, (c, tot) in fam.items()}
-        return out, (f'rocprofv3 --kernel-trace --stats over scripts/short_generate.py ({model_name}, {batch} x 8 s) in this run, '
-                     f'{time.time() - t0:.0f} s: {out["gemm"][0]} GEMM launches')
+        return out, (f'rocprofv3 --kernel-trace --stats over scripts/short_generate.py ({model_name}, {batch} x {duration:g} s after a '
+                     f'2 s warm-up generate) in this run, {time.time() - t0:.0f} s: {out["gemm"][0]} GEMM launches')
     except Exception as e:   # noqa: BLE001
         return None, f'the kernel-trace pass failed: {type(e).__name__}'
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic_live(timeout_s: int = 150):
+def pmc_traffic_live(model_name: str = 'facebook/musicgen-medium', B_eff: int = 16, timeout_s: int = 200):
     """-> (HBM bytes per GEMM launch, source) MEASURED in this run: two `rocprofv3 --pmc` child processes (FETCH_SIZE and
     WRITE_SIZE in separate passes, counters only -- no trace domains -- as MI355X_MICROARCH.md prescribes) over
     scripts/dbg_chain.py, the same launch chain `measure_lin_kernel` times; same arithmetic as pmc_traffic_per_launch.
@@ -332,8 +353,8 @@ def pmc_traffic_live(timeout_s: int = 150):
         try:
             env = dict(os.environ, TMPDIR='/tmp')
             cmd = [exe, '--pmc', name, '--output-format', 'csv', '-d', tmp, '--', sys.executable,
-                   os.path.join(ROOT, 'scripts', 'dbg_chain.py')]
-            subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                   os.path.join(ROOT, 'scripts', 'dbg_chain.py'), model_name, str(B_eff)]
+            _run_child(cmd, env, timeout_s)
             files = glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True)
             if not files:
                 return None, f'the {name} pass wrote no counter_collection.csv'
@@ -350,11 +371,11 @@ def pmc_traffic_live(timeout_s: int = 150):
             return None, f'the {name} pass failed: {type(e).__name__}'
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    src = f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/dbg_chain.py, {time.time() - t0:.0f} s'
+    src = f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/dbg_chain.py {model_name} {B_eff}, {time.time() - t0:.0f} s'
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
-def attn_traffic_committed(context: int):
+def attn_traffic_committed(context: int, bytes_per_launch: int = 73826304):
     """HBM bytes per self-attention launch from the COMMITTED PMC passes (profiles/r05_attn_pmc_t751.txt: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate passes, over scripts/attn_bench.py --contexts 751 at the configs[2] geometry; same
     gfx950 arithmetic as pmc_traffic_per_launch) -- not measured live; None for another context."""
@@ -365,8 +386,9 @@ def attn_traffic_committed(context: int):
             if 'attn_decode_kernel' in line:
                 f = line.strip().split(',')
                 vals[f[-3]] = float(f[-2])
-        if context != 751 or 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
-            return {"traffic": None, "traffic_source": f"the committed PMC passes are of context 751 (this run: {context})"}
+        if context != 751 or bytes_per_launch != 73826304 or 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
+            return {"traffic": None, "traffic_source": f"the committed PMC passes are of the configs[2] geometry at context 751 "
+                                                       f"(this run: context {context}, {bytes_per_launch} B per launch)"}
         return {"traffic": int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024),
                 "traffic_source": "committed passes (round 5, profiles/r05_attn_pmc_t751.txt): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over scripts/attn_bench.py --contexts 751"}
     except OSError:
@@ -538,6 +560,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dump-tokens', default='', help='rank 0 saves the gathered tokens of the last step here (tests)')
+    ap.add_argument('--melody-seconds', type=float, default=10.0, help='melody clip per prompt for a melody model (configs[4])')
+    ap.add_argument('--insitu-duration', type=float, default=-1.0,
+                    help='seconds generated by the in-situ kernel-trace child (default: the bench duration, at most 30)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:   # no external launcher: spawn the ranks here
@@ -565,7 +590,16 @@ def main():
     T = int(args.duration * model.frame_rate)
     descriptions = [f"synthetic prompt {i}" for i in range(B_global)]
 
+    melody = 'melody' in args.model
+    if melody and world > 1:
+        sys.exit("bench.py: the melody configuration (configs[4]) is a single-GPU line")
+    mel = (torch.randn(B, 1, int(32000 * args.melody_seconds), generator=torch.Generator().manual_seed(5)).to(dev)
+           if melody else None)
+
     def step(i):
+        if melody:   # configs[4]: chroma front-end on the device + the prepended prefix are inside the step
+            wav, tokens = model.generate_with_chroma(descriptions, mel, 32000, return_tokens=True)
+            return tokens, wav
         tokens, wav = adist.generate_sharded(model, descriptions if rank == 0 else None, B_global, T,
                                              decode=True, base_seed=1000 * i)
         return tokens, wav
@@ -588,8 +622,14 @@ def main():
         tokens, wav = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if torch.distributed.get_backend() != 'gloo' else 'cpu', dtype=torch.float64)
+        # every rank's own clock over the same barrier-bracketed region: the MAX is the job's time, the list localises a straggler
+        cdev = dev if torch.distributed.get_backend() != 'gloo' else 'cpu'
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(every, t)
+        per_rank = [float(e.item()) for e in every]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert tokens.shape == (B_global, 4, T) and wav.shape == (B, 1, T * 640)
@@ -602,6 +642,7 @@ def main():
         "value": round(value, 3), "unit": "audio-s / wall-s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, synthetic T5 stand-in)",
+        "per_rank_s": [round(e / args.steps, 4) for e in per_rank],
         "config": {"workload": f"{args.model} bf16, batch {B} prompts x {args.duration:.0f} s per GPU, CFG, "
                                f"{'greedy' if args.greedy else f'top-k {args.top_k}'}, {T + 3} AR positions + EnCodec-32k decode "
                                f"({config_tag(args)})",
@@ -612,7 +653,8 @@ def main():
     if rank == 0:
         lm = model.lm
         n_pos = T + 3
-        alg = lm_algorithmic_bytes(lm, 2 * B, n_pos, args.text_len)
+        prefix = int(getattr(lm, '_last_n_prepend', 0))   # prepended condition rows (melody: chroma frames + text), already in the caches
+        alg = lm_algorithmic_bytes(lm, 2 * B, n_pos, args.text_len, prefix=prefix)
         job_bytes = alg['total'] * world   # every rank streams its own replica / KV shard
         out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes": job_bytes,
                                 "achieved": round(job_bytes * args.steps / elapsed / 1e9, 1),
@@ -623,18 +665,22 @@ def main():
             r = measure_lin_kernel(model, 2 * B)
             ach = r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9
             on_cfg2 = config_tag(args).endswith('configs[2]')
-            if not on_cfg2:
-                traffic, traffic_src = None, 'the PMC passes are of the configs[2] chain'
-            else:
-                traffic, traffic_src = pmc_traffic_live() if world == 1 else (None, 'multi-GPU run')
-                if traffic is None:   # fall back to the committed passes, and say why
-                    why = traffic_src
-                    traffic, traffic_src = pmc_traffic_per_launch()
-                    traffic_src = f'{traffic_src}; not measured live: {why}'
+            traffic, traffic_src = pmc_traffic_live(args.model, 2 * B) if world == 1 else (None, 'multi-GPU run')
+            if traffic is None and on_cfg2:   # fall back to the committed passes (they are of the configs[2] chain), and say why
+                why = traffic_src
+                traffic, traffic_src = pmc_traffic_per_launch()
+                traffic_src = f'{traffic_src}; not measured live: {why}'
             # the roofline fraction is that of the kernels IN SITU (inside the real decode graph, rocprofv3 kernel trace of a
             # short generate of this model); the isolated GEMM-only chain (HIP events) is reported next to it
-            insitu, insitu_src = in_situ_kernel_stats(args.model, B) if world == 1 else (None, 'multi-GPU run')
+            is_dur = min(args.duration, 30.0) if args.insitu_duration <= 0 else args.insitu_duration
+            insitu, insitu_src = (in_situ_kernel_stats(args.model, B, duration=is_dur, greedy=args.greedy,
+                                                       melody_seconds=args.melody_seconds if melody else 0.0)
+                                  if world == 1 else (None, 'multi-GPU run'))
             avg_us = insitu['gemm'][1] if insitu is not None else r['avg_us']
+            # the traced population against the one the numerator describes: decode positions of the warm-up (2 s) and the main
+            # generate x the GEMM launches of a position (a prefix goes through the one-forward prefill: other kernels)
+            is_positions = (int(2.0 * model.frame_rate) + 3) + (int(is_dur * model.frame_rate) + 3)
+            calls_expected = r['launches_per_position'] * is_positions
             ach_is = r['bytes_per_launch'] / (avg_us * 1e-6) / 1e9
             out["roofline"] = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach_is, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -647,7 +693,9 @@ def main():
                                "launches_per_position": r['launches_per_position']}
             if insitu is not None:
                 out["roofline"]["in_situ_us"] = {k: round(v[1], 3) for k, v in insitu.items()}
-            ra = measure_attn_kernel(model, 2 * B, T)
+                out["roofline"]["in_situ_gemm_launches"] = {"traced": insitu['gemm'][0], "expected_decode_launches": calls_expected,
+                                                            "note": "numerator and denominator describe the same launches when these agree"}
+            ra = measure_attn_kernel(model, 2 * B, T, prefix=prefix)
             out["roofline_attn"] = {"kernel": "attn_decode_kernel (single-query self-attention over the bf16 KV cache)", "bound": "hbm",
                                     "achieved": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -655,9 +703,26 @@ def main():
                                     "bytes_per_launch": int(ra['bytes_per_launch']), "avg_launch_us": round(ra['avg_us'], 3),
                                     "context": ra['context'], "launches": ra['launches'],
                                     "note": "one launch per layer at the mean context of the generate, every layer's own (cold) cache"}
-            out["roofline_attn"].update(attn_traffic_committed(ra['context']))
+            out["roofline_attn"].update(attn_traffic_committed(ra['context'], int(ra['bytes_per_launch'])))
+            if insitu is not None and 'self_attn' in insitu:
+                # in situ: the same kernel inside the decode graph of the traced generates; bytes = the mean K / V stream of
+                # those launches (context t + 1 at position t, + the prefix), every (row, head) read once
+                kv = model.lm._run['k']
+                Hh, hd_, bk_ = kv.shape[2], kv.shape[4], kv.element_size()
+                ctxs = [prefix + t + 1 for n in (int(2.0 * model.frame_rate) + 3, int(is_dur * model.frame_rate) + 3) for t in range(n)]
+                mean_bytes = 2 * (2 * B) * Hh * hd_ * bk_ * (sum(ctxs) / len(ctxs))
+                c_sa, us_sa = insitu['self_attn']
+                out["roofline_attn"]["in_situ"] = {
+                    "avg_launch_us": round(us_sa, 3), "launches": c_sa, "expected_launches": len(ctxs) * kv.shape[0],
+                    "mean_context": round(sum(ctxs) / len(ctxs), 1), "bytes_per_launch": int(mean_bytes),
+                    "achieved": round(mean_bytes / (us_sa * 1e-6) / 1e9, 1),
+                    "frac": round(mean_bytes / (us_sa * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "rocprofv3 kernel trace of the in-situ child (2 s warm-up + the main generate); frac above is the isolated launch at the mean context"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, B, args.duration, args.text_len, args.top_k)
+            if melody:
+                out["cpu_baseline"] = None   # (the port's timed sample has no prepended prefix; configs[2] carries the CPU line)
+            else:
+                out["cpu_baseline"] = cpu_baseline(model, B, args.duration, args.text_len, args.top_k)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

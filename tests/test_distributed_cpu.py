@@ -122,6 +122,12 @@ def test_gloo_rank_beyond_the_nodes_devices_stays_on_the_host(monkeypatch):
     monkeypatch.setattr(dist, 'init_process_group', lambda backend, **kw: calls.setdefault('init', (backend, kw)))
     assert adist.init_from_env('gloo') == (1, 2, 1)
     assert 'set_device' not in calls and calls['init'][0] == 'gloo'
+    # ... but it may not GENERATE: that would put two ranks on device 0 without the shared-device switch
+    with pytest.raises(RuntimeError, match='LOCAL_RANK=1'):
+        adist.require_own_device()
+    monkeypatch.setenv('ACMI_ALLOW_SHARED_DEVICE', '1')
+    adist.require_own_device()
+    monkeypatch.delenv('ACMI_ALLOW_SHARED_DEVICE', raising=False)
     # rank 0 of the same node does bind its device
     calls.clear()
     monkeypatch.setenv('RANK', '0')
