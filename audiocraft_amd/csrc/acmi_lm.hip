@@ -41,7 +41,7 @@ struct EmbedArgs {
 // kernel every released model runs is unchanged.
 template <bool BF16, int KQ, bool ADD = false>
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
-    __shared__ float sred[4];
+    __shared__ float sred[4], sred2[4];    // one slot set per reduction: a single barrier each
     const int m = blockIdx.x;              // row = position-of-the-call * Beff + CFG row
     int pidx, m0;
     if (p.npos_pad > 0) { m0 = m / p.npos_pad; pidx = min(m - m0 * p.npos_pad, p.npos - 1); }
@@ -99,8 +99,17 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
         cnt = i + 1;
         sum += v;
     }
-    // two-pass (mean, M2) of the row for the first LayerNorm
-    const float mean = block_sum(sum, sred) / (float)p.d;
+    // two-pass (mean, M2) of the row for the first LayerNorm (same summation order as block_sum: wave butterflies, then the
+    // waves in order; the second reduction uses its own slots, so neither needs a trailing barrier)
+    auto bsum1 = [&](float x, float* slot) {
+        x = wave_sum(x);
+        if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = x;
+        __syncthreads();
+        float r = 0.f;
+        for (int w = 0; w < 4; ++w) r += slot[w];
+        return r;
+    };
+    const float mean = bsum1(sum, sred) / (float)p.d;
     const float shift = p.shift_out != nullptr ? mean : 0.f;   // single-term fragments are stored relative to the row mean
     float q = 0.f;
 #pragma unroll
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs p) {
             }
         }
     }
-    q = block_sum(q, sred);
+    q = bsum1(q, sred2);
     if (threadIdx.x == 0) {
         p.stats[(size_t)m * 2] = mean; p.stats[(size_t)m * 2 + 1] = q;
         if (p.shift_out != nullptr) p.shift_out[m] = mean;
@@ -219,62 +228,112 @@ __device__ __forceinline__ float block_sum(float v, float* sval) {
     return r;
 }
 
+// Round 6: the same arithmetic (bit-identical probabilities, threshold and race as the round-2 kernel, so a (seed, logits) pair
+// gives the same token), restructured around what the launch was waiting for (15.5 us per position for 32 workgroups):
+//   * EPT elements per thread stay in REGISTERS (8 for card <= 2048: the loads of a row group are 8, not 16, requests);
+//   * every block reduction has its own LDS slots: ONE barrier each instead of two;
+//   * radix select: the FIRST pass looks at the top byte of a probability's bit pattern (sign + 7 exponent bits), which takes
+//     a handful of distinct values -- 2048 LDS atomics on 3-4 addresses serialise; the lanes of a wave holding the same
+//     digit now elect a leader that adds their count (wave-aggregated atomic), and the next pass's bins are cleared while
+//     this pass is scanned (double-buffered histogram);
+//   * the race runs over a COMPACTED candidate list (~top_k entries: one Philox per thread) instead of card / 256 rounds in
+//     which every wave executes the Philox because some lane holds a candidate;
+//   * the previous value of the written-back sequence slot is requested at kernel start, and the position counter's ticket
+//     needs no fence (every block's read of pos[0] completed long before it takes its ticket; the kernel boundary publishes
+//     the rest): __threadfence() is an L2 write-back + invalidate, microseconds on the tail of every position.
+template <int EPT>
 __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
-    __shared__ float vals[ACMI_MAX_CARD];
+    __shared__ float vals[EPT * 256];          // top-p path: the probabilities; race: candidate probabilities
+    __shared__ int cand[EPT * 256];            // race: candidate indexes
+    __shared__ float red_a[4], red_b[4];
     __shared__ float sval[4];
     __shared__ int sidx[4];
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[2][256];
     __shared__ unsigned sel[2];
     __shared__ unsigned wtot[4];
     const int k = blockIdx.x, b = blockIdx.y;
     const int card = p.card;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* cond = p.logits + ((size_t)b * p.K + k) * card;
     // row groups: PAIR [cond; uncond], DOUBLE [cond (text + wav); wav; uncond]; a group the mode does not have aliases
     // `cond`, so that the loads below are unconditional (a branch around a load costs a memory round trip of its own:
     // the loads of one phase must be requested back to back)
     const float* second = p.use_cfg != ACMI_CFG_NONE ? p.logits + ((size_t)(p.B + b) * p.K + k) * card : cond;
     const float* third = p.use_cfg == ACMI_CFG_DOUBLE ? p.logits + ((size_t)(2 * p.B + b) * p.K + k) * card : cond;
-    const int gpos = p.pos ? p.pos[0] : 0;
-    constexpr int EPT = ACMI_MAX_CARD / 256;   // elements per thread
     float lc[EPT], l2[EPT], l3[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = min((int)threadIdx.x + e * 256, card - 1);
         lc[e] = cond[i]; l2[e] = second[i]; l3[e] = third[i];
     }
+    const int gpos = p.pos ? p.pos[0] : 0;
+    // the sequence slot this position fills (lm.py:540-562) and what it holds now (a prompt token stays): requested here
+    const int offset = (gpos - p.P) + 1;
+    const bool wb = p.gen_sequence != nullptr && offset >= 0 && offset < p.S;
+    int64_t* const dst = wb ? p.gen_sequence + ((size_t)b * p.K + k) * p.S + offset : nullptr;
+    int64_t prev = -1; uint8_t mk = 0;
+    if (threadIdx.x == 0 && wb) { prev = *dst; mk = p.seq_mask[(size_t)k * p.S + offset]; }
+    float v[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = (int)threadIdx.x + e * 256;
-        if (i >= card) break;
-        float v = lc[e];
+        float x = lc[e];
         if (p.use_cfg == ACMI_CFG_PAIR) {  // uncond + (cond - uncond) * coef, rounded after every op like the reference (no fma)
             const float u = l2[e];
-            v = __fadd_rn(u, __fmul_rn(__fsub_rn(v, u), p.cfg_coef));
+            x = __fadd_rn(u, __fmul_rn(__fsub_rn(x, u), p.cfg_coef));
         } else if (p.use_cfg == ACMI_CFG_DOUBLE) {  // uncond + coef * (wav + beta * (cond - wav) - uncond), lm.py:372-376
             const float w = l2[e], u = l3[e];
-            const float inner = __fsub_rn(__fadd_rn(w, __fmul_rn(p.cfg_beta, __fsub_rn(v, w))), u);
-            v = __fadd_rn(u, __fmul_rn(p.cfg_coef, inner));
+            const float inner = __fsub_rn(__fadd_rn(w, __fmul_rn(p.cfg_beta, __fsub_rn(x, w))), u);
+            x = __fadd_rn(u, __fmul_rn(p.cfg_coef, inner));
         }
-        vals[i] = v;
-        if (p.mixed_out) p.mixed_out[((size_t)b * p.K + k) * card + i] = v;
+        v[e] = x;
+        if (p.mixed_out && i < card) p.mixed_out[((size_t)b * p.K + k) * card + i] = x;
     }
-    __syncthreads();
+    // one barrier per reduction: the partials of consecutive reductions live in different slots
+    auto bsum = [&](float x, float* slot) {
+        x = wave_sum(x);
+        if (lane == 0) slot[wave] = x;
+        __syncthreads();
+        float r = 0.f;
+        for (int w = 0; w < 4; ++w) r += slot[w];
+        return r;
+    };
     int token;
     if (!(p.use_sampling && p.temp > 0.f)) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int i = threadIdx.x; i < card; i += blockDim.x)
-            if (vals[i] > bv) { bv = vals[i]; bi = i; }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = (int)threadIdx.x + e * 256;
+            if (i < card && v[e] > bv) { bv = v[e]; bi = i; }
+        }
         token = block_argmax(bv, bi, sval, sidx);
     } else {
         // softmax(logits / temp)
         float mx = -INFINITY;
-        for (int i = threadIdx.x; i < card; i += blockDim.x) { vals[i] = vals[i] / p.temp; mx = fmaxf(mx, vals[i]); }
-        mx = block_max(mx, sval);
-        float sum = 0.f;
-        for (int i = threadIdx.x; i < card; i += blockDim.x) { const float e = expf(vals[i] - mx); vals[i] = e; sum += e; }
-        sum = block_sum(sum, sval);
-        for (int i = threadIdx.x; i < card; i += blockDim.x) vals[i] = vals[i] / sum;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = (int)threadIdx.x + e * 256;
+            v[e] = v[e] / p.temp;
+            if (i < card) mx = fmaxf(mx, v[e]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) red_a[wave] = mx;
         __syncthreads();
+        mx = fmaxf(fmaxf(red_a[0], red_a[1]), fmaxf(red_a[2], red_a[3]));
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = (int)threadIdx.x + e * 256;
+            const float ex = expf(v[e] - mx);
+            v[e] = ex;
+            if (i < card) sum += ex;
+        }
+        sum = bsum(sum, red_b);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = (int)threadIdx.x + e * 256;
+            v[e] = i < card ? v[e] / sum : 0.f;    // (elements past the vocabulary: probability 0, never a candidate)
+        }
         float thr = 0.f;
         if (p.top_p > 0.f) {
             // utils.sample_top_p (utils.py:125-141): in descending order, keep i unless the mass sorted strictly before it
@@ -283,6 +342,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
             // the float bit pattern (non-negative floats order like their bits): 31 block reductions instead of the
             // card^2 comparisons of a direct evaluation.  Only the group of values equal to x* can be kept partially
             // (ties are ordered by index, like a stable sort).
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int i = (int)threadIdx.x + e * 256;
+                if (i < card) vals[i] = v[e];
+            }
+            __syncthreads();
             auto mass_above = [&](float x) {
                 float m = 0.f;
                 for (int i = threadIdx.x; i < card; i += blockDim.x) m += vals[i] > x ? vals[i] : 0.f;
@@ -298,84 +363,109 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
             float ties = 0.f;
             for (int i = threadIdx.x; i < card; i += blockDim.x) ties += vals[i] == xs ? 1.f : 0.f;
             ties = block_sum(ties, sval);
-            unsigned dropmask = 0u;   // card <= 4096 -> <= 16 elements per thread
-            int cnt = 0;
-            for (int i = threadIdx.x; i < card; i += blockDim.x, ++cnt) {
-                const float pi = vals[i];
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int i = (int)threadIdx.x + e * 256;
+                if (i >= card) continue;
+                const float pi = v[e];
                 bool keep = pi >= xs;
                 if (keep && pi == xs && ties > 1.5f) {   // rank of this element inside its tie group (rare path)
                     int r = 0;
                     for (int j = 0; j < i; ++j) r += vals[j] == xs ? 1 : 0;
                     keep = fstar + (float)r * xs <= p.top_p;
                 }
-                if (!keep) dropmask |= 1u << cnt;
+                if (!keep) v[e] = 0.f;
             }
-            __syncthreads();   // every thread has read what it needs of the un-filtered probabilities
-            cnt = 0;
-            for (int i = threadIdx.x; i < card; i += blockDim.x, ++cnt)
-                if (dropmask & (1u << cnt)) vals[i] = 0.f;
-            __syncthreads();
+            __syncthreads();   // every thread has read what it needs of the un-filtered probabilities (vals is reused below)
         } else if (p.top_k > 0 && p.top_k < card) {
             // k-th largest probability by 4-pass radix select on the (non-negative) float bit patterns
             unsigned prefix = 0u, mask = 0u, remaining = (unsigned)p.top_k;
+            hist[0][threadIdx.x] = 0u;
+            __syncthreads();
+#pragma unroll
             for (int pass = 3; pass >= 0; --pass) {
-                for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0u;
-                __syncthreads();
-                for (int i = threadIdx.x; i < card; i += blockDim.x) {
-                    const unsigned bits = __float_as_uint(vals[i]);
-                    if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> (8 * pass)) & 255u], 1u);
+                unsigned* const hc = hist[pass & 1 ? 0 : 1];
+                unsigned* const hn = hist[pass & 1 ? 1 : 0];
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    const int i = (int)threadIdx.x + e * 256;
+                    const unsigned bits = __float_as_uint(v[e]);
+                    const bool act = i < card && (bits & mask) == prefix;
+                    const unsigned digit = (bits >> (8 * pass)) & 255u;
+                    if (pass == 3) {
+                        // wave-aggregated: one atomic per distinct digit of the wave (a few exponent values), not one per lane
+                        unsigned long long todo = __ballot(act);
+                        while (todo) {
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const unsigned dl = (unsigned)__shfl((int)digit, leader, 64);
+                            const unsigned long long same = __ballot(act && digit == dl);
+                            if (lane == leader) atomicAdd(&hc[dl], (unsigned)__popcll(same));
+                            todo &= ~same;
+                        }
+                    } else if (act) {
+                        atomicAdd(&hc[digit], 1u);
+                    }
                 }
                 __syncthreads();
                 {   // suffix sums S[t] = sum_{j >= t} hist[j] with 256 threads; digit d is selected when
                     // S[d] >= remaining > S[d+1]
-                    const unsigned hcnt = hist[threadIdx.x];
+                    const unsigned hcnt = hc[threadIdx.x];
+                    hn[threadIdx.x] = 0u;     // the next pass's bins
                     unsigned sfx = hcnt;
-                    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const unsigned o = __shfl_down(sfx, off, 64);
-                        if (ln + off < 64) sfx += o;
+                        if (lane + off < 64) sfx += o;
                     }
-                    if (ln == 0) wtot[wv] = sfx;
+                    if (lane == 0) wtot[wave] = sfx;
                     __syncthreads();
-                    for (int w2 = wv + 1; w2 < 4; ++w2) sfx += wtot[w2];
+                    for (int w2 = wave + 1; w2 < 4; ++w2) sfx += wtot[w2];
                     if (sfx >= remaining && sfx - hcnt < remaining) { sel[0] = threadIdx.x; sel[1] = remaining - (sfx - hcnt); }
                 }
                 __syncthreads();
                 prefix |= sel[0] << (8 * pass);
                 mask |= 255u << (8 * pass);
                 remaining = sel[1];
-                __syncthreads();
             }
             thr = __uint_as_float(prefix);
+            __syncthreads();   // (sel / wtot are rewritten by nobody below; vals / cand are free)
         }
-        // multinomial(num_samples=1) as an exponential race: argmax_i p_i / q_i, q_i ~ Exp(1)
+        // multinomial(num_samples=1) as an exponential race: argmax_i p_i / q_i, q_i ~ Exp(1), over the compacted support
+        int mine = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) mine += (v[e] >= thr && v[e] > 0.f) ? 1 : 0;
+        int incl = mine;   // inclusive prefix over the block: wave scan, then the waves' totals
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) sidx[wave] = incl;
+        __syncthreads();
+        int base = incl - mine, total = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) base += sidx[w]; total += sidx[w]; }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            if (v[e] >= thr && v[e] > 0.f) { cand[base] = (int)threadIdx.x + e * 256; vals[base] = v[e]; ++base; }
+        }
+        __syncthreads();
         const uint64_t stepc = p.step + (uint64_t)gpos;
         float bv = -1.f; int bi = 0x7fffffff;
-        for (int i = threadIdx.x; i < card; i += blockDim.x) {
-            const float pi = vals[i];
-            if (pi >= thr && pi > 0.f) {
-                uint32_t c4[4] = {(uint32_t)i, (uint32_t)(b * p.K + k), (uint32_t)stepc, (uint32_t)(stepc >> 32)};
-                philox4x32_10(c4, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
-                const float u = ((float)(c4[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                const float r = pi / (-logf(u));
-                if (r > bv) { bv = r; bi = i; }
-            }
+        for (int j = threadIdx.x; j < total; j += 256) {
+            const int i = cand[j];
+            const float pi = vals[j];
+            uint32_t c4[4] = {(uint32_t)i, (uint32_t)(b * p.K + k), (uint32_t)stepc, (uint32_t)(stepc >> 32)};
+            philox4x32_10(c4, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+            const float u = ((float)(c4[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float r = pi / (-logf(u));
+            if (r > bv || (r == bv && i < bi)) { bv = r; bi = i; }
         }
         token = block_argmax(bv, bi, sval, sidx);
     }
     if (threadIdx.x == 0) {
         if (p.tokens_out) p.tokens_out[(size_t)b * p.K + k] = token;
-        if (p.gen_sequence) {
-            const int offset = (gpos - p.P) + 1;  // sequence step being filled (lm.py:540-562)
-            if (offset >= 0 && offset < p.S) {
-                const int64_t tok = p.seq_mask[(size_t)k * p.S + offset] ? (int64_t)token : (int64_t)p.card;
-                int64_t* dst = p.gen_sequence + ((size_t)b * p.K + k) * p.S + offset;
-                if (*dst == -1) *dst = tok;
-            }
-        }
-        if (p.advance) {  // every block has read pos[0] before taking its ticket
-            __threadfence();
+        if (wb && prev == -1) *dst = mk ? (int64_t)token : (int64_t)p.card;
+        if (p.advance) {  // every block has read pos[0] (it computed with it) before it takes its ticket
             const int ticket = atomicAdd(&p.pos[1], 1);
             if (ticket == (int)(gridDim.x * gridDim.y) - 1) {
                 p.pos[1] = 0;
@@ -388,7 +478,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p) {
 static int launch_sample(const SampleArgs& a, hipStream_t st) {
     ACMI_REQUIRE(a.card > 0 && a.card <= ACMI_MAX_CARD, "acmi_sample: card=%d unsupported (max %d)", a.card, ACMI_MAX_CARD);
     ACMI_REQUIRE(a.B > 0 && a.K > 0, "acmi_sample: bad shape");
-    hipLaunchKernelGGL(sample_kernel, dim3(a.K, a.B), dim3(256), 0, st, a);
+    if (a.card <= 2048) hipLaunchKernelGGL(sample_kernel<8>, dim3(a.K, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(sample_kernel<ACMI_MAX_CARD / 256>, dim3(a.K, a.B), dim3(256), 0, st, a);
     return acmi_check_launch("sample_kernel");
 }
 
