@@ -88,7 +88,7 @@ class LMState(C.Structure):
                 ('use_sampling', i32), ('temp', f32), ('top_k', i32), ('top_p', f32), ('cfg_coef', f32),
                 ('seed', u64), ('cfg_coef_beta', f32), ('cross_len_rows', vp), ('rope_first', i32), ('rope_shift', i32),
                 ('xshift', vp), ('cross_active_rows', i32), ('pf_xn', vp), ('pf_vt', vp), ('pf_tcap', i32), ('cvt_tcap', i32),
-                ('row_off', vp), ('input_add', vp), ('n_add', i32), ('xs_rows', i32)]
+                ('row_off', vp), ('input_add', vp), ('n_add', i32), ('xs_rows', i32), ('qkv_hand', vp), ('hand_err', vp)]
 
 
 def _sig(name, argtypes, restype=i32):
@@ -152,6 +152,7 @@ _linear_ex = _sig('acmi_linear_ex', [C.POINTER(LinearDesc), vp])
 FFN_ENGINE_FLAG_BYTES = 16384
 _ffn_engine = _sig('acmi_ffn_engine', [C.POINTER(FfnEngineDesc), vp])
 _cross_fold = _sig('acmi_cross_fold', [C.POINTER(CrossFoldDesc), vp])
+qkv_attn_launches = _sig('acmi_qkv_attn_launches', [], C.c_longlong)
 _ffn_engine_supported = _sig('acmi_ffn_engine_supported', [i32, i32, i32, i32])
 _linear_pair = _sig('acmi_linear_pair', [C.POINTER(LinearDesc), C.POINTER(LinearDesc), vp])
 _attn_ex = _sig('acmi_attn_decode_ex', [C.POINTER(AttnDesc), vp])
@@ -181,7 +182,7 @@ EXPORTS = ['acmi_group_norm_work_floats', 'acmi_group_norm', 'acmi_channel_add',
            'acmi_fir_bank', 'acmi_band_stats', 'acmi_band_mix', 'acmi_linear_big', 'acmi_attn_prefill', 'acmi_resample_frac', 'acmi_chroma', 'acmi_chroma_frames', 'acmi_version', 'acmi_last_error', 'acmi_rvq_codebook_norms', 'acmi_rvq_encode', 'acmi_rvq_decode',
            'acmi_conv1d', 'acmi_conv1d_gn', 'acmi_conv1d_tile_weights', 'acmi_conv1d_weight_floats', 'acmi_conv1d_work_floats', 'acmi_lstm_layer', 'acmi_lstm_work_floats', 'acmi_lstm_layer_ex', 'acmi_lstm_layer_work_floats', 'acmi_lstm_stack2', 'acmi_lstm_stack2_work_floats', 'acmi_lstm_stack2_supported', 'acmi_lm_step', 'acmi_linear',
            'acmi_attn_decode', 'acmi_kv_store', 'acmi_sample', 'acmi_pos_table', 'acmi_ln_tile', 'acmi_linear_ex', 'acmi_ln_tile_reduce', 'acmi_linear_pair', 'acmi_attn_decode_ex', 'acmi_layer_norm_rows',
-           'acmi_ffn_engine', 'acmi_ffn_engine_supported', 'acmi_cross_fold']
+           'acmi_ffn_engine', 'acmi_ffn_engine_supported', 'acmi_cross_fold', 'acmi_qkv_attn_launches']
 
 
 # ctypes mirror -> C type of include/acmi.h (tests/test_host_cpu.py compiles the header with gcc and compares every

@@ -7,6 +7,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
 
 // Two translation units, one source: the f32-weight instantiations of the launchers below (half of the kernels of this
 // file) are compiled by acmi_gemm_f32.hip, which defines ACMI_GEMM_F32_TU and includes this file; everything that is not
@@ -588,13 +589,15 @@ __device__ __forceinline__ void tl_chunk_ht(LinArgs& p, const int aoff, const u3
 // form (EPI_GEN) keeps every flag a run-time test; all forms are the same source, so their arithmetic is the same.
 // Why: the timeline showed ~1.1-1.3 us between the barrier and the last store of EVERY launch -- ~200 executed
 // instructions, but spread over ~30 taken branches of cold code, each a new instruction-cache line fetched from L2.
-enum { EPI_GEN = 0, EPI_PRODX = 1, EPI_TILED = 2, EPI_F32 = 3, EPI_QKV = 4 };
+enum { EPI_GEN = 0, EPI_PRODX = 1, EPI_TILED = 2, EPI_F32 = 3, EPI_QKV = 4, EPI_QKVH = 5 };
 //   EPI_PRODX  x <- x + a W^T (+ bias): f32 in place, the raw fragments of the new x (single term, optional shift),
 //              optional statistics partials.  No activation, no LayerNorm, no split-K.
 //   EPI_TILED  out = act(LN?(a) W^T + bias) in A-fragment order (FFN1)
 //   EPI_F32    out = LN?(a) W^T + bias (+ residual), row-major f32 (heads, the paired cross-query GEMM)
 //   EPI_QKV    the QKV scatter of a decode step (one position per call, head size and model width multiples of 16, so
 //              that a 16-feature tile lies in ONE of q / k / v / r and in ONE head: all index divisions are per tile)
+//   EPI_QKVH   the same features handed to the attention workgroups of the SAME launch (qkv_attn_kernel): q | k | v as f32 words
+//              with write-through stores into the sentinel-armed hand-off row q_out [M][3 d] (acmi_attn_fused.h); r as in EPI_QKV
 
 // the nw partial sums of one tile element, added in wave order; nw is 1, 2, 4 or 8 (tiled_waves): one uniform branch, then
 // straight-line LDS reads (a run-time loop over nw costs a compare + branch per term and hides the reads from each other)
@@ -629,7 +632,7 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
     constexpr bool G = EPI == EPI_GEN;
     constexpr int XT = (HT ? 1 : NT) * MT;   // first extra tile (row sums / Gram) of the reduction buffer
     const bool split = G ? ksp > 1 : false;
-    const bool qkv = G ? p.qkv != 0 : EPI == EPI_QKV;
+    const bool qkv = G ? p.qkv != 0 : (EPI == EPI_QKV || EPI == EPI_QKVH);
     const bool has_res = G || EPI == EPI_F32 ? p.residual != nullptr : EPI == EPI_PRODX;
     const bool has_stats = G || EPI == EPI_PRODX ? p.stats_out != nullptr : false;
     const bool has_xt = G ? p.xt_hi != nullptr : EPI == EPI_PRODX;
@@ -705,7 +708,7 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
         }
         if (qkv) {
             int part, f, h, dd, pidx, brow;
-            if (EPI == EPI_QKV) {
+            if (EPI == EPI_QKV || EPI == EPI_QKVH) {
                 // per 16-feature tile (wave-uniform values: scalar arithmetic): the tile lies in one part and one head
                 // (no division: four parts at most, and the launcher admits power-of-two head sizes only: p.hd_shift)
                 const int fb = __builtin_amdgcn_readfirstlane(n0 + 16 * t);
@@ -719,7 +722,10 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
                 h = f / p.hd; dd = f - h * p.hd;
                 pidx = gm / p.rpp; brow = gm - pidx * p.rpp;  // several positions per call (prefill)
             }
-            if (part == 0) {
+            if (EPI == EPI_QKVH && part != 3) {   // agent-scope (write-through) store: the consumer polls this very word
+                __hip_atomic_store(reinterpret_cast<unsigned*>(p.q_out) + (size_t)gm * 3 * p.d + part * p.d + f, __float_as_uint(v),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (part == 0) {
                 p.q_out[(size_t)gm * p.d + f] = v;
             } else if (part == 3) {
                 p.r_out[(size_t)gm * p.r_ld + f] = v;
@@ -741,7 +747,8 @@ __device__ __forceinline__ void tl_epilogue(const LinArgs& p, const TlExtras& ex
 
 // NT = 2: the workgroup owns two adjacent n-tiles (32 features) and every activation fragment feeds both -- for
 // the wide GEMMs (N / 16 > 256) whose 16-feature grid would put two workgroups on some CUs.
-template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false>
+// CCAP: largest straight-line chunk this instance compiles (its register budget); HAND: the EPI_QKVH epilogue is reachable
+template <typename WT, int MT, int LN, int NT = 1, int NS = 8, bool HT = false, int CCAP = 24, bool HAND = false>
 __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const int wgtile, const int kslice) {
     static_assert(NT == 1 || NT == 2, "one or two n-tiles per workgroup");
     static_assert(!HT || (NT == 1 && LN == 0), "half-tile workgroups: plain GEMM, one (half) n-tile");
@@ -753,7 +760,8 @@ __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const in
     // without scratch (a kernel with a private segment starts its waves measurably slower) inside the 256
     // VGPRs of a 2-waves-per-SIMD launch
     constexpr int CQ = HT ? 52 / (1 + 2 * MT) : ((PART ? (NS > 8 ? 36 : 44) : (GRAM ? 48 : 52)) / (NT + MT * D));
-    constexpr int CMAX = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
+    constexpr int CMAX0 = CQ >= 24 ? 24 : (CQ >= 16 ? 16 : (CQ >= 12 ? 12 : (CQ >= 8 ? 8 : (CQ >= 6 ? 6 : (CQ >= 4 ? 4 : 2)))));
+    constexpr int CMAX = CMAX0 < CCAP ? CMAX0 : CCAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     TlTrace tr{};
     ACMI_TR(tr.t, 0);
@@ -885,6 +893,7 @@ __device__ __forceinline__ void tl_body(const TlHot& h, const int aoff, const in
     else if (!HT && LN != 3 && epi_kind == EPI_TILED) ACMI_TL_EPI(EPI_TILED);
     else if (!HT && epi_kind == EPI_F32) ACMI_TL_EPI(EPI_F32);
     else if (!HT && (LN == 1 || LN == 2 || LN == 4) && epi_kind == EPI_QKV) ACMI_TL_EPI(EPI_QKV);
+    else if (HAND && epi_kind == EPI_QKVH) ACMI_TL_EPI(EPI_QKVH);
     else ACMI_TL_EPI_W(EPI_GEN, 0);
 #undef ACMI_TL_EPI
 #undef ACMI_TL_EPI_W
@@ -1136,6 +1145,70 @@ int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
 #undef ACMI_PAIR_CASE
     return acmi_check_launch("lin_pair_kernel");
 }
+
+#if ACMI_GEMM_MAIN
+// -----------------------------------------------------------------------------------------------------
+// qkv_attn_kernel (round 6): the decode step's QKV GEMM and the self-attention that consumes it as ONE launch.  Workgroups
+// [0, tiles) run tl_body (16 output features each, 4 waves, folded LayerNorm with the statistics from the fragments) with the
+// hand-off epilogue; workgroups [tiles, tiles + rows * H) run attn_fused_role (acmi_attn_fused.h): the K / V stream of a layer
+// -- the only large stream of the layer that does not depend on the previous launch's output -- is requested while the weights
+// stream, and the 3.6 us a self-attention launch spends before its first byte arrives overlap the GEMM.
+// Kernarg: 14 preloaded dwords (weights, activation, its shift, the two caches, four packed words), then the LinArgs block at
+// byte ACMI_TL_ARGS_OFF_PAIR and the FusedAttnArgs block behind it.
+//   g0 = K tiles | K tiles per slice << 16   g1 = fragments per wave | waves << 12 | heads << 16
+//   g2 = a_rbs | M << 16                     g3 = GEMM workgroups | cache capacity << 16
+#include "acmi_attn_fused.h"
+static_assert(sizeof(FusedAttnArgs) % 8 == 0, "kernarg layout of qkv_attn_kernel");
+template <int CCAP>
+__global__ __launch_bounds__(256) void qkv_attn_kernel(const u32x4* hw, const u32x4* ha, const float* hsh, const void* hkc, const void* hvc,
+                                                       unsigned g0, unsigned g1, unsigned g2, unsigned g3, const LinArgs, const FusedAttnArgs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tiles = (int)(g3 & 0xffffu);
+    if ((int)blockIdx.x < tiles) {
+        const TlHot h = tl_unpack(hw, ha, nullptr, hsh, g0, (g1 & 0xffffu) | (1u << 16), g2, 0u);
+        tl_body<bf16_t, 1, 4, 1, 8, false, CCAP, true>(h, ACMI_TL_ARGS_OFF_PAIR, (int)blockIdx.x, 0);
+    } else {
+        attn_fused_role(hkc, hvc, (int)(g1 >> 16), (int)(g3 >> 16), (int)blockIdx.x - tiles,
+                        ACMI_TL_ARGS_OFF_PAIR + (int)sizeof(LinArgs), smem);
+    }
+}
+
+static std::atomic<long long> g_qkv_attn_launches{0};
+extern "C" long long acmi_qkv_attn_launches(void) { return g_qkv_attn_launches.load(std::memory_order_relaxed); }
+
+int acmi_launch_qkv_attn(LinArgs& a, FusedAttnArgs& f, const void* kc, const void* vc, int H, int Tcap, hipStream_t st) {
+    int rc = tiled_prepare<bf16_t>(a);
+    if (rc) return rc;
+    const int tiles = (a.N + 15) / 16, nw = 4;
+    ACMI_REQUIRE(a.colsum != nullptr && a.a_stats == nullptr && a.a_lo == nullptr && a.M <= 16 && a.N % 16 == 0 && a.qkv &&
+                 a.NKC % nw == 0 && a.NKC / nw <= 16 && tiles <= 0xffff && Tcap <= 0xffff && H <= 0xffff && a.hd == 64 &&
+                 a.kv_bf16 && a.M == a.rpp,
+                 "acmi_qkv_attn: needs the fragment-statistics LayerNorm, <= 16 rows, head size 64, a bf16 cache and K tiles a "
+                 "multiple of 4 with at most 16 per wave (M=%d N=%d K=%d hd=%d)", a.M, a.N, a.K, a.hd);
+    a.ksplit = 1; a.kcs = a.NKC; a.fpw = a.NKC / nw;
+    if (a.r_ld <= 0) a.r_ld = a.d;
+    a.epi = EPI_QKVH;
+    a.inv_K = 1.0f / (float)a.K;
+    a.hd_shift = 6;
+#ifdef ACMI_TRACE
+    a.trace = nullptr;
+#endif
+    f.rows = a.M; f.d = a.d;
+    const size_t lds_g = (size_t)3 * nw * 1024 + 128, lds_a = 2048 + (f.stage_k ? (size_t)nw * 8192 : 0);
+    const size_t lds = lds_g > lds_a ? lds_g : lds_a;
+    const unsigned g0 = (unsigned)a.NKC | ((unsigned)a.kcs << 16), g1 = (unsigned)a.fpw | ((unsigned)nw << 12) | ((unsigned)H << 16);
+    const unsigned g2 = (unsigned)a.a_rbs | ((unsigned)a.M << 16), g3 = (unsigned)tiles | ((unsigned)Tcap << 16);
+    const dim3 grid(tiles + a.M * H), block(nw * 64);
+    if (a.fpw <= 12)
+        hipLaunchKernelGGL(qkv_attn_kernel<12>, grid, block, lds, st, reinterpret_cast<const u32x4*>(a.w), reinterpret_cast<const u32x4*>(a.a),
+                           a.a_shift, kc, vc, g0, g1, g2, g3, a, f);
+    else
+        hipLaunchKernelGGL(qkv_attn_kernel<16>, grid, block, lds, st, reinterpret_cast<const u32x4*>(a.w), reinterpret_cast<const u32x4*>(a.a),
+                           a.a_shift, kc, vc, g0, g1, g2, g3, a, f);
+    g_qkv_attn_launches.fetch_add(1, std::memory_order_relaxed);
+    return acmi_check_launch("qkv_attn_kernel");
+}
+#endif
 
 #if !ACMI_GEMM_MAIN
 template int launch_rowmajor<float>(LinArgs&, hipStream_t);

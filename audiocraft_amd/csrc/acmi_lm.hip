@@ -7,6 +7,7 @@
 // Reference semantics: audiocraft/models/lm.py:221-268,323-418,536-565;
 // audiocraft/modules/transformer.py:70-89,550-574,693-713; audiocraft/utils/utils.py:88-141.
 #include "acmi_lm_internal.h"
+#include "acmi_attn_fused.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -925,6 +926,14 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     const bool xs = pair && npos == 1 && s->xs_rows > 0 && s->xs_rows <= s->Beff && m->layers[0].w_qkvs != nullptr &&
                     !c.use_lo && s->cross_len_rows == nullptr && xs_hl <= 1024 && d / 16 <= 128;
 
+    // QKV -> self-attention as one launch (acmi_lm_state.qkv_hand; acmi_attn_fused.h): the caller opts in per state, the geometry
+    // decides per step; ACMI_QKV_STAGE_K=0 keeps the K half of the second round out of LDS (A/B)
+    static const bool stage_k = !(getenv("ACMI_QKV_STAGE_K") != nullptr && getenv("ACMI_QKV_STAGE_K")[0] == '0');
+    const bool fuse_qkv = mode == ACMI_STEP_DECODE && npos == 1 && s->qkv_hand != nullptr && s->hand_err != nullptr && wbf && kvbf &&
+                          hd == 64 && c.lnm == LN_FOLD && c.gram && M <= 16 && !post && !xs && m->rope_freq == nullptr &&
+                          m->past_context <= 0 && s->row_off == nullptr && c.nkc_d % 4 == 0 && c.nkc_d / 4 <= 16 && s->Tmax <= 0xffff &&
+                          d % c.kt == 0;
+
     EmbedArgs e = {};
     for (int k = 0; k < m->n_q; ++k) e.emb[k] = m->emb[k];
     e.w_bf16 = wbf; e.gen_sequence = s->gen_sequence; e.B = s->B; e.Beff = s->Beff; e.K = m->n_q; e.S = s->S; e.card = m->card;
@@ -950,6 +959,24 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         const float* const sh_l = c.xsh;   // shift of the layer's input fragments (the cross-attention query's r is built on them)
         if (shifted) c.nsh = shbuf[(li + 1) & 1];
         // norm1 -> QKV ; K, V appended in place at position g, q to scratch
+        if (fuse_qkv && L.q_ln_g == nullptr && L.k_ln_g == nullptr) {
+            // ... and the self-attention over positions [0, g] in the SAME launch: q | k | v go through the hand-off row
+            LinArgs a = {};
+            a.mean_out = c.nsh;
+            a.qkv = 1; a.q_out = reinterpret_cast<float*>(s->qkv_hand); a.k_cache = L.k_cache; a.v_cache = L.v_cache; a.kv_bf16 = 1;
+            a.H = H; a.hd = hd; a.Tcap = s->Tmax; a.d = d; a.pos = s->pos; a.rpp = s->Beff;
+            a.a_tiled = 1; a.M = c.rows; a.K = d; a.a = c.xh; a.a_rbs = c.rbs; a.a_np = c.np; a.a_cnt = c.cnt; a.eps = m->eps;
+            a.a_shift = c.xsh;
+            if (pair) { a.r_out = s->r; a.w = L.w_qkvx; a.bias = L.b_qkvx; a.colsum = L.cs_qkvx; a.N = 4 * d; }
+            else { a.w = L.w_qkv; a.bias = L.b_qkv; a.colsum = L.cs_qkv; a.N = 3 * d; }
+            FusedAttnArgs f = {};
+            f.len_dev = s->pos; f.hand = reinterpret_cast<unsigned*>(s->qkv_hand); f.err = s->hand_err; f.len_bias = 1;
+            f.scale = 1.0f / sqrtf((float)hd); f.stage_k = stage_k ? 1 : 0;
+            if (pair) { f.out = c.xh; f.out_rbs = c.rbs; f.out_col0 = c.nkc_d * c.kt; }
+            else { f.out = s->att; f.out_rbs = c.nkc_d; f.out_col0 = 0; }
+            if ((rc = acmi_launch_qkv_attn(a, f, L.k_cache, L.v_cache, H, s->Tmax, st))) return rc;
+            goto attn_done;
+        }
         {
             LinArgs a = {};
             a.mean_out = c.nsh;   // single-term mode: the row means of x0 = the shift of this layer's producers
@@ -982,6 +1009,7 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         }
         // self attention over positions [0, g]; output in A-fragment order for the out projection: into `att`,
         // or next to x ([x | att], columns d_pad ..) when the out projection is paired with the cross query
+        {
         acmi_attn_desc sa = {};
         sa.q = s->q; sa.k_cache = L.k_cache; sa.v_cache = L.v_cache; sa.kvdtype = m->kvdtype;
         sa.out_mode = ACMI_OUT_TILED; sa.out_dtype = m->wdtype; sa.Beff = M; sa.H = H; sa.hd = hd; sa.Tcap = s->Tmax;
@@ -990,7 +1018,8 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
         if (pair) { sa.out = c.xh; sa.out_rbs = c.rbs; sa.out_col0 = c.nkc_d * c.kt; }
         else sa.out = s->att;
         if ((rc = acmi_attn_decode_ex(&sa, stream))) return rc;
-
+        }
+    attn_done:
         if (!m->cross_attention) {
             if ((rc = gemm_produce_x(c, s->att, L.w_out, d, false, L.b_out))) return rc;
             if (post && (rc = post_ln(c, L.n1_g, L.n1_b))) return rc;

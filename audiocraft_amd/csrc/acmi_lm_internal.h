@@ -96,6 +96,9 @@ int acmi_launch_cross_fold(const CrossFoldArgs& a, int wdtype, int rows, hipStre
 // launchers of acmi_gemm.hip used by acmi_lm_step
 int acmi_launch_lin(LinArgs& a, int wdtype, hipStream_t st);                 // tiled or row-major activation
 int acmi_launch_pair(LinArgs& p0, LinArgs& p1, int wdtype, hipStream_t st);  // two tiled GEMMs, one launch
+struct FusedAttnArgs;
+// the decode step's QKV GEMM + the self-attention consuming it as ONE launch (bf16; acmi_attn_fused.h)
+int acmi_launch_qkv_attn(LinArgs& a, FusedAttnArgs& f, const void* kc, const void* vc, int H, int Tcap, hipStream_t st);
 int acmi_launch_ln_tile(float* x, void* out, int wdtype, int M, int K, float eps, const float* slabs, int nslabs,
                         hipStream_t st);
 

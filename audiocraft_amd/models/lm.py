@@ -19,6 +19,7 @@ nothing between steps except replay (and the optional progress callback).
    call as extra rows (streaming == batch, reference tests/modules/test_transformer.py:16-49).
 """
 import ctypes as C
+import os
 import math
 import typing as tp
 from contextlib import contextmanager
@@ -584,8 +585,32 @@ class LMModel(nn.Module):
         run['cross_len_rows'] = torch.full((Beff,), max(Lc, 1), device=dev, dtype=torch.int32)
         run['gen_sequence'] = torch.zeros(B, self.n_q, S, device=dev, dtype=torch.int64)
         run['seq_mask'] = torch.zeros(self.n_q, S, device=dev, dtype=torch.uint8)
+        # QKV -> self-attention as one launch (acmi_lm_state.qkv_hand): the hand-off row, every word the sentinel, + the error word
+        if self.QKV_ATTN_FUSED:
+            run['qkv_hand'] = torch.full((Beff, 3 * d), self.HAND_SENTINEL, device=dev, dtype=torch.int32)
+            run['hand_err'] = torch.zeros(4, device=dev, dtype=torch.int32)
         self._run = run
         return run
+
+    # The decode step's QKV GEMM + self-attention as ONE launch where the geometry allows (include/acmi.h, acmi_lm_state.qkv_hand;
+    # same arithmetic as the two launches; DESIGN.md section 5.11: +3.0 % medium B = 8, +4.0 % large, +4.6 % small B = 1, +5.8 % medium
+    # B = 4 on one box, whole GPU suite green in both modes).  ACMI_QKV_ATTN=0 restores the two launches.
+    QKV_ATTN_FUSED = os.environ.get('ACMI_QKV_ATTN', '1') != '0'
+    HAND_SENTINEL = 0x7fc0dead
+
+    def _hand_arm(self, run):
+        """Before a sequence of decode steps: every hand-off slot armed, the error word cleared."""
+        if 'qkv_hand' in run:
+            run['qkv_hand'].fill_(self.HAND_SENTINEL)
+            run['hand_err'].zero_()
+
+    def _hand_check(self, run):
+        """After them: a poll that gave up means a step consumed garbage (one host read per generate)."""
+        if 'qkv_hand' in run and int(run['hand_err'][0]) != 0:
+            n = int(run['hand_err'][0])
+            self._hand_arm(run)
+            raise _C.AcmiError(f"acmi_lm_step: {n} hand-off polls of the fused QKV + self-attention launch gave up "
+                               "(set ACMI_QKV_ATTN=0 for the two launches)")
 
     def _make_state(self, run, B, use_cfg, Tmax, Lc, S, prepend, record_logits, use_sampling, temp, top_k, top_p,
                     cfg_coef, seed, cfg_coef_beta: float = 0.0, cross_lens: tp.Optional[torch.Tensor] = None,
@@ -634,6 +659,8 @@ class LMModel(nn.Module):
         st.step_logits = run['step_logits'].data_ptr() if record_logits else None
         st.use_sampling, st.temp, st.top_k, st.top_p = int(use_sampling), float(temp), int(top_k), float(top_p)
         st.cfg_coef, st.seed = float(cfg_coef), int(seed) & ((1 << 64) - 1)
+        st.qkv_hand = run['qkv_hand'].data_ptr() if 'qkv_hand' in run else None
+        st.hand_err = run['hand_err'].data_ptr() if 'qkv_hand' in run else None
         return st
 
     def _project_cross_kv(self, run, cross_src: torch.Tensor):
@@ -924,6 +951,7 @@ class LMModel(nn.Module):
         self._prefill(desc, state, P + start_offset_sequence - 1)
 
         # ---- decode: one hipGraph replay per position
+        self._hand_arm(run)
         n_steps = S - start_offset_sequence
         all_logits = []
         graph = None
@@ -939,6 +967,7 @@ class LMModel(nn.Module):
             if callback is not None:
                 callback(1 + i, n_steps)
         gen_sequence = run['gen_sequence'].clone()
+        self._hand_check(run)
 
         if check:
             assert not (gen_sequence == unknown_token).any()
@@ -1111,9 +1140,12 @@ class LMModel(nn.Module):
             add = st.pop('add_first', None) if off == 0 else None    # (mixed order: what the first call adds to its token rows)
             run['input_add'][:, off:off + S] = (add if add is not None else ConditionFuser.input_add_rows(st['ops'], S)).to(self.device)
         outs = []
+        if off == 0:
+            self._hand_arm(run)
         for _ in range(S):
             _C.lm_step(st['desc'], st['state'], _C.STEP_DECODE)
             outs.append(run['step_logits'].clone())
+        self._hand_check(run)
         st['steps'] = off + S
         return torch.stack(outs, dim=2)
 
@@ -1217,6 +1249,7 @@ class LMModel(nn.Module):
             self._project_cross_kv(run, cross_src.to(device=dev, dtype=torch.float32).contiguous())
         self._prefill(desc, state, P)
         outs = torch.empty(B, K, S, self.card, device=dev, dtype=torch.float32)
+        self._hand_arm(run)
         graph = self._capture(desc, state) if S > 2 else None   # one captured position, replayed S times
         for i in range(S):
             if graph is not None:
@@ -1224,6 +1257,7 @@ class LMModel(nn.Module):
             else:
                 _C.lm_step(desc, state, _C.STEP_DECODE)
             outs[:, :, i].copy_(run['step_logits'])  # the sampler only writes slots still at -1
+        self._hand_check(run)
         return outs
 
     # ------------------------------------------------------------------------------------- reference forward API

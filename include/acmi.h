@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ACMI_VERSION 190 /* 0.1.9: post-norm layers (acmi_lm_model.post_norm, acmi_lm_layer.n1_g .. n2_b; acmi_ln_tile with eps < 0 = raw rows); score-folded cross-attention (acmi_cross_fold, acmi_lm_layer.w_qkvs .., acmi_lm_state.xs_rows).  0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
+#define ACMI_VERSION 200 /* 0.2.0: acmi_lm_state.qkv_hand / hand_err (the decode step's QKV GEMM and self-attention as one launch with a per-(row, head) hand-off; opt-in per state).  0.1.9: post-norm layers (acmi_lm_model.post_norm, acmi_lm_layer.n1_g .. n2_b; acmi_ln_tile with eps < 0 = raw rows); score-folded cross-attention (acmi_cross_fold, acmi_lm_layer.w_qkvs .., acmi_lm_state.xs_rows).  0.1.8: acmi_ffn_engine (the tail of a decode layer as one persistent launch; measured slower than the launches, not used by
                             acmi_lm_step), the decode step's cross-attention as a kernel of its own (cross_q_kernel, inside acmi_attn_decode_ex).  0.1.7: qk_layer_norm (acmi_lm_layer.q_ln_g .. cq_ln_b, acmi_layer_norm_rows), fuser 'sum' / 'input_interpolate'
                             (acmi_lm_state.input_add).  0.1.6: acmi_lstm_layer_ex / acmi_lstm_layer_work_floats (one recurrence per XCD at H = 1024).  0.1.5: folded LayerNorm with the row statistics taken from the activation fragments (acmi_linear_desc:
                             colsum without a_stats), left-padded streams (acmi_lm_state.row_off, acmi_attn_desc.start_rows: two_step_cfg
@@ -354,6 +354,15 @@ typedef struct {
                                for all rows (cross_len_rows NULL), H * Lc <= 1024, r with room for Beff * N floats where N = xs_rows * H * Lc
                                rounded up to 16 (the tables' N: w_qkvs / w_g2 hold zero rows behind xs_rows * H * Lc, b_qkvs /
                                cs_qkvs / b_gs zeros); otherwise the step runs the separate launches */
+    /* QKV -> self-attention as ONE launch (0.2.0; reference op sequence transformer.py:362-399, 412-414; DESIGN.md sections
+     * 5.10 / 5.11).  Non-NULL qkv_hand + hand_err opt a DECODE step in where its geometry allows (bf16 weights and cache, head
+     * size 64, <= 16 rows, LayerNorm statistics from the fragments, no rotary positions / qk_layer_norm / bounded context /
+     * left-padded streams); otherwise, and in every other case, the step runs the two launches.  Results are bit-identical. */
+    void* qkv_hand;         /* [Beff][3 * dim] 32-bit words, every word 0x7fc0dead (the hand-off sentinel) before the first step:
+                               the GEMM workgroups store q | k | v of the new position there, the attention workgroups of the same
+                               launch consume and re-arm them */
+    int* hand_err;          /* [1]: number of hand-off polls that gave up (bounded spin); non-zero = the step's result is not to
+                               be trusted (the caller checks it once per generate), and later launches do not spin again */
 } acmi_lm_state;
 
 #define ACMI_CFG_NONE 0
@@ -554,6 +563,10 @@ typedef struct {
 int acmi_ffn_engine(const acmi_ffn_engine_desc* desc, void* stream);
 /* 1 when acmi_ffn_engine supports the geometry (else acmi_lm_step keeps the three launches) */
 int acmi_ffn_engine_supported(int M, int d, int ffn, int wdtype);
+
+/* Diagnostic (0.2.0): how many fused QKV + self-attention launches (acmi_lm_state.qkv_hand) this process has enqueued -- lets a
+ * caller (tests, bench) see whether a step took the one-launch form or fell back to the two launches. */
+long long acmi_qkv_attn_launches(void);
 
 /* Single-query attention over a [Beff, H, Tcap, hd] cache, positions [0, len): the
  * F.scaled_dot_product_attention call of transformer.py:412-414 for one new step.

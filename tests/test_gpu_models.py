@@ -467,6 +467,58 @@ def test_lm_sampling_generate_is_well_formed():
     assert not torch.equal(toks, toks3)
 
 
+_FUSED_AB = r"""
+import sys, torch
+from audiocraft_amd import _C
+from audiocraft_amd.models import builders
+torch.manual_seed(0)
+cross, B, out = sys.argv[1] == '1', int(sys.argv[2]), sys.argv[3]
+cfgd = dict(dim=1536, num_heads=24, num_layers=2, n_q=4, card=512, hidden_scale=4, cfg_coef=3.0)
+if cross:
+    cfgd.update(conditioners={'description': {'kind': 't5', 'embedder': 'synthetic', 'dim': 48, 'length': 5}}, fuser={'cross': ['description']})
+lm = builders.get_lm_model(cfgd, 'cuda', torch.bfloat16)
+kw = dict(num_samples=B, max_gen_len=330, use_sampling=True, top_k=50, seed=77, return_logits=True)
+if cross:
+    src = torch.randn(2 * B, 5, 1536, generator=torch.Generator().manual_seed(3))
+    src[B:] = 0
+    kw['condition_tensors'] = {'description': (src.cuda(), torch.ones(2 * B, 5, dtype=torch.int64).cuda())}
+prompt = torch.randint(0, 512, (B, 4, 70), generator=torch.Generator().manual_seed(4)).cuda()
+n0 = _C.qkv_attn_launches()
+t_a, l_a = lm.generate(None, [], **kw)
+t_b, l_b = lm.generate(prompt, [], **dict(kw, max_gen_len=150))
+err = int(lm._run['hand_err'][0]) if 'hand_err' in lm._run else 0
+armed = bool((lm._run['qkv_hand'] == lm.HAND_SENTINEL).all()) if 'qkv_hand' in lm._run else True
+torch.save({'t_a': t_a.cpu(), 'l_a': l_a.cpu(), 't_b': t_b.cpu(), 'l_b': l_b.cpu(), 'fused': _C.qkv_attn_launches() - n0, 'err': err, 'armed': armed}, out)
+"""
+
+
+@pytest.mark.parametrize('cross,B', [(True, 8), (True, 3), (False, 16), (False, 5)])
+def test_fused_qkv_attention_launch_is_bit_identical(cross, B, tmp_path):
+    """acmi_lm_state.qkv_hand (0.2.0): the decode step's QKV GEMM and the self-attention that consumes it as ONE launch with a
+    per-(row, head) sentinel hand-off (csrc/acmi_attn_fused.h; reference op sequence transformer.py:362-399, 412-414).  The
+    attention's arithmetic is the separate kernel's in the same order, and with the SAME split of K over the GEMM's waves
+    (ACMI_LIN_WIDE=0: 16-feature workgroups of 4 waves, what the fused launch runs) tokens AND logits are bit-identical --
+    sampled, 330 frames (contexts crossing the 64-position chunks and the second round that is staged in LDS), MusicGen-medium's
+    width and head count, with and without cross-attention (the paired and the plain out-projection layouts), 16 / 6 / 16 / 5
+    rows, and behind a prompt (prefill, then decode).  One subprocess per mode: the switches are read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for fused in ('0', '1'):
+        out = str(tmp_path / f'ab{fused}.pt')
+        env = dict(os.environ, ACMI_QKV_ATTN=fused, ACMI_LIN_WIDE='0', PYTHONPATH=root)
+        r = subprocess.run([sys.executable, '-c', _FUSED_AB, '1' if cross else '0', str(B), out], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[fused] = torch.load(out)
+    assert res['0']['fused'] == 0 and res['1']['fused'] > 0, (res['0']['fused'], res['1']['fused'])   # the one-launch form did run
+    assert res['1']['err'] == 0 and res['1']['armed']
+    for key in ('t_a', 'l_a', 't_b', 'l_b'):
+        assert torch.equal(res['0'][key], res['1'][key]), key
+
+
 def test_two_host_threads_generate_serialised():
     """Concurrency is a DEFINED behaviour (audiocraft_amd/_C.py, device_lock): two host threads, each with its own LM replica
     and its own HIP stream, call generate / codec decode at the same time; the process-wide lock serialises them around
