@@ -50,8 +50,22 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
     const bf16_t* kbase = reinterpret_cast<const bf16_t*>(hkc) + ((size_t)b * H + h) * Tcap * HD;   // (uniform)
     const bf16_t* kb = kbase + c * DPL;
     const bf16_t* vb = reinterpret_cast<const bf16_t*>(hvc) + ((size_t)b * H + h) * Tcap * HD + c * DPL;
+    // The argument block and the length word come FIRST (two dependent scalar round trips, ~1 us): unlike the stand-alone kernel
+    // this role is not latency-bound at its start -- the launch is bandwidth-bound from its first request (delaying
+    // these requests by 2 us changed nothing) -- and a speculative first chunk clamped to the cache capacity costs REAL bytes at
+    // short contexts (up to 25 MB per launch next to the weight stream; PMC: 1.35 x the algorithmic bytes at a mean context of 67).
+    FusedAttnArgs p;
+    {
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        __builtin_memcpy(&p, (const void __attribute__((address_space(4)))*)__builtin_assume_aligned(
+                                 (const void __attribute__((address_space(4)))*)(ka + aoff), 8), sizeof(FusedAttnArgs));
+    }
+    const int tnew = __builtin_amdgcn_readfirstlane(*p.len_dev) + p.len_bias - 1;   // position appended by this step
+    const int len = tnew + 1;
+    const bool dead = __builtin_amdgcn_readfirstlane(*p.err) != 0;   // an earlier launch timed out: do not spin again
     rawv kr[NI], vr[NI];
-    int lim = Tcap;   // speculative: clamped to the capacity, masked once the length is known
+    const int lim = max(tnew, 1);   // position tnew is not in the cache yet: it arrives through the hand-off
+    const int r0 = wave * CH, r1 = (wave + NW) * CH;
     auto load_kv = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -61,22 +75,8 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    load_kv(wave * CH);
-    // the argument block and the length word: scalar loads behind the first chunk's requests
-    int opaque0 = 0;
-    asm volatile("" : "+s"(opaque0));
-    opaque0 = __builtin_amdgcn_readfirstlane(opaque0);
-    FusedAttnArgs p;
-    {
-        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        __builtin_memcpy(&p, (const void __attribute__((address_space(4)))*)__builtin_assume_aligned(
-                                 (const void __attribute__((address_space(4)))*)(ka + (aoff + opaque0)), 8), sizeof(FusedAttnArgs));
-    }
-    const int tnew = __builtin_amdgcn_readfirstlane(*p.len_dev) + p.len_bias - 1;   // position appended by this step
-    const int len = tnew + 1;
-    const bool dead = __builtin_amdgcn_readfirstlane(*p.err) != 0;   // an earlier launch timed out: do not spin again
+    load_kv(r0);   // (a wave past the context re-reads the last valid position: cache hits, no branch around the requests)
     unsigned char* kst = smem + 2048;   // [NW][8 KB] staged K of the second round
-    const int r1 = (wave + NW) * CH;
     const bool staged = p.stage_k != 0 && r1 < tnew;   // (wave-uniform) the second round exists in the cache
     if (staged) {
         const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(__attribute__((address_space(3))) void*)kst + wave * 8192u));
@@ -86,7 +86,6 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
             fa_lds_dma(kbase, (unsigned)((t * HD + c * DPL) * 2), dst + i * 1024u);
         }
     }
-    lim = max(tnew, 1);   // position tnew is not in the cache yet: it arrives through the hand-off
     // ---- the hand-off: q | k | v of (row b, head h); lane (c, *) needs dims [8 c, 8 c + 8) of each
     float qv[DPL];
     rawv knew, vnew;
@@ -94,6 +93,12 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hand + (size_t)b * 3 * p.d + h * HD, 0, -1, 0x00020000);
         u32x4 w[6];
         unsigned spins = 0;
+        // ONE poller per workgroup: wave 0 polls and hands the 3 x 64 words over through LDS, the other waves wait at the barrier.
+        // Same speed as every wave polling for itself (profiles/r06_fused_qkv_attn_one_poller_ab.txt), a quarter of the poll
+        // traffic: agent-scope loads of lines the producers' write-through stores dropped from L2 are fabric reads (PMC: the
+        // polls of four waves were ~9 MB per launch).
+        unsigned* hw = reinterpret_cast<unsigned*>(smem + 1280);   // [3][64] words
+        if (wave == 0)
         for (;;) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -108,6 +113,19 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
             if (!__any(bad) || dead) break;
             if (++spins > 20000u) { if (lane == 0) atomicAdd(p.err, 1); break; }
             __builtin_amdgcn_s_sleep(1);
+        }
+        if (wave == 0 && pp == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                *reinterpret_cast<u32x4*>(hw + j * 64 + c * DPL) = w[2 * j];
+                *reinterpret_cast<u32x4*>(hw + j * 64 + c * DPL + 4) = w[2 * j + 1];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            w[2 * j] = *reinterpret_cast<const u32x4*>(hw + j * 64 + c * DPL);
+            w[2 * j + 1] = *reinterpret_cast<const u32x4*>(hw + j * 64 + c * DPL + 4);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -167,7 +185,6 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
         }
         m = m_new;
     };
-    const int r0 = wave * CH;
     if (r0 < len) {
         process(r0);
         if (r1 < len) {
@@ -219,8 +236,10 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
         const int f = h * HD + threadIdx.x;
         reinterpret_cast<bf16_t*>(p.out)[tiled_index<bf16_t>(b, p.out_col0 + f, p.out_rbs)] = f32_to_bf16(r);
     }
-    if (threadIdx.x < 3 * HD) {   // every wave has read its words (barrier above): re-arm the slots for the next launch
-        const int j = threadIdx.x / HD, dd = threadIdx.x % HD;
-        __hip_atomic_store(p.hand + (size_t)b * 3 * p.d + j * p.d + h * HD + dd, ACMI_HAND_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 3 * HD / 4) {   // every wave has read its words (barrier above): re-arm the slots for the next launch (16-byte stores)
+        const int j = threadIdx.x / (HD / 4), dd = (threadIdx.x % (HD / 4)) * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.hand, 0, -1, 0x00020000);
+        const u32x4 w4 = {ACMI_HAND_SENTINEL, ACMI_HAND_SENTINEL, ACMI_HAND_SENTINEL, ACMI_HAND_SENTINEL};
+        __builtin_amdgcn_raw_buffer_store_b128(w4, rs, (int)(((size_t)b * 3 * p.d + j * p.d + h * HD + dd) * 4), 0, 16);   // aux 16 = sc1
     }
 }

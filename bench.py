@@ -307,7 +307,8 @@ def in_situ_kernel_stats(model_name: str, batch: int, timeout_s: int = 420, dura
         with open(files[0]) as f:
             for row in csv.DictReader(f):
                 n = row['Name']
-                key = ('gemm' if ('lin_tiled_kernel' in n or 'lin_pair_kernel' in n) else
+                key = ('fused' if 'qkv_attn_kernel' in n else
+                       'gemm' if ('lin_tiled_kernel' in n or 'lin_pair_kernel' in n) else
                        'self_attn' if 'attn_decode_kernel' in n and ', false>' in n else
                        'cross_attn' if ('cross_q_kernel' in n or ('attn_decode_kernel' in n and ', true>' in n)) else None)
                 if key is None:
@@ -373,6 +374,52 @@ def pmc_traffic_live(model_name: str = 'facebook/musicgen-medium', B_eff: int = 
             shutil.rmtree(tmp, ignore_errors=True)
     src = f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/dbg_chain.py {model_name} {B_eff}, {time.time() - t0:.0f} s'
     return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
+
+
+def pmc_traffic_fused(model_name: str, batch: int, duration: float = 3.0, greedy: bool = False, timeout_s: int = 420):
+    """-> (HBM bytes per qkv_attn_kernel launch, source), MEASURED in this run: two `rocprofv3 --pmc` child passes (FETCH_SIZE,
+    WRITE_SIZE; counters only) over scripts/fused_chain.py (the bench model's LM with 4 layers -- the per-launch traffic does not
+    depend on the depth --, tokens only: a 2 s warm-up + `duration` s), averaged over the fused QKV + self-attention dispatches;
+    same gfx950 arithmetic as pmc_traffic_per_launch.  The caller prices the same dispatches' algorithmic bytes (weights + the
+    mean K / V stream of those positions).  (A counter pass over a whole MusicGen.generate incl. the codec crashes rocprofv3.)"""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if os.environ.get('ACMI_BENCH_PMC', '1') == '0':
+        return None, 'ACMI_BENCH_PMC=0'
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    if any(k.startswith(('ROCPROF', 'ROCP_', 'ROCPROFILER')) for k in os.environ):
+        return None, 'this process runs under a profiler'
+    vals = {}
+    t0 = time.time()
+    for name in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix=f'acmi_pmcf_{name}_', dir='/tmp')
+        try:
+            cmd = [exe, '--pmc', name, '--output-format', 'csv', '-d', tmp, '--', sys.executable,
+                   os.path.join(ROOT, 'scripts', 'fused_chain.py'), model_name, str(batch), str(duration), '4']
+            _run_child(cmd, dict(os.environ, TMPDIR='/tmp'), timeout_s)
+            files = glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True)
+            if not files:
+                return None, f'the {name} pass wrote no counter_collection.csv'
+            total = n = 0.0
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row['Counter_Name'] == name and 'qkv_attn_kernel' in row['Kernel_Name']:
+                        total += float(row['Counter_Value'])
+                        n += 1
+            if n == 0:
+                return None, f'no qkv_attn_kernel dispatches in the {name} pass'
+            vals[name] = total / n
+        except Exception as e:   # noqa: BLE001
+            return None, f'the {name} pass failed: {type(e).__name__}'
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return int((2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), (
+        f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over scripts/fused_chain.py {model_name} '
+        f'{batch} {duration:g} 4, qkv_attn_kernel dispatches only, {time.time() - t0:.0f} s')
 
 
 def attn_traffic_committed(context: int, bytes_per_launch: int = 73826304):
@@ -680,21 +727,63 @@ def main():
             # the traced population against the one the numerator describes: decode positions of the warm-up (2 s) and the main
             # generate x the GEMM launches of a position (a prefix goes through the one-forward prefill: other kernels)
             is_positions = (int(2.0 * model.frame_rate) + 3) + (int(is_dur * model.frame_rate) + 3)
-            calls_expected = r['launches_per_position'] * is_positions
-            ach_is = r['bytes_per_launch'] / (avg_us * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
+            # the default decode step runs the QKV GEMM inside the fused QKV + self-attention launch (qkv_attn_kernel) where the
+            # geometry allows: its launches then leave the GEMM family's population, and its bytes the family's numerator
+            fused_on = insitu is not None and 'fused' in insitu
+            L_ = lm.num_layers
+            w_qkv = (2 if lm.weight_dtype == torch.bfloat16 else 4) * (4 if lm.has_cross_attention else 3) * lm.dim * lm.dim
+            lpp = r['launches_per_position'] - (L_ if fused_on else 0)
+            gemm_bytes = (r['bytes_per_launch'] * r['launches_per_position'] - (L_ * w_qkv if fused_on else 0)) / lpp
+            calls_expected = lpp * is_positions
+            ach_is = gemm_bytes / (avg_us * 1e-6) / 1e9
+            gemm_obj = {"kernel": "lin_tiled_kernel + lin_pair_kernel (weight-streaming skinny GEMM, LayerNorm folded into its epilogue)", "bound": "hbm",
                                "achieved": round(ach_is, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach_is / HBM_PEAK_GBS, 4), "frac_of_copy_bw": round(ach_is / HBM_COPY_GBS, 4),
                                "traffic": traffic, "traffic_source": traffic_src,
-                               "bytes_per_launch": int(r['bytes_per_launch']), "avg_launch_us": round(avg_us, 3),
+                               "bytes_per_launch": int(gemm_bytes), "avg_launch_us": round(avg_us, 3),
                                "avg_launch_source": ("in situ: " + insitu_src) if insitu is not None else
                                                     f"isolated GEMM chain (HIP events); in-situ pass unavailable: {insitu_src}",
                                "frac_isolated_chain": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us_isolated_chain": round(r['avg_us'], 3),
-                               "launches_per_position": r['launches_per_position']}
+                               "launches_per_position": lpp}
             if insitu is not None:
-                out["roofline"]["in_situ_us"] = {k: round(v[1], 3) for k, v in insitu.items()}
-                out["roofline"]["in_situ_gemm_launches"] = {"traced": insitu['gemm'][0], "expected_decode_launches": calls_expected,
-                                                            "note": "numerator and denominator describe the same launches when these agree"}
+                gemm_obj["in_situ_us"] = {k: round(v[1], 3) for k, v in insitu.items()}
+                gemm_obj["in_situ_gemm_launches"] = {"traced": insitu['gemm'][0], "expected_decode_launches": calls_expected,
+                                                     "note": "numerator and denominator describe the same launches when these agree"}
+            if fused_on:
+                # the DOMINANT kernel of the decode step (by time): QKV GEMM + self-attention as one launch.  Algorithmic bytes of a
+                # launch = the layer's QKV (+ cross-query) weights + the K / V stream of its position (every (row, head) read once)
+                gemm_obj["note"] = ("the GEMM launches OUTSIDE the fused QKV + self-attention launch; frac_isolated_chain / traffic are of the "
+                                    "isolated chain, which still runs the QKV GEMM as a launch of its own")
+                kv = model.lm._run['k']
+                Hh, hd_, bk_ = kv.shape[2], kv.shape[4], kv.element_size()
+                ctx_f = [prefix + t + 1 for n in (int(2.0 * model.frame_rate) + 3, int(is_dur * model.frame_rate) + 3) for t in range(n)]
+                f_bytes = w_qkv + 2 * (2 * B) * Hh * hd_ * bk_ * (sum(ctx_f) / len(ctx_f))
+                c_f, us_f = insitu['fused']
+                pmc_dur = 3.0   # (rocprofv3 --pmc segfaults on longer generates of this chain: 10 s and 30 s both, profiles/r06_pmc_fused_chain_durations.txt)
+                f_traffic, f_src = pmc_traffic_fused(args.model, B, pmc_dur, args.greedy) if (world == 1 and not melody) else (None, 'not collected')
+                ctx_p = [t + 1 for n in (int(2.0 * model.frame_rate) + 3, int(pmc_dur * model.frame_rate) + 3) for t in range(n)]
+                f_bytes_pmc = w_qkv + 2 * (2 * B) * Hh * hd_ * bk_ * (sum(ctx_p) / len(ctx_p))
+                out["roofline"] = {"kernel": "qkv_attn_kernel (the layer's QKV GEMM with the LayerNorm folded in + the self-attention that consumes it, ONE launch: "
+                                             "weights and the K / V stream overlap; sentinel hand-off per (row, head))", "bound": "hbm",
+                                   "achieved": round(f_bytes / (us_f * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(f_bytes / (us_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "frac_of_copy_bw": round(f_bytes / (us_f * 1e-6) / 1e9 / HBM_COPY_GBS, 4),
+                                   "traffic": f_traffic, "traffic_source": f_src,
+                                   "traffic_algorithmic_bytes_of_those_launches": int(f_bytes_pmc),
+                                   "traffic_note": ("the counter passes run a 2 s + 3 s generate (mean context ~67: the profiler crashes on longer ones), so `traffic` "
+                                                    "compares with traffic_algorithmic_bytes_of_those_launches, not with bytes_per_launch; the difference is a "
+                                                    "context-independent overhead (hand-off polls and stores, activation re-reads per XCD)"),
+                                   "traffic_overhead_bytes": None if f_traffic is None else int(f_traffic - f_bytes_pmc),
+                                   "traffic_over_algorithmic_at_the_bench_context_derived": None if f_traffic is None else
+                                       round((f_bytes + (f_traffic - f_bytes_pmc)) / f_bytes, 3),
+                                   "bytes_per_launch": int(f_bytes), "avg_launch_us": round(us_f, 3),
+                                   "mean_context": round(sum(ctx_f) / len(ctx_f), 1),
+                                   "avg_launch_source": "in situ: " + insitu_src,
+                                   "launches": {"traced": c_f, "expected": len(ctx_f) * L_},
+                                   "share_of_decode_time": "the largest single kernel of the step (DESIGN.md section 5.11)"}
+                out["roofline_gemm"] = gemm_obj
+            else:
+                out["roofline"] = gemm_obj
             ra = measure_attn_kernel(model, 2 * B, T, prefix=prefix)
             out["roofline_attn"] = {"kernel": "attn_decode_kernel (single-query self-attention over the bf16 KV cache)", "bound": "hbm",
                                     "achieved": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
@@ -702,7 +791,8 @@ def main():
                                     "frac_of_copy_bw": round(ra['bytes_per_launch'] / (ra['avg_us'] * 1e-6) / 1e9 / HBM_COPY_GBS, 4),
                                     "bytes_per_launch": int(ra['bytes_per_launch']), "avg_launch_us": round(ra['avg_us'], 3),
                                     "context": ra['context'], "launches": ra['launches'],
-                                    "note": "one launch per layer at the mean context of the generate, every layer's own (cold) cache"}
+                                    "note": "one launch per layer at the mean context of the generate, every layer's own (cold) cache; the stand-alone kernel "
+                                            "(the decode step uses it where the fused QKV + self-attention launch does not apply)"}
             out["roofline_attn"].update(attn_traffic_committed(ra['context'], int(ra['bytes_per_launch'])))
             if insitu is not None and 'self_attn' in insitu:
                 # in situ: the same kernel inside the decode graph of the traced generates; bytes = the mean K / V stream of
