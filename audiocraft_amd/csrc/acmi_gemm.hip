@@ -1166,14 +1166,14 @@ int launch_pair(LinArgs& p0, LinArgs& p1, hipStream_t st) {
 //   g2 = a_rbs | M << 16                     g3 = GEMM workgroups | cache capacity << 16
 #include "acmi_attn_fused.h"
 static_assert(sizeof(FusedAttnArgs) % 8 == 0, "kernarg layout of qkv_attn_kernel");
-template <int CCAP>
+template <int CCAP, int MT = 1>
 __global__ __launch_bounds__(256) void qkv_attn_kernel(const u32x4* hw, const u32x4* ha, const float* hsh, const void* hkc, const void* hvc,
                                                        unsigned g0, unsigned g1, unsigned g2, unsigned g3, const LinArgs, const FusedAttnArgs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tiles = (int)(g3 & 0xffffu);
     if ((int)blockIdx.x < tiles) {
         const TlHot h = tl_unpack(hw, ha, nullptr, hsh, g0, (g1 & 0xffffu) | (1u << 16), g2, 0u);
-        tl_body<bf16_t, 1, 4, 1, 8, false, CCAP, true>(h, ACMI_TL_ARGS_OFF_PAIR, (int)blockIdx.x, 0);
+        tl_body<bf16_t, MT, 4, 1, 8, false, CCAP, true>(h, ACMI_TL_ARGS_OFF_PAIR, (int)blockIdx.x, 0);
     } else {
         attn_fused_role(hkc, hvc, (int)(g1 >> 16), (int)(g3 >> 16), (int)blockIdx.x - tiles,
                         ACMI_TL_ARGS_OFF_PAIR + (int)sizeof(LinArgs), smem);
@@ -1187,10 +1187,10 @@ int acmi_launch_qkv_attn(LinArgs& a, FusedAttnArgs& f, const void* kc, const voi
     int rc = tiled_prepare<bf16_t>(a);
     if (rc) return rc;
     const int tiles = (a.N + 15) / 16, nw = 4;
-    ACMI_REQUIRE(a.colsum != nullptr && a.a_stats == nullptr && a.a_lo == nullptr && a.M <= 16 && a.N % 16 == 0 && a.qkv &&
+    ACMI_REQUIRE(a.colsum != nullptr && a.a_stats == nullptr && a.a_lo == nullptr && a.M <= 32 && a.N % 16 == 0 && a.qkv &&
                  a.NKC % nw == 0 && a.NKC / nw <= 16 && tiles <= 0xffff && Tcap <= 0xffff && H <= 0xffff && a.hd == 64 &&
                  a.kv_bf16 && a.M == a.rpp,
-                 "acmi_qkv_attn: needs the fragment-statistics LayerNorm, <= 16 rows, head size 64, a bf16 cache and K tiles a "
+                 "acmi_qkv_attn: needs the fragment-statistics LayerNorm, <= 32 rows, head size 64, a bf16 cache and K tiles a "
                  "multiple of 4 with at most 16 per wave (M=%d N=%d K=%d hd=%d)", a.M, a.N, a.K, a.hd);
     a.ksplit = 1; a.kcs = a.NKC; a.fpw = a.NKC / nw;
     if (a.r_ld <= 0) a.r_ld = a.d;
@@ -1201,12 +1201,16 @@ int acmi_launch_qkv_attn(LinArgs& a, FusedAttnArgs& f, const void* kc, const voi
     a.trace = nullptr;
 #endif
     f.rows = a.M; f.d = a.d;
-    const size_t lds_g = (size_t)3 * nw * 1024 + 128, lds_a = 2048 + (f.stage_k ? (size_t)nw * 8192 : 0);
+    const int mt = a.M > 16 ? 2 : 1;   // 16-row blocks sharing each weight fragment
+    const size_t lds_g = (size_t)3 * mt * nw * 1024 + (size_t)mt * 128, lds_a = 2048 + (f.stage_k ? (size_t)nw * 8192 : 0);
     const size_t lds = lds_g > lds_a ? lds_g : lds_a;
     const unsigned g0 = (unsigned)a.NKC | ((unsigned)a.kcs << 16), g1 = (unsigned)a.fpw | ((unsigned)nw << 12) | ((unsigned)H << 16);
     const unsigned g2 = (unsigned)a.a_rbs | ((unsigned)a.M << 16), g3 = (unsigned)tiles | ((unsigned)Tcap << 16);
     const dim3 grid(tiles + a.M * H), block(nw * 64);
-    if (a.fpw <= 12)
+    if (mt == 2)
+        hipLaunchKernelGGL((qkv_attn_kernel<12, 2>), grid, block, lds, st, reinterpret_cast<const u32x4*>(a.w), reinterpret_cast<const u32x4*>(a.a),
+                           a.a_shift, kc, vc, g0, g1, g2, g3, a, f);
+    else if (a.fpw <= 12)
         hipLaunchKernelGGL(qkv_attn_kernel<12>, grid, block, lds, st, reinterpret_cast<const u32x4*>(a.w), reinterpret_cast<const u32x4*>(a.a),
                            a.a_shift, kc, vc, g0, g1, g2, g3, a, f);
     else

@@ -929,8 +929,12 @@ extern "C" int acmi_lm_step(const acmi_lm_model* m, const acmi_lm_state* s, int 
     // QKV -> self-attention as one launch (acmi_lm_state.qkv_hand; acmi_attn_fused.h): the caller opts in per state, the geometry
     // decides per step; ACMI_QKV_STAGE_K=0 keeps the K half of the second round out of LDS (A/B)
     static const bool stage_k = !(getenv("ACMI_QKV_STAGE_K") != nullptr && getenv("ACMI_QKV_STAGE_K")[0] == '0');
+    // rows: one 16-row block by default; the kernel also takes two (<= 32 rows: bit-identical, but measured neutral -- melody 16 x 30 s
+    // RTF 102.3 vs 101.9, medium 16 x 30 s 96.6 vs 96.8: 167 VGPRs, a third of the attention workgroups wait for a slot) --
+    // ACMI_QKV_ATTN_ROWS=32 lets them in
+    static const int fuse_rows = getenv("ACMI_QKV_ATTN_ROWS") != nullptr ? atoi(getenv("ACMI_QKV_ATTN_ROWS")) : 16;
     const bool fuse_qkv = mode == ACMI_STEP_DECODE && npos == 1 && s->qkv_hand != nullptr && s->hand_err != nullptr && wbf && kvbf &&
-                          hd == 64 && c.lnm == LN_FOLD && c.gram && M <= 16 && !post && !xs && m->rope_freq == nullptr &&
+                          hd == 64 && c.lnm == LN_FOLD && c.gram && M <= fuse_rows && !post && !xs && m->rope_freq == nullptr &&
                           m->past_context <= 0 && s->row_off == nullptr && c.nkc_d % 4 == 0 && c.nkc_d / 4 <= 16 && s->Tmax <= 0xffff &&
                           d % c.kt == 0;
 

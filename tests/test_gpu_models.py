@@ -492,7 +492,7 @@ torch.save({'t_a': t_a.cpu(), 'l_a': l_a.cpu(), 't_b': t_b.cpu(), 'l_b': l_b.cpu
 """
 
 
-@pytest.mark.parametrize('cross,B', [(True, 8), (True, 3), (False, 16), (False, 5)])
+@pytest.mark.parametrize('cross,B', [(True, 8), (True, 3), (False, 16), (False, 5), (True, 16), (False, 27)])
 def test_fused_qkv_attention_launch_is_bit_identical(cross, B, tmp_path):
     """acmi_lm_state.qkv_hand (0.2.0): the decode step's QKV GEMM and the self-attention that consumes it as ONE launch with a
     per-(row, head) sentinel hand-off (csrc/acmi_attn_fused.h; reference op sequence transformer.py:362-399, 412-414).  The
@@ -500,7 +500,7 @@ def test_fused_qkv_attention_launch_is_bit_identical(cross, B, tmp_path):
     (ACMI_LIN_WIDE=0: 16-feature workgroups of 4 waves, what the fused launch runs) tokens AND logits are bit-identical --
     sampled, 330 frames (contexts crossing the 64-position chunks and the second round that is staged in LDS), MusicGen-medium's
     width and head count, with and without cross-attention (the paired and the plain out-projection layouts), 16 / 6 / 16 / 5
-    rows, and behind a prompt (prefill, then decode).  One subprocess per mode: the switches are read once per process."""
+    rows in one 16-row block and 32 / 27 rows in two, and behind a prompt (prefill, then decode).  One subprocess per mode: the switches are read once per process."""
     import os
     import subprocess
     import sys
@@ -508,7 +508,7 @@ def test_fused_qkv_attention_launch_is_bit_identical(cross, B, tmp_path):
     res = {}
     for fused in ('0', '1'):
         out = str(tmp_path / f'ab{fused}.pt')
-        env = dict(os.environ, ACMI_QKV_ATTN=fused, ACMI_LIN_WIDE='0', PYTHONPATH=root)
+        env = dict(os.environ, ACMI_QKV_ATTN=fused, ACMI_QKV_ATTN_ROWS='32', ACMI_LIN_WIDE='0', PYTHONPATH=root)
         r = subprocess.run([sys.executable, '-c', _FUSED_AB, '1' if cross else '0', str(B), out], env=env, cwd=root, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
