@@ -51,6 +51,7 @@ struct ConvArgs {
 // geometry shared by the weight tiler, the packer and the main kernel
 struct ConvGeom {
     bool fewout;
+    bool pw;               // pointwise (k = 1) channel-doubling conv of a SEANet resnet block on a long signal: conv_pw_kernel
     int cic, nchunks, KCE, KCP, LP, XSZ, Tq, tq, my;
     long long Qp;
     size_t wt_floats, work_floats, lds;
@@ -67,7 +68,13 @@ static int conv_geometry(const acmi_conv_desc& d, ConvGeom& g) {
     static const bool fewout_ok = !(getenv("ACMI_CONV_FEWOUT") != nullptr && getenv("ACMI_CONV_FEWOUT")[0] == '0');
     g.fewout = fewout_ok && d.Cout <= 2 && d.ksize == 7 && d.stride == 1 && d.dilation == 1 && d.shuffle == 1;
     g.Tq = d.shuffle > 1 ? (int)(((long long)d.Tout + d.trim_left + d.shuffle - 1) / d.shuffle) : d.Tout;
-    if (g.fewout) {
+    // the second conv of a SEANet resnet block (seanet.py:16-60: ELU -> k = 1 conv C / 2 -> C, + skip) in the narrow, long stages:
+    // as a 64-row MFMA tile with K = 32 or 64 it is all staging, barriers and a pack pass (7 TF/s, 1.1 TB/s); see conv_pw_kernel
+    static const bool pw_ok = !(getenv("ACMI_CONV_PW") != nullptr && getenv("ACMI_CONV_PW")[0] == '0');
+    g.pw = pw_ok && !g.fewout && d.ksize == 1 && d.stride == 1 && d.dilation == 1 && d.shuffle == 1 && d.pad_left == 0 && d.elu_in &&
+           d.Tout == d.Tin && d.Tout % 4 == 0 && ((d.Cin == 32 && d.Cout == 64) || (d.Cin == 64 && d.Cout == 128)) &&
+           (long long)d.B * d.Tout >= 65536;
+    if (g.fewout || g.pw) {
         g.cic = g.nchunks = g.KCE = g.KCP = g.LP = g.XSZ = g.tq = g.my = 0; g.Qp = 0; g.lds = 0;
         g.wt_floats = (size_t)d.Cout * d.Cin * d.ksize;   // the raw weights
         g.work_floats = g.pack_floats = 0;
@@ -387,6 +394,70 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
 }
 
 // -----------------------------------------------------------------------------------------------------
+// Pointwise channel-doubling convolution of a resnet block (k = 1, CI -> 2 CI, ELU on the input, bias, skip add) on a long signal.
+// One thread = four (CI = 32) or two (CI = 64) consecutive time steps: its inputs are loaded once (16- / 8-byte loads, coalesced
+// along time), ELU'd once, and held in registers; the weights sit in LDS and are read as wave-uniform 16-byte broadcasts; one output
+// channel per loop trip, each an ascending-k fmaf chain from 0 (the order of the MFMA kernel's accumulation), then + bias, + skip like its epilogue.
+// Memory-bound by construction (EnCodec-32k, 8 x 30 s, 32 -> 64 at T = 960 000: 4.9 GB once, no pack pass).
+// -----------------------------------------------------------------------------------------------------
+template <int CI>
+__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvArgs a) {
+    constexpr int CO = 2 * CI, TT = CI <= 32 ? 4 : 2;   // time steps per thread: CI x TT input registers
+    typedef float vec_t __attribute__((ext_vector_type(TT)));
+    __shared__ __attribute__((aligned(16))) float ws[CO * CI];
+    const acmi_conv_desc& d = a.d;
+    const int tid = threadIdx.x, b = blockIdx.z;
+    for (int i = tid; i < CO * CI / 4; i += 256) reinterpret_cast<float4*>(ws)[i] = reinterpret_cast<const float4*>(a.w)[i];
+    const long long t = ((long long)blockIdx.x * 256 + tid) * TT;
+    const bool live = t < d.Tout;   // Tout is a multiple of TT: every step of a live thread exists
+    const long long tc = live ? t : 0;
+    float xin[CI][TT];
+    const float* xb = a.x + (size_t)b * CI * d.Tin + tc;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(xb + (size_t)ci * d.Tin);
+#pragma unroll
+        for (int u = 0; u < TT; ++u) xin[ci][u] = v[u];
+    }
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int u = 0; u < TT; ++u) { const float v = xin[ci][u]; xin[ci][u] = v > 0.f ? v : d.elu_alpha * expm1f(v); }
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < CO; ++c) {   // one output channel per trip: TT independent fmaf chains, nothing but the inputs stays live
+        float acc[TT];
+#pragma unroll
+        for (int u = 0; u < TT; ++u) acc[u] = 0.f;
+        const float* wr = ws + c * CI;
+#pragma unroll
+        for (int ci = 0; ci < CI; ci += 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wr + ci);   // wave uniform: one LDS broadcast
+#pragma unroll
+            for (int u = 0; u < TT; ++u) {
+                acc[u] = fmaf(w4.x, xin[ci][u], acc[u]);
+                acc[u] = fmaf(w4.y, xin[ci + 1][u], acc[u]);
+                acc[u] = fmaf(w4.z, xin[ci + 2][u], acc[u]);
+                acc[u] = fmaf(w4.w, xin[ci + 3][u], acc[u]);
+            }
+        }
+        if (live) {
+            const size_t oi = ((size_t)b * CO + c) * d.Tout + (size_t)t;
+            const float bv = a.bias ? a.bias[c] : 0.f;
+            vec_t v;
+#pragma unroll
+            for (int u = 0; u < TT; ++u) v[u] = acc[u] + bv;
+            if (a.res) {
+                const vec_t r = *reinterpret_cast<const vec_t*>(a.res + oi);
+#pragma unroll
+                for (int u = 0; u < TT; ++u) v[u] += r[u];
+            }
+            *reinterpret_cast<vec_t*>(a.y + oi) = v;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
 // Convolutions with ONE or TWO output channels (the decoder's last conv: 64 -> 1 channel, k = 7, on the full-rate
 // signal).  As a 64-row MFMA tile 63 of 64 rows are padding -- that launch alone was ~1/5 of the EnCodec-32k decode.
 // Here: 256 threads x 4 consecutive outputs; per chunk of 8 input channels the span (ELU, padding applied on load, like
@@ -465,7 +536,7 @@ extern "C" int acmi_conv1d_tile_weights(const acmi_conv_desc* dp, const float* w
     ACMI_REQUIRE(dp != nullptr && w != nullptr && wt != nullptr, "acmi_conv1d_tile_weights: null argument");
     ConvGeom g;
     if (int rc = conv_geometry(*dp, g)) return rc;
-    if (g.fewout) {   // the few-output kernel reads the weights as they are
+    if (g.fewout || g.pw) {   // the few-output and the pointwise kernels read the weights as they are
         if (hipMemcpyAsync(wt, w, g.wt_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
             acmi_set_error("acmi_conv1d_tile_weights: hipMemcpyAsync failed");
             return ACMI_ELAUNCH;
@@ -503,6 +574,14 @@ static int conv1d_impl(const acmi_conv_desc* dp, const float* x, const float* wt
         if (d.Cout == 1) hipLaunchKernelGGL((conv_fewout_kernel<1, 7>), grid, block, 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((conv_fewout_kernel<2, 7>), grid, block, 0, (hipStream_t)stream, a);
         return acmi_check_launch("conv_fewout_kernel");
+    }
+    if (g.pw) {
+        ACMI_REQUIRE(gn == nullptr, "acmi_conv1d_gn: not for the pointwise kernel");
+        const int tt = d.Cin == 32 ? 4 : 2;   // time steps per thread (conv_pw_kernel)
+        dim3 grid((unsigned)((d.Tout / tt + 255) / 256), 1, d.B), block(256);
+        if (d.Cin == 32) hipLaunchKernelGGL(conv_pw_kernel<32>, grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv_pw_kernel<64>, grid, block, 0, (hipStream_t)stream, a);
+        return acmi_check_launch("conv_pw_kernel");
     }
     ACMI_REQUIRE(work != nullptr, "acmi_conv1d: work buffer (acmi_conv1d_work_floats) missing");
     ACMI_REQUIRE(a.cin_pad <= 65535 && d.B <= 65535, "acmi_conv1d: Cin=%d / B=%d exceed the grid", d.Cin, d.B);

@@ -65,7 +65,7 @@ def profile_pass(args, extra, pattern, timeout_s=300):
 
 
 def family(name):
-    for key in ('conv_mfma_kernel', 'conv_fewout_kernel', 'conv_pack_kernel', 'rvq_encode_kernel', 'rvq_decode_kernel', 'lstm_'):
+    for key in ('conv_mfma_kernel', 'conv_fewout_kernel', 'conv_pw_kernel', 'resblock_kernel', 'conv_pack_kernel', 'rvq_encode_kernel', 'rvq_decode_kernel', 'lstm_'):
         if key in name:
             return key.rstrip('_')
     return None
@@ -84,11 +84,20 @@ def main():
     torch.cuda.synchronize()
     # flops / bytes of one pass, counted at the C-ABI boundary
     import audiocraft_amd.modules.seanet as seanet
-    acc = {'flops': 0.0, 'lstm_steps': 0}
+    acc = {'flops': 0.0, 'lstm_steps': 0, 'pw_bytes': 0.0, 'pw_flops': 0.0}
     conv0, lstm0, lstm20 = _C.conv1d_tiled, _C.lstm_layer, _C.lstm_stack2
 
+    pw_on = os.environ.get('ACMI_CONV_PW', '1') != '0'
+
     def conv1d(d, x, w, bias, residual, y):
-        acc['flops'] += 2.0 * d.B * d.Cout * d.Cin * d.ksize * (d.Tout // max(d.shuffle, 1) if d.shuffle > 1 else d.Tout)
+        fl = 2.0 * d.B * d.Cout * d.Cin * d.ksize * (d.Tout // max(d.shuffle, 1) if d.shuffle > 1 else d.Tout)
+        # (the condition of conv_geometry's pointwise path, acmi_conv.hip: those launches are conv_pw_kernel's, a stream, not the MFMA kernel's)
+        if (pw_on and d.ksize == 1 and d.stride == 1 and d.elu_in and d.Tout == d.Tin and d.Tout % 4 == 0 and d.B * d.Tout >= 65536 and
+                (d.Cin, d.Cout) in ((32, 64), (64, 128))):
+            acc['pw_flops'] += fl
+            acc['pw_bytes'] += 4.0 * d.B * d.Tout * (d.Cin + d.Cout * (2 if residual is not None else 1))
+        else:
+            acc['flops'] += fl
         return conv0(d, x, w, bias, residual, y)
 
     def lstm_layer(gates, w_hh, skip, out, work, Bq, H, T):
@@ -155,6 +164,12 @@ def main():
                            "flops_per_pass": acc['flops'], "launches_per_pass": fam['conv_mfma_kernel'][0] // passes,
                            "avg_launch_us": round(fam['conv_mfma_kernel'][1] / fam['conv_mfma_kernel'][0] / 1e3, 3),
                            "traffic": None, "note": "all convolutions of one encode + decode pass incl. the LSTM input projections"}
+        if 'conv_pw_kernel' in fam and acc['pw_bytes'] > 0:
+            pw_s = fam['conv_pw_kernel'][1] / passes * 1e-9
+            out["roofline_pw"] = {"kernel": "conv_pw_kernel (the k = 1 channel-doubling conv of the narrow resnet blocks: ELU, bias, skip; VALU fmaf chains)",
+                                  "bound": "hbm", "achieved": round(acc['pw_bytes'] / pw_s / 1e9, 1), "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(acc['pw_bytes'] / pw_s / 1e9 / bench.HBM_PEAK_GBS, 4), "bytes_per_pass": acc['pw_bytes'],
+                                  "launches_per_pass": fam['conv_pw_kernel'][0] // passes, "tflops": round(acc['pw_flops'] / pw_s / 1e12, 2)}
         if 'rvq_encode_kernel' in fam:
             rvq_bytes = 4 * B * D * T + 8 * B * K * T + 4 * K * bins * D
             us = fam['rvq_encode_kernel'][1] / fam['rvq_encode_kernel'][0] / 1e3

@@ -103,6 +103,8 @@ CONV_CASES = [
     (64, 1, 7, 1, 2, False, 'constant', 300),    # dilated: stays on the MFMA kernel
     (1024, 128, 7, 1, 1, False, 'constant', 50),
     (128, 1024, 7, 1, 1, True, 'constant', 75),
+    (32, 64, 1, 1, 1, False, 'constant', 32772),    # long pointwise channel-doubling conv behind an ELU: conv_pw_kernel (ragged last block)
+    (64, 128, 1, 1, 1, True, 'constant', 32800),    # ... its 64 -> 128 form
 ]
 
 
