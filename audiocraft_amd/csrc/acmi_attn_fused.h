@@ -94,9 +94,9 @@ __device__ __forceinline__ void attn_fused_role(const void* hkc, const void* hvc
         u32x4 w[6];
         unsigned spins = 0;
         // ONE poller per workgroup: wave 0 polls and hands the 3 x 64 words over through LDS, the other waves wait at the barrier.
-        // Same speed as every wave polling for itself (profiles/r06_fused_qkv_attn_one_poller_ab.txt), a quarter of the poll
-        // traffic: agent-scope loads of lines the producers' write-through stores dropped from L2 are fabric reads (PMC: the
-        // polls of four waves were ~9 MB per launch).
+        // Same speed as every wave polling for itself (profiles/r06_fused_qkv_attn_one_poller_ab.txt) and the same HBM-side traffic by
+        // PMC (34.3 MB per launch at a mean context of 67 either way): kept because it is a quarter of the poll requests in the
+        // CU's memory queue.
         unsigned* hw = reinterpret_cast<unsigned*>(smem + 1280);   // [3][64] words
         if (wave == 0)
         for (;;) {
